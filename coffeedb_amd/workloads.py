@@ -1,0 +1,129 @@
+"""Deterministic synthetic corpora and pattern batches.
+
+The reference's own tests draw from an unseeded `random` (test/test-string.py:26), so they are not
+reproducible; these generators use a counter-based splitmix64 so that every test, the bench and the
+CPU baseline see byte-identical inputs for a given (shape, seed).
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    """Vectorised splitmix64 finaliser over a uint64 array of counters."""
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def _draws(count, seed, stream):
+    base = np.uint64((seed * 0x100000001B3 + stream * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF)
+    out = np.empty(count, dtype=np.uint64)
+    step = 1 << 22
+    for s in range(0, count, step):
+        e = min(count, s + step)
+        with np.errstate(over="ignore"):
+            out[s:e] = splitmix64(np.arange(s, e, dtype=np.uint64) + base)
+    return out
+
+
+def random_bytes(n, seed, lo=0x20, hi=0x7E, stream=0):
+    """n bytes uniform over [lo, hi] (8 bytes per 64-bit draw, scaled from 0..255)."""
+    span = hi - lo + 1
+    out = np.empty(((n + 7) // 8) * 8, dtype=np.uint8)
+    step = 1 << 22  # draws per chunk
+    ndraw = len(out) // 8
+    base = np.uint64((seed * 0x100000001B3 + stream * 0x9E3779B1) & 0xFFFFFFFFFFFFFFFF)
+    for s in range(0, ndraw, step):
+        e = min(ndraw, s + step)
+        with np.errstate(over="ignore"):
+            r = splitmix64(np.arange(s, e, dtype=np.uint64) + base)
+        b = r.view(np.uint8).reshape(-1, 8).astype(np.uint16)
+        out[s * 8:e * 8] = (lo + ((b * span) >> 8)).astype(np.uint8).reshape(-1)
+    return out[:n]
+
+
+def uniform_docs(ndocs, doclen):
+    return np.arange(ndocs + 1, dtype=np.uint64) * np.uint64(doclen)
+
+
+def ascii_corpus(ndocs, doclen, seed=12345, lo=0x20, hi=0x7E):
+    """C0/C1-style corpus: ndocs documents of exactly doclen bytes, uniform over [lo, hi]."""
+    return random_bytes(ndocs * doclen, seed, lo, hi), uniform_docs(ndocs, doclen)
+
+
+def ragged_corpus(ndocs, maxlen, seed=7, lo=0x61, hi=0x7A, empty_every=0):
+    """Documents of varying length in [0, maxlen] (optionally every k-th one empty)."""
+    lens = (_draws(ndocs, seed, 1) % np.uint64(maxlen + 1)).astype(np.uint64)
+    if empty_every:
+        lens[::empty_every] = 0
+    doc_start = np.zeros(ndocs + 1, dtype=np.uint64)
+    np.cumsum(lens, out=doc_start[1:])
+    return random_bytes(int(doc_start[-1]), seed, lo, hi), doc_start
+
+
+def zipf_corpus(ndocs, doclen, seed=2, nsym=64, base=0x30):
+    """C2-style skewed alphabet: nsym symbols base+rank with P(rank k) ∝ 1/k (k = 1..nsym)."""
+    w = 1.0 / np.arange(1, nsym + 1)
+    cdf = np.cumsum(w / w.sum())
+    n = ndocs * doclen
+    out = np.empty(n, dtype=np.uint8)
+    step = 1 << 22
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        u = (_draws(e - s, seed, 3 + s // step) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        out[s:e] = (base + np.searchsorted(cdf, u, side="right").clip(0, nsym - 1)).astype(np.uint8)
+    return out, uniform_docs(ndocs, doclen)
+
+
+def utf8_corpus(ndocs, approx_doclen, seed=4):
+    """C4-style valid UTF-8: 50 % 1-byte, 30 % 2-byte (U+0080–07FF), 20 % 3-byte (U+0800–FFFF minus
+    surrogates) code points; documents are cut at code-point boundaries near approx_doclen bytes."""
+    parts, doc_start = [], [0]
+    total = 0
+    for d in range(ndocs):
+        ncp = max(1, int(approx_doclen / 1.7))
+        r = _draws(ncp * 2, seed, 10 + d)
+        cls = (r[:ncp] % np.uint64(10)).astype(np.int64)
+        val = r[ncp:]
+        cp = np.where(cls < 5, 0x20 + (val % np.uint64(0x5F)).astype(np.int64),
+                      np.where(cls < 8, 0x80 + (val % np.uint64(0x780)).astype(np.int64),
+                               0x800 + (val % np.uint64(0xD000)).astype(np.int64)))  # < 0xD800
+        s = "".join(map(chr, cp.tolist())).encode("utf-8")
+        parts.append(np.frombuffer(s, dtype=np.uint8))
+        total += len(s)
+        doc_start.append(total)
+    blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    return blob, np.asarray(doc_start, dtype=np.uint64)
+
+
+def sample_patterns(blob, doc_start, npat, mmin=4, mmax=16, seed=99, miss_frac=0.1, miss_byte=None):
+    """Pattern batch: substrings sampled at uniform (doc, offset) — guaranteed ≥1 hit — plus a
+    miss_frac tail of patterns whose last byte is replaced so that most of them do not occur.
+    Returns (pattern_blob uint8[], offsets uint64[npat+1])."""
+    nd = len(doc_start) - 1
+    r = _draws(npat * 4, seed, 2)
+    lens = doc_start[1:] - doc_start[:-1]
+    nonempty = np.nonzero(lens > 0)[0]
+    assert len(nonempty) > 0
+    docs = nonempty[(r[:npat] % np.uint64(len(nonempty))).astype(np.int64)]
+    m = (mmin + (r[npat:2 * npat] % np.uint64(mmax - mmin + 1))).astype(np.int64)
+    dl = lens[docs].astype(np.int64)
+    m = np.minimum(m, dl)
+    off = (r[2 * npat:3 * npat] % (dl - m + 1).astype(np.uint64)).astype(np.int64)
+    start = doc_start[docs].astype(np.int64) + off
+    offsets = np.zeros(npat + 1, dtype=np.uint64)
+    np.cumsum(m.astype(np.uint64), out=offsets[1:])
+    idx = np.repeat(start - offsets[:-1].astype(np.int64), m) + np.arange(int(offsets[-1]), dtype=np.int64)
+    pblob = blob[idx].copy()
+    nmiss = int(npat * miss_frac)
+    if nmiss:
+        which = (r[3 * npat:3 * npat + nmiss] % np.uint64(npat)).astype(np.int64)
+        last = offsets[which + 1].astype(np.int64) - 1
+        if miss_byte is None:
+            pblob[last] = np.where(pblob[last] == 0x7E, 0x21, pblob[last] + 1).astype(np.uint8)
+        else:
+            pblob[last] = miss_byte
+    return pblob, offsets
