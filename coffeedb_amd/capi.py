@@ -1,0 +1,193 @@
+"""ctypes binding of libcoffeedb_gpu.so (include/coffeedb_gpu.h).
+
+`GpuStringIndex` mirrors the reference's string_index surface (add / build / query,
+/root/reference/src/index.h:54-86) plus the batched query.  There is no CPU fallback: loading fails
+loudly when the HIP library is missing, and cdb_create fails when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
+_LIB = None
+
+EXPORTS = [
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device",
+    "cdb_query", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
+    "cdb_profile_dump", "cdb_profile_reset",
+]
+
+
+class CdbResult(C.Structure):
+    _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
+                ("row_ptr", C.POINTER(C.c_uint64)), ("ids", C.POINTER(C.c_int64)), ("counts", C.POINTER(C.c_int64))]
+
+
+class CdbDeviceResult(C.Structure):
+    _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
+                ("d_row_ptr", C.c_void_p), ("d_ids", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+def build_library(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing — build it with `make -C {CSRC}` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i64, cp = C.c_void_p, C.c_uint64, C.c_int64, C.c_char_p
+    lib.cdb_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.cdb_destroy.argtypes = [vp]
+    lib.cdb_destroy.restype = None
+    lib.cdb_last_error.argtypes = [vp]
+    lib.cdb_last_error.restype = cp
+    lib.cdb_add.argtypes = [vp, i64, cp, C.c_size_t]
+    lib.cdb_add_bulk.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_build.argtypes = [vp]
+    lib.cdb_build_device.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
+                              C.POINTER(C.c_size_t)]
+    lib.cdb_free.argtypes = [vp]
+    lib.cdb_free.restype = None
+    lib.cdb_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
+    lib.cdb_result_free.argtypes = [C.POINTER(CdbResult)]
+    lib.cdb_result_free.restype = None
+    lib.cdb_query_batch_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(CdbDeviceResult)]
+    for f in ("cdb_size", "cdb_bits", "cdb_mask"):
+        getattr(lib, f).argtypes = [vp]
+        getattr(lib, f).restype = u64
+    lib.cdb_sa_width.argtypes = [vp]
+    lib.cdb_sa_copy.argtypes = [vp, vp, u64]
+    lib.cdb_set_option.argtypes = [vp, cp, i64]
+    lib.cdb_get_stat.argtypes = [vp, cp, C.POINTER(C.c_double)]
+    lib.cdb_profile_get.argtypes = [vp, cp, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    lib.cdb_profile_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.cdb_profile_reset.argtypes = [vp]
+    lib.cdb_profile_reset.restype = None
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GpuStringIndex:
+    """string_index on the GPU: add() / build() / query() as in the reference, plus query_batch()."""
+
+    def __init__(self, device=-1):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.cdb_create(C.byref(h), device)
+        if rc != 0:
+            raise RuntimeError(f"cdb_create failed (code {rc}): no usable gfx950 device — there is no CPU fallback")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cdb_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.cdb_last_error(self._h).decode(errors="replace"))
+
+    # ---- reference surface
+    def add(self, id_, value: bytes):
+        self._check(self._lib.cdb_add(self._h, int(id_), value, len(value)))
+
+    def add_bulk(self, ids, blob, doc_start):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+        assert len(doc_start) == len(ids) + 1
+        self._check(self._lib.cdb_add_bulk(self._h, _ptr(ids), _ptr(blob), _ptr(doc_start), len(ids)))
+
+    def build(self):
+        self._check(self._lib.cdb_build(self._h))
+
+    def build_device(self, d_text_ptr, doc_start, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+        self._check(self._lib.cdb_build_device(self._h, C.c_void_p(d_text_ptr), _ptr(doc_start), _ptr(ids), len(ids)))
+
+    def query(self, kw: bytes):
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        self._check(self._lib.cdb_query(self._h, kw, len(kw), C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = [(ids[i], cnt[i]) for i in range(n.value)]
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return out
+
+    # ---- batched
+    def query_batch(self, blob, offsets):
+        """Returns (row_ptr uint64[npat+1], ids int64[nrows], counts int64[nrows], nhits)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        npat = len(offsets) - 1
+        r = CdbResult()
+        self._check(self._lib.cdb_query_batch(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r)))
+        try:
+            row_ptr = np.ctypeslib.as_array(r.row_ptr, shape=(npat + 1,)).copy()
+            nrows = int(r.nrows)
+            ids = np.ctypeslib.as_array(r.ids, shape=(max(nrows, 1),))[:nrows].copy()
+            cnt = np.ctypeslib.as_array(r.counts, shape=(max(nrows, 1),))[:nrows].copy()
+            return row_ptr, ids, cnt, int(r.nhits)
+        finally:
+            self._lib.cdb_result_free(C.byref(r))
+
+    def query_batch_device(self, d_blob_ptr, d_offsets_ptr, npat, blob_bytes):
+        r = CdbDeviceResult()
+        self._check(self._lib.cdb_query_batch_device(self._h, C.c_void_p(d_blob_ptr), C.c_void_p(d_offsets_ptr), npat,
+                                                     blob_bytes, C.byref(r)))
+        return r
+
+    # ---- introspection / options / measurements
+    size = property(lambda s: s._lib.cdb_size(s._h))
+    bits = property(lambda s: s._lib.cdb_bits(s._h))
+    mask = property(lambda s: s._lib.cdb_mask(s._h))
+    sa_width = property(lambda s: s._lib.cdb_sa_width(s._h))
+
+    def sa(self):
+        n, w = self.size, self.sa_width
+        out = np.empty(n, dtype=np.uint32 if w == 4 else np.uint64)
+        if n:
+            self._check(self._lib.cdb_sa_copy(self._h, _ptr(out), out.nbytes))
+        return out
+
+    def set_option(self, name, value):
+        self._check(self._lib.cdb_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name):
+        v = C.c_double(0)
+        if self._lib.cdb_get_stat(self._h, name.encode(), C.byref(v)) != 0:
+            raise KeyError(name)
+        return v.value
+
+    def profile(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._lib.cdb_profile_dump(self._h, buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, launches, nbytes = line.split()
+            out[name] = {"ms": float(ms), "launches": int(launches), "bytes": int(nbytes)}
+        return out
+
+    def profile_reset(self):
+        self._lib.cdb_profile_reset(self._h)

@@ -1,0 +1,356 @@
+// capi.hip — the C ABI of libcoffeedb_gpu.so (include/coffeedb_gpu.h).  Host logic only: staging of
+// cdb_add, the reference's width rule, uploads/downloads and error translation.  All device work is in
+// sa_build.hip / query.hip / radix_sort.h.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/coffeedb_gpu.h"
+#include "index_impl.h"
+
+using namespace cdb;
+
+struct cdb_index {
+    Index ix;
+};
+
+namespace {
+
+double wall_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename F>
+int guarded(cdb_index* h, F&& f) {
+    try {
+        f();
+        return CDB_OK;
+    } catch (const Error& e) {
+        h->ix.err = e.what();
+        const bool dev = std::strncmp(e.what(), "HIP error", 9) == 0;
+        const bool internal = std::strstr(e.what(), "internal") != nullptr;
+        return dev ? CDB_E_DEVICE : (internal ? CDB_E_INTERNAL : CDB_E_INVALID);
+    } catch (const std::bad_alloc&) {
+        h->ix.err = "out of host memory";
+        return CDB_E_DEVICE;
+    } catch (const std::exception& e) {
+        h->ix.err = e.what();
+        return CDB_E_INTERNAL;
+    }
+}
+
+// bits / mask / size / width exactly as string_index::build does (reference src/index.cpp:182-208)
+void compute_layout(Index& ix) {
+    const uint64_t ndocs = ix.ids.size();
+    uint64_t size = 0, mask1 = 1, mask2 = 1;
+    while (mask1 < ndocs) mask1 = (mask1 << 1) + 1;
+    for (uint64_t d = 0; d < ndocs; ++d) {
+        const uint64_t len = ix.doc_start[d + 1] - ix.doc_start[d];
+        size += len;
+        while (mask2 < len) mask2 = (mask2 << 1) + 1;
+    }
+    const int bits1 = __builtin_popcountll(mask1), bits2 = __builtin_popcountll(mask2);
+    if (bits1 + bits2 > 64) throw Error("The amount of data exceeds the maximum range that CoffeeDB can handle");
+    if (bits1 > 32) throw Error("The number of objects exceeds the maximum range that CoffeeDB can handle");
+    ix.size = size;
+    ix.mask = mask1;
+    ix.bits = (uint64_t)bits1;
+    ix.width = bits1 + bits2 <= 32 ? 4 : 8;
+    ix.ndocs = ndocs;
+}
+
+void upload_tables(Index& ix) {
+    hipStream_t s = ix.stream;
+    ix.d_doc_start.alloc((ix.ndocs + 1) * sizeof(uint64_t));
+    CDB_HIP(hipMemcpyAsync(ix.d_doc_start.p, ix.doc_start.data(), (ix.ndocs + 1) * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, s));
+    ix.d_ids.alloc(std::max<uint64_t>(ix.ndocs, 1) * sizeof(int64_t));
+    if (ix.ndocs)
+        CDB_HIP(hipMemcpyAsync(ix.d_ids.p, ix.ids.data(), ix.ndocs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+}
+
+void set_device(Index& ix) { CDB_HIP(hipSetDevice(ix.device)); }
+
+}  // namespace
+
+extern "C" {
+
+int cdb_create(cdb_index** out, int device) {
+    if (!out) return CDB_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return CDB_E_DEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return CDB_E_DEVICE;
+    }
+    if (device >= count) return CDB_E_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return CDB_E_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CDB_E_DEVICE;  // kernels exist for gfx950 only
+    cdb_index* h = new (std::nothrow) cdb_index();
+    if (!h) return CDB_E_DEVICE;
+    h->ix.device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return CDB_E_DEVICE;
+    }
+    *out = h;
+    return CDB_OK;
+}
+
+void cdb_destroy(cdb_index* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ix.device);
+    if (h->ix.stream) {
+        (void)hipStreamSynchronize(h->ix.stream);
+        (void)hipStreamDestroy(h->ix.stream);
+    }
+    delete h;
+}
+
+const char* cdb_last_error(const cdb_index* h) { return h ? h->ix.err.c_str() : "null handle"; }
+
+int cdb_add(cdb_index* h, int64_t id, const char* value, size_t len) {
+    if (!h || (!value && len)) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        ix.ids.push_back(id);
+        ix.host_text.append(value, len);
+        ix.doc_start.push_back(ix.host_text.size());
+    });
+}
+
+int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs) {
+    if (!h || (ndocs && (!ids || !doc_start))) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        if (!ndocs) return;
+        const uint64_t base = ix.host_text.size();
+        ix.host_text.append(blob + doc_start[0], doc_start[ndocs] - doc_start[0]);
+        for (uint64_t d = 0; d < ndocs; ++d) {
+            ix.ids.push_back(ids[d]);
+            ix.doc_start.push_back(base + doc_start[d + 1] - doc_start[0]);
+        }
+    });
+}
+
+int cdb_build(cdb_index* h) {
+    if (!h) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        compute_layout(ix);
+        const uint64_t n = ix.size;
+        ix.d_text_owned.alloc(n + TEXT_PAD);
+        CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + n, 0, TEXT_PAD, ix.stream));
+        if (n) CDB_HIP(hipMemcpyAsync(ix.d_text_owned.p, ix.host_text.data(), n, hipMemcpyHostToDevice, ix.stream));
+        ix.d_text = ix.d_text_owned.as<uint8_t>();
+        ix.text_padded = true;
+        upload_tables(ix);
+        build_suffix_array(ix);
+    });
+}
+
+int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start, const int64_t* ids, uint64_t ndocs) {
+    if (!h || (ndocs && (!doc_start || !ids))) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        if (((uintptr_t)d_text & 15u) != 0) throw Error("device text must be 16-byte aligned");
+        ix.ids.assign(ids, ids + ndocs);
+        ix.doc_start.resize(ndocs + 1);
+        ix.doc_start[0] = 0;
+        for (uint64_t d = 0; d < ndocs; ++d) {
+            if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+            ix.doc_start[d + 1] = doc_start[d + 1] - doc_start[0];
+        }
+        ix.host_text.clear();
+        compute_layout(ix);
+        ix.d_text_owned.release();
+        ix.d_text = static_cast<const uint8_t*>(d_text) + doc_start[0];
+        if (doc_start[0] & 15u) throw Error("first document must start 16-byte aligned");
+        ix.text_padded = false;
+        upload_tables(ix);
+        build_suffix_array(ix);
+    });
+}
+
+void cdb_free(void* p) { std::free(p); }
+
+int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+    if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        for (uint64_t j = 0; j < npat; ++j)
+            if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        const double t0 = wall_ms();
+        hipStream_t s = ix.stream;
+        const uint64_t base = npat ? offsets[0] : 0;
+        const uint64_t nbytes = npat ? offsets[npat] - base : 0;
+        ix.q_pat.ensure(nbytes + 16);
+        ix.q_offs.ensure((npat + 1) * 8);
+        std::vector<uint64_t> rel(npat + 1);
+        for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
+        if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
+        CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
+        const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+        out->npat = npat;
+        out->nrows = r.nrows;
+        out->nhits = r.nhits;
+        out->row_ptr = (uint64_t*)std::malloc((npat + 1) * 8);
+        out->ids = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
+        out->counts = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
+        if (!out->row_ptr || !out->ids || !out->counts) throw std::bad_alloc();
+        CDB_HIP(hipMemcpyAsync(out->row_ptr, ix.q_rowptr.p, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (r.nrows) {
+            CDB_HIP(hipMemcpyAsync(out->ids, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(out->counts, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+        }
+        CDB_HIP(hipStreamSynchronize(s));
+        ix.qstats.query_ms = wall_ms() - t0;
+        ix.qstats.nhits = r.nhits;
+        ix.qstats.nrows = r.nrows;
+    });
+}
+
+void cdb_result_free(cdb_result* r) {
+    if (!r) return;
+    std::free(r->row_ptr);
+    std::free(r->ids);
+    std::free(r->counts);
+    std::memset(r, 0, sizeof(*r));
+}
+
+int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows) {
+    if (!h || !ids || !counts || !nrows) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    const uint64_t offs[2] = {0, (uint64_t)len};
+    cdb_result r;
+    const int rc = cdb_query_batch(h, keyword, offs, 1, &r);
+    if (rc != CDB_OK) return rc;
+    *ids = r.ids;
+    *counts = r.counts;
+    *nrows = (size_t)r.nrows;
+    std::free(r.row_ptr);
+    return CDB_OK;
+}
+
+int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
+                           uint64_t blob_bytes, cdb_device_result* out) {
+    if (!h || !out) return CDB_E_INVALID;
+    (void)blob_bytes;
+    std::memset(out, 0, sizeof(*out));
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        const double t0 = wall_ms();
+        const DeviceCsr r = query_batch_on_device(ix, static_cast<const uint8_t*>(d_blob), d_offsets, npat);
+        out->npat = npat;
+        out->nrows = r.nrows;
+        out->nhits = r.nhits;
+        out->d_row_ptr = ix.q_rowptr.as<uint64_t>();
+        out->d_ids = ix.q_ids.as<int64_t>();
+        out->d_counts = ix.q_counts.as<int64_t>();
+        ix.qstats.query_ms = wall_ms() - t0;
+        ix.qstats.nhits = r.nhits;
+        ix.qstats.nrows = r.nrows;
+    });
+}
+
+uint64_t cdb_size(const cdb_index* h) { return h ? h->ix.size : 0; }
+uint64_t cdb_bits(const cdb_index* h) { return h ? h->ix.bits : 0; }
+uint64_t cdb_mask(const cdb_index* h) { return h ? h->ix.mask : 0; }
+int cdb_sa_width(const cdb_index* h) { return h ? h->ix.width : 0; }
+
+int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes) {
+    if (!h || !host_out) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        const uint64_t need = ix.size * (uint64_t)ix.width;
+        if (capacity_bytes < need) throw Error("cdb_sa_copy: buffer too small");
+        if (need) {
+            CDB_HIP(hipMemcpyAsync(host_out, ix.d_sa.p, need, hipMemcpyDeviceToHost, ix.stream));
+            CDB_HIP(hipStreamSynchronize(ix.stream));
+        }
+    });
+}
+
+int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
+    if (!h || !name) return CDB_E_INVALID;
+    Index& ix = h->ix;
+    if (!std::strcmp(name, "profile")) ix.prof.enabled = value != 0;
+    else if (!std::strcmp(name, "reference_compat")) ix.reference_compat = value != 0;
+    else if (!std::strcmp(name, "force_doubling")) ix.force_doubling = value != 0;
+    else if (!std::strcmp(name, "initial_passes")) ix.initial_passes = (int)value;
+    else {
+        ix.err = std::string("unknown option: ") + name;
+        return CDB_E_INVALID;
+    }
+    return CDB_OK;
+}
+
+int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
+    if (!h || !name || !value) return CDB_E_INVALID;
+    const BuildStats& b = h->ix.bstats;
+    const QueryStats& q = h->ix.qstats;
+    struct { const char* n; double v; } tab[] = {
+        {"build_ms", b.build_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
+        {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
+        {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built},
+        {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
+        {"alphabet", (double)b.alphabet}, {"final_depth", (double)b.final_depth},
+        {"query_ms", q.query_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
+    };
+    for (auto& e : tab)
+        if (!std::strcmp(e.n, name)) {
+            *value = e.v;
+            return CDB_OK;
+        }
+    return CDB_E_INVALID;
+}
+
+int cdb_profile_get(cdb_index* h, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* bytes) {
+    if (!h || !kernel) return CDB_E_INVALID;
+    std::lock_guard<std::mutex> g(h->ix.mu);
+    auto it = h->ix.prof.recs.find(kernel);
+    if (it == h->ix.prof.recs.end()) return CDB_E_INVALID;
+    if (total_ms) *total_ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+    if (bytes) *bytes = it->second.bytes;
+    return CDB_OK;
+}
+
+int cdb_profile_dump(cdb_index* h, char* buf, size_t cap) {
+    if (!h || !buf || cap == 0) return CDB_E_INVALID;
+    std::lock_guard<std::mutex> g(h->ix.mu);
+    std::string s;
+    for (auto& kv : h->ix.prof.recs) {
+        char line[256];
+        std::snprintf(line, sizeof(line), "%s %.6f %llu %llu\n", kv.first.c_str(), kv.second.ms,
+                      (unsigned long long)kv.second.launches, (unsigned long long)kv.second.bytes);
+        s += line;
+    }
+    std::strncpy(buf, s.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+    return CDB_OK;
+}
+
+void cdb_profile_reset(cdb_index* h) {
+    if (!h) return;
+    std::lock_guard<std::mutex> g(h->ix.mu);
+    h->ix.prof.reset();
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// index_impl.h — state of one GPU string index (the object behind the opaque cdb_index handle).
+#pragma once
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "radix_sort.h"
+
+namespace cdb {
+
+constexpr int TEXT_PAD = 128;  // readable zero bytes behind library-owned text
+
+struct BuildStats {
+    double build_ms = 0;
+    int rounds = 0;              // refinement rounds after the initial key sort
+    int ext_rounds = 0;          // ... of which text-extension rounds
+    int dbl_rounds = 0;          // ... of which prefix-doubling rounds
+    uint64_t unresolved_initial = 0;
+    uint64_t unresolved_max = 0;
+    int sort_passes = 0;         // onesweep launches
+    int sort_passes_skipped = 0;
+    int isa_built = 0;
+    int key_symbols = 0, symbol_bits = 0, alphabet = 0;
+    uint64_t final_depth = 0;    // symbols compared when the last group was resolved
+};
+
+struct QueryStats {
+    double query_ms = 0;
+    uint64_t nhits = 0, nrows = 0;
+};
+
+struct Index {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;  // serialises device work of one index (queries from several host threads)
+
+    // ---- host staging (cdb_add)
+    std::vector<int64_t> ids;
+    std::vector<uint64_t> doc_start{0};
+    std::string host_text;
+
+    // ---- reference-visible parameters (src/index.h:56-57)
+    uint64_t bits = 1, mask = 1, size = 0;
+    int width = 0;  // 4 / 8, 0 = never built
+    uint64_t ndocs = 0;
+
+    // ---- device state
+    DevBuf d_text_owned;
+    const uint8_t* d_text = nullptr;  // n bytes (+TEXT_PAD when owned)
+    bool text_padded = false;
+    DevBuf d_doc_start;               // ndocs + 1 u64
+    DevBuf d_ids;                     // ndocs i64
+    DevBuf d_sa;                      // size * width bytes
+
+    // ---- scratch kept across calls
+    RadixWorkspace rws;
+    DevBuf scan_partials;
+    DevBuf q_pat, q_offs, q_left, q_right, q_hoff, q_keys0, q_keys1, q_flags, q_rowptr, q_ids, q_counts;
+
+    // ---- options
+    bool reference_compat = false;
+    bool force_doubling = false;
+    int initial_passes = 0;
+
+    Profiler prof;
+    BuildStats bstats;
+    QueryStats qstats;
+    std::string err;
+};
+
+// sa_build.hip
+void build_suffix_array(Index& ix);
+
+// query.hip — patterns already on the device; leaves CSR results in ix.q_rowptr / q_ids / q_counts
+struct DeviceCsr {
+    uint64_t npat = 0, nrows = 0, nhits = 0;
+};
+DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+
+}  // namespace cdb

@@ -1,0 +1,233 @@
+// query.hip — batched substring match on the GPU suffix array.
+//
+// Replaces string_index::query (reference /root/reference/src/index.cpp:237-326) for a whole batch of
+// keywords at once:
+//   a9/a10  two binary searches per keyword with the reference's exact probe sequence
+//           (index.cpp:260-287: lower bound saturating at size-1, then the prefix upper bound) —
+//           the same midpoints are visited, so results agree with the reference on any SA it could
+//           have produced, including the not-globally-sorted one of SURVEY.md Q2;
+//   a11     hit gather (doc = entry & mask) + sort by document: one stable radix sort of
+//           (pattern id ∘ doc) keys for the whole batch instead of one sort per keyword;
+//   a12     run-length encoding into CSR rows (ids[doc], count), ascending document index.
+#include "index_impl.h"
+#include "scan.h"
+
+namespace cdb {
+namespace {
+
+__device__ __forceinline__ uint64_t load_be8(const uint8_t* p) {
+    // 8 text bytes as a big-endian integer: integer order == unsigned lexicographic order
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+
+// three-way compare of keyword k[0..m) against suffix s[0..sl) on their common length, then the
+// reference's two predicates are derived from (c, m, sl):
+//   keyword <= suffix  <=>  c < 0 || (c == 0 && m <= sl)          (index.cpp:267, string_view <=)
+//   suffix starts with keyword <=> sl >= m && c == 0               (index.cpp:280)
+__device__ __forceinline__ int cmp_common(const uint8_t* __restrict__ k, uint64_t m, const uint8_t* __restrict__ s,
+                                          uint64_t sl) {
+    const uint64_t len = m < sl ? m : sl;
+    uint64_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        const uint64_t a = load_be8(k + i), b = load_be8(s + i);
+        if (a != b) return a < b ? -1 : 1;
+    }
+    for (; i < len; ++i) {
+        const uint8_t a = k[i], b = s[i];
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa, uint64_t n,
+                                                       const uint8_t* __restrict__ text,
+                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                       const uint8_t* __restrict__ blob,
+                                                       const uint64_t* __restrict__ offs, uint64_t npat,
+                                                       int64_t* __restrict__ left_out, uint64_t* __restrict__ hits_out) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= npat) return;
+    const uint8_t* k = blob + offs[j];
+    const uint64_t m = offs[j + 1] - offs[j];
+    int64_t L = 0, R = (int64_t)n - 1;
+    while (L < R) {
+        const int64_t M = L + (R - L) / 2;
+        const V e = sa[M];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
+        const int c = cmp_common(k, m, text + b, sl);
+        if (c < 0 || (c == 0 && m <= sl)) R = M; else L = M + 1;
+    }
+    const int64_t left = L;
+    L = left - 1;
+    R = (int64_t)n - 1;
+    while (L < R) {
+        const int64_t M = L + (R - L + 1) / 2;
+        const V e = sa[M];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
+        const bool pref = sl >= m && cmp_common(k, m, text + b, sl) == 0;
+        if (pref) L = M; else R = M - 1;
+    }
+    const int64_t right = L + 1;
+    left_out[j] = left;
+    hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
+}
+
+struct HitsIn {
+    const uint64_t* hits;
+    __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return hits[j]; }
+};
+struct HitsOut {
+    uint64_t* hoff;
+    uint64_t npat;
+    __device__ __forceinline__ void operator()(uint64_t j, uint64_t ex, uint64_t in) const {
+        hoff[j] = ex;
+        if (j + 1 == npat) hoff[npat] = in;
+    }
+};
+
+// one thread per hit slot: find the owning pattern (binary search over the hit offsets), emit
+// (pattern << dbits) | doc
+template <typename V>
+__global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa, uint64_t mask, int dbits,
+                                                       const int64_t* __restrict__ left,
+                                                       const uint64_t* __restrict__ hoff, uint64_t npat, uint64_t H,
+                                                       uint64_t* __restrict__ keys) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= H) return;
+    uint64_t lo = 0, hi = npat - 1;  // largest j with hoff[j] <= t
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (hoff[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t j = lo;
+    const uint64_t i = (uint64_t)left[j] + (t - hoff[j]);
+    keys[t] = (j << dbits) | ((uint64_t)sa[i] & mask);
+}
+
+struct RunIn {  // 1 at the first hit of every (pattern, doc) run
+    const uint64_t* keys;
+    __device__ __forceinline__ uint64_t operator()(uint64_t t) const { return (t == 0 || keys[t] != keys[t - 1]) ? 1ull : 0ull; }
+};
+struct RunOut {  // row r starts at hit slot t: remember t, decode the doc
+    const uint64_t* keys;
+    uint64_t* row_first;  // [nrows + 1] first hit slot of each row
+    uint64_t* row_key;
+    uint64_t H;
+    __device__ __forceinline__ void operator()(uint64_t t, uint64_t ex, uint64_t in) const {
+        if (in != ex) {
+            row_first[ex] = t;
+            row_key[ex] = keys[t];
+        }
+        if (t + 1 == H) row_first[in] = H;
+    }
+};
+
+__global__ __launch_bounds__(256) void q_rows_kernel(const uint64_t* __restrict__ row_first,
+                                                     const uint64_t* __restrict__ row_key, uint64_t nrows, int dbits,
+                                                     const int64_t* __restrict__ ids, int64_t* __restrict__ out_ids,
+                                                     int64_t* __restrict__ out_counts) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const uint64_t doc = row_key[r] & ((1ull << dbits) - 1ull);
+    out_ids[r] = ids[doc];
+    out_counts[r] = (int64_t)(row_first[r + 1] - row_first[r]);
+}
+
+// row_ptr[j] = first row whose pattern id >= j  (rows are sorted by (pattern, doc))
+__global__ __launch_bounds__(256) void q_rowptr_kernel(const uint64_t* __restrict__ row_key, uint64_t nrows, int dbits,
+                                                       uint64_t npat, uint64_t* __restrict__ row_ptr) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > npat) return;
+    uint64_t lo = 0, hi = nrows;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if ((row_key[mid] >> dbits) < j) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[j] = lo;
+}
+
+template <typename V>
+DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    hipStream_t s = ix.stream;
+    DeviceCsr out;
+    out.npat = npat;
+    ix.q_rowptr.ensure((npat + 1) * 8);
+    if (npat == 0 || ix.size == 0 || ix.width == 0) {
+        CDB_HIP(hipMemsetAsync(ix.q_rowptr.p, 0, (npat + 1) * 8, s));
+        ix.q_ids.ensure(16);
+        ix.q_counts.ensure(16);
+        CDB_HIP(hipStreamSynchronize(s));
+        return out;
+    }
+    const V* sa = ix.d_sa.as<V>();
+    const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
+    ix.q_left.ensure(npat * 8);
+    ix.q_right.ensure(npat * 8);  // hit counts
+    ix.q_hoff.ensure((npat + 1) * 8);
+    int t = ix.prof.begin(s);
+    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                       doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, ix.q_left.as<int64_t>(),
+                       ix.q_right.as<uint64_t>());
+    ix.prof.end(t, "q_search", npat * 2 * (uint64_t)bit_width64(ix.size) * 128, s);
+
+    HitsIn hin{ix.q_right.as<uint64_t>()};
+    const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    out.nhits = H;
+    if (H == 0) {
+        CDB_HIP(hipMemsetAsync(ix.q_rowptr.p, 0, (npat + 1) * 8, s));
+        ix.q_ids.ensure(16);
+        ix.q_counts.ensure(16);
+        CDB_HIP(hipStreamSynchronize(s));
+        return out;
+    }
+    const int dbits = (int)ix.bits;
+    const int jbits = bit_width64(npat - 1);
+    if (dbits + jbits > 64) throw Error("pattern batch too large for one call");
+    ix.q_keys0.ensure(H * 8);
+    ix.q_keys1.ensure(H * 8);
+    t = ix.prof.begin(s);
+    hipLaunchKernelGGL((q_expand_kernel<V>), dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, s, sa, ix.mask, dbits,
+                       (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, H,
+                       ix.q_keys0.as<uint64_t>());
+    ix.prof.end(t, "q_expand", H * (sizeof(V) + 8), s);
+    // stable sort of the whole batch by (pattern ∘ doc); passes over constant digits are skipped
+    const int sel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(),
+                                                (NoVal*)nullptr, (NoVal*)nullptr, H, 0, dbits + jbits, nullptr);
+    const uint64_t* keys = sel == 0 ? ix.q_keys0.as<uint64_t>() : ix.q_keys1.as<uint64_t>();
+    uint64_t* spare = sel == 0 ? ix.q_keys1.as<uint64_t>() : ix.q_keys0.as<uint64_t>();
+
+    RunIn rin{keys};
+    const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, rin, H, OpAdd{}, (uint64_t)0);
+    out.nrows = nrows;
+    ix.q_flags.ensure((nrows + 1) * 8);  // row_first
+    // row keys go to the spare key buffer (nrows <= H)
+    scan_apply<uint64_t>(s, ix.scan_partials, rin, H, OpAdd{}, (uint64_t)0, RunOut{keys, ix.q_flags.as<uint64_t>(), spare, H});
+    ix.q_ids.ensure(nrows * 8);
+    ix.q_counts.ensure(nrows * 8);
+    hipLaunchKernelGGL(q_rows_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, s,
+                       (const uint64_t*)ix.q_flags.as<uint64_t>(), (const uint64_t*)spare, nrows, dbits,
+                       (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+    hipLaunchKernelGGL(q_rowptr_kernel, dim3((unsigned)ceil_div(npat + 1, 256)), dim3(256), 0, s, (const uint64_t*)spare,
+                       nrows, dbits, npat, ix.q_rowptr.as<uint64_t>());
+    CDB_HIP(hipGetLastError());
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    return out;
+}
+
+}  // namespace
+
+DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat)
+                                : query_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    ix.prof.resolve();
+    return r;
+}
+
+}  // namespace cdb

@@ -1,0 +1,366 @@
+// radix_sort.h — stable LSD radix sort for gfx950 (8-bit digits, one read + one write of the data per
+// pass: "onesweep" with chained-scan decoupled look-back).
+//
+// This is the bandwidth-dominant primitive of the suffix-array build (replaces the reference's
+// multithreaded MSD radix + std::sort leaves, /root/reference/src/index.cpp:75-128) and of the
+// hit->document grouping in the query path (replaces index.cpp:294-315).
+//
+// Per pass and per element the kernel moves sizeof(K)+sizeof(V) bytes in and the same out; that is the
+// "algorithmic bytes" figure used for the HBM roofline.
+//
+// Hardware mapping:
+//   * 64-wide wavefronts: per-digit ranks inside a wave come from 8 ballots (one per digit bit) —
+//     lanes with equal digits find each other without LDS atomics, which keeps the sort stable;
+//   * LDS: keys (and values) of one tile are staged in sorted-by-digit order so that the global
+//     write-out has consecutive lanes writing consecutive addresses inside each digit run;
+//   * 8 XCDs with non-coherent L2s: tiles exchange {epoch,state,count} words only through agent-scope
+//     relaxed atomic loads/stores (one 8-byte granule is both flag and payload — MI355X guide §G16 R2),
+//     tile ids come from an atomic ticket so a tile only ever waits on tiles that already started, and
+//     every spin is bounded (a stuck look-back raises an error flag instead of hanging the GPU).
+#pragma once
+#include "common.h"
+
+namespace cdb {
+
+constexpr int RS_NT = 256;            // threads per workgroup (4 waves)
+constexpr int RS_NW = RS_NT / 64;
+constexpr int RS_MAX_PASSES = 8;
+constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+
+struct NoVal {};
+
+template <typename K, typename V> struct RsTraits { static constexpr int IPT = 12; };
+template <> struct RsTraits<uint64_t, uint32_t> { static constexpr int IPT = 15; };  // 46 KB tile -> 3 WG/CU
+template <> struct RsTraits<uint64_t, uint64_t> { static constexpr int IPT = 12; };  // 48 KB tile
+template <> struct RsTraits<uint64_t, NoVal> { static constexpr int IPT = 16; };
+template <> struct RsTraits<uint32_t, uint32_t> { static constexpr int IPT = 16; };
+template <> struct RsTraits<uint32_t, NoVal> { static constexpr int IPT = 16; };
+
+// ---------------------------------------------------------------------------------------------
+// upfront histogram of every pass's digit (one read of the keys)
+// ---------------------------------------------------------------------------------------------
+template <typename K>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, int begin_bit,
+                                                      int npass, uint32_t last_mask,
+                                                      unsigned long long* __restrict__ ghist) {
+    __shared__ uint32_t sh[RS_MAX_PASSES * 256];
+    for (int i = threadIdx.x; i < npass * 256; i += 256) sh[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const K k = keys[i];
+#pragma unroll
+        for (int p = 0; p < RS_MAX_PASSES; ++p) {
+            if (p < npass) {
+                uint32_t d = (uint32_t)(k >> (begin_bit + 8 * p)) & 0xFFu;
+                if (p == npass - 1) d &= last_mask;
+                atomicAdd(&sh[p * 256 + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npass * 256; i += 256)
+        if (sh[i]) atomicAdd(&ghist[i], (unsigned long long)sh[i]);
+}
+
+// exclusive scan of each pass's 256 counts -> first output slot of each digit
+static __global__ __launch_bounds__(256) void rs_digit_start_kernel(const unsigned long long* __restrict__ ghist,
+                                                             unsigned long long* __restrict__ gstart) {
+    __shared__ unsigned long long s[256];
+    const int p = blockIdx.x, t = threadIdx.x;
+    const unsigned long long c = ghist[p * 256 + t];
+    s[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned long long v = t >= off ? s[t - off] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    gstart[p * 256 + t] = s[t] - c;
+}
+
+__device__ __forceinline__ uint64_t rs_ld_status(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rs_st_status(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one radix pass: rank inside the tile, look back for the global prefix, scatter
+// ---------------------------------------------------------------------------------------------
+template <typename K, typename V, int IPT>
+__global__ __launch_bounds__(RS_NT) void rs_onesweep_kernel(
+    const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
+    int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
+    uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err) {
+    constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    constexpr int TILE = RS_NT * IPT;
+    constexpr int WCHUNK = 64 * IPT;  // elements owned by one wave (contiguous => stable)
+    using VS = typename std::conditional<HAS_V, V, uint32_t>::type;
+
+    __shared__ uint32_t s_whist[RS_NW][256];
+    __shared__ uint32_t s_tstart[256];
+    __shared__ uint64_t s_gbase[256];
+    __shared__ uint32_t s_wsum[RS_NW];
+    __shared__ uint32_t s_tile;
+    __shared__ K s_keys[TILE];
+    __shared__ VS s_vals[HAS_V ? TILE : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < RS_NW; ++w) s_whist[w][tid] = 0;
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    const uint64_t base = tile * TILE;
+    const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
+
+    // ---- load keys, wave-striped (lane-contiguous 512 B per load instruction)
+    K key[IPT];
+    const uint32_t wbase = wave * WCHUNK + lane;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint32_t li = wbase + j * 64;
+        key[j] = li < valid ? kin[base + li] : (K)~(K)0;
+    }
+
+    // ---- rank inside the wave: lanes with the same digit find each other with 8 ballots
+    uint32_t rank[IPT];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint32_t li = wbase + j * 64;
+        // out-of-range slots take digit 255: they have the largest indices of the tile, so they end
+        // up behind every real element and are simply not written out.
+        const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t below = __popcll(m & lt_mask);
+        uint32_t old = 0;
+        if (below == 0) {  // lowest lane of the group owns the counter update
+            old = s_whist[wave][d];
+            s_whist[wave][d] = old + __popcll(m);
+        }
+        old = __shfl(old, __ffsll((unsigned long long)m) - 1);
+        rank[j] = old + below;
+    }
+    __syncthreads();
+
+    // ---- per-digit totals of the tile, exclusive prefix across waves and across digits
+    uint32_t cnt = 0;
+    {
+        const int d = tid;  // RS_NT == 256: one thread per digit
+#pragma unroll
+        for (int w = 0; w < RS_NW; ++w) {
+            const uint32_t t = s_whist[w][d];
+            s_whist[w][d] = cnt;
+            cnt += t;
+        }
+        // block exclusive scan of cnt over the 256 digits
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wpre = 0;
+#pragma unroll
+        for (int w = 0; w < RS_NW; ++w)
+            if (w < wave) wpre += s_wsum[w];
+        const uint32_t tstart = wpre + incl - cnt;
+        s_tstart[d] = tstart;
+
+        // real (in-range) count of this digit: padding only ever sits in digit 255
+        const uint64_t real = d == 255 ? (uint64_t)cnt - (uint64_t)(TILE - valid) : (uint64_t)cnt;
+
+        // ---- chained scan: publish the aggregate, look back, publish the inclusive prefix
+        const uint64_t tag = (uint64_t)epoch << 56;
+        uint64_t* my = status + tile * 256 + d;
+        uint64_t excl = 0;
+        if (tile == 0) {
+            rs_st_status(my, tag | (2ull << 54) | real);
+        } else {
+            rs_st_status(my, tag | (1ull << 54) | real);
+            uint64_t p = tile - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const uint64_t s = rs_ld_status(status + p * 256 + d);
+                const uint32_t st = (uint32_t)(s >> 54) & 3u;
+                if ((s >> 56) == (uint64_t)epoch && st != 0) {
+                    excl += s & RS_VAL_MASK;
+                    if (st == 2) break;
+                    --p;  // tile 0 always publishes an inclusive prefix, so p never underflows
+                    spins = 0;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > RS_SPIN_LIMIT) {
+                        atomicExch(err, 1u);
+                        break;
+                    }
+                }
+            }
+            rs_st_status(my, tag | (2ull << 54) | (excl + real));
+        }
+        s_gbase[d] = (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
+    }
+    __syncthreads();
+
+    // ---- place keys (and values) in LDS in sorted-by-digit order
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint32_t li = wbase + j * 64;
+        const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
+        const uint32_t pos = s_tstart[d] + s_whist[wave][d] + rank[j];
+        rank[j] = pos;
+        s_keys[pos] = key[j];
+    }
+    if constexpr (HAS_V) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            if (li < valid) s_vals[rank[j]] = vin[base + li];
+        }
+    }
+    __syncthreads();
+
+    // ---- coalesced write-out: consecutive lanes -> consecutive slots of one digit run
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint32_t i = j * RS_NT + tid;
+        if (i < valid) {
+            const K k = s_keys[i];
+            const uint32_t d = (uint32_t)(k >> shift) & dmask;
+            const uint64_t dst = s_gbase[d] + i;
+            kout[dst] = k;
+            if constexpr (HAS_V) vout[dst] = s_vals[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+struct RadixWorkspace {
+    DevBuf hist;     // [2][RS_MAX_PASSES][256] u64 : counts, then digit starts
+    DevBuf status;   // [tiles][256] u64
+    DevBuf tickets;  // [256] u32 tickets (indexed by epoch) + [1] u32 error flag
+    uint32_t epoch = 0;
+    uint64_t min_tile = 0;
+
+    void prepare(uint64_t n, int tile, hipStream_t s) {
+        const uint64_t tiles = ceil_div(n, (uint64_t)tile);
+        if (!hist.p) hist.alloc(2 * RS_MAX_PASSES * 256 * sizeof(uint64_t));
+        if (!tickets.p) {
+            tickets.alloc(257 * sizeof(uint32_t));
+            CDB_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes, s));
+        }
+        const size_t need = (size_t)tiles * 256 * sizeof(uint64_t);
+        if (need > status.bytes) {
+            status.alloc(need + need / 4);
+            CDB_HIP(hipMemsetAsync(status.p, 0, status.bytes, s));
+            CDB_HIP(hipMemsetAsync(tickets.p, 0, 256 * sizeof(uint32_t), s));
+            epoch = 0;
+        }
+    }
+    uint32_t next_epoch(hipStream_t s) {
+        if (epoch == 255) {  // tags wrap: forget every published word
+            CDB_HIP(hipMemsetAsync(status.p, 0, status.bytes, s));
+            CDB_HIP(hipMemsetAsync(tickets.p, 0, 256 * sizeof(uint32_t), s));
+            epoch = 0;
+        }
+        return ++epoch;
+    }
+    uint32_t* ticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + (e & 255u); }
+    uint32_t* err_ptr() { return tickets.as<uint32_t>() + 256; }
+    void release() { hist.release(); status.release(); tickets.release(); epoch = 0; }
+};
+
+template <typename K, typename V> inline const char* rs_kernel_name();
+template <> inline const char* rs_kernel_name<uint64_t, uint32_t>() { return "rs_onesweep_k64_v32"; }
+template <> inline const char* rs_kernel_name<uint64_t, uint64_t>() { return "rs_onesweep_k64_v64"; }
+template <> inline const char* rs_kernel_name<uint64_t, NoVal>() { return "rs_onesweep_k64"; }
+template <> inline const char* rs_kernel_name<uint32_t, uint32_t>() { return "rs_onesweep_k32_v32"; }
+template <> inline const char* rs_kernel_name<uint32_t, NoVal>() { return "rs_onesweep_k32"; }
+
+struct SortStats {
+    int passes_run = 0, passes_skipped = 0;
+};
+
+// Sorts n (key, value) pairs by key bits [begin_bit, end_bit), stable.  Buffers 0 hold the input; the
+// result ends up in buffers `return value` (0 or 1).  Passes whose digit is constant are skipped.
+template <typename K, typename V>
+int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
+               int begin_bit, int end_bit, SortStats* stats = nullptr) {
+    constexpr int IPT = RsTraits<K, V>::IPT;
+    constexpr int TILE = RS_NT * IPT;
+    constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    const int nbits = end_bit - begin_bit;
+    const int npass = (int)ceil_div(nbits, 8);
+    if (npass > RS_MAX_PASSES) throw Error("radix_sort: more than 64 key bits requested");
+    const int last_bits = nbits - 8 * (npass - 1);
+    const uint32_t last_mask = (1u << last_bits) - 1u;
+    ws.prepare(n, TILE, s);
+
+    unsigned long long* d_hist = ws.hist.as<unsigned long long>();
+    unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
+    CDB_HIP(hipMemsetAsync(d_hist, 0, RS_MAX_PASSES * 256 * sizeof(uint64_t), s));
+    {
+        const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16), 256 * 8);
+        int t = prof.begin(s);
+        hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(256), 0, s, (const K*)k0, n, begin_bit, npass,
+                           last_mask, d_hist);
+        prof.end(t, "rs_hist", n * sizeof(K), s);
+    }
+    hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
+    std::vector<uint64_t> h_hist((size_t)npass * 256);
+    CDB_HIP(hipMemcpyAsync(h_hist.data(), d_hist, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+
+    K* kb[2] = {k0, k1};
+    V* vb[2] = {v0, v1};
+    int cur = 0;
+    const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
+    for (int p = 0; p < npass; ++p) {
+        bool trivial = false;
+        for (int d = 0; d < 256; ++d)
+            if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
+        if (trivial) {
+            if (stats) stats->passes_skipped++;
+            continue;
+        }
+        const uint32_t e = ws.next_epoch(s);
+        const uint32_t dmask = p == npass - 1 ? last_mask : 0xFFu;
+        int t = prof.begin(s);
+        hipLaunchKernelGGL((rs_onesweep_kernel<K, V, IPT>), dim3(tiles), dim3(RS_NT), 0, s, (const K*)kb[cur],
+                           kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, begin_bit + 8 * p, dmask,
+                           (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
+                           ws.ticket_ptr(e), e, ws.err_ptr());
+        prof.end(t, rs_kernel_name<K, V>(), 2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+        cur ^= 1;
+        if (stats) stats->passes_run++;
+    }
+    CDB_HIP(hipGetLastError());
+    return cur;
+}
+
+// throws if any look-back spin hit its bound (the sort result is then garbage)
+inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
+    if (!ws.tickets.p) return;
+    uint32_t e = 0;
+    CDB_HIP(hipMemcpyAsync(&e, ws.err_ptr(), sizeof(e), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    if (e) throw Error("radix sort look-back timed out (internal error)");
+}
+
+}  // namespace cdb

@@ -1,0 +1,454 @@
+// sa_build.hip — generalised suffix-array construction on gfx950.
+//
+// Replaces string_index::build()'s sort (reference /root/reference/src/index.cpp:209-231: fill
+// sa[k] = (off << bits) | doc, then multithreaded MSD radix with std::sort leaves,
+// index.cpp:75-128).  Result contract: the same multiset of entries, ordered by suffix text in
+// unsigned byte order with "end of document" smallest (index.h:61-73), and equal suffixes (identical
+// tails of different documents) ordered by document index — the canonical form of the reference's
+// arbitrary tie order.
+//
+// Algorithm (GPU-first; none of the reference's task queue survives):
+//   1. alphabet scan   : which byte values occur -> dense order-preserving codes, `symbits` per symbol
+//   2. key generation  : every suffix's first `nsym` symbols packed big-endian into one 64-bit key
+//                        (code 0 = end of document, so shorter suffixes sort first); the value is the
+//                        reference entry (off << bits) | doc.  Text is read once, coalesced, through LDS.
+//   3. initial sort    : stable LSD radix sort of (key, entry)  (radix_sort.h)
+//   4. refinement      : only groups of still-equal keys are touched again.  While few suffixes are
+//                        unresolved they are re-keyed straight from the text (next symbols);
+//                        otherwise an inverse array (rank per text position) is built and classic
+//                        prefix doubling runs on the unresolved groups (sort key = group id ∘ rank of the
+//                        suffix h symbols further on).  A group whose members end inside the compared
+//                        prefix is final: its members are identical suffixes, and because every sort is
+//                        stable and the initial order is text order they already ascend by document.
+#include <algorithm>
+#include <chrono>
+
+#include "index_impl.h"
+#include "scan.h"
+
+namespace cdb {
+namespace {
+
+constexpr int KG_TILE = 2048;  // suffixes per workgroup in key generation
+constexpr int KG_LOOK = 64;    // look-ahead bytes staged behind the tile
+
+// ---------------------------------------------------------------------------------------------
+// 1. alphabet
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_alphabet_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                          uint32_t* __restrict__ present) {
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t words = n / 16;
+    const uint4* t4 = reinterpret_cast<const uint4*>(text);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += stride) {
+        const uint4 v = t4[w];
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[x[q] & 0xFF] = 1;
+            s[(x[q] >> 8) & 0xFF] = 1;
+            s[(x[q] >> 16) & 0xFF] = 1;
+            s[x[q] >> 24] = 1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) s[text[words * 16 + threadIdx.x]] = 1;
+    __syncthreads();
+    if (s[threadIdx.x]) present[threadIdx.x] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. key generation
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t doc_upper(const uint64_t* __restrict__ doc_start, uint64_t lo, uint64_t hi,
+                                              uint64_t p) {
+    // largest d in [lo, hi] with doc_start[d] <= p (empty documents share a start; the last one wins,
+    // which is the non-empty document that really contains p)
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (doc_start[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void sa_keygen_kernel(const uint8_t* __restrict__ text,
+                                                        const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                        uint64_t n, int bits, const uint16_t* __restrict__ symmap,
+                                                        int symbits, int nsym, bool padded,
+                                                        uint64_t* __restrict__ keys, V* __restrict__ vals) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[KG_TILE + KG_LOOK];
+    __shared__ uint16_t s_map[256];
+    __shared__ uint64_t s_drange[2];
+    const int tid = threadIdx.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * KG_TILE;
+    const uint32_t cnt = (uint32_t)((n - p0) < (uint64_t)KG_TILE ? (n - p0) : (uint64_t)KG_TILE);
+    s_map[tid] = symmap[tid];
+    if (tid == 0) s_drange[0] = doc_upper(doc_start, 0, ndocs - 1, p0);
+    if (tid == 1) s_drange[1] = doc_upper(doc_start, 0, ndocs - 1, p0 + cnt - 1);
+    // stage the tile (+ look-ahead) in LDS with 16-byte loads; the tail of a caller-owned buffer that
+    // has no padding is fetched bytewise
+    for (uint32_t i = tid * 16; i < KG_TILE + KG_LOOK; i += 256 * 16) {
+        const uint64_t g = p0 + i;
+        if (padded ? (g < n + KG_LOOK) : (g + 16 <= n)) {
+            *reinterpret_cast<uint4*>(&s_text[i]) = *reinterpret_cast<const uint4*>(text + g);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) s_text[i + b] = (g + b < n) ? text[g + b] : (uint8_t)0;
+        }
+    }
+    __syncthreads();
+    const uint64_t dlo = s_drange[0], dhi = s_drange[1];
+#pragma unroll
+    for (int j = 0; j < KG_TILE / 256; ++j) {
+        const uint32_t li = j * 256 + tid;
+        if (li >= cnt) break;
+        const uint64_t p = p0 + li;
+        const uint64_t d = doc_upper(doc_start, dlo, dhi, p);
+        const uint64_t ds = doc_start[d];
+        const uint64_t rem = doc_start[d + 1] - p;
+        uint64_t key = 0;
+        for (int k = 0; k < nsym; ++k) {
+            const uint64_t sym = (uint64_t)k < rem ? (uint64_t)s_map[s_text[li + k]] : 0ull;
+            key = (key << symbits) | sym;
+        }
+        keys[p] = key;
+        vals[p] = (V)(((p - ds) << bits) | d);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// group flags: bit0 = first entry of a group of equal prefixes, bit1 = still unresolved
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                           uint64_t symmask, uint8_t* __restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    const bool head = i == 0 || keys[i - 1] != k;
+    const bool tail = i + 1 == n || keys[i + 1] != k;
+    const bool exhausted = (k & symmask) == 0;  // an end-of-document code inside the key
+    flags[i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+}
+
+struct FlagIn {
+    const uint8_t* flags;
+    __device__ __forceinline__ U2 operator()(uint64_t i) const {
+        const uint8_t f = flags[i];
+        const uint64_t u = (f >> 1) & 1u;
+        return U2{u, u & (uint64_t)(f & 1u)};
+    }
+};
+
+// compaction of the unresolved entries + construction of their sort keys
+template <typename V, typename I, typename R, bool USE_ISA>
+struct CompactOut {
+    const uint8_t* flags;
+    const V* sa;
+    I* U;
+    uint64_t* skey;
+    V* sval;
+    const uint64_t* doc_start;
+    const uint8_t* text;
+    const uint16_t* symmap;
+    const R* rank;
+    int bits;
+    uint64_t mask;
+    uint64_t h;
+    int kbits, nsym2, symbits;
+    __device__ __forceinline__ void operator()(uint64_t i, const U2& ex, const U2& in) const {
+        if (!(flags[i] & 2)) return;
+        const uint64_t j = ex.a;
+        const uint64_t gid = in.b - 1;
+        const V v = sa[i];
+        const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
+        const uint64_t ds = doc_start[d];
+        uint64_t key2 = 0;
+        if constexpr (USE_ISA) {
+            key2 = (uint64_t)rank[ds + d + off + h];  // extended position: one end slot per document
+        } else {
+            const uint64_t rem = doc_start[d + 1] - ds - off - h;  // >= 0: unresolved => length >= h
+            const uint8_t* p = text + ds + off + h;
+            for (int k = 0; k < nsym2; ++k) {
+                const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[p[k]] : 0ull;
+                key2 = (key2 << symbits) | sym;
+            }
+        }
+        U[j] = (I)i;
+        skey[j] = (gid << kbits) | key2;
+        sval[j] = v;
+    }
+};
+
+template <typename I>
+__global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restrict__ skey, const I* __restrict__ U,
+                                                         const uint8_t* __restrict__ flags, uint64_t m,
+                                                         uint8_t* __restrict__ nh) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const bool oldhead = flags[U[j]] & 1;
+    nh[j] = (uint8_t)(oldhead || j == 0 || skey[j] != skey[j - 1]);
+}
+
+template <typename V, typename I>
+__device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const V* sval, const I* U, const uint8_t* nh,
+                                         const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, V* sa,
+                                         uint8_t* flags, uint64_t& ext_pos) {
+    const V v = sval[j];
+    const uint64_t i = U[j];
+    const bool head = nh[j];
+    const bool last = j + 1 == m || nh[j + 1];
+    const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
+    const uint64_t ds = doc_start[d];
+    const uint64_t rem = doc_start[d + 1] - ds - off;
+    const bool exhausted = rem < hnew;
+    sa[i] = v;
+    flags[i] = (uint8_t)((head ? 1 : 0) | ((!(head && last) && !exhausted) ? 2 : 0));
+    ext_pos = ds + d + off;
+}
+
+template <typename V, typename I>
+__global__ __launch_bounds__(256) void sa_update_kernel(const V* __restrict__ sval, const I* __restrict__ U,
+                                                        const uint8_t* __restrict__ nh, uint64_t m,
+                                                        const uint64_t* __restrict__ doc_start, int bits,
+                                                        uint64_t mask, uint64_t hnew, V* __restrict__ sa,
+                                                        uint8_t* __restrict__ flags) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    uint64_t q;
+    sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q);
+}
+
+template <typename I>
+struct HeadIn {  // group start (+1) of compacted entry j, 0 for non-heads  -> max-scan
+    const uint8_t* nh;
+    const I* U;
+    __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return nh[j] ? (uint64_t)U[j] + 1 : 0ull; }
+};
+template <typename V, typename I, typename R>
+struct UpdateOut {
+    const V* sval;
+    const I* U;
+    const uint8_t* nh;
+    uint64_t m;
+    const uint64_t* doc_start;
+    int bits;
+    uint64_t mask, hnew;
+    V* sa;
+    uint8_t* flags;
+    R* rank;
+    __device__ __forceinline__ void operator()(uint64_t j, uint64_t, uint64_t incl) const {
+        uint64_t q;
+        sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q);
+        rank[q] = (R)incl;
+    }
+};
+
+// inverse array from the current grouping: rank[ext(sa[i])] = group start + 1
+struct AllHeadIn {
+    const uint8_t* flags;
+    __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return (flags[i] & 1) ? i + 1 : 0ull; }
+};
+template <typename V, typename R>
+struct IsaOut {
+    const V* sa;
+    const uint64_t* doc_start;
+    int bits;
+    uint64_t mask;
+    R* rank;
+    __device__ __forceinline__ void operator()(uint64_t i, uint64_t, uint64_t incl) const {
+        const V v = sa[i];
+        const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
+        rank[doc_start[d] + d + off] = (R)incl;
+    }
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename V>
+void build_typed(Index& ix) {
+    using I = uint32_t;
+    using R = uint32_t;
+    hipStream_t s = ix.stream;
+    const uint64_t n = ix.size, D = ix.ndocs;
+    BuildStats& st = ix.bstats;
+    st = BuildStats{};
+    ix.d_sa.release();
+    if (n == 0) {
+        ix.d_sa.alloc(16);
+        return;
+    }
+    if (n + D + 2 >= (1ull << 32))
+        throw Error("corpus too large for this build of the GPU index (text bytes + documents must stay below 2^32)");
+    const uint8_t* text = ix.d_text;
+    const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
+
+    // ---- 1. alphabet -> order-preserving dense codes
+    DevBuf d_present, d_symmap;
+    d_present.alloc(256 * sizeof(uint32_t));
+    d_symmap.alloc(256 * sizeof(uint16_t));
+    CDB_HIP(hipMemsetAsync(d_present.p, 0, 256 * sizeof(uint32_t), s));
+    {
+        const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16 * 4), 256 * 8);
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_alphabet_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, n, d_present.as<uint32_t>());
+        ix.prof.end(t, "sa_alphabet", n, s);
+    }
+    uint32_t h_present[256];
+    CDB_HIP(hipMemcpyAsync(h_present, d_present.p, sizeof(h_present), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    uint16_t h_map[256];
+    int sigma = 0;
+    for (int b = 0; b < 256; ++b) h_map[b] = h_present[b] ? (uint16_t)(++sigma) : (uint16_t)0;
+    const int symbits = std::max(1, bit_width64((uint64_t)sigma));
+    CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
+
+    int passes = ix.initial_passes > 0 ? ix.initial_passes : (int)ceil_div(bit_width64(n) + 24, 8);
+    passes = std::min(std::max(passes, 1), 8);
+    int nsym = std::min((8 * passes) / symbits, 64 / symbits);
+    nsym = std::min(std::max(nsym, 1), KG_LOOK);
+    const int key_bits = nsym * symbits;
+    st.key_symbols = nsym;
+    st.symbol_bits = symbits;
+    st.alphabet = sigma;
+
+    // ---- 2. keys + entries
+    DevBuf keys[2], vals[2], flags;
+    keys[0].alloc(n * sizeof(uint64_t));
+    keys[1].alloc(n * sizeof(uint64_t));
+    vals[0].alloc(n * sizeof(V));
+    vals[1].alloc(n * sizeof(V));
+    flags.alloc(n);
+    {
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text, doc_start, D,
+                           n, (int)ix.bits, d_symmap.as<uint16_t>(), symbits, nsym, ix.text_padded,
+                           keys[0].as<uint64_t>(), vals[0].as<V>());
+        ix.prof.end(t, "sa_keygen", n * (1 + sizeof(uint64_t) + sizeof(V)), s);
+    }
+
+    // ---- 3. initial sort
+    SortStats ss;
+    const int sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(),
+                                            vals[0].as<V>(), vals[1].as<V>(), n, 0, key_bits, &ss);
+    {
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
+                           (const uint64_t*)keys[sel].as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>());
+        ix.prof.end(t, "sa_initflags", n * 9, s);
+    }
+    CDB_HIP(hipStreamSynchronize(s));
+    keys[0].release();
+    keys[1].release();
+    vals[sel ^ 1].release();
+    V* sa = vals[sel].as<V>();
+
+    // ---- 4. refinement rounds
+    DevBuf U, skey[2], sval[2], nh, rank;
+    uint64_t h = (uint64_t)nsym;
+    bool isa = false;
+    uint64_t cap = 0;
+    for (;;) {
+        FlagIn fin{flags.as<uint8_t>()};
+        const U2 tot = scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+        const uint64_t m = tot.a, G = tot.b;
+        if (st.rounds == 0) st.unresolved_initial = m;
+        st.unresolved_max = std::max(st.unresolved_max, m);
+        if (m == 0) break;
+        const int gbits = bit_width64(G - 1);
+        int nsym2 = std::min((64 - gbits) / symbits, KG_LOOK);
+        if (!isa) {
+            const bool use_text = !ix.force_doubling && m <= n / 32 && st.ext_rounds < 4 && nsym2 >= 1;
+            if (!use_text) {
+                rank.alloc((n + D + 1) * sizeof(R));
+                CDB_HIP(hipMemsetAsync(rank.p, 0, (n + D + 1) * sizeof(R), s));
+                AllHeadIn ain{flags.as<uint8_t>()};
+                (void)scan_totals<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0);
+                IsaOut<V, R> iout{sa, doc_start, (int)ix.bits, ix.mask, rank.as<R>()};
+                int t = ix.prof.begin(s);
+                scan_apply<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0, iout);
+                ix.prof.end(t, "sa_isa_init", n * (1 + sizeof(V) + sizeof(R)), s);
+                isa = true;
+                st.isa_built = 1;
+                // the partials buffer now belongs to the max-scan: redo the compaction totals
+                (void)scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+            }
+        }
+        const int kbits = isa ? bit_width64(n) : nsym2 * symbits;
+        if (kbits + gbits > 64) throw Error("refinement key does not fit 64 bits (internal limit)");
+        if (m > cap) {
+            cap = m;
+            U.alloc(m * sizeof(I));
+            skey[0].alloc(m * 8);
+            skey[1].alloc(m * 8);
+            sval[0].alloc(m * sizeof(V));
+            sval[1].alloc(m * sizeof(V));
+            nh.alloc(m);
+        }
+        {
+            int t = ix.prof.begin(s);
+            if (isa) {
+                CompactOut<V, I, R, true> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
+                                             doc_start, text, d_symmap.as<uint16_t>(), rank.as<R>(), (int)ix.bits,
+                                             ix.mask, h, kbits, nsym2, symbits};
+                scan_apply<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0}, co);
+            } else {
+                CompactOut<V, I, R, false> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
+                                              doc_start, text, d_symmap.as<uint16_t>(), nullptr, (int)ix.bits,
+                                              ix.mask, h, kbits, nsym2, symbits};
+                scan_apply<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0}, co);
+            }
+            ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
+        }
+        const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
+                                               sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss);
+        hipLaunchKernelGGL((sa_newhead_kernel<I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
+                           (const uint64_t*)skey[rs].as<uint64_t>(), (const I*)U.as<I>(),
+                           (const uint8_t*)flags.as<uint8_t>(), m, nh.as<uint8_t>());
+        const uint64_t hnew = isa ? 2 * h : h + (uint64_t)nsym2;
+        {
+            int t = ix.prof.begin(s);
+            if (isa) {
+                HeadIn<I> hin{nh.as<uint8_t>(), U.as<I>()};
+                (void)scan_totals<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0);
+                UpdateOut<V, I, R> uo{sval[rs].as<V>(), U.as<I>(), nh.as<uint8_t>(), m, doc_start, (int)ix.bits,
+                                      ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>()};
+                scan_apply<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0, uo);
+                st.dbl_rounds++;
+            } else {
+                hipLaunchKernelGGL((sa_update_kernel<V, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
+                                   (const V*)sval[rs].as<V>(), (const I*)U.as<I>(), (const uint8_t*)nh.as<uint8_t>(), m,
+                                   doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>());
+                st.ext_rounds++;
+            }
+            ix.prof.end(t, "sa_update", m * (2 * sizeof(V) + sizeof(I) + 2 + (isa ? sizeof(R) : 0)), s);
+        }
+        h = hnew;
+        st.rounds++;
+        if (st.rounds > 80) throw Error("suffix-array refinement did not converge (internal error)");
+    }
+    st.final_depth = h;
+    st.sort_passes = ss.passes_run;
+    st.sort_passes_skipped = ss.passes_skipped;
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    ix.d_sa = std::move(vals[sel]);
+}
+
+}  // namespace
+
+void build_suffix_array(Index& ix) {
+    const double t0 = now_ms();
+    if (ix.width == 4) build_typed<uint32_t>(ix);
+    else build_typed<uint64_t>(ix);
+    CDB_HIP(hipStreamSynchronize(ix.stream));
+    ix.prof.resolve();
+    ix.bstats.build_ms = now_ms() - t0;
+}
+
+}  // namespace cdb

@@ -1,0 +1,148 @@
+// scan.h — generic device-wide scan (reduce → scan of tile partials → apply) used for stream compaction,
+// group-start propagation (max-scan) and CSR offsets.  Tile = 256 threads × 8 consecutive items.
+//
+// The input is a functor In: (uint64_t i) -> T, the consumer a functor Out: (i, exclusive, inclusive);
+// both are evaluated on the device, so producers/consumers (gathers, key packing, scatters) are fused
+// into the scan instead of materialising intermediate arrays in HBM.
+#pragma once
+#include "common.h"
+
+namespace cdb {
+
+constexpr int SC_NT = 256;
+constexpr int SC_IPT = 8;
+constexpr int SC_TILE = SC_NT * SC_IPT;
+
+struct OpAdd {
+    template <typename T> __device__ __forceinline__ T operator()(const T& a, const T& b) const { return a + b; }
+};
+struct OpMax {
+    template <typename T> __device__ __forceinline__ T operator()(const T& a, const T& b) const { return a > b ? a : b; }
+};
+struct U2 {
+    uint64_t a, b;
+    __host__ __device__ U2 operator+(const U2& o) const { return U2{a + o.a, b + o.b}; }
+};
+
+// inclusive scan of one value per thread across the 256-thread workgroup; returns the inclusive
+// value and the workgroup total.
+template <typename T, typename Op>
+__device__ __forceinline__ T block_scan_incl(T v, Op op, T* s_buf /*[SC_NT]*/, T& total) {
+    const int t = threadIdx.x;
+    s_buf[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < SC_NT; off <<= 1) {
+        T x = v;
+        if (t >= off) x = op(s_buf[t - off], v);
+        __syncthreads();
+        v = x;
+        s_buf[t] = v;
+        __syncthreads();
+    }
+    total = s_buf[SC_NT - 1];
+    return v;
+}
+
+template <typename T, typename In, typename Op>
+__global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(In in, uint64_t n, Op op, T identity, T* partials) {
+    __shared__ T s_buf[SC_NT];
+    const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+    T acc = identity;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k)
+        if (base + k < n) acc = op(acc, in(base + k));
+    T total;
+    block_scan_incl(acc, op, s_buf, total);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of the tile partials by one workgroup; partials[nb] receives the grand total
+template <typename T, typename Op>
+__global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint64_t nb, Op op, T identity) {
+    __shared__ T s_buf[SC_NT];
+    T carry = identity;
+    for (uint64_t c = 0; c < nb; c += SC_TILE) {
+        const uint64_t base = c + (uint64_t)threadIdx.x * SC_IPT;
+        T v[SC_IPT];
+        T acc = identity;
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) {
+            v[k] = base + k < nb ? partials[base + k] : identity;
+            acc = op(acc, v[k]);
+        }
+        T total;
+        const T incl = block_scan_incl(acc, op, s_buf, total);
+        // exclusive start of this thread = carry ∘ (inclusive of the previous thread)
+        __syncthreads();
+        s_buf[threadIdx.x] = incl;
+        __syncthreads();
+        T run = carry;
+        if (threadIdx.x > 0) run = op(carry, s_buf[threadIdx.x - 1]);
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) {
+            if (base + k < nb) partials[base + k] = run;
+            run = op(run, v[k]);
+        }
+        carry = op(carry, total);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[nb] = carry;
+}
+
+template <typename T, typename In, typename Out, typename Op>
+__global__ __launch_bounds__(SC_NT) void scan_apply_kernel(In in, uint64_t n, Op op, T identity, const T* partials,
+                                                           Out out) {
+    __shared__ T s_buf[SC_NT];
+    const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+    T v[SC_IPT];
+    T acc = identity;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) {
+        v[k] = base + k < n ? in(base + k) : identity;
+        acc = op(acc, v[k]);
+    }
+    T total;
+    const T incl = block_scan_incl(acc, op, s_buf, total);
+    __syncthreads();
+    s_buf[threadIdx.x] = incl;
+    __syncthreads();
+    T run = partials[blockIdx.x];
+    if (threadIdx.x > 0) run = op(run, s_buf[threadIdx.x - 1]);
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) {
+        const T nxt = op(run, v[k]);
+        if (base + k < n) out(base + k, run, nxt);
+        run = nxt;
+    }
+}
+
+template <typename T> struct ScanWorkspace {
+    DevBuf partials;
+    uint64_t nb = 0;
+};
+
+// Phase 1: reduce + scan of partials; returns the grand total (synchronises the stream).
+template <typename T, typename In, typename Op>
+T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity) {
+    const uint64_t nb = ceil_div(n, SC_TILE);
+    partials.ensure((nb + 1) * sizeof(T));
+    T* d_part = partials.as<T>();
+    if (nb) hipLaunchKernelGGL((scan_reduce_kernel<T, In, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity, d_part);
+    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SC_NT), 0, s, d_part, nb, op, identity);
+    T total;
+    CDB_HIP(hipMemcpyAsync(&total, d_part + nb, sizeof(T), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    return total;
+}
+
+// Phase 2: apply (uses the partials left by scan_totals for the same `in`, n, op).
+template <typename T, typename In, typename Out, typename Op>
+void scan_apply(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity, Out out) {
+    const uint64_t nb = ceil_div(n, SC_TILE);
+    if (!nb) return;
+    hipLaunchKernelGGL((scan_apply_kernel<T, In, Out, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity,
+                       (const T*)partials.as<T>(), out);
+}
+
+}  // namespace cdb

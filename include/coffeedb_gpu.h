@@ -1,0 +1,134 @@
+/* coffeedb_gpu.h — C ABI of libcoffeedb_gpu.so, the MI355X (gfx950) implementation of CoffeeDB's
+ * string-index hot path (suffix-array build + substring-match scan).
+ *
+ * Every entry point states the reference interface it replaces (paths relative to the CoffeeDB tree,
+ * /root/reference in the build container).  The reference-side binding is a ~60-line C++ shim
+ * (coffeedb_amd/csrc/index.h + index.cpp, shown in INTEGRATION.md) that keeps the reference's
+ * `index` / `string_index` classes so src/database.cpp compiles and behaves unchanged.
+ *
+ * Conventions: plain C types, no exceptions across the boundary.  Functions returning `int` return
+ * CDB_OK (0) or a CDB_E_* code; the message for the last failure on a handle is cdb_last_error(h)
+ * and uses the reference's own wording where the reference throws (index.cpp:196,199,240).
+ * A handle may be used from several host threads at once for queries (reference contract:
+ * query() is const and runs under a shared lock, database.cpp:388); build is exclusive.
+ */
+#ifndef COFFEEDB_GPU_H
+#define COFFEEDB_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDB_OK 0
+#define CDB_E_INVALID 1   /* bad argument / empty keyword / capacity limit (reference: std::runtime_error) */
+#define CDB_E_DEVICE 2    /* HIP runtime failure, no usable gfx950 device, out of device memory */
+#define CDB_E_INTERNAL 3  /* internal invariant violated (e.g. bounded look-back spin expired) */
+
+typedef struct cdb_index cdb_index; /* opaque; replaces `string_index` (src/index.h:54-86) */
+
+/* Result of a batched query in CSR form: pattern j owns rows [row_ptr[j], row_ptr[j+1]); each row is
+ * (ids[r], counts[r]) = (object id, number of overlapping occurrences = $correlation), rows of one
+ * pattern ascending by document insertion index — the order string_index::query returns
+ * (src/index.cpp:316-322).  Host memory, owned by the library until cdb_result_free(). */
+typedef struct cdb_result {
+    uint64_t npat;
+    uint64_t nrows;
+    uint64_t nhits;      /* total suffix-array entries matched over the batch */
+    uint64_t* row_ptr;   /* npat + 1 */
+    int64_t* ids;        /* nrows */
+    int64_t* counts;     /* nrows */
+} cdb_result;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* replaces std::make_unique<string_index>() (src/database.cpp:255, :303).  device < 0 selects the
+ * current HIP device.  Fails with CDB_E_DEVICE when no gfx950 GPU is usable: there is no CPU path. */
+int cdb_create(cdb_index** out, int device);
+
+/* replaces string_index::~string_index (src/index.h:80-84) */
+void cdb_destroy(cdb_index* h);
+
+const char* cdb_last_error(const cdb_index* h);
+
+/* ---- ingest ---------------------------------------------------------------------------------- */
+
+/* replaces string_index::add(int64_t id, std::string_view value) (src/index.cpp:174-177).
+ * The bytes are copied into a host staging buffer (the reference keeps a non-owning view instead). */
+int cdb_add(cdb_index* h, int64_t id, const char* value, size_t len);
+
+/* Bulk form of cdb_add for callers that already hold a concatenated column:
+ * document d = blob[doc_start[d] .. doc_start[d+1]), ndocs documents. */
+int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
+
+/* ---- build ----------------------------------------------------------------------------------- */
+
+/* replaces string_index::build() (src/index.cpp:178-236): computes bits/mask/size and the entry width
+ * exactly as the reference does (index.cpp:182-208), uploads the staged text and constructs the
+ * suffix array on the GPU.  Errors reuse the reference's messages (index.cpp:196,199). */
+int cdb_build(cdb_index* h);
+
+/* Same build, but over text that already resides in device memory (HBM-resident timing in bench.py,
+ * multi-GPU shards).  d_text must stay valid for the lifetime of the index (the reference's
+ * string_view contract, database.cpp:262-264); doc_start/ids are host arrays and are copied. */
+int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start, const int64_t* ids,
+                     uint64_t ndocs);
+
+/* ---- query ----------------------------------------------------------------------------------- */
+
+/* replaces string_index::query(const std::string& keyword) (src/index.cpp:237-326).  On success
+ * *ids / *counts point to *nrows entries allocated by the library (release with cdb_free).
+ * Empty keyword -> CDB_E_INVALID, message "Empty keywords are not allowed" (index.cpp:239-241).
+ * A never-built index returns zero rows (the reference reads uninitialised state there). */
+int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows);
+void cdb_free(void* p);
+
+/* Batched form (no reference counterpart — interface.cpp:79-113 loops query() per keyword): pattern j
+ * = blob[offsets[j] .. offsets[j+1]).  Any empty pattern fails the whole call like cdb_query. */
+int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
+void cdb_result_free(cdb_result* r);
+
+/* Batched query with patterns and results left in device memory (multi-GPU merge over RCCL, HBM-
+ * resident timing).  d_blob/d_offsets are device pointers.  On return the library-owned device arrays
+ * d_row_ptr (npat+1 u64), d_ids (nrows i64), d_counts (nrows i64) stay valid until the next query on
+ * this handle or cdb_destroy. */
+typedef struct cdb_device_result {
+    uint64_t npat, nrows, nhits;
+    const uint64_t* d_row_ptr;
+    const int64_t* d_ids;
+    const int64_t* d_counts;
+} cdb_device_result;
+int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
+                           uint64_t blob_bytes, cdb_device_result* out);
+
+/* ---- introspection (parity tests; mirrors the private members src/index.h:56-60) -------------- */
+uint64_t cdb_size(const cdb_index* h);  /* number of suffixes = text bytes */
+uint64_t cdb_bits(const cdb_index* h);  /* doc-index bits of an entry */
+uint64_t cdb_mask(const cdb_index* h);
+int cdb_sa_width(const cdb_index* h);   /* 4 or 8 bytes per entry; 0 before build */
+/* copies the suffix array ((offset << bits) | doc entries, cdb_sa_width bytes each) to host memory */
+int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes);
+
+/* ---- options & measurements -------------------------------------------------------------------- */
+/* name: "profile" (0/1: time kernels with HIP events), "reference_compat" (0/1: reproduce the
+ * reference's signed-char bucket order for bytes >= 0x80), "initial_passes" (radix
+ * passes of the initial key sort, 0 = automatic), "force_doubling" (0/1). */
+int cdb_set_option(cdb_index* h, const char* name, int64_t value);
+
+/* statistic by name: "build_ms", "rounds", "unresolved_after_initial", "sort_passes", "isa_built",
+ * "key_symbols", "symbol_bits", "query_ms", ... returns CDB_E_INVALID for unknown names */
+int cdb_get_stat(const cdb_index* h, const char* name, double* value);
+
+/* accumulated HIP-event time of one kernel family since cdb_profile_reset (needs option profile=1).
+ * bytes = algorithmic bytes moved by those launches. */
+int cdb_profile_get(cdb_index* h, const char* kernel, double* total_ms, uint64_t* launches, uint64_t* bytes);
+/* writes up to cap bytes of a NUL-terminated, newline-separated "name ms launches bytes" table */
+int cdb_profile_dump(cdb_index* h, char* buf, size_t cap);
+void cdb_profile_reset(cdb_index* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COFFEEDB_GPU_H */
