@@ -1,0 +1,257 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X string index (BASELINE.json metric:
+"SA build GiB/s + batched substring matches/sec").
+
+One step = one pass of the hot path over one batch of synthetic input, per GPU:
+    cdb_build_device   : suffix-array construction over the rank's corpus shard (text resident in HBM)
+    cdb_query_batch_device : the whole pattern batch against that suffix array (patterns resident in HBM)
+    (N > 1) RCCL all-gather merge of the per-shard match lists into one CSR result.
+Default workload = BASELINE.json configs[1] ("c1"): 2^20 docs x 1024 B printable ASCII = 1 GiB of text
+per GPU, 100 000 patterns of length 4..16 (weak scaling: the corpus grows with N).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline"     — the dominant kernel (radix-sort onesweep pass) timed live with HIP events
+  "cpu_baseline" — the CPU restatement of the reference (oracle/, kind "port") timed on this host on a
+                   bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (docs per GPU, doc length, patterns, min len, max len)
+    "c0": (10_000, 256, 1_000, 4, 16),
+    "c1": (1 << 20, 1024, 100_000, 4, 16),
+    "mid": (1 << 16, 1024, 100_000, 4, 16),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class _DevArr:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def merge_shard_results(torch, dist, r, npat, world, rank, device):
+    """All-gather merge of per-shard CSR match lists (rows of one pattern: shard 0's docs, then shard
+    1's, ... — already ascending in global document index because shards are doc-aligned ranges)."""
+    nrows = int(r.nrows)
+    row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
+    cnt = (row_ptr[1:] - row_ptr[:-1]).contiguous()
+    all_cnt = torch.empty(world, npat, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_cnt, cnt)
+    rows_per_rank = all_cnt.sum(1)
+    maxrows = max(int(rows_per_rank.max().item()), 1)
+    pad = torch.zeros(2, maxrows, dtype=torch.int64, device=device)
+    if nrows:
+        pad[0, :nrows] = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=device)
+        pad[1, :nrows] = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
+    allrows = torch.empty(world, 2, maxrows, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allrows, pad)
+    total = all_cnt.sum(0)
+    g_row_ptr = torch.zeros(npat + 1, dtype=torch.int64, device=device)
+    torch.cumsum(total, 0, out=g_row_ptr[1:])
+    before = torch.cumsum(all_cnt, 0) - all_cnt  # rows of earlier shards, per pattern
+    out = torch.empty(2, int(g_row_ptr[-1].item()), dtype=torch.int64, device=device)
+    pats = torch.arange(npat, device=device)
+    for q in range(world):
+        nq = int(rows_per_rank[q].item())
+        if nq == 0:
+            continue
+        pat = torch.repeat_interleave(pats, all_cnt[q])
+        rp_q = torch.cumsum(all_cnt[q], 0) - all_cnt[q]
+        dest = g_row_ptr[pat] + before[q][pat] + (torch.arange(nq, device=device) - rp_q[pat])
+        out[:, dest] = allrows[q, :, :nq]
+    return g_row_ptr, out
+
+
+def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
+    """Times the CPU restatement (oracle/cpu_ref.cpp) on a bounded prefix of the same corpus."""
+    from oracle import OracleIndex
+    nd = min(ndocs_sample, budget_docs)
+    ds = W.uniform_docs(nd, doclen)
+    blob = host_text[: nd * doclen]
+    cores = os.cpu_count() or 1
+    o = OracleIndex()
+    o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
+    t = time.time()
+    o.build(0)  # hardware_concurrency threads, as index.cpp:225
+    tb = time.time() - t
+    # patterns drawn from the sample itself so that the hit structure matches the full-size run
+    spb, spo = W.sample_patterns(blob, ds, min(len(po) - 1, 100_000), 4, 16, seed=99)
+    t = time.time()
+    _, _, _, hits1 = o.query_batch(spb, spo, nthreads=1, want_rows=False)
+    tq1 = time.time() - t
+    t = time.time()
+    o.query_batch(spb, spo, nthreads=cores, want_rows=False)
+    tqa = time.time() - t
+    npat = len(spo) - 1
+    return {
+        "value": round(nd * doclen / 2**30 / tb, 6),
+        "unit": "GiB/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the same corpus, SA build with {cores} threads; "
+                  f"{npat} patterns len 4-16 sampled from that prefix",
+        "build_s": round(tb, 3),
+        "query_patterns_per_s_1thread": round(npat / tq1, 1),
+        "query_patterns_per_s_allcores": round(npat / tqa, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample-docs", type=int, default=1 << 15, help="docs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from coffeedb_amd import capi, workloads as W
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    ndocs, doclen, npat, mmin, mmax = WORKLOADS[args.workload]
+    n = ndocs * doclen
+    # ---- synthetic shard of this rank (stream = rank => different text per shard), generated in HBM
+    text = W.random_bytes_torch(n, 12345, 0x20, 0x7E, stream=rank, device=device)
+    doc_start = W.uniform_docs(ndocs, doclen)
+    ids = np.arange(ndocs, dtype=np.int64) + rank * ndocs
+    host_text = text.cpu().numpy() if rank == 0 else None
+
+    # ---- one pattern batch for every shard (rank 0 samples it from its own text, then broadcast)
+    if rank == 0:
+        pb, po = W.sample_patterns(host_text, doc_start, npat, mmin, mmax, seed=99)
+        meta = torch.tensor([len(pb)], dtype=torch.int64, device=device)
+    else:
+        meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if world > 1:
+        dist.broadcast(meta, 0)
+    nbytes = int(meta.item())
+    d_blob = torch.zeros(nbytes + 16, dtype=torch.uint8, device=device)
+    d_offs = torch.zeros(npat + 1, dtype=torch.int64, device=device)
+    if rank == 0:
+        d_blob[:nbytes] = torch.from_numpy(pb).to(device)
+        d_offs.copy_(torch.from_numpy(po.astype(np.int64)).to(device))
+    if world > 1:
+        dist.broadcast(d_blob, 0)
+        dist.broadcast(d_offs, 0)
+
+    g = capi.GpuStringIndex(device=local_rank)
+    g.set_option("profile", 1)
+
+    def step():
+        g.build_device(text.data_ptr(), doc_start, ids)
+        tb = g.stat("build_ms")
+        r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+        tq = g.stat("query_ms")
+        if world > 1:
+            merge_shard_results(torch, dist, r, npat, world, rank, device)
+        return tb, tq, int(r.nhits), int(r.nrows)
+
+    for _ in range(args.warmup):
+        step()
+    g.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    build_ms = query_ms = 0.0
+    hits = rows = 0
+    for _ in range(args.steps):
+        tb, tq, hits, rows = step()
+        build_ms += tb
+        query_ms += tq
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, build_ms, query_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
+
+    prof = g.profile()
+    dom_name = max((k for k in prof if k.startswith("rs_onesweep")), key=lambda k: prof[k]["ms"])
+    dom = prof[dom_name]
+    dom_avg_ms = dom["ms"] / dom["launches"]
+    dom_gbs = dom["bytes"] / dom["launches"] / (dom_avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        steps = args.steps
+        gib_total = world * n * steps / 2**30
+        out = {
+            "metric": "sa_build_GiB_per_s",
+            "value": round(gib_total / elapsed, 4),
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 text / u64 sort keys / u32 suffix entries",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {ndocs} docs x {doclen} B printable ASCII per GPU ({n / 2**30:.3f} GiB), "
+                            f"{npat} patterns len {mmin}-{mmax}; step = SA build + batched query"
+                            + (" + RCCL all-gather merge" if world > 1 else ""),
+                "docs_per_gpu": ndocs, "doc_len": doclen, "patterns": npat,
+            },
+            "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
+            "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
+            "query_hits_per_batch": hits,
+            "query_rows_per_batch": rows,
+            "build_stats": {k: g.stat(k) for k in ("rounds", "ext_rounds", "dbl_rounds", "unresolved_after_initial",
+                                                   "sort_passes", "sort_passes_skipped", "key_symbols", "symbol_bits",
+                                                   "isa_built")},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom_name,
+                "achieved": round(dom_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "avg_launch_ms": round(dom_avg_ms, 4),
+                "launches": dom["launches"],
+                "algorithmic_bytes_per_launch": dom["bytes"] // dom["launches"],
+            },
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.cpu_sample_docs > 0:
+            out["cpu_baseline"] = cpu_baseline(W, host_text, ndocs, doclen, pb, po, args.cpu_sample_docs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

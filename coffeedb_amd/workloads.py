@@ -127,3 +127,33 @@ def sample_patterns(blob, doc_start, npat, mmin=4, mmax=16, seed=99, miss_frac=0
         else:
             pblob[last] = miss_byte
     return pblob, offsets
+
+
+# ---- the same byte stream generated with torch ops (on the GPU for the bench; bit-identical to
+# random_bytes so a host-side prefix can be regenerated with numpy for the CPU baseline) ----------
+def _torch_lsr(x, k):
+    import torch
+    return (x >> k) & torch.tensor((1 << (64 - k)) - 1, dtype=torch.int64, device=x.device)
+
+
+def _as_i64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def random_bytes_torch(n, seed, lo=0x20, hi=0x7E, stream=0, device="cpu", chunk_draws=1 << 24):
+    import torch
+    span = hi - lo + 1
+    ndraw = (n + 7) // 8
+    out = torch.empty(ndraw * 8, dtype=torch.uint8, device=device)
+    base = _as_i64(seed * 0x100000001B3 + stream * 0x9E3779B1)
+    c0, c1, c2 = _as_i64(0x9E3779B97F4A7C15), _as_i64(0xBF58476D1CE4E5B9), _as_i64(0x94D049BB133111EB)
+    for s in range(0, ndraw, chunk_draws):
+        e = min(ndraw, s + chunk_draws)
+        z = torch.arange(s, e, dtype=torch.int64, device=device) + base + c0
+        z = (z ^ _torch_lsr(z, 30)) * c1
+        z = (z ^ _torch_lsr(z, 27)) * c2
+        z = z ^ _torch_lsr(z, 31)
+        b = z.view(torch.uint8).to(torch.int32)
+        out[s * 8:e * 8] = (lo + ((b * span) >> 8)).to(torch.uint8)
+    return out[:n]
