@@ -75,15 +75,19 @@ def merge_shard_results(torch, dist, r, npat, world, rank, device):
 def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
     """Times the CPU restatement (oracle/cpu_ref.cpp) on a bounded prefix of the same corpus."""
     from oracle import OracleIndex
-    nd = min(ndocs_sample, budget_docs)
-    ds = W.uniform_docs(nd, doclen)
-    blob = host_text[: nd * doclen]
     cores = os.cpu_count() or 1
-    o = OracleIndex()
-    o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
-    t = time.time()
-    o.build(0)  # hardware_concurrency threads, as index.cpp:225
-    tb = time.time() - t
+    nd = min(ndocs_sample, budget_docs)
+    while True:  # grow the sample until the build takes a few seconds (bounded: <= 2^18 docs)
+        ds = W.uniform_docs(nd, doclen)
+        blob = host_text[: nd * doclen]
+        o = OracleIndex()
+        o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
+        t = time.time()
+        o.build(0)  # hardware_concurrency threads, as index.cpp:225
+        tb = time.time() - t
+        if tb >= 4.0 or nd * 4 > min(ndocs_sample, 1 << 18):
+            break
+        nd *= 4
     # patterns drawn from the sample itself so that the hit structure matches the full-size run
     spb, spo = W.sample_patterns(blob, ds, min(len(po) - 1, 100_000), 4, 16, seed=99)
     t = time.time()

@@ -91,16 +91,21 @@ struct View {
 struct WorkList {
     std::mutex mu;
     std::deque<Task> q;
+    std::atomic<int64_t> queued{0};  // lets idle workers poll without taking the lock (the
+                                     // reference's idle workers only read two atomics, index.cpp:36-40)
     std::atomic<uint64_t> remaining{0};
     void push(Task t) {
         std::lock_guard<std::mutex> g(mu);
         q.push_back(t);
+        queued.fetch_add(1, std::memory_order_release);
     }
     bool pop(Task& t) {
+        if (queued.load(std::memory_order_acquire) <= 0) return false;
         std::lock_guard<std::mutex> g(mu);
         if (q.empty()) return false;
         t = q.front();
         q.pop_front();
+        queued.fetch_sub(1, std::memory_order_release);
         return true;
     }
 };
