@@ -19,7 +19,7 @@ EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device",
     "cdb_query", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
-    "cdb_profile_dump", "cdb_profile_reset",
+    "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
 ]
 
 
@@ -78,6 +78,10 @@ def load_library():
     lib.cdb_profile_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.cdb_profile_reset.argtypes = [vp]
     lib.cdb_profile_reset.restype = None
+    lib.cdb_release_cached_memory.argtypes = []
+    lib.cdb_release_cached_memory.restype = None
+    lib.cdb_cached_memory_bytes.argtypes = []
+    lib.cdb_cached_memory_bytes.restype = u64
     _LIB = lib
     return lib
 

@@ -305,7 +305,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
     const BuildStats& b = h->ix.bstats;
     const QueryStats& q = h->ix.qstats;
     struct { const char* n; double v; } tab[] = {
-        {"build_ms", b.build_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
+        {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
         {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built},
@@ -346,6 +346,10 @@ int cdb_profile_dump(cdb_index* h, char* buf, size_t cap) {
     buf[cap - 1] = 0;
     return CDB_OK;
 }
+
+void cdb_release_cached_memory(void) { DevPool::get().trim(); }
+
+uint64_t cdb_cached_memory_bytes(void) { return (uint64_t)DevPool::get().cached_bytes(); }
 
 void cdb_profile_reset(cdb_index* h) {
     if (!h) return;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -25,28 +26,104 @@ struct Error : std::runtime_error {
 inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline int bit_width64(uint64_t x) { return x == 0 ? 0 : 64 - __builtin_clzll(x); }
 
-// Owning device allocation (hipMalloc / hipFree).
+// Process-wide cache of device blocks.  hipMalloc of multi-GiB buffers costs ~30 ms per GiB on MI355X
+// (the driver maps and clears VRAM), i.e. ~1 s for the ~30 GiB working set of a 1 GiB build — ten times
+// the build itself.  CoffeeDB rebuilds a fresh index object on every `build` (database.cpp:170-281) while
+// the old one keeps serving, so freed blocks are kept and handed to the next build instead of going
+// back to the driver; cdb_release_cached_memory() returns them.  288 GB of HBM makes this cheap.
+class DevPool {
+public:
+    static DevPool& get() {
+        static DevPool p;
+        return p;
+    }
+    void* alloc(size_t bytes, int device, size_t& actual) {
+        const size_t gran = bytes >= (8u << 20) ? (2u << 20) : 256;
+        const size_t need = (bytes + gran - 1) / gran * gran;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            int best = -1;
+            for (int i = 0; i < (int)free_.size(); ++i) {
+                const Block& b = free_[i];
+                if (b.device != device || b.bytes < need) continue;
+                const size_t slack = need >= (64u << 20) ? need / 4 : need + (1u << 20);
+                if (b.bytes > need + slack) continue;
+                if (best < 0 || b.bytes < free_[best].bytes) best = i;
+            }
+            if (best >= 0) {
+                Block b = free_[best];
+                free_.erase(free_.begin() + best);
+                cached_ -= b.bytes;
+                actual = b.bytes;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
+            (void)hipGetLastError();
+            trim();
+            e = hipMalloc(&p, need);
+        }
+        if (e != hipSuccess) throw Error(std::string("HIP error in hipMalloc: ") + hipGetErrorString(e));
+        actual = need;
+        return p;
+    }
+    void free(void* p, size_t bytes, int device) {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.push_back(Block{p, bytes, device});
+        cached_ += bytes;
+    }
+    void trim() {
+        std::vector<Block> blocks;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            blocks.swap(free_);
+            cached_ = 0;
+        }
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (auto& b : blocks) {
+            (void)hipSetDevice(b.device);
+            (void)hipFree(b.p);
+        }
+        (void)hipSetDevice(cur);
+    }
+    size_t cached_bytes() {
+        std::lock_guard<std::mutex> g(mu_);
+        return cached_;
+    }
+
+private:
+    struct Block { void* p; size_t bytes; int device; };
+    std::mutex mu_;
+    std::vector<Block> free_;
+    size_t cached_ = 0;
+};
+
+// Owning device allocation, served by DevPool.
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int device = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), device(o.device) { o.p = nullptr; o.bytes = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; device = o.device; o.p = nullptr; o.bytes = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void alloc(size_t n) {
         release();
         if (n == 0) n = 16;
-        CDB_HIP(hipMalloc(&p, n));
-        bytes = n;
+        CDB_HIP(hipGetDevice(&device));
+        p = DevPool::get().alloc(n, device, bytes);
     }
     void ensure(size_t n) { if (n > bytes) alloc(n); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) DevPool::get().free(p, bytes, device);
         p = nullptr;
         bytes = 0;
     }

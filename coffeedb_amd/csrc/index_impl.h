@@ -12,7 +12,7 @@ namespace cdb {
 constexpr int TEXT_PAD = 128;  // readable zero bytes behind library-owned text
 
 struct BuildStats {
-    double build_ms = 0;
+    double build_ms = 0, alloc_ms = 0, free_ms = 0;
     int rounds = 0;              // refinement rounds after the initial key sort
     int ext_rounds = 0;          // ... of which text-extension rounds
     int dbl_rounds = 0;          // ... of which prefix-doubling rounds

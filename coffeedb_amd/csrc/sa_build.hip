@@ -278,7 +278,11 @@ void build_typed(Index& ix) {
     const uint64_t n = ix.size, D = ix.ndocs;
     BuildStats& st = ix.bstats;
     st = BuildStats{};
-    ix.d_sa.release();
+    {
+        const double tf = now_ms();
+        ix.d_sa.release();
+        st.free_ms += now_ms() - tf;
+    }
     if (n == 0) {
         ix.d_sa.alloc(16);
         return;
@@ -319,11 +323,13 @@ void build_typed(Index& ix) {
 
     // ---- 2. keys + entries
     DevBuf keys[2], vals[2], flags;
+    double ta = now_ms();
     keys[0].alloc(n * sizeof(uint64_t));
     keys[1].alloc(n * sizeof(uint64_t));
     vals[0].alloc(n * sizeof(V));
     vals[1].alloc(n * sizeof(V));
     flags.alloc(n);
+    st.alloc_ms += now_ms() - ta;
     {
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text, doc_start, D,
@@ -343,9 +349,11 @@ void build_typed(Index& ix) {
         ix.prof.end(t, "sa_initflags", n * 9, s);
     }
     CDB_HIP(hipStreamSynchronize(s));
+    ta = now_ms();
     keys[0].release();
     keys[1].release();
     vals[sel ^ 1].release();
+    st.free_ms += now_ms() - ta;
     V* sa = vals[sel].as<V>();
 
     // ---- 4. refinement rounds
@@ -444,8 +452,16 @@ void build_typed(Index& ix) {
 
 void build_suffix_array(Index& ix) {
     const double t0 = now_ms();
-    if (ix.width == 4) build_typed<uint32_t>(ix);
-    else build_typed<uint64_t>(ix);
+    try {
+        if (ix.width == 4) build_typed<uint32_t>(ix);
+        else build_typed<uint64_t>(ix);
+    } catch (...) {
+        // scratch buffers go back to the shared block cache when the stack unwinds: make sure no
+        // kernel of this build is still using them
+        (void)hipStreamSynchronize(ix.stream);
+        ix.prof.resolve();
+        throw;
+    }
     CDB_HIP(hipStreamSynchronize(ix.stream));
     ix.prof.resolve();
     ix.bstats.build_ms = now_ms() - t0;

@@ -128,6 +128,12 @@ int cdb_profile_get(cdb_index* h, const char* kernel, double* total_ms, uint64_t
 int cdb_profile_dump(cdb_index* h, char* buf, size_t cap);
 void cdb_profile_reset(cdb_index* h);
 
+/* Device blocks released by builds/queries are cached process-wide for the next build (hipMalloc of the
+ * ~30 GiB working set of a 1 GiB build costs ~1 s on MI355X — the driver maps and clears VRAM).  This
+ * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size. */
+void cdb_release_cached_memory(void);
+uint64_t cdb_cached_memory_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif
