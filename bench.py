@@ -176,6 +176,7 @@ def main():
             merge_shard_results(torch, dist, r, npat, world, rank, device)
         return tb, tq, int(r.nhits), int(r.nrows)
 
+    torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
     for _ in range(args.warmup):
         step()
     g.profile_reset()

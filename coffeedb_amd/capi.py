@@ -20,6 +20,7 @@ EXPORTS = [
     "cdb_query", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
+    "cdb_debug_radix_sort",
 ]
 
 
@@ -46,6 +47,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    try:
+        # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process do not see each
+        # other's devices.  Loading torch first makes this library bind to the runtime torch uses
+        # (tests and bench.py share device pointers with torch).  C/C++ hosts simply use /opt/rocm's.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing — build it with `make -C {CSRC}` (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
@@ -82,6 +90,8 @@ def load_library():
     lib.cdb_release_cached_memory.restype = None
     lib.cdb_cached_memory_bytes.argtypes = []
     lib.cdb_cached_memory_bytes.restype = u64
+    lib.cdb_debug_radix_sort.argtypes = [C.c_int, vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int)]
     _LIB = lib
     return lib
 
@@ -195,3 +205,14 @@ class GpuStringIndex:
 
     def profile_reset(self):
         self._lib.cdb_profile_reset(self._h)
+
+
+def debug_radix_sort(d_keys_ptr, d_vals_ptr, n, val_bytes, key_bits, variant=0, device=-1):
+    """In-place device sort through the library's radix primitive; returns (onesweep_ms, passes)."""
+    lib = load_library()
+    ms, passes = C.c_double(0), C.c_int(0)
+    rc = lib.cdb_debug_radix_sort(device, C.c_void_p(d_keys_ptr), C.c_void_p(d_vals_ptr) if d_vals_ptr else None, n,
+                                  val_bytes, key_bits, variant, C.byref(ms), C.byref(passes))
+    if rc != 0:
+        raise RuntimeError(f"cdb_debug_radix_sort failed ({rc})")
+    return ms.value, passes.value

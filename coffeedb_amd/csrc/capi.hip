@@ -293,6 +293,8 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "reference_compat")) ix.reference_compat = value != 0;
     else if (!std::strcmp(name, "force_doubling")) ix.force_doubling = value != 0;
     else if (!std::strcmp(name, "initial_passes")) ix.initial_passes = (int)value;
+    else if (!std::strcmp(name, "sort_variant")) ix.sort_variant = (int)value;
+    else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else {
         ix.err = std::string("unknown option: ") + name;
         return CDB_E_INVALID;
@@ -310,7 +312,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
         {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
-        {"alphabet", (double)b.alphabet}, {"final_depth", (double)b.final_depth},
+        {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth},
         {"query_ms", q.query_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
     };
     for (auto& e : tab)
@@ -345,6 +347,54 @@ int cdb_profile_dump(cdb_index* h, char* buf, size_t cap) {
     std::strncpy(buf, s.c_str(), cap - 1);
     buf[cap - 1] = 0;
     return CDB_OK;
+}
+
+int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int val_bytes, int key_bits,
+                         int variant, double* onesweep_ms, int* passes) {
+    if (!d_keys || (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) || key_bits < 1 || key_bits > 64)
+        return CDB_E_INVALID;
+    try {
+        if (device >= 0) CDB_HIP(hipSetDevice(device));
+        hipStream_t s;
+        CDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        {
+            RadixWorkspace ws;
+            Profiler prof;
+            prof.enabled = true;
+            DevBuf k1, v1;
+            k1.alloc(n * 8);
+            if (val_bytes) v1.alloc(n * val_bytes);
+            SortStats st;
+            int sel = 0;
+            uint64_t* k0 = static_cast<uint64_t*>(d_keys);
+            if (val_bytes == 4)
+                sel = radix_sort<uint64_t, uint32_t>(s, ws, prof, k0, k1.as<uint64_t>(), static_cast<uint32_t*>(d_vals),
+                                                     v1.as<uint32_t>(), n, 0, key_bits, &st, variant);
+            else if (val_bytes == 8)
+                sel = radix_sort<uint64_t, uint64_t>(s, ws, prof, k0, k1.as<uint64_t>(), static_cast<uint64_t*>(d_vals),
+                                                     v1.as<uint64_t>(), n, 0, key_bits, &st, variant);
+            else
+                sel = radix_sort<uint64_t, NoVal>(s, ws, prof, k0, k1.as<uint64_t>(), (NoVal*)nullptr, (NoVal*)nullptr, n,
+                                                  0, key_bits, &st, variant);
+            if (sel == 1) {
+                CDB_HIP(hipMemcpyAsync(d_keys, k1.p, n * 8, hipMemcpyDeviceToDevice, s));
+                if (val_bytes) CDB_HIP(hipMemcpyAsync(d_vals, v1.p, n * val_bytes, hipMemcpyDeviceToDevice, s));
+            }
+            radix_check_error(s, ws);
+            CDB_HIP(hipStreamSynchronize(s));
+            prof.resolve();
+            double ms = 0;
+            for (auto& kv : prof.recs)
+                if (kv.first.rfind("rs_onesweep", 0) == 0) ms += kv.second.ms;
+            if (onesweep_ms) *onesweep_ms = ms;
+            if (passes) *passes = st.passes_run;
+        }
+        (void)hipStreamDestroy(s);
+        return CDB_OK;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "cdb_debug_radix_sort: %s\n", e.what());
+        return CDB_E_DEVICE;
+    }
 }
 
 void cdb_release_cached_memory(void) { DevPool::get().trim(); }

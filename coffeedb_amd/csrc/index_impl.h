@@ -21,7 +21,7 @@ struct BuildStats {
     int sort_passes = 0;         // onesweep launches
     int sort_passes_skipped = 0;
     int isa_built = 0;
-    int key_symbols = 0, symbol_bits = 0, alphabet = 0;
+    int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
 };
 
@@ -62,6 +62,8 @@ struct Index {
     bool reference_compat = false;
     bool force_doubling = false;
     int initial_passes = 0;
+    int sort_variant = 0;
+    int digit_bits = 0;
 
     Profiler prof;
     BuildStats bstats;

@@ -18,13 +18,15 @@
 //     tile ids come from an atomic ticket so a tile only ever waits on tiles that already started, and
 //     every spin is bounded (a stuck look-back raises an error flag instead of hanging the GPU).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cdb {
 
 constexpr int RS_NT = 256;            // threads per workgroup (4 waves)
 constexpr int RS_NW = RS_NT / 64;
-constexpr int RS_MAX_PASSES = 8;
+constexpr int RS_MAX_PASSES = 16;
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 
@@ -42,7 +44,7 @@ template <> struct RsTraits<uint32_t, NoVal> { static constexpr int IPT = 16; };
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, uint64_t n, int begin_bit,
-                                                      int npass, uint32_t last_mask,
+                                                      int npass, int dbits, uint32_t last_mask,
                                                       unsigned long long* __restrict__ ghist) {
     __shared__ uint32_t sh[RS_MAX_PASSES * 256];
     for (int i = threadIdx.x; i < npass * 256; i += 256) sh[i] = 0;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys
 #pragma unroll
         for (int p = 0; p < RS_MAX_PASSES; ++p) {
             if (p < npass) {
-                uint32_t d = (uint32_t)(k >> (begin_bit + 8 * p)) & 0xFFu;
+                uint32_t d = (uint32_t)(k >> (begin_bit + dbits * p)) & ((1u << dbits) - 1u);
                 if (p == npass - 1) d &= last_mask;
                 atomicAdd(&sh[p * 256 + d], 1u);
             }
@@ -91,40 +93,83 @@ __device__ __forceinline__ void rs_st_status(uint64_t* p, uint64_t v) {
 // ---------------------------------------------------------------------------------------------
 // one radix pass: rank inside the tile, look back for the global prefix, scatter
 // ---------------------------------------------------------------------------------------------
-template <typename K, typename V, int IPT>
-__global__ __launch_bounds__(RS_NT) void rs_onesweep_kernel(
+// Kernel configuration.  IPT = keys per thread (tile = 256 * IPT); REUSE = keys and values share one
+// LDS staging buffer (two write-out phases, smaller footprint -> more workgroups per CU); EARLYV =
+// values are fetched together with the keys instead of after the look-back.
+template <int IPT_, bool REUSE_, bool EARLYV_, int NT_ = 256, bool NONTEMP_ = false, int MINW_ = 1, int ABL_ = 0,
+          int LB_ = 1>
+struct RsCfg {
+    static constexpr int LB = LB_;            // look-back window: predecessors polled per round trip
+    static constexpr int ABL = ABL_;          // timing-only ablations (WRONG results): 1 = no look-back,
+                                              // 2 = linear (unscattered) write-out, 4 = no ranking
+    static constexpr int MINW = MINW_;        // min waves per SIMD the register allocator must allow
+    static constexpr int IPT = IPT_;
+    static constexpr bool REUSE = REUSE_;
+    static constexpr bool EARLYV = EARLYV_;
+    static constexpr int NT = NT_;            // threads per workgroup (>= 256, multiple of 64)
+    static constexpr bool NONTEMP = NONTEMP_;  // streaming (non-temporal) global loads/stores
+};
+
+template <bool NT_, typename T> __device__ __forceinline__ T rs_load(const T* p) {
+    if constexpr (NT_) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT_, typename T> __device__ __forceinline__ void rs_store(T* p, T v) {
+    if constexpr (NT_) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <typename K, typename V, typename Cfg>
+__global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
     uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err) {
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
-    constexpr int TILE = RS_NT * IPT;
+    constexpr int IPT = Cfg::IPT;
+    constexpr bool REUSE = Cfg::REUSE && HAS_V;
+    constexpr bool EARLYV = (Cfg::EARLYV || REUSE) && HAS_V;
+    constexpr int NT = Cfg::NT;
+    constexpr int NW = NT / 64;
+    constexpr bool NTM = Cfg::NONTEMP;
+    constexpr int TILE = NT * IPT;
     constexpr int WCHUNK = 64 * IPT;  // elements owned by one wave (contiguous => stable)
     using VS = typename std::conditional<HAS_V, V, uint32_t>::type;
+    constexpr size_t STAGE_K = sizeof(K) * TILE;
+    constexpr size_t STAGE_V = HAS_V ? sizeof(VS) * TILE : 0;
+    constexpr size_t STAGE_BYTES = REUSE ? (STAGE_K > STAGE_V ? STAGE_K : STAGE_V) : STAGE_K + STAGE_V;
 
-    __shared__ uint32_t s_whist[RS_NW][256];
-    __shared__ uint32_t s_tstart[256];
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
     __shared__ uint64_t s_gbase[256];
-    __shared__ uint32_t s_wsum[RS_NW];
+    __shared__ uint32_t s_whist[NW][256];
+    __shared__ uint32_t s_tstart[256];
+    __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_tile;
-    __shared__ K s_keys[TILE];
-    __shared__ VS s_vals[HAS_V ? TILE : 1];
+    K* s_keys = reinterpret_cast<K*>(s_stage);
+    VS* s_vals = reinterpret_cast<VS*>(s_stage + (REUSE ? 0 : STAGE_K));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int w = 0; w < RS_NW; ++w) s_whist[w][tid] = 0;
+    for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
     const uint64_t tile = s_tile;
     const uint64_t base = tile * TILE;
     const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
 
-    // ---- load keys, wave-striped (lane-contiguous 512 B per load instruction)
+    // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
     K key[IPT];
+    VS val[EARLYV ? IPT : 1];
     const uint32_t wbase = wave * WCHUNK + lane;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
-        key[j] = li < valid ? kin[base + li] : (K)~(K)0;
+        key[j] = li < valid ? rs_load<NTM>(kin + base + li) : (K)~(K)0;
+    }
+    if constexpr (EARLYV) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            val[j] = li < valid ? rs_load<NTM>(vin + base + li) : VS(0);
+        }
     }
 
     // ---- rank inside the wave: lanes with the same digit find each other with 8 ballots
@@ -138,7 +183,7 @@ __global__ __launch_bounds__(RS_NT) void rs_onesweep_kernel(
         const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < ((Cfg::ABL & 4) ? 0 : 8); ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             m &= bit ? bal : ~bal;
@@ -155,94 +200,145 @@ __global__ __launch_bounds__(RS_NT) void rs_onesweep_kernel(
     __syncthreads();
 
     // ---- per-digit totals of the tile, exclusive prefix across waves and across digits
-    uint32_t cnt = 0;
-    {
-        const int d = tid;  // RS_NT == 256: one thread per digit
+    // (threads 0..255 own one digit each; wider workgroups leave the other waves idle here)
+    const int d = tid;
+    uint32_t cnt = 0, incl = 0;
+    uint64_t real = 0;
+    const uint64_t tag = (uint64_t)epoch << 56;
+    uint64_t* my = status + tile * 256 + (d & 255);
+    if (tid < 256) {
 #pragma unroll
-        for (int w = 0; w < RS_NW; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const uint32_t t = s_whist[w][d];
             s_whist[w][d] = cnt;
             cnt += t;
         }
-        // block exclusive scan of cnt over the 256 digits
-        uint32_t incl = cnt;
+        // real (in-range) count of this digit: padding only ever sits in digit 255
+        real = d == 255 ? (uint64_t)cnt - (uint64_t)(TILE - valid) : (uint64_t)cnt;
+        // publish the aggregate as early as possible: successors can already add it up
+        rs_st_status(my, tag | ((tile == 0 ? 2ull : 1ull) << 54) | real);
+        // exclusive scan of cnt over the 256 digits: wave scan, then across the 4 digit-owning waves
+        incl = cnt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = __shfl_up(incl, off);
             if (lane >= off) incl += v;
         }
         if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < 256) {
         uint32_t wpre = 0;
 #pragma unroll
-        for (int w = 0; w < RS_NW; ++w)
+        for (int w = 0; w < 4; ++w)
             if (w < wave) wpre += s_wsum[w];
         const uint32_t tstart = wpre + incl - cnt;
         s_tstart[d] = tstart;
 
-        // real (in-range) count of this digit: padding only ever sits in digit 255
-        const uint64_t real = d == 255 ? (uint64_t)cnt - (uint64_t)(TILE - valid) : (uint64_t)cnt;
-
-        // ---- chained scan: publish the aggregate, look back, publish the inclusive prefix
-        const uint64_t tag = (uint64_t)epoch << 56;
-        uint64_t* my = status + tile * 256 + d;
+        // ---- chained scan: look back over the predecessors, then publish the inclusive prefix
         uint64_t excl = 0;
-        if (tile == 0) {
-            rs_st_status(my, tag | (2ull << 54) | real);
-        } else {
-            rs_st_status(my, tag | (1ull << 54) | real);
-            uint64_t p = tile - 1;
+        if (tile != 0 && !(Cfg::ABL & 1)) {
+            // A tile becomes ready every pass_time / tiles (~0.1 us at 1 Gi keys) while one agent-scope
+            // load costs ~1 us on this part (it has to leave the XCD's L2), so a one-at-a-time walk
+            // falls behind and the walk gets ever longer.  LB predecessors are therefore fetched per
+            // round trip; they are consumed nearest-first up to the first inclusive prefix.
+            constexpr int LB = Cfg::LB;
+            int64_t p = (int64_t)tile - 1;
             uint32_t spins = 0;
-            for (;;) {
-                const uint64_t s = rs_ld_status(status + p * 256 + d);
-                const uint32_t st = (uint32_t)(s >> 54) & 3u;
-                if ((s >> 56) == (uint64_t)epoch && st != 0) {
-                    excl += s & RS_VAL_MASK;
-                    if (st == 2) break;
-                    --p;  // tile 0 always publishes an inclusive prefix, so p never underflows
-                    spins = 0;
-                } else {
-                    __builtin_amdgcn_s_sleep(2);
+            bool done = false;
+            while (!done) {
+                uint64_t sw[LB];
+#pragma unroll
+                for (int k = 0; k < LB; ++k)
+                    sw[k] = p - k >= 0 ? rs_ld_status(status + (uint64_t)(p - k) * 256 + d) : 0ull;
+                int used = 0;
+                bool open = true;
+#pragma unroll
+                for (int k = 0; k < LB; ++k) {
+                    const uint32_t st = (sw[k] >> 56) == (uint64_t)epoch ? ((uint32_t)(sw[k] >> 54) & 3u) : 0u;
+                    const bool take = open && st != 0;
+                    excl += take ? (sw[k] & RS_VAL_MASK) : 0ull;
+                    used += take ? 1 : 0;
+                    done = done || (take && st == 2);
+                    open = take && st != 2;
+                }
+                if ((Cfg::ABL & 8) && d == 0) {  // measurement only: look-back depth / round trips
+                    atomicAdd(err + 1, (uint32_t)used);
+                    atomicAdd(err + 2, 1u);
+                }
+                p -= used;  // tile 0 always publishes an inclusive prefix, so p never underflows
+                if (used == 0) {
+                    __builtin_amdgcn_s_sleep(1);
                     if (++spins > RS_SPIN_LIMIT) {
                         atomicExch(err, 1u);
                         break;
                     }
+                } else {
+                    spins = 0;
                 }
             }
             rs_st_status(my, tag | (2ull << 54) | (excl + real));
         }
-        s_gbase[d] = (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
+        s_gbase[d] = (Cfg::ABL & 2) ? base : (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
     }
     __syncthreads();
 
-    // ---- place keys (and values) in LDS in sorted-by-digit order
+    // ---- place keys in LDS in sorted-by-digit order
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
-        const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
-        const uint32_t pos = s_tstart[d] + s_whist[wave][d] + rank[j];
+        const uint32_t dd = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
+        const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
     }
-    if constexpr (HAS_V) {
+    if constexpr (HAS_V && !REUSE) {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
-            if (li < valid) s_vals[rank[j]] = vin[base + li];
+            if constexpr (EARLYV) {
+                s_vals[rank[j]] = val[j];
+            } else {
+                if (li < valid) s_vals[rank[j]] = rs_load<NTM>(vin + base + li);
+            }
         }
     }
     __syncthreads();
 
     // ---- coalesced write-out: consecutive lanes -> consecutive slots of one digit run
+    if constexpr (!REUSE) {
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const uint32_t i = j * RS_NT + tid;
-        if (i < valid) {
-            const K k = s_keys[i];
-            const uint32_t d = (uint32_t)(k >> shift) & dmask;
-            const uint64_t dst = s_gbase[d] + i;
-            kout[dst] = k;
-            if constexpr (HAS_V) vout[dst] = s_vals[i];
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = j * NT + tid;
+            if (i < valid) {
+                const K k = s_keys[i];
+                const uint32_t dd = (uint32_t)(k >> shift) & dmask;
+                const uint64_t dst = s_gbase[dd] + i;
+                rs_store<NTM>(kout + dst, k);
+                if constexpr (HAS_V) rs_store<NTM>(vout + dst, (V)s_vals[i]);
+            }
+        }
+    } else {
+        uint8_t dig[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = j * NT + tid;
+            dig[j] = 0;
+            if (i < valid) {
+                const K k = s_keys[i];
+                const uint32_t dd = (uint32_t)(k >> shift) & dmask;
+                dig[j] = (uint8_t)dd;
+                rs_store<NTM>(kout + s_gbase[dd] + i, k);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) s_vals[rank[j]] = val[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = j * NT + tid;
+            if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
         }
     }
 }
@@ -261,7 +357,7 @@ struct RadixWorkspace {
         const uint64_t tiles = ceil_div(n, (uint64_t)tile);
         if (!hist.p) hist.alloc(2 * RS_MAX_PASSES * 256 * sizeof(uint64_t));
         if (!tickets.p) {
-            tickets.alloc(257 * sizeof(uint32_t));
+            tickets.alloc(260 * sizeof(uint32_t));
             CDB_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes, s));
         }
         const size_t need = (size_t)tiles * 256 * sizeof(uint64_t);
@@ -296,19 +392,24 @@ struct SortStats {
     int passes_run = 0, passes_skipped = 0;
 };
 
-// Sorts n (key, value) pairs by key bits [begin_bit, end_bit), stable.  Buffers 0 hold the input; the
-// result ends up in buffers `return value` (0 or 1).  Passes whose digit is constant are skipped.
-template <typename K, typename V>
-int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
-               int begin_bit, int end_bit, SortStats* stats = nullptr) {
-    constexpr int IPT = RsTraits<K, V>::IPT;
-    constexpr int TILE = RS_NT * IPT;
+struct SortPlan {
+    int npass, begin_bit;
+    uint32_t last_mask;
+    std::vector<uint64_t> h_hist;
+};
+
+template <typename K, typename V, typename Cfg>
+int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
+                   int begin_bit, int end_bit, SortStats* stats, int dbits) {
+    constexpr int IPT = Cfg::IPT;
+    constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     if (n == 0 || end_bit <= begin_bit) return 0;
     const int nbits = end_bit - begin_bit;
-    const int npass = (int)ceil_div(nbits, 8);
-    if (npass > RS_MAX_PASSES) throw Error("radix_sort: more than 64 key bits requested");
-    const int last_bits = nbits - 8 * (npass - 1);
+    if (dbits < 1 || dbits > 8) dbits = 8;
+    const int npass = (int)ceil_div(nbits, dbits);
+    if (npass > RS_MAX_PASSES) throw Error("radix_sort: too many passes requested");
+    const int last_bits = nbits - dbits * (npass - 1);
     const uint32_t last_mask = (1u << last_bits) - 1u;
     ws.prepare(n, TILE, s);
 
@@ -319,7 +420,7 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
         const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16), 256 * 8);
         int t = prof.begin(s);
         hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(256), 0, s, (const K*)k0, n, begin_bit, npass,
-                           last_mask, d_hist);
+                           dbits, last_mask, d_hist);
         prof.end(t, "rs_hist", n * sizeof(K), s);
     }
     hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
@@ -340,10 +441,10 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             continue;
         }
         const uint32_t e = ws.next_epoch(s);
-        const uint32_t dmask = p == npass - 1 ? last_mask : 0xFFu;
+        const uint32_t dmask = p == npass - 1 ? last_mask : ((1u << dbits) - 1u);
         int t = prof.begin(s);
-        hipLaunchKernelGGL((rs_onesweep_kernel<K, V, IPT>), dim3(tiles), dim3(RS_NT), 0, s, (const K*)kb[cur],
-                           kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, begin_bit + 8 * p, dmask,
+        hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg>), dim3(tiles), dim3(Cfg::NT), 0, s, (const K*)kb[cur],
+                           kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, begin_bit + dbits * p, dmask,
                            (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
                            ws.ticket_ptr(e), e, ws.err_ptr());
         prof.end(t, rs_kernel_name<K, V>(), 2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
@@ -354,6 +455,44 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
     return cur;
 }
 
+// Sorts n (key, value) pairs by key bits [begin_bit, end_bit), stable.  Buffers 0 hold the input; the
+// result ends up in buffers `return value` (0 or 1).  Passes whose digit is constant are skipped.
+// `variant` selects a kernel configuration (0 = the tuned default; others exist for A/B measurements).
+template <typename K, typename V>
+int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
+               int begin_bit, int end_bit, SortStats* stats = nullptr, int variant = 0, int dbits = 8) {
+    constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    if constexpr (!HAS_V) {
+        return radix_sort_cfg<K, V, RsCfg<16, false, false>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits);
+    } else {
+        // variant 0 picks by size: big tiles (16 Ki keys, one workgroup per CU) give the longest per-digit
+        // runs and therefore the best-coalesced scatter, but need >= a few hundred tiles to fill 256 CUs
+        if (variant == 0) variant = n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1);
+#define CDB_RS(...) return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits)
+        switch (variant) {
+            // production configurations: IPT, REUSE, EARLYV, NT, NONTEMP, MINW, ABL, LB
+            default:
+            case 21: CDB_RS(16, true, true, 1024, false, 1, 0, 4);   // 16 Ki-key tile, 1 WG/CU
+            case 26: CDB_RS(18, true, true, 256, false, 1, 0, 4);    // 4.5 Ki-key tile, 3 WG/CU
+            case 1: CDB_RS(15, true, true, 256, false, 1, 0, 1);     // 3.75 Ki-key tile, 4 WG/CU
+            // kept for A/B measurements (tools/sort_bench.py, profiles/): earlier design points
+            case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);   // round-1 first version
+            case 3: CDB_RS(18, true, true, 256, false, 1, 0, 1);
+            case 7: CDB_RS(12, true, true, 512, false, 1, 0, 1);
+            case 11: CDB_RS(16, true, true, 1024, false, 1, 0, 1);
+            case 12: CDB_RS(16, true, true, 512, false, 4, 0, 1);
+            case 22: CDB_RS(16, true, true, 1024, false, 1, 0, 8);
+            case 10: CDB_RS(18, true, true, 256, true, 1, 0, 1);     // non-temporal loads/stores
+            // timing-only ablations (results are WRONG by construction; never used by the product path)
+            case 101: CDB_RS(16, true, true, 1024, false, 1, 1, 1);  // no look-back
+            case 102: CDB_RS(16, true, true, 1024, false, 1, 2, 1);  // linear write-out
+            case 103: CDB_RS(16, true, true, 1024, false, 1, 3, 1);  // both
+            case 114: CDB_RS(16, true, true, 1024, false, 1, 8, 4);  // look-back depth counters
+        }
+#undef CDB_RS
+    }
+}
+
 // throws if any look-back spin hit its bound (the sort result is then garbage)
 inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
     if (!ws.tickets.p) return;
@@ -361,6 +500,11 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
     CDB_HIP(hipMemcpyAsync(&e, ws.err_ptr(), sizeof(e), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
     if (e) throw Error("radix sort look-back timed out (internal error)");
+    if (getenv("CDB_LOOKBACK_STATS")) {
+        uint32_t c[3] = {0, 0, 0};
+        CDB_HIP(hipMemcpy(c, ws.err_ptr(), sizeof(c), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[lookback] consumed=%u round_trips=%u\n", c[1], c[2]);
+    }
 }
 
 }  // namespace cdb

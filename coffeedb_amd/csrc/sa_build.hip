@@ -312,11 +312,21 @@ void build_typed(Index& ix) {
     const int symbits = std::max(1, bit_width64((uint64_t)sigma));
     CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
 
-    int passes = ix.initial_passes > 0 ? ix.initial_passes : (int)ceil_div(bit_width64(n) + 24, 8);
+    int passes = ix.initial_passes > 0 ? ix.initial_passes : (int)ceil_div(bit_width64(n) + 12, 8);
     passes = std::min(std::max(passes, 1), 8);
     int nsym = std::min((8 * passes) / symbits, 64 / symbits);
     nsym = std::min(std::max(nsym, 1), KG_LOOK);
     const int key_bits = nsym * symbits;
+    // digit width of the initial sort: whole symbols per digit when that costs no extra pass — the
+    // digit then takes at most alphabet+1 values, which lengthens the per-digit runs of a tile
+    // (better write coalescing) for small alphabets such as ASCII text
+    int dbits = 8;
+    if (symbits <= 8) {
+        const int dsym = 8 / symbits;
+        if ((int)ceil_div(nsym, dsym) <= (int)ceil_div(key_bits, 8)) dbits = dsym * symbits;
+    }
+    if (ix.digit_bits > 0) dbits = ix.digit_bits;
+    st.digit_bits = dbits;
     st.key_symbols = nsym;
     st.symbol_bits = symbits;
     st.alphabet = sigma;
@@ -341,7 +351,7 @@ void build_typed(Index& ix) {
     // ---- 3. initial sort
     SortStats ss;
     const int sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(),
-                                            vals[0].as<V>(), vals[1].as<V>(), n, 0, key_bits, &ss);
+                                            vals[0].as<V>(), vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits);
     {
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
@@ -414,7 +424,7 @@ void build_typed(Index& ix) {
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
         const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
-                                               sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss);
+                                               sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss, ix.sort_variant);
         hipLaunchKernelGGL((sa_newhead_kernel<I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                            (const uint64_t*)skey[rs].as<uint64_t>(), (const I*)U.as<I>(),
                            (const uint8_t*)flags.as<uint8_t>(), m, nh.as<uint8_t>());

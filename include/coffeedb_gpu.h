@@ -11,6 +11,10 @@
  * and uses the reference's own wording where the reference throws (index.cpp:196,199,240).
  * A handle may be used from several host threads at once for queries (reference contract:
  * query() is const and runs under a shared lock, database.cpp:388); build is exclusive.
+ * Device pointers handed to the *_device entry points must hold complete data when the call is made:
+ * the library works on its own non-blocking HIP stream and does not wait for the caller's streams
+ * (callers synchronise first, e.g. torch.cuda.synchronize()); every entry point returns only after its
+ * own device work has finished.
  */
 #ifndef COFFEEDB_GPU_H
 #define COFFEEDB_GPU_H
@@ -114,7 +118,8 @@ int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes);
 /* ---- options & measurements -------------------------------------------------------------------- */
 /* name: "profile" (0/1: time kernels with HIP events), "reference_compat" (0/1: reproduce the
  * reference's signed-char bucket order for bytes >= 0x80), "initial_passes" (radix
- * passes of the initial key sort, 0 = automatic), "force_doubling" (0/1). */
+ * passes of the initial key sort, 0 = automatic), "force_doubling" (0/1), "sort_variant" (radix kernel
+ * configuration, 0 = default). */
 int cdb_set_option(cdb_index* h, const char* name, int64_t value);
 
 /* statistic by name: "build_ms", "rounds", "unresolved_after_initial", "sort_passes", "isa_built",
@@ -133,6 +138,13 @@ void cdb_profile_reset(cdb_index* h);
  * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size. */
 void cdb_release_cached_memory(void);
 uint64_t cdb_cached_memory_bytes(void);
+
+/* Test hook for the radix-sort primitive (tests/test_gpu_sort.py, tools/sort_bench.py): stable sort of
+ * n 64-bit keys (+ optional 4- or 8-byte values, val_bytes = 0/4/8) held in DEVICE memory by key bits
+ * [0, key_bits), in place.  variant = kernel configuration (0 = default).  Reports the summed HIP-event
+ * time of the onesweep launches and how many passes ran. */
+int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int val_bytes, int key_bits,
+                         int variant, double* onesweep_ms, int* passes);
 
 #ifdef __cplusplus
 }

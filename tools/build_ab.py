@@ -1,0 +1,27 @@
+"""A/B of SA-build options on the C1 corpus (one process, interleaved): sort kernel variant, digit width."""
+import sys, os, time, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from coffeedb_amd import capi, workloads as W
+
+nd = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 3, 7, 11]
+dbits_list = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 8]
+dl = 1024
+text = W.random_bytes_torch(nd * dl, 12345, device="cuda")
+ds = W.uniform_docs(nd, dl); ids = np.arange(nd, dtype=np.int64)
+torch.cuda.synchronize()
+g = capi.GpuStringIndex(); g.set_option("profile", 1)
+res = {}
+for rnd in range(3):
+    for v, db in itertools.product(variants, dbits_list):
+        g.set_option("sort_variant", v); g.set_option("digit_bits", db)
+        g.profile_reset()
+        g.build_device(text.data_ptr(), ds, ids)
+        p = g.profile()
+        os_ = p["rs_onesweep_k64_v32"]
+        res.setdefault((v, db), []).append((g.stat("build_ms"), os_["ms"], os_["bytes"], g.stat("sort_passes"), g.stat("digit_bits"), g.stat("unresolved_after_initial")))
+for k, r in res.items():
+    b = sorted(x[0] for x in r[1:])[0]
+    o = min(r[1:], key=lambda x: x[1])
+    print(f"variant {k[0]:2d} digit_bits {k[1]} (used {o[4]:.0f}): build {b:7.2f} ms = {nd*dl/2**30/(b*1e-3):6.2f} GiB/s | onesweep {o[1]:7.2f} ms {o[2]/(o[1]*1e-3)/1e9:6.0f} GB/s passes {o[3]:.0f} unres0 {o[5]:.0f}")
