@@ -1,0 +1,94 @@
+// index.h — drop-in replacement for CoffeeDB's src/index.h (reference /root/reference/src/index.h:1-87).
+//
+// Same five classes, same public members, same `number` type tags (index.h:29,37,47,76 — they are the
+// on-disk type bytes read by database.cpp:200-245), so the reference's database.cpp compiles and runs
+// unchanged against this header:
+//     std::make_unique<string_index>()              database.cpp:255, :303
+//     dynamic_cast<string_index*>(ptr)->add(id, v)  database.cpp:257-264, :147
+//     indices[key]->build() / ->query(range)        database.cpp:277, :392  (through `index*`)
+// Only string_index changed: it no longer owns a CPU suffix array but a handle of the MI355X library
+// (include/coffeedb_gpu.h).  bool/integer/double indexes keep the reference's behaviour.
+#ifndef INDEX_GUARD
+#define INDEX_GUARD
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+struct cdb_index;  // opaque GPU index (include/coffeedb_gpu.h)
+
+class index {
+public:
+    using result_type = std::vector<std::pair<int64_t, int64_t>>;
+    index() = default;
+    index(const index&) = delete;
+    index(index&&) = delete;
+    index& operator=(const index&) = delete;
+    index& operator=(index&&) = delete;
+    virtual result_type query(const std::string& range) const;  // throws std::logic_error (index.h:16-18)
+    virtual void build();                                        // throws std::logic_error (index.h:19-21)
+    virtual ~index() = default;
+};
+
+class bool_index : public index {
+public:
+    using value_type = bool;
+    static constexpr int8_t number = 0;
+    void add(int64_t id, bool value);
+    void build() override;
+    result_type query(const std::string& range) const override;
+
+private:
+    std::array<std::vector<int64_t>, 2> data;
+};
+
+class integer_index : public index {
+public:
+    using value_type = int64_t;
+    static constexpr int8_t number = 1;
+    void add(int64_t id, int64_t value);
+    void build() override;
+    result_type query(const std::string& range) const override;
+
+private:
+    std::vector<std::pair<value_type, int64_t>> data;
+};
+
+class double_index : public index {
+public:
+    using value_type = double;
+    static constexpr int8_t number = 2;
+    void add(int64_t id, double value);
+    void build() override;
+    result_type query(const std::string& range) const override;
+
+private:
+    std::vector<std::pair<value_type, int64_t>> data;
+};
+
+class string_index : public index {
+public:
+    using value_type = std::string;
+    static constexpr int8_t number = 3;
+    string_index();
+    ~string_index() override;
+    // index.cpp:174-177.  The bytes are copied (the GPU build uploads them); the caller's string may
+    // be released afterwards, which is weaker than what the reference requires of database.cpp.
+    void add(int64_t id, std::string_view value);
+    // index.cpp:178-236: suffix-array construction, now on the GPU.  Throws std::runtime_error with
+    // the reference's messages for the capacity limits (index.cpp:196,199).
+    void build() override;
+    // index.cpp:237-326: (object id, occurrence count) per matching document, ascending insertion
+    // order.  Throws std::runtime_error("Empty keywords are not allowed") for "" (index.cpp:239-241).
+    result_type query(const std::string& keyword) const override;
+    // Batched form used by callers that resolve many keywords at once (interface.cpp:79-113 loops
+    // query() per keyword): one result list per keyword, same contents as query().
+    std::vector<result_type> query_batch(const std::vector<std::string>& keywords) const;
+
+private:
+    cdb_index* handle = nullptr;
+};
+#endif

@@ -1,0 +1,31 @@
+"""The reference-side C++ binding (coffeedb_amd/csrc/shim/index.{h,cpp}): compiled against the C ABI and
+driven the way the reference's database.cpp drives its indexes."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _build():
+    from coffeedb_amd import capi
+    capi.build_library()
+    subprocess.check_call(["make", "-C", CPP, "test_index_shim"], stdout=subprocess.DEVNULL)
+    return os.path.join(CPP, "test_index_shim")
+
+
+def test_shim_compiles_and_numeric_indexes_behave():
+    exe = _build()
+    out = subprocess.run([exe, "numeric"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_string_index_on_gpu():
+    exe = os.path.join(CPP, "test_index_shim")
+    if not os.path.exists(exe):
+        exe = _build()
+    out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
