@@ -39,37 +39,16 @@ class _DevArr:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def merge_shard_results(torch, dist, r, npat, world, rank, device):
-    """All-gather merge of per-shard CSR match lists (rows of one pattern: shard 0's docs, then shard
-    1's, ... — already ascending in global document index because shards are doc-aligned ranges)."""
+def merge_on_device(torch, dist, shard, r, npat, world, device):
+    """Wraps the library's device-resident CSR of this shard and merges it across ranks over RCCL."""
     nrows = int(r.nrows)
     row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
-    cnt = (row_ptr[1:] - row_ptr[:-1]).contiguous()
-    all_cnt = torch.empty(world, npat, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(all_cnt, cnt)
-    rows_per_rank = all_cnt.sum(1)
-    maxrows = max(int(rows_per_rank.max().item()), 1)
-    pad = torch.zeros(2, maxrows, dtype=torch.int64, device=device)
     if nrows:
-        pad[0, :nrows] = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=device)
-        pad[1, :nrows] = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
-    allrows = torch.empty(world, 2, maxrows, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(allrows, pad)
-    total = all_cnt.sum(0)
-    g_row_ptr = torch.zeros(npat + 1, dtype=torch.int64, device=device)
-    torch.cumsum(total, 0, out=g_row_ptr[1:])
-    before = torch.cumsum(all_cnt, 0) - all_cnt  # rows of earlier shards, per pattern
-    out = torch.empty(2, int(g_row_ptr[-1].item()), dtype=torch.int64, device=device)
-    pats = torch.arange(npat, device=device)
-    for q in range(world):
-        nq = int(rows_per_rank[q].item())
-        if nq == 0:
-            continue
-        pat = torch.repeat_interleave(pats, all_cnt[q])
-        rp_q = torch.cumsum(all_cnt[q], 0) - all_cnt[q]
-        dest = g_row_ptr[pat] + before[q][pat] + (torch.arange(nq, device=device) - rp_q[pat])
-        out[:, dest] = allrows[q, :, :nq]
-    return g_row_ptr, out
+        ids = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=device)
+        cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
+    else:
+        ids = cnt = torch.empty(0, dtype=torch.int64, device=device)
+    return shard.merge_shard_results(torch, dist, row_ptr, ids, cnt, world)
 
 
 def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
@@ -128,7 +107,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from coffeedb_amd import capi, workloads as W
+    from coffeedb_amd import capi, shard, workloads as W
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X GPU (the HIP path has no CPU fallback)")
@@ -173,7 +152,7 @@ def main():
         r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
         tq = g.stat("query_ms")
         if world > 1:
-            merge_shard_results(torch, dist, r, npat, world, rank, device)
+            merge_on_device(torch, dist, shard, r, npat, world, device)
         return tb, tq, int(r.nhits), int(r.nrows)
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them

@@ -312,7 +312,8 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
         {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
-        {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth},
+        {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
+        {"compat_depth", (double)b.compat_depth},
         {"query_ms", q.query_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
     };
     for (auto& e : tab)

@@ -23,6 +23,7 @@ struct BuildStats {
     int isa_built = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
+    uint64_t compat_rotations = 0, compat_depth = 0;  // reference_compat pass (bytes >= 0x80)
 };
 
 struct QueryStats {
@@ -59,7 +60,7 @@ struct Index {
     DevBuf q_pat, q_offs, q_left, q_right, q_hoff, q_keys0, q_keys1, q_flags, q_rowptr, q_ids, q_counts;
 
     // ---- options
-    bool reference_compat = false;
+    bool reference_compat = true;   // bit-parity with the reference also for bytes >= 0x80
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;

@@ -265,6 +265,92 @@ struct IsaOut {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// reference-compatible ordering for text with bytes >= 0x80
+// ---------------------------------------------------------------------------------------------
+// The reference buckets radix nodes by `(int)char - CHAR_MIN + 1` with a SIGNED char (index.h:72), so
+// while a bucket holds more than chuck_size suffixes its children are laid out
+//     [end of document][bytes 0x80..0xFF][bytes 0x00..0x7F]
+// whereas leaves (<= chuck_size, index.cpp:86-95) and both binary searches compare unsigned.  Given the
+// plain unsigned order built above, the reference's order is reached by rotating the two byte blocks
+// of every "big" bucket, level by level down the trie.  compat_bounds_kernel finds, for one big bucket
+// at depth `depth`, where each of the 257 unsigned symbols starts (the bucket is sorted by that symbol).
+struct CompatBucket {
+    unsigned long long lo, hi;
+};
+
+template <typename V>
+__global__ __launch_bounds__(320) void compat_bounds_kernel(const V* __restrict__ sa,
+                                                            const uint8_t* __restrict__ text,
+                                                            const uint64_t* __restrict__ doc_start, int bits,
+                                                            uint64_t mask, const CompatBucket* __restrict__ buckets,
+                                                            uint64_t depth, unsigned long long* __restrict__ bounds) {
+    const int c = threadIdx.x;  // symbol 0 = end of document, 1..256 = byte + 1; 257 = one past
+    if (c > 257) return;
+    const CompatBucket b = buckets[blockIdx.x];
+    uint64_t lo = b.lo, hi = b.hi;
+    if (c == 257) {
+        bounds[(uint64_t)blockIdx.x * 258 + c] = b.hi;
+        return;
+    }
+    while (lo < hi) {  // first slot whose symbol at `depth` is >= c
+        const uint64_t mid = lo + (hi - lo) / 2;
+        const V e = sa[mid];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t p = doc_start[d] + off + depth;
+        const uint32_t sym = p == doc_start[d + 1] ? 0u : (uint32_t)text[p] + 1u;
+        if (sym < (uint32_t)c) lo = mid + 1; else hi = mid;
+    }
+    bounds[(uint64_t)blockIdx.x * 258 + c] = lo;
+}
+
+template <typename V>
+void apply_reference_order(Index& ix, V* sa) {
+    hipStream_t s = ix.stream;
+    const uint64_t n = ix.size;
+    const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
+    std::vector<CompatBucket> level{{0ull, (unsigned long long)n}};
+    if (n <= chuck) return;
+    DevBuf d_buckets, d_bounds, tmp;
+    uint64_t depth = 0;
+    while (!level.empty()) {
+        const size_t nb = level.size();
+        d_buckets.ensure(nb * sizeof(CompatBucket));
+        d_bounds.ensure(nb * 258 * sizeof(uint64_t));
+        CDB_HIP(hipMemcpyAsync(d_buckets.p, level.data(), nb * sizeof(CompatBucket), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL((compat_bounds_kernel<V>), dim3((unsigned)nb), dim3(320), 0, s, (const V*)sa, ix.d_text,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const CompatBucket*)d_buckets.as<CompatBucket>(), depth,
+                           d_bounds.as<unsigned long long>());
+        std::vector<unsigned long long> hb(nb * 258);
+        CDB_HIP(hipMemcpyAsync(hb.data(), d_bounds.p, hb.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        std::vector<CompatBucket> next;
+        for (size_t b = 0; b < nb; ++b) {
+            const unsigned long long* bd = &hb[b * 258];
+            const uint64_t a0 = bd[1], b0 = bd[129], end = bd[257];  // [a0,b0) = 0x00..0x7F, [b0,end) = 0x80..0xFF
+            const uint64_t lenA = b0 - a0, lenB = end - b0;
+            if (lenA && lenB) {
+                tmp.ensure((lenA + lenB) * sizeof(V));
+                CDB_HIP(hipMemcpyAsync(tmp.p, sa + a0, (lenA + lenB) * sizeof(V), hipMemcpyDeviceToDevice, s));
+                CDB_HIP(hipMemcpyAsync(sa + a0, tmp.as<V>() + lenA, lenB * sizeof(V), hipMemcpyDeviceToDevice, s));
+                CDB_HIP(hipMemcpyAsync(sa + a0 + lenB, tmp.p, lenA * sizeof(V), hipMemcpyDeviceToDevice, s));
+                ix.bstats.compat_rotations++;
+            }
+            for (int v = 0; v < 256; ++v) {
+                const uint64_t len = bd[v + 2] - bd[v + 1];
+                if (len <= chuck) continue;
+                const uint64_t start = v >= 128 ? a0 + (bd[v + 1] - b0) : a0 + lenB + (bd[v + 1] - a0);
+                next.push_back(CompatBucket{(unsigned long long)start, (unsigned long long)(start + len)});
+            }
+        }
+        level.swap(next);
+        ++depth;
+    }
+    ix.bstats.compat_depth = depth;
+    CDB_HIP(hipStreamSynchronize(s));
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -308,7 +394,11 @@ void build_typed(Index& ix) {
     CDB_HIP(hipStreamSynchronize(s));
     uint16_t h_map[256];
     int sigma = 0;
-    for (int b = 0; b < 256; ++b) h_map[b] = h_present[b] ? (uint16_t)(++sigma) : (uint16_t)0;
+    bool high_bytes = false;
+    for (int b = 0; b < 256; ++b) {
+        h_map[b] = h_present[b] ? (uint16_t)(++sigma) : (uint16_t)0;
+        if (b >= 128 && h_present[b]) high_bytes = true;
+    }
     const int symbits = std::max(1, bit_width64((uint64_t)sigma));
     CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
 
@@ -455,6 +545,7 @@ void build_typed(Index& ix) {
     st.sort_passes_skipped = ss.passes_skipped;
     radix_check_error(s, ix.rws);
     CDB_HIP(hipStreamSynchronize(s));
+    if (ix.reference_compat && high_bytes) apply_reference_order<V>(ix, sa);
     ix.d_sa = std::move(vals[sel]);
 }
 

@@ -1,0 +1,63 @@
+"""Multi-GPU sharding of the string index.
+
+Suffixes never cross document boundaries (reference src/index.h:61-65) and a result row belongs to
+exactly one document (src/index.cpp:317-321), so the corpus is split into doc-aligned byte ranges, one
+independent suffix array per GPU.  Every shard answers the whole (broadcast) pattern batch for its
+documents; the per-shard CSR match lists are merged with all-gathers over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Concatenating the rows of a
+pattern in shard order is already ascending in global document index — no reduction is needed.
+"""
+import numpy as np
+
+
+def shard_bounds(doc_start, world):
+    """Doc-aligned split into `world` contiguous ranges balanced by bytes.
+    Returns doc indices b[0..world] with shard r = docs [b[r], b[r+1])."""
+    doc_start = np.asarray(doc_start, dtype=np.uint64)
+    nd = len(doc_start) - 1
+    total = int(doc_start[-1])
+    b = [0]
+    for r in range(1, world):
+        target = total * r // world
+        d = int(np.searchsorted(doc_start, np.uint64(target), side="left"))
+        b.append(min(max(d, b[-1]), nd))
+    b.append(nd)
+    return b
+
+
+def merge_shard_results(torch, dist, row_ptr, ids, counts, world):
+    """All-gather merge of per-shard CSR results.
+
+    row_ptr: int64[npat+1], ids/counts: int64[nrows] of THIS shard (torch tensors on the collective's
+    device).  Returns (global_row_ptr int64[npat+1], global_ids, global_counts), identical on every rank.
+    """
+    device = row_ptr.device
+    npat = row_ptr.numel() - 1
+    nrows = int(ids.numel())
+    cnt = (row_ptr[1:] - row_ptr[:-1]).contiguous()
+    cnt_list = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnt_list, cnt)
+    all_cnt = torch.stack(cnt_list)                      # [world, npat]
+    rows_per_rank = all_cnt.sum(1)
+    maxrows = max(int(rows_per_rank.max().item()), 1)
+    pad = torch.zeros(2, maxrows, dtype=torch.int64, device=device)
+    if nrows:
+        pad[0, :nrows] = ids
+        pad[1, :nrows] = counts
+    pad_list = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(pad_list, pad)                       # all-gatherv via padding to the longest list
+    total = all_cnt.sum(0)
+    g_row_ptr = torch.zeros(npat + 1, dtype=torch.int64, device=device)
+    torch.cumsum(total, 0, out=g_row_ptr[1:])
+    before = torch.cumsum(all_cnt, 0) - all_cnt          # rows of earlier shards, per pattern
+    out = torch.empty(2, int(g_row_ptr[-1].item()), dtype=torch.int64, device=device)
+    pats = torch.arange(npat, device=device)
+    for q in range(world):
+        nq = int(rows_per_rank[q].item())
+        if nq == 0:
+            continue
+        pat = torch.repeat_interleave(pats, all_cnt[q])
+        rp_q = torch.cumsum(all_cnt[q], 0) - all_cnt[q]
+        dest = g_row_ptr[pat] + before[q][pat] + (torch.arange(nq, device=device) - rp_q[pat])
+        out[:, dest] = pad_list[q][:, :nq]
+    return g_row_ptr, out[0], out[1]

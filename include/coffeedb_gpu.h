@@ -116,8 +116,10 @@ int cdb_sa_width(const cdb_index* h);   /* 4 or 8 bytes per entry; 0 before buil
 int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes);
 
 /* ---- options & measurements -------------------------------------------------------------------- */
-/* name: "profile" (0/1: time kernels with HIP events), "reference_compat" (0/1: reproduce the
- * reference's signed-char bucket order for bytes >= 0x80), "initial_passes" (radix
+/* name: "profile" (0/1: time kernels with HIP events), "reference_compat" (default 1: reproduce the
+ * reference's signed-char bucket order for text with bytes >= 0x80 — SURVEY.md Q2 — so that the suffix
+ * array and the (then partly wrong) counts are bit-identical to the reference's; 0 = plain unsigned
+ * order with true counts; no effect and no cost on pure-ASCII text), "initial_passes" (radix
  * passes of the initial key sort, 0 = automatic), "force_doubling" (0/1), "sort_variant" (radix kernel
  * configuration, 0 = default). */
 int cdb_set_option(cdb_index* h, const char* name, int64_t value);

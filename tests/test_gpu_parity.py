@@ -181,11 +181,11 @@ def test_many_hits_single_char_patterns(G):
 
 
 def test_high_bytes_native_order_matches_brute_force(G):
-    # bytes >= 0x80: the GPU index sorts in plain unsigned order, so its counts are the true counts
-    # (the reference's own answers are wrong here — SURVEY.md Q2; compat mode is tested separately)
+    # reference_compat = 0: plain unsigned order, so counts are the TRUE counts (the reference's own
+    # answers are wrong for bytes >= 0x80 — SURVEY.md Q2)
     from oracle import brute_count
     blob, ds = W.ascii_corpus(500, 64, seed=21, lo=0x00, hi=0xFF)
-    g = _gpu(G, blob, ds, np.arange(500, dtype=np.int64))
+    g = _gpu(G, blob, ds, np.arange(500, dtype=np.int64), reference_compat=0)
     sa = g.sa()
     txt = blob.tobytes()
     suf = [txt[int(ds[int(e & g.mask)]) + int(e >> g.bits):int(ds[int(e & g.mask) + 1])] for e in sa[:4000]]
@@ -195,6 +195,37 @@ def test_high_bytes_native_order_matches_brute_force(G):
         kw = bytes(pb[int(po[j]):int(po[j + 1])])
         want = brute_count(blob, ds, kw)
         assert dict(g.query(kw)) == {int(d): int(want[d]) for d in np.nonzero(want)[0]}
+
+
+def _few_symbols(n, seed, alphabet):
+    r = W.random_bytes(n, seed, 0, len(alphabet) - 1)
+    return np.asarray(alphabet, dtype=np.uint8)[r]
+
+
+def test_reference_compat_bit_parity_high_bytes(G):
+    # default mode: the reference's signed-bucket / unsigned-leaf order is reproduced exactly, so the
+    # suffix array AND the (partly wrong) counts equal the reference's (oracle restates index.h:66-73)
+    # (a) uniform random bytes 0..255 — one level of big buckets
+    blob, ds = W.ascii_corpus(600, 64, seed=21, lo=0x00, hi=0xFF)
+    pats = W.sample_patterns(blob, ds, 300, 1, 3, seed=2, miss_frac=0)
+    g, o = _check_parity(G, blob, ds, patterns=pats)
+    assert o.inversions() > 0 and g.stat("compat_rotations") >= 1
+    # (b) four symbols (two of them >= 0x80, like the UTF-8 bytes of 'é'): big buckets many levels deep
+    blob = _few_symbols(400000, 5, [0x41, 0x42, 0xC3, 0xA9])
+    ds = W.uniform_docs(4000, 100)
+    pats = W.sample_patterns(blob, ds, 300, 1, 8, seed=4, miss_frac=0)
+    g, o = _check_parity(G, blob, ds, patterns=pats)
+    assert g.stat("compat_depth") >= 3 and g.stat("compat_rotations") > 4
+    # (c) the same through the prefix-doubling path
+    _check_parity(G, blob, ds, patterns=pats, force_doubling=1)
+    # (d) valid UTF-8 documents of ragged length (BASELINE config 4 shape, scaled down)
+    blob, ds = W.utf8_corpus(300, 120, seed=4)
+    pats = W.sample_patterns(blob, ds, 200, 1, 6, seed=6, miss_frac=0)
+    _check_parity(G, blob, ds, patterns=pats)
+    # (e) below the radix threshold (n <= 4096) the reference is one comparison-sorted leaf
+    blob, ds = W.ascii_corpus(40, 64, seed=21, lo=0x00, hi=0xFF)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 50, 1, 2, seed=1, miss_frac=0))
+    assert g.stat("compat_rotations") == 0 and o.inversions() == 0
 
 
 def test_concurrent_queries_same_handle(G):
