@@ -119,11 +119,48 @@ template <bool NT_, typename T> __device__ __forceinline__ void rs_store(T* p, T
     else *p = v;
 }
 
-template <typename K, typename V, typename Cfg>
+// Optional producer for the FIRST pass of the suffix-array sort: instead of reading (key, entry) pairs
+// that a separate kernel would have to write first, the pass computes them from the text on the fly —
+// key = the suffix's first `nsym` symbol codes (0 = end of document), entry = (off << bits) | doc.
+// Saves one write and one read of 8+w bytes per suffix plus the key read of the histogram kernel.
+struct NoGen {};
+struct TextGen {
+    const uint8_t* text;
+    const uint64_t* doc_start;
+    const uint16_t* symmap;
+    uint64_t ndocs;
+    int bits, symbits, nsym;
+    bool padded;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
+    const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
+};
+constexpr int RS_GEN_LOOK = 64;
+
+__device__ __forceinline__ uint64_t rs_doc_upper(const uint64_t* __restrict__ doc_start, uint64_t lo, uint64_t hi,
+                                                 uint64_t p) {
+    while (lo < hi) {  // largest d in [lo, hi] with doc_start[d] <= p
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (doc_start[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// document holding the first position of every tile (tile_doc[tiles] = the last document): turns the
+// two ~log2(D)-step searches per tile into one parallel pre-pass
+static __global__ __launch_bounds__(256) void rs_tiledoc_kernel(const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                                uint64_t n, uint64_t tile_elems, uint64_t tiles,
+                                                                uint64_t* __restrict__ tile_doc) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t > tiles) return;
+    const uint64_t p = t * tile_elems < n ? t * tile_elems : n - 1;
+    tile_doc[t] = rs_doc_upper(doc_start, 0, ndocs - 1, p);
+}
+
+template <typename K, typename V, typename Cfg, typename Gen = NoGen>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
-    uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err) {
+    uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen()) {
+    constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr int IPT = Cfg::IPT;
     constexpr bool REUSE = Cfg::REUSE && HAS_V;
@@ -159,16 +196,104 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     K key[IPT];
     VS val[EARLYV ? IPT : 1];
     const uint32_t wbase = wave * WCHUNK + lane;
+    if constexpr (GEN) {
+        static_assert(!GEN || (EARLYV && sizeof(K) == 8), "generator pass needs early values and 64-bit keys");
+        static_assert(!GEN || STAGE_BYTES >= (size_t)TILE + RS_GEN_LOOK + 2048, "staging buffer too small for the text tile");
+        // stage the text of this tile (+ look-ahead) in the still unused LDS staging buffer
+        uint8_t* s_text = s_stage;
+        uint16_t* s_map = reinterpret_cast<uint16_t*>(s_stage + ((TILE + RS_GEN_LOOK + 15) / 16) * 16);
+        // document boundaries of this tile, copied to LDS when they fit (binary searches then cost
+        // LDS instead of L2 latency); s_docs[i] = doc_start[dlo + i]
+        constexpr uint32_t DOC_OFF = ((TILE + RS_GEN_LOOK + 15) / 16) * 16 + 512;
+        constexpr uint32_t DOC_CAP = (uint32_t)((STAGE_BYTES - DOC_OFF) / 8);
+        uint64_t* s_docs = reinterpret_cast<uint64_t*>(s_stage + DOC_OFF);
+        const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
+        const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOC_CAP;
+        if (docs_in_lds)
+            for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
+        for (int i = tid; i < 256; i += NT) s_map[i] = gen.symmap[i];
+        for (uint32_t i = tid * 16; i < (uint32_t)TILE + RS_GEN_LOOK; i += NT * 16) {
+            const uint64_t g = base + i;
+            if (gen.padded ? (g < n + RS_GEN_LOOK) : (g + 16 <= n)) {
+                *reinterpret_cast<uint4*>(&s_text[i]) = *reinterpret_cast<const uint4*>(gen.text + g);
+            } else {
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const uint32_t li = wbase + j * 64;
-        key[j] = li < valid ? rs_load<NTM>(kin + base + li) : (K)~(K)0;
-    }
-    if constexpr (EARLYV) {
+                for (int b = 0; b < 16; ++b) s_text[i + b] = (g + b < n) ? gen.text[g + b] : (uint8_t)0;
+            }
+        }
+        __syncthreads();
+        // translate the staged bytes to symbol codes in place: one table lookup per text byte instead
+        // of one per (suffix, symbol)
+        for (uint32_t i = tid * 16; i < (uint32_t)TILE + RS_GEN_LOOK; i += NT * 16) {
+            uint4 w = *reinterpret_cast<const uint4*>(&s_text[i]);
+            uint32_t x[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                x[q] = (uint32_t)s_map[x[q] & 0xFF] | ((uint32_t)s_map[(x[q] >> 8) & 0xFF] << 8) |
+                       ((uint32_t)s_map[(x[q] >> 16) & 0xFF] << 16) | ((uint32_t)s_map[x[q] >> 24] << 24);
+            *reinterpret_cast<uint4*>(&s_text[i]) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        __syncthreads();
+        uint64_t d = dlo;
+        uint64_t dend = 0;  // doc_start[d + 1] of the current document (0 = not looked up yet)
+        const int nsym = gen.nsym, symbits = gen.symbits;
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
-            val[j] = li < valid ? rs_load<NTM>(vin + base + li) : VS(0);
+            key[j] = (K)~(K)0;
+            val[j] = VS(0);
+            if (li < valid) {
+                const uint64_t p = base + li;
+                // positions of one thread ascend by 64: usually the same or the next document
+                if (dend == 0 || p >= dend) {
+                    if (docs_in_lds) {
+                        d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
+                        dend = s_docs[d - dlo + 1];
+                    } else {
+                        d = rs_doc_upper(gen.doc_start, d, dhi, p);
+                        dend = gen.doc_start[d + 1];
+                    }
+                }
+                const uint64_t ds = docs_in_lds ? s_docs[d - dlo] : gen.doc_start[d];
+                const uint64_t rem = dend - p;
+                // the codes of positions li .. li+15 as two 64-bit windows (aligned dword reads)
+                const uint32_t wi = li >> 2, sh = (li & 3u) * 8u;
+                const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+                uint64_t lo8 = ((uint64_t)w1 << 32) | w0, hi8 = 0;  // codes of li&~3 .. +7
+                if (nsym > 8) {
+                    const uint32_t w3 = s_words[wi + 3], w4 = s_words[wi + 4];
+                    hi8 = ((uint64_t)w3 << 32) | w2;
+                    if (sh) hi8 = (hi8 >> sh) | ((uint64_t)w4 << (64 - sh));
+                }
+                if (sh) lo8 = (lo8 >> sh) | ((uint64_t)w2 << (64 - sh));  // drop li&3 bytes, refill from the next word
+                uint64_t kk = 0;
+                for (int q = 0; q < nsym; ++q) {
+                    const uint64_t c = q < 8 ? (lo8 >> (8 * q)) & 0xFF : (hi8 >> (8 * (q - 8))) & 0xFF;
+                    kk = (kk << symbits) | c;
+                }
+                // symbols at or behind the end of the document count as 0 ("end"): clear them
+                if (rem < (uint64_t)nsym) {
+                    const int drop = (nsym - (int)rem) * symbits;
+                    kk = (kk >> drop) << drop;
+                }
+                key[j] = (K)kk;
+                val[j] = (VS)(((p - ds) << gen.bits) | d);
+            }
+        }
+        __syncthreads();  // the staging buffer is reused for the sorted keys below
+    } else {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            key[j] = li < valid ? rs_load<NTM>(kin + base + li) : (K)~(K)0;
+        }
+        if constexpr (EARLYV) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                val[j] = li < valid ? rs_load<NTM>(vin + base + li) : VS(0);
+            }
         }
     }
 
@@ -350,6 +475,7 @@ struct RadixWorkspace {
     DevBuf hist;     // [2][RS_MAX_PASSES][256] u64 : counts, then digit starts
     DevBuf status;   // [tiles][256] u64
     DevBuf tickets;  // [256] u32 tickets (indexed by epoch) + [1] u32 error flag
+    DevBuf tile_doc; // [tiles + 1] u64, generated first pass only
     uint32_t epoch = 0;
     uint64_t min_tile = 0;
 
@@ -378,7 +504,7 @@ struct RadixWorkspace {
     }
     uint32_t* ticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + (e & 255u); }
     uint32_t* err_ptr() { return tickets.as<uint32_t>() + 256; }
-    void release() { hist.release(); status.release(); tickets.release(); epoch = 0; }
+    void release() { hist.release(); status.release(); tickets.release(); tile_doc.release(); epoch = 0; }
 };
 
 template <typename K, typename V> inline const char* rs_kernel_name();
@@ -398,12 +524,17 @@ struct SortPlan {
     std::vector<uint64_t> h_hist;
 };
 
-template <typename K, typename V, typename Cfg>
+// One sort.  `h_hist_in` (optional, host, [npass][256]) supplies the per-pass digit histograms when the
+// caller can derive them more cheaply than by reading the keys; `gen` (optional) makes the first pass
+// produce its (key, value) input on the fly (buffers 0 are then never read).
+template <typename K, typename V, typename Cfg, typename Gen = NoGen>
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
-                   int begin_bit, int end_bit, SortStats* stats, int dbits) {
+                   int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
+                   const Gen* gen = nullptr) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     if (n == 0 || end_bit <= begin_bit) return 0;
     const int nbits = end_bit - begin_bit;
     if (dbits < 1 || dbits > 8) dbits = 8;
@@ -415,39 +546,62 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
 
     unsigned long long* d_hist = ws.hist.as<unsigned long long>();
     unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
-    CDB_HIP(hipMemsetAsync(d_hist, 0, RS_MAX_PASSES * 256 * sizeof(uint64_t), s));
-    {
+    std::vector<uint64_t> h_hist((size_t)npass * 256);
+    if (h_hist_in) {
+        std::copy(h_hist_in, h_hist_in + h_hist.size(), h_hist.begin());
+        CDB_HIP(hipMemcpyAsync(d_hist, h_hist.data(), h_hist.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
+        CDB_HIP(hipStreamSynchronize(s));  // h_hist is pageable host memory
+    } else {
+        if (GEN) throw Error("radix_sort: a generated first pass needs caller-supplied histograms (internal)");
+        CDB_HIP(hipMemsetAsync(d_hist, 0, RS_MAX_PASSES * 256 * sizeof(uint64_t), s));
         const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16), 256 * 8);
         int t = prof.begin(s);
         hipLaunchKernelGGL(rs_hist_kernel<K>, dim3(grid), dim3(256), 0, s, (const K*)k0, n, begin_bit, npass,
                            dbits, last_mask, d_hist);
         prof.end(t, "rs_hist", n * sizeof(K), s);
+        hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
+        CDB_HIP(hipMemcpyAsync(h_hist.data(), d_hist, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
     }
-    hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
-    std::vector<uint64_t> h_hist((size_t)npass * 256);
-    CDB_HIP(hipMemcpyAsync(h_hist.data(), d_hist, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    CDB_HIP(hipStreamSynchronize(s));
 
     K* kb[2] = {k0, k1};
     V* vb[2] = {v0, v1};
     int cur = 0;
+    bool materialised = !GEN;  // with a generator the input exists only after the first executed pass
     const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
     for (int p = 0; p < npass; ++p) {
         bool trivial = false;
         for (int d = 0; d < 256; ++d)
             if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
-        if (trivial) {
+        if (trivial && (materialised || p + 1 < npass)) {
             if (stats) stats->passes_skipped++;
             continue;
         }
         const uint32_t e = ws.next_epoch(s);
         const uint32_t dmask = p == npass - 1 ? last_mask : ((1u << dbits) - 1u);
         int t = prof.begin(s);
-        hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg>), dim3(tiles), dim3(Cfg::NT), 0, s, (const K*)kb[cur],
-                           kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, begin_bit + dbits * p, dmask,
-                           (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
-                           ws.ticket_ptr(e), e, ws.err_ptr());
-        prof.end(t, rs_kernel_name<K, V>(), 2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+        if (!materialised) {
+            if constexpr (GEN) {
+                Gen g2 = *gen;
+                ws.tile_doc.ensure(((size_t)tiles + 1) * sizeof(uint64_t));
+                hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles + 1, 256)), dim3(256), 0, s,
+                                   g2.doc_start, g2.ndocs, n, (uint64_t)TILE, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
+                g2.tile_doc = ws.tile_doc.as<uint64_t>();
+                hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen>), dim3(tiles), dim3(Cfg::NT), 0, s,
+                                   (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vb[cur ^ 1], n,
+                                   begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
+                                   ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), g2);
+            }
+            prof.end(t, "rs_onesweep_textgen", n * (1 + sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+            materialised = true;
+        } else {
+            hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen>), dim3(tiles), dim3(Cfg::NT), 0, s,
+                               (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n,
+                               begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
+                               ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), NoGen());
+            prof.end(t, rs_kernel_name<K, V>(), 2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+        }
         cur ^= 1;
         if (stats) stats->passes_run++;
     }
@@ -457,24 +611,32 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
 
 // Sorts n (key, value) pairs by key bits [begin_bit, end_bit), stable.  Buffers 0 hold the input; the
 // result ends up in buffers `return value` (0 or 1).  Passes whose digit is constant are skipped.
-// `variant` selects a kernel configuration (0 = the tuned default; others exist for A/B measurements).
+// `variant` selects a kernel configuration (0 = by size; others exist for A/B measurements).
 template <typename K, typename V>
 int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
-               int begin_bit, int end_bit, SortStats* stats = nullptr, int variant = 0, int dbits = 8) {
+               int begin_bit, int end_bit, SortStats* stats = nullptr, int variant = 0, int dbits = 8,
+               const uint64_t* h_hist_in = nullptr, const TextGen* gen = nullptr) {
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     if constexpr (!HAS_V) {
-        return radix_sort_cfg<K, V, RsCfg<16, false, false>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits);
+        return radix_sort_cfg<K, V, RsCfg<16, false, false>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
     } else {
         // variant 0 picks by size: big tiles (16 Ki keys, one workgroup per CU) give the longest per-digit
         // runs and therefore the best-coalesced scatter, but need >= a few hundred tiles to fill 256 CUs
         if (variant == 0) variant = n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1);
-#define CDB_RS(...) return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits)
+#define CDB_RS(...) return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in)
+#define CDB_RS_GEN(...)                                                                                               \
+    if (gen)                                                                                                          \
+        return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
+                                                                 stats, dbits, h_hist_in, gen);                       \
+    CDB_RS(__VA_ARGS__)
+        if (gen && variant != 21 && variant != 26 && variant != 1)
+            throw Error("radix_sort: this kernel configuration has no generated first pass (internal)");
         switch (variant) {
             // production configurations: IPT, REUSE, EARLYV, NT, NONTEMP, MINW, ABL, LB
             default:
-            case 21: CDB_RS(16, true, true, 1024, false, 1, 0, 4);   // 16 Ki-key tile, 1 WG/CU
-            case 26: CDB_RS(18, true, true, 256, false, 1, 0, 4);    // 4.5 Ki-key tile, 3 WG/CU
-            case 1: CDB_RS(15, true, true, 256, false, 1, 0, 1);     // 3.75 Ki-key tile, 4 WG/CU
+            case 21: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4);   // 16 Ki-key tile, 1 WG/CU
+            case 26: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4);    // 4.5 Ki-key tile, 3 WG/CU
+            case 1: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1);     // 3.75 Ki-key tile, 4 WG/CU
             // kept for A/B measurements (tools/sort_bench.py, profiles/): earlier design points
             case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);   // round-1 first version
             case 3: CDB_RS(18, true, true, 256, false, 1, 0, 1);
@@ -490,6 +652,7 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 114: CDB_RS(16, true, true, 1024, false, 1, 8, 4);  // look-back depth counters
         }
 #undef CDB_RS
+#undef CDB_RS_GEN
     }
 }
 

@@ -33,10 +33,10 @@ constexpr int KG_TILE = 2048;  // suffixes per workgroup in key generation
 constexpr int KG_LOOK = 64;    // look-ahead bytes staged behind the tile
 
 // ---------------------------------------------------------------------------------------------
-// 1. alphabet
+// 1. alphabet: how often every byte value occurs
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sa_alphabet_kernel(const uint8_t* __restrict__ text, uint64_t n,
-                                                          uint32_t* __restrict__ present) {
+__global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                           unsigned long long* __restrict__ counts) {
     __shared__ uint32_t s[256];
     s[threadIdx.x] = 0;
     __syncthreads();
@@ -48,15 +48,45 @@ __global__ __launch_bounds__(256) void sa_alphabet_kernel(const uint8_t* __restr
         const uint32_t x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            s[x[q] & 0xFF] = 1;
-            s[(x[q] >> 8) & 0xFF] = 1;
-            s[(x[q] >> 16) & 0xFF] = 1;
-            s[x[q] >> 24] = 1;
+            atomicAdd(&s[x[q] & 0xFF], 1u);
+            atomicAdd(&s[(x[q] >> 8) & 0xFF], 1u);
+            atomicAdd(&s[(x[q] >> 16) & 0xFF], 1u);
+            atomicAdd(&s[x[q] >> 24], 1u);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) s[text[words * 16 + threadIdx.x]] = 1;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) atomicAdd(&s[text[words * 16 + threadIdx.x]], 1u);
     __syncthreads();
-    if (s[threadIdx.x]) present[threadIdx.x] = 1;
+    if (s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
+// Digit histograms of the initial sort without reading any key: with one symbol per digit, the digit of
+// pass p is the symbol k = nsym-1-p positions into the suffix, so its histogram is the symbol histogram
+// of the text minus the symbols sitting at offsets < k of their document, and the "end" code counts the
+// suffixes shorter than k+1.  This kernel gathers those document-head corrections:
+//   first[j][c] = documents whose byte at offset j has code c   (j < nsym-1)
+//   lencnt[L]   = documents of length L                          (L < nsym)
+constexpr int HC_MAXSYM = 16;
+__global__ __launch_bounds__(256) void sa_headcorr_kernel(const uint8_t* __restrict__ text,
+                                                          const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                          const uint16_t* __restrict__ symmap, int nsym,
+                                                          unsigned long long* __restrict__ first /*[HC_MAXSYM][257]*/,
+                                                          unsigned long long* __restrict__ lencnt /*[HC_MAXSYM]*/) {
+    __shared__ uint32_t s_first[HC_MAXSYM * 257];
+    __shared__ uint32_t s_len[HC_MAXSYM];
+    for (int i = threadIdx.x; i < HC_MAXSYM * 257; i += 256) s_first[i] = 0;
+    if (threadIdx.x < HC_MAXSYM) s_len[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < ndocs; d += stride) {
+        const uint64_t ds = doc_start[d], len = doc_start[d + 1] - ds;
+        if (len < (uint64_t)nsym) atomicAdd(&s_len[len], 1u);
+        const int lim = (int)(len < (uint64_t)(nsym - 1) ? len : (uint64_t)(nsym - 1));
+        for (int j = 0; j < lim; ++j) atomicAdd(&s_first[j * 257 + symmap[text[ds + j]]], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HC_MAXSYM * 257; i += 256)
+        if (s_first[i]) atomicAdd(&first[i], (unsigned long long)s_first[i]);
+    if (threadIdx.x < HC_MAXSYM && s_len[threadIdx.x]) atomicAdd(&lencnt[threadIdx.x], (unsigned long long)s_len[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,10 +165,22 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
 
 struct FlagIn {
     const uint8_t* flags;
-    __device__ __forceinline__ U2 operator()(uint64_t i) const {
-        const uint8_t f = flags[i];
+    static __device__ __forceinline__ U2 decode(uint32_t f) {
         const uint64_t u = (f >> 1) & 1u;
         return U2{u, u & (uint64_t)(f & 1u)};
+    }
+    __device__ __forceinline__ U2 operator()(uint64_t i) const { return decode(flags[i]); }
+    // 8 consecutive flag bytes in one load (tiles start at multiples of 8; the flag array is a
+    // library allocation, so it is 8-byte aligned)
+    __device__ __forceinline__ void load8(uint64_t base, uint64_t n, const U2& identity, U2 (&v)[SC_IPT]) const {
+        if (base + 8 <= n) {
+            const uint64_t w = *reinterpret_cast<const uint64_t*>(flags + base);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = decode((uint32_t)(w >> (8 * k)) & 0xFFu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = base + k < n ? decode(flags[base + k]) : identity;
+        }
     }
 };
 
@@ -159,7 +201,7 @@ struct CompactOut {
     uint64_t h;
     int kbits, nsym2, symbits;
     __device__ __forceinline__ void operator()(uint64_t i, const U2& ex, const U2& in) const {
-        if (!(flags[i] & 2)) return;
+        if (in.a == ex.a) return;  // not an unresolved entry
         const uint64_t j = ex.a;
         const uint64_t gid = in.b - 1;
         const V v = sa[i];
@@ -379,25 +421,26 @@ void build_typed(Index& ix) {
     const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
 
     // ---- 1. alphabet -> order-preserving dense codes
-    DevBuf d_present, d_symmap;
-    d_present.alloc(256 * sizeof(uint32_t));
+    DevBuf d_counts, d_symmap;
+    d_counts.alloc(256 * sizeof(uint64_t));
     d_symmap.alloc(256 * sizeof(uint16_t));
-    CDB_HIP(hipMemsetAsync(d_present.p, 0, 256 * sizeof(uint32_t), s));
+    CDB_HIP(hipMemsetAsync(d_counts.p, 0, 256 * sizeof(uint64_t), s));
     {
         const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16 * 4), 256 * 8);
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL(sa_alphabet_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, n, d_present.as<uint32_t>());
-        ix.prof.end(t, "sa_alphabet", n, s);
+        hipLaunchKernelGGL(sa_bytecount_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, n,
+                           d_counts.as<unsigned long long>());
+        ix.prof.end(t, "sa_bytecount", n, s);
     }
-    uint32_t h_present[256];
-    CDB_HIP(hipMemcpyAsync(h_present, d_present.p, sizeof(h_present), hipMemcpyDeviceToHost, s));
+    uint64_t h_counts[256];
+    CDB_HIP(hipMemcpyAsync(h_counts, d_counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
     uint16_t h_map[256];
     int sigma = 0;
     bool high_bytes = false;
     for (int b = 0; b < 256; ++b) {
-        h_map[b] = h_present[b] ? (uint16_t)(++sigma) : (uint16_t)0;
-        if (b >= 128 && h_present[b]) high_bytes = true;
+        h_map[b] = h_counts[b] ? (uint16_t)(++sigma) : (uint16_t)0;
+        if (b >= 128 && h_counts[b]) high_bytes = true;
     }
     const int symbits = std::max(1, bit_width64((uint64_t)sigma));
     CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
@@ -421,7 +464,7 @@ void build_typed(Index& ix) {
     st.symbol_bits = symbits;
     st.alphabet = sigma;
 
-    // ---- 2. keys + entries
+    // ---- 2 + 3. keys + entries, initial sort
     DevBuf keys[2], vals[2], flags;
     double ta = now_ms();
     keys[0].alloc(n * sizeof(uint64_t));
@@ -430,18 +473,63 @@ void build_typed(Index& ix) {
     vals[1].alloc(n * sizeof(V));
     flags.alloc(n);
     st.alloc_ms += now_ms() - ta;
-    {
-        int t = ix.prof.begin(s);
-        hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text, doc_start, D,
-                           n, (int)ix.bits, d_symmap.as<uint16_t>(), symbits, nsym, ix.text_padded,
-                           keys[0].as<uint64_t>(), vals[0].as<V>());
-        ix.prof.end(t, "sa_keygen", n * (1 + sizeof(uint64_t) + sizeof(V)), s);
-    }
-
-    // ---- 3. initial sort
     SortStats ss;
-    const int sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(),
-                                            vals[0].as<V>(), vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits);
+    int sel;
+    const bool fused = ix.fuse_keygen && dbits == symbits && nsym <= HC_MAXSYM &&
+                       (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1);
+    st.fused_keygen = fused ? 1 : 0;
+    if (fused) {
+        // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
+        DevBuf d_corr;
+        const size_t corr_words = (size_t)HC_MAXSYM * 257 + HC_MAXSYM;
+        d_corr.alloc(corr_words * sizeof(uint64_t));
+        CDB_HIP(hipMemsetAsync(d_corr.p, 0, corr_words * sizeof(uint64_t), s));
+        {
+            const int grid = (int)std::min<uint64_t>(ceil_div(D, 256), 256 * 4);
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL(sa_headcorr_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D,
+                               (const uint16_t*)d_symmap.as<uint16_t>(), nsym, d_corr.as<unsigned long long>(),
+                               d_corr.as<unsigned long long>() + (size_t)HC_MAXSYM * 257);
+            ix.prof.end(t, "sa_headcorr", D * (16 + (uint64_t)nsym), s);
+        }
+        std::vector<uint64_t> h_corr(corr_words);
+        CDB_HIP(hipMemcpyAsync(h_corr.data(), d_corr.p, corr_words * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        const uint64_t* first = h_corr.data();
+        const uint64_t* lencnt = h_corr.data() + (size_t)HC_MAXSYM * 257;
+        uint64_t code_count[257] = {0};
+        for (int b = 0; b < 256; ++b)
+            if (h_map[b]) code_count[h_map[b]] = h_counts[b];
+        std::vector<uint64_t> h_hist((size_t)nsym * 256, 0);
+        for (int p = 0; p < nsym; ++p) {
+            const int k = nsym - 1 - p;  // LSD: pass 0 sorts on the last symbol of the key
+            uint64_t* hp = &h_hist[(size_t)p * 256];
+            uint64_t shorter = 0, ends = 0;  // documents shorter than k, bytes they hold
+            for (int L = 0; L < k; ++L) {
+                shorter += lencnt[L];
+                ends += (uint64_t)L * lencnt[L];
+            }
+            hp[0] = ends + (uint64_t)k * (D - shorter);  // suffixes with fewer than k+1 symbols left
+            for (int c = 1; c <= sigma; ++c) {
+                uint64_t head = 0;
+                for (int j = 0; j < k; ++j) head += first[(size_t)j * 257 + c];
+                hp[c] = code_count[c] - head;
+            }
+        }
+        TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, symbits, nsym, ix.text_padded};
+        sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
+                                      vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+    } else {
+        {
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text,
+                               doc_start, D, n, (int)ix.bits, d_symmap.as<uint16_t>(), symbits, nsym, ix.text_padded,
+                               keys[0].as<uint64_t>(), vals[0].as<V>());
+            ix.prof.end(t, "sa_keygen", n * (1 + sizeof(uint64_t) + sizeof(V)), s);
+        }
+        sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
+                                      vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits);
+    }
     {
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,

@@ -24,34 +24,61 @@ struct U2 {
     __host__ __device__ U2 operator+(const U2& o) const { return U2{a + o.a, b + o.b}; }
 };
 
-// inclusive scan of one value per thread across the 256-thread workgroup; returns the inclusive
-// value and the workgroup total.
-template <typename T, typename Op>
-__device__ __forceinline__ T block_scan_incl(T v, Op op, T* s_buf /*[SC_NT]*/, T& total) {
-    const int t = threadIdx.x;
-    s_buf[t] = v;
-    __syncthreads();
+// 64-bit-safe lane shuffle for trivially copyable T (built from 32-bit DPP/bpermute moves)
+template <typename T>
+__device__ __forceinline__ T shfl_up_any(const T& v, int delta) {
+    static_assert(sizeof(T) % 4 == 0, "shuffle payload must be a multiple of 4 bytes");
+    T out;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
 #pragma unroll
-    for (int off = 1; off < SC_NT; off <<= 1) {
-        T x = v;
-        if (t >= off) x = op(s_buf[t - off], v);
-        __syncthreads();
-        v = x;
-        s_buf[t] = v;
-        __syncthreads();
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = __shfl_up(src[i], delta);
+    return out;
+}
+
+// inclusive scan of one value per thread across the 256-thread workgroup (wave-level shuffle scan,
+// then one LDS exchange of the 4 wave totals); returns the inclusive value and the workgroup total.
+template <typename T, typename Op>
+__device__ __forceinline__ T block_scan_incl(T v, Op op, T* s_buf /*[>= 4]*/, T& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T x = shfl_up_any(v, off);
+        if (lane >= off) v = op(x, v);
     }
-    total = s_buf[SC_NT - 1];
+    __syncthreads();  // s_buf may still be read by a previous call
+    if (lane == 63) s_buf[wave] = v;
+    __syncthreads();
+    T pre = s_buf[0];
+    total = op(op(s_buf[0], s_buf[1]), op(s_buf[2], s_buf[3]));
+    if (wave >= 2) pre = op(pre, s_buf[1]);
+    if (wave >= 3) pre = op(pre, s_buf[2]);
+    if (wave >= 1) v = op(pre, v);
     return v;
+}
+
+// Input functors may offer `load8(base, n, identity, v[8])` to fetch 8 consecutive items at once (e.g.
+// one 8-byte load for byte flags); the default falls back to operator().
+template <typename In, typename T>
+__device__ __forceinline__ auto scan_load8(const In& in, uint64_t base, uint64_t n, const T& identity, T (&v)[SC_IPT], int)
+    -> decltype(in.load8(base, n, identity, v), void()) {
+    in.load8(base, n, identity, v);
+}
+template <typename In, typename T>
+__device__ __forceinline__ void scan_load8(const In& in, uint64_t base, uint64_t n, const T& identity, T (&v)[SC_IPT], long) {
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) v[k] = base + k < n ? in(base + k) : identity;
 }
 
 template <typename T, typename In, typename Op>
 __global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(In in, uint64_t n, Op op, T identity, T* partials) {
-    __shared__ T s_buf[SC_NT];
+    __shared__ T s_buf[8];
     const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+    T v[SC_IPT];
+    scan_load8(in, base, n, identity, v, 0);
     T acc = identity;
 #pragma unroll
-    for (int k = 0; k < SC_IPT; ++k)
-        if (base + k < n) acc = op(acc, in(base + k));
+    for (int k = 0; k < SC_IPT; ++k) acc = op(acc, v[k]);
     T total;
     block_scan_incl(acc, op, s_buf, total);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
@@ -60,7 +87,7 @@ __global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(In in, uint64_t n, O
 // in-place exclusive scan of the tile partials by one workgroup; partials[nb] receives the grand total
 template <typename T, typename Op>
 __global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint64_t nb, Op op, T identity) {
-    __shared__ T s_buf[SC_NT];
+    __shared__ T s_buf[8];
     T carry = identity;
     for (uint64_t c = 0; c < nb; c += SC_TILE) {
         const uint64_t base = c + (uint64_t)threadIdx.x * SC_IPT;
@@ -74,11 +101,13 @@ __global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint6
         T total;
         const T incl = block_scan_incl(acc, op, s_buf, total);
         // exclusive start of this thread = carry ∘ (inclusive of the previous thread)
+        T prev = shfl_up_any(incl, 1);
         __syncthreads();
-        s_buf[threadIdx.x] = incl;
+        if ((threadIdx.x & 63) == 63) s_buf[4 + (threadIdx.x >> 6)] = incl;
         __syncthreads();
+        if ((threadIdx.x & 63) == 0 && threadIdx.x > 0) prev = s_buf[4 + (threadIdx.x >> 6) - 1];
         T run = carry;
-        if (threadIdx.x > 0) run = op(carry, s_buf[threadIdx.x - 1]);
+        if (threadIdx.x > 0) run = op(carry, prev);
 #pragma unroll
         for (int k = 0; k < SC_IPT; ++k) {
             if (base + k < nb) partials[base + k] = run;
@@ -93,22 +122,23 @@ __global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint6
 template <typename T, typename In, typename Out, typename Op>
 __global__ __launch_bounds__(SC_NT) void scan_apply_kernel(In in, uint64_t n, Op op, T identity, const T* partials,
                                                            Out out) {
-    __shared__ T s_buf[SC_NT];
+    __shared__ T s_buf[8];
     const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
     T v[SC_IPT];
+    scan_load8(in, base, n, identity, v, 0);
     T acc = identity;
 #pragma unroll
-    for (int k = 0; k < SC_IPT; ++k) {
-        v[k] = base + k < n ? in(base + k) : identity;
-        acc = op(acc, v[k]);
-    }
+    for (int k = 0; k < SC_IPT; ++k) acc = op(acc, v[k]);
     T total;
     const T incl = block_scan_incl(acc, op, s_buf, total);
+    // exclusive start of this thread = tile prefix ∘ inclusive value of the previous thread
+    T prev = shfl_up_any(incl, 1);
     __syncthreads();
-    s_buf[threadIdx.x] = incl;
+    if ((threadIdx.x & 63) == 63) s_buf[4 + (threadIdx.x >> 6)] = incl;
     __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x > 0) prev = s_buf[4 + (threadIdx.x >> 6) - 1];
     T run = partials[blockIdx.x];
-    if (threadIdx.x > 0) run = op(run, s_buf[threadIdx.x - 1]);
+    if (threadIdx.x > 0) run = op(run, prev);
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k) {
         const T nxt = op(run, v[k]);

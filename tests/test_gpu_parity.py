@@ -91,6 +91,22 @@ def test_c0_full(G):
     assert g.stat("rounds") >= 1  # ties exist (~14k tied pairs at this shape)
 
 
+@pytest.mark.parametrize("opts", [dict(fuse_keygen=0), dict(fuse_keygen=1, sort_variant=26), dict(fuse_keygen=1, sort_variant=1),
+                                  dict(fuse_keygen=1, sort_variant=21), dict(fuse_keygen=0, digit_bits=8)])
+def test_fused_and_materialised_first_pass_agree(G, opts):
+    # the first radix pass either reads keys written by sa_keygen_kernel or computes them from the text
+    blob, ds = W.ragged_corpus(20000, 90, seed=15, empty_every=13)   # ragged: document-head corrections matter
+    pats = W.sample_patterns(blob, ds, 300, 1, 6, seed=3, miss_byte=0x7B)
+    _check_parity(G, blob, ds, patterns=pats, **opts)             # a-z: 5-bit symbols, unaligned 8-bit digits
+    blob, ds = W.ascii_corpus(3000, 333, seed=2)                      # printable ASCII, 7-bit symbols
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 200, 2, 9, seed=5), **opts)
+    assert g.stat("fused_keygen") == opts["fuse_keygen"]
+    if "digit_bits" not in opts:
+        for passes in (3, 6, 8):   # key widths of 3, 6 and 9 symbols (9 needs the second byte window)
+            g, o = _check_parity(G, blob, ds, initial_passes=passes, **opts)
+            assert g.stat("key_symbols") == {3: 3, 6: 6, 8: 9}[passes]
+
+
 def test_test_string_shape_property(G):
     # test/test-string.py shape (a-z, 3-char keywords) scaled to 300 x 5000, brute-force oracle
     from oracle import brute_count
