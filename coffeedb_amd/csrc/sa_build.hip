@@ -154,13 +154,35 @@ __global__ __launch_bounds__(256) void sa_keygen_kernel(const uint8_t* __restric
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __restrict__ keys, uint64_t n,
                                                            uint64_t symmask, uint8_t* __restrict__ flags) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = keys[i];
-    const bool head = i == 0 || keys[i - 1] != k;
-    const bool tail = i + 1 == n || keys[i + 1] != k;
-    const bool exhausted = (k & symmask) == 0;  // an end-of-document code inside the key
-    flags[i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+    // four consecutive keys per thread (two 16-byte loads), four flag bytes in one store
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    uint64_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
+    if (i0 + 4 <= n) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(keys + i0);
+        const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(keys + i0 + 2);
+        k[1] = a.x; k[2] = a.y; k[3] = b.x; k[4] = b.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? keys[i0 + q] : 0;
+    }
+    k[0] = i0 > 0 ? keys[i0 - 1] : ~k[1];
+    k[5] = i0 + 4 < n ? keys[i0 + 4] : 0;
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t i = i0 + q;
+        if (i >= n) break;
+        const bool head = i == 0 || k[q] != k[q + 1];
+        const bool tail = i + 1 == n || k[q + 2] != k[q + 1];
+        const bool exhausted = (k[q + 1] & symmask) == 0;  // an end-of-document code inside the key
+        out |= (uint32_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0)) << (8 * q);
+    }
+    if (i0 + 4 <= n) {
+        *reinterpret_cast<uint32_t*>(flags + i0) = out;
+    } else {
+        for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
+    }
 }
 
 struct FlagIn {
@@ -170,16 +192,18 @@ struct FlagIn {
         return U2{u, u & (uint64_t)(f & 1u)};
     }
     __device__ __forceinline__ U2 operator()(uint64_t i) const { return decode(flags[i]); }
-    // 8 consecutive flag bytes in one load (tiles start at multiples of 8; the flag array is a
-    // library allocation, so it is 8-byte aligned)
+    // a thread's 16 consecutive flag bytes in one load (tiles start at multiples of 16; the flag array
+    // is a library allocation, so it is 16-byte aligned)
     __device__ __forceinline__ void load8(uint64_t base, uint64_t n, const U2& identity, U2 (&v)[SC_IPT]) const {
-        if (base + 8 <= n) {
-            const uint64_t w = *reinterpret_cast<const uint64_t*>(flags + base);
+        static_assert(SC_IPT == 16, "flag loader assumes 16 items per thread");
+        if (base + 16 <= n) {
+            const uint4 w = *reinterpret_cast<const uint4*>(flags + base);
+            const uint32_t x[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = decode((uint32_t)(w >> (8 * k)) & 0xFFu);
+            for (int k = 0; k < 16; ++k) v[k] = decode((x[k >> 2] >> (8 * (k & 3))) & 0xFFu);
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = base + k < n ? decode(flags[base + k]) : identity;
+            for (int k = 0; k < 16; ++k) v[k] = base + k < n ? decode(flags[base + k]) : identity;
         }
     }
 };
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restr
 template <typename V, typename I>
 __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const V* sval, const I* U, const uint8_t* nh,
                                          const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, V* sa,
-                                         uint8_t* flags, uint64_t& ext_pos) {
+                                         uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open) {
     const V v = sval[j];
     const uint64_t i = U[j];
     const bool head = nh[j];
@@ -246,8 +270,10 @@ __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const V* sval, 
     const uint64_t ds = doc_start[d];
     const uint64_t rem = doc_start[d + 1] - ds - off;
     const bool exhausted = rem < hnew;
+    const bool open = !(head && last) && !exhausted;
     sa[i] = v;
-    flags[i] = (uint8_t)((head ? 1 : 0) | ((!(head && last) && !exhausted) ? 2 : 0));
+    flags[i] = (uint8_t)((head ? 1 : 0) | (open ? 2 : 0));
+    if (open) atomicAdd(still_open, 1ull);  // the compiler folds this into one add per wave
     ext_pos = ds + d + off;
 }
 
@@ -256,11 +282,12 @@ __global__ __launch_bounds__(256) void sa_update_kernel(const V* __restrict__ sv
                                                         const uint8_t* __restrict__ nh, uint64_t m,
                                                         const uint64_t* __restrict__ doc_start, int bits,
                                                         uint64_t mask, uint64_t hnew, V* __restrict__ sa,
-                                                        uint8_t* __restrict__ flags) {
+                                                        uint8_t* __restrict__ flags,
+                                                        unsigned long long* __restrict__ still_open) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     uint64_t q;
-    sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q);
+    sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
 }
 
 template <typename I>
@@ -281,9 +308,10 @@ struct UpdateOut {
     V* sa;
     uint8_t* flags;
     R* rank;
+    unsigned long long* still_open;
     __device__ __forceinline__ void operator()(uint64_t j, uint64_t, uint64_t incl) const {
         uint64_t q;
-        sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q);
+        sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
         rank[q] = (R)incl;
     }
 };
@@ -532,7 +560,7 @@ void build_typed(Index& ix) {
     }
     {
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                            (const uint64_t*)keys[sel].as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>());
         ix.prof.end(t, "sa_initflags", n * 9, s);
     }
@@ -549,8 +577,17 @@ void build_typed(Index& ix) {
     uint64_t h = (uint64_t)nsym;
     bool isa = false;
     uint64_t cap = 0;
+    DevBuf d_open;  // entries still unresolved after the last round (saves a full flag scan to learn "none")
+    d_open.alloc(sizeof(uint64_t));
     for (;;) {
         FlagIn fin{flags.as<uint8_t>()};
+        if (st.rounds > 0) {
+            uint64_t still = 0;
+            CDB_HIP(hipMemcpyAsync(&still, d_open.p, sizeof(still), hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            if (still == 0) break;
+        }
+        CDB_HIP(hipMemsetAsync(d_open.p, 0, sizeof(uint64_t), s));
         const U2 tot = scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
         const uint64_t m = tot.a, G = tot.b;
         if (st.rounds == 0) st.unresolved_initial = m;
@@ -613,13 +650,13 @@ void build_typed(Index& ix) {
                 HeadIn<I> hin{nh.as<uint8_t>(), U.as<I>()};
                 (void)scan_totals<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0);
                 UpdateOut<V, I, R> uo{sval[rs].as<V>(), U.as<I>(), nh.as<uint8_t>(), m, doc_start, (int)ix.bits,
-                                      ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>()};
+                                      ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>(), d_open.as<unsigned long long>()};
                 scan_apply<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0, uo);
                 st.dbl_rounds++;
             } else {
                 hipLaunchKernelGGL((sa_update_kernel<V, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[rs].as<V>(), (const I*)U.as<I>(), (const uint8_t*)nh.as<uint8_t>(), m,
-                                   doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>());
+                                   doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>(), d_open.as<unsigned long long>());
                 st.ext_rounds++;
             }
             ix.prof.end(t, "sa_update", m * (2 * sizeof(V) + sizeof(I) + 2 + (isa ? sizeof(R) : 0)), s);

@@ -1,5 +1,5 @@
 // scan.h — generic device-wide scan (reduce → scan of tile partials → apply) used for stream compaction,
-// group-start propagation (max-scan) and CSR offsets.  Tile = 256 threads × 8 consecutive items.
+// group-start propagation (max-scan) and CSR offsets.  Tile = 256 threads × 16 consecutive items.
 //
 // The input is a functor In: (uint64_t i) -> T, the consumer a functor Out: (i, exclusive, inclusive);
 // both are evaluated on the device, so producers/consumers (gathers, key packing, scatters) are fused
@@ -10,7 +10,7 @@
 namespace cdb {
 
 constexpr int SC_NT = 256;
-constexpr int SC_IPT = 8;
+constexpr int SC_IPT = 16;
 constexpr int SC_TILE = SC_NT * SC_IPT;
 
 struct OpAdd {
@@ -57,8 +57,8 @@ __device__ __forceinline__ T block_scan_incl(T v, Op op, T* s_buf /*[>= 4]*/, T&
     return v;
 }
 
-// Input functors may offer `load8(base, n, identity, v[8])` to fetch 8 consecutive items at once (e.g.
-// one 8-byte load for byte flags); the default falls back to operator().
+// Input functors may offer `load8(base, n, identity, v[SC_IPT])` to fetch a thread's consecutive items at once
+// (e.g. one 16-byte load for byte flags); the default falls back to operator().
 template <typename In, typename T>
 __device__ __forceinline__ auto scan_load8(const In& in, uint64_t base, uint64_t n, const T& identity, T (&v)[SC_IPT], int)
     -> decltype(in.load8(base, n, identity, v), void()) {
