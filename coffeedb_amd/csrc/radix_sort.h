@@ -352,60 +352,16 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         if (lane == 63) s_wsum[wave] = incl;
     }
     __syncthreads();
+    uint32_t tstart = 0;
     if (tid < 256) {
         uint32_t wpre = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (w < wave) wpre += s_wsum[w];
-        const uint32_t tstart = wpre + incl - cnt;
+        tstart = wpre + incl - cnt;
         s_tstart[d] = tstart;
-
-        // ---- chained scan: look back over the predecessors, then publish the inclusive prefix
-        uint64_t excl = 0;
-        if (tile != 0 && !(Cfg::ABL & 1)) {
-            // A tile becomes ready every pass_time / tiles (~0.1 us at 1 Gi keys) while one agent-scope
-            // load costs ~1 us on this part (it has to leave the XCD's L2), so a one-at-a-time walk
-            // falls behind and the walk gets ever longer.  LB predecessors are therefore fetched per
-            // round trip; they are consumed nearest-first up to the first inclusive prefix.
-            constexpr int LB = Cfg::LB;
-            int64_t p = (int64_t)tile - 1;
-            uint32_t spins = 0;
-            bool done = false;
-            while (!done) {
-                uint64_t sw[LB];
-#pragma unroll
-                for (int k = 0; k < LB; ++k)
-                    sw[k] = p - k >= 0 ? rs_ld_status(status + (uint64_t)(p - k) * 256 + d) : 0ull;
-                int used = 0;
-                bool open = true;
-#pragma unroll
-                for (int k = 0; k < LB; ++k) {
-                    const uint32_t st = (sw[k] >> 56) == (uint64_t)epoch ? ((uint32_t)(sw[k] >> 54) & 3u) : 0u;
-                    const bool take = open && st != 0;
-                    excl += take ? (sw[k] & RS_VAL_MASK) : 0ull;
-                    used += take ? 1 : 0;
-                    done = done || (take && st == 2);
-                    open = take && st != 2;
-                }
-                if ((Cfg::ABL & 8) && d == 0) {  // measurement only: look-back depth / round trips
-                    atomicAdd(err + 1, (uint32_t)used);
-                    atomicAdd(err + 2, 1u);
-                }
-                p -= used;  // tile 0 always publishes an inclusive prefix, so p never underflows
-                if (used == 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > RS_SPIN_LIMIT) {
-                        atomicExch(err, 1u);
-                        break;
-                    }
-                } else {
-                    spins = 0;
-                }
-            }
-            rs_st_status(my, tag | (2ull << 54) | (excl + real));
-        }
-        s_gbase[d] = (Cfg::ABL & 2) ? base : (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
     }
+
     __syncthreads();
 
     // ---- place keys in LDS in sorted-by-digit order
@@ -428,6 +384,53 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
     }
+    // (the keys now live in LDS: their registers are free during the look-back below)
+
+    // ---- chained scan: look back over the predecessors, then publish the inclusive prefix.
+    // A tile becomes ready every pass_time / tiles (~0.1 us at 1 Gi keys) while one agent-scope load
+    // costs ~1 us on this part (it has to leave the XCD's L2), so a one-at-a-time walk falls behind and
+    // the walk gets ever longer.  LB predecessors are therefore fetched per round trip and consumed
+    // nearest-first up to the first inclusive prefix.
+    uint64_t excl = 0;
+    if (tid < 256 && tile != 0 && !(Cfg::ABL & 1)) {
+        constexpr int LB = Cfg::LB;
+        int64_t p = (int64_t)tile - 1;
+        uint32_t spins = 0;
+        bool done = false;
+        while (!done) {
+            uint64_t sw[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k)
+                sw[k] = p - k >= 0 ? rs_ld_status(status + (uint64_t)(p - k) * 256 + d) : 0ull;
+            int used = 0;
+            bool open = true;
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const uint32_t st = (sw[k] >> 56) == (uint64_t)epoch ? ((uint32_t)(sw[k] >> 54) & 3u) : 0u;
+                const bool take = open && st != 0;
+                excl += take ? (sw[k] & RS_VAL_MASK) : 0ull;
+                used += take ? 1 : 0;
+                done = done || (take && st == 2);
+                open = take && st != 2;
+            }
+            if ((Cfg::ABL & 8) && d == 0) {  // measurement only: look-back depth / round trips
+                atomicAdd(err + 1, (uint32_t)used);
+                atomicAdd(err + 2, 1u);
+            }
+            p -= used;  // tile 0 always publishes an inclusive prefix, so p never underflows
+            if (used == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > RS_SPIN_LIMIT) {
+                    atomicExch(err, 1u);
+                    break;
+                }
+            } else {
+                spins = 0;
+            }
+        }
+        rs_st_status(my, tag | (2ull << 54) | (excl + real));
+    }
+    if (tid < 256) s_gbase[d] = (Cfg::ABL & 2) ? base : (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
     __syncthreads();
 
     // ---- coalesced write-out: consecutive lanes -> consecutive slots of one digit run
@@ -644,6 +647,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 11: CDB_RS(16, true, true, 1024, false, 1, 0, 1);
             case 12: CDB_RS(16, true, true, 512, false, 4, 0, 1);
             case 22: CDB_RS(16, true, true, 1024, false, 1, 0, 8);
+            case 23: CDB_RS(16, true, true, 1024, false, 1, 0, 16);
+            case 24: CDB_RS(16, true, true, 1024, false, 1, 0, 2);
             case 10: CDB_RS(18, true, true, 256, true, 1, 0, 1);     // non-temporal loads/stores
             // timing-only ablations (results are WRONG by construction; never used by the product path)
             case 101: CDB_RS(16, true, true, 1024, false, 1, 1, 1);  // no look-back
