@@ -51,6 +51,18 @@ def merge_on_device(torch, dist, shard, r, npat, world, device):
     return shard.merge_shard_results(torch, dist, row_ptr, ids, cnt, world)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic_latest.json, written by tools/summarize_profile.py; FETCH_SIZE x2-corrected as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself; null if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+        return round(k["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
     """Times the CPU restatement (oracle/cpu_ref.cpp) on a bounded prefix of the same corpus."""
     from oracle import OracleIndex
@@ -179,7 +191,7 @@ def main():
         elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
 
     prof = g.profile()
-    dom_name = max((k for k in prof if k.startswith("rs_onesweep")), key=lambda k: prof[k]["ms"])
+    dom_name = max((k for k in prof if k.startswith("rs_onesweep_k")), key=lambda k: prof[k]["ms"])
     dom = prof[dom_name]
     dom_avg_ms = dom["ms"] / dom["launches"]
     dom_gbs = dom["bytes"] / dom["launches"] / (dom_avg_ms * 1e-3) / 1e9
@@ -220,7 +232,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(dom_name),
                 "avg_launch_ms": round(dom_avg_ms, 4),
                 "launches": dom["launches"],
                 "algorithmic_bytes_per_launch": dom["bytes"] // dom["launches"],

@@ -387,7 +387,7 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
             prof.resolve();
             double ms = 0;
             for (auto& kv : prof.recs)
-                if (kv.first.rfind("rs_onesweep", 0) == 0) ms += kv.second.ms;
+                if (kv.first.rfind("rs_onesweep", 0) == 0) ms += kv.second.ms;  // every tile size
             if (onesweep_ms) *onesweep_ms = ms;
             if (passes) *passes = st.passes_run;
         }

@@ -596,14 +596,16 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                    begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
                                    ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), g2);
             }
-            prof.end(t, "rs_onesweep_textgen", n * (1 + sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+            prof.end(t, (std::string("rs_onesweep_textgen_t") + std::to_string(TILE)).c_str(),
+                     n * (1 + sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
             materialised = true;
         } else {
             hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen>), dim3(tiles), dim3(Cfg::NT), 0, s,
                                (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n,
                                begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
                                ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), NoGen());
-            prof.end(t, rs_kernel_name<K, V>(), 2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+            prof.end(t, (std::string(rs_kernel_name<K, V>()) + "_t" + std::to_string(TILE)).c_str(),
+                     2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
         }
         cur ^= 1;
         if (stats) stats->passes_run++;

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 find $OUT -name "*.csv" | head -20
-python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+python tools/summarize_profile.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small artefacts for the merge back
 find $OUT -name "*kernel_trace.csv" -size +8M -delete

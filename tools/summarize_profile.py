@@ -1,9 +1,17 @@
-"""Summarises rocprofv3 output of bench.py: per-kernel stats + HBM traffic of the dominant kernel.
-FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
-corrected read traffic is 2 x FETCH_SIZE; FETCH_SIZE/WRITE_SIZE are in KiB units (x1024 bytes)."""
+"""Summarises rocprofv3 output of bench.py: per-kernel stats + HBM traffic per launch from the PMC passes.
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB (x1024 -> bytes).  On gfx950 FETCH_SIZE under-reports wide
+coalesced reads by 2x (MI355X_MICROARCH.md §HBM: requests tallied at 64 B instead of 128 B), so the
+corrected read traffic is 2 x FETCH_SIZE; WRITE_SIZE is taken as is.  Kernel instantiations are mapped
+to the names the library's own HIP-event profiler uses (rs_onesweep_k64_v32_t<tile>, ...), so that
+bench.py can quote `roofline.traffic` for exactly the kernel it times.
+usage: summarize_profile.py <gpurun_out/prof_dir> [traffic.json]
+"""
 import csv
 import glob
+import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -15,36 +23,55 @@ def find(sub, pat):
     return r[0] if r else None
 
 
+def family(name):
+    """rocprof kernel name -> the library profiler's name for the same instantiation."""
+    m = re.search(r"rs_onesweep_kernel<unsigned long, (unsigned int|unsigned long|cdb::NoVal), cdb::RsCfg<(\d+), \w+, \w+, (\d+)", name)
+    if m:
+        v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(1)]
+        tile = int(m.group(2)) * int(m.group(3))
+        gen = "textgen" if "TextGen" in name else "k64" + v
+        return f"rs_onesweep_{gen}_t{tile}"
+    m = re.search(r"(?:cdb::(?:\(anonymous namespace\)::)?)(\w+?)(?:_kernel)?[<(]", name)
+    return m.group(1) if m and "cdb::" in name else name.split("(")[0][:48]
+
+
 stats = find("trace", "*kernel_stats.csv")
 if stats:
-    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1) ==")
-    rows = list(csv.DictReader(open(stats)))
-    for r in rows[:14]:
-        print(f"{r['Name'][:70]:70s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
+    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1 --no-cpu-baseline) ==")
+    for r in list(csv.DictReader(open(stats)))[:12]:
+        print(f"{family(r['Name']):34s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={r['Percentage']}")
 
 
 def pmc(sub, counter):
     f = find(sub, "*counter_collection.csv")
-    if not f:
-        return {}
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == counter:
-            k = r["Kernel_Name"].split("(")[0][:60]
-            acc[k][0] += float(r["Counter_Value"])
-            acc[k][1] += 1
+    if f:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                k = family(r["Kernel_Name"])
+                acc[k][0] += float(r["Counter_Value"])
+                acc[k][1] += 1
     return acc
 
 
 fetch = pmc("pmc_fetch", "FETCH_SIZE")
 write = pmc("pmc_write", "WRITE_SIZE")
+traffic = {}
 if fetch or write:
-    print("== PMC (separate passes), per launch, KiB units x1024; read side corrected x2 for gfx950 ==")
+    print("== PMC (separate passes: FETCH_SIZE / WRITE_SIZE), bytes per launch; read side corrected x2 ==")
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 1])[0])):
+        if not k.startswith(("rs_", "sa_", "scan_", "q_")):
+            continue
         f, nf = fetch.get(k, [0.0, 1])
         w, nw = write.get(k, [0.0, 1])
         fb = f * 1024 / max(nf, 1)
         wb = w * 1024 / max(nw, 1)
-        print(f"{k:60s} launches={nf:4d} FETCH={fb/1e9:8.3f} GB (x2 -> {2*fb/1e9:8.3f}) WRITE={wb/1e9:8.3f} GB "
-              f"traffic_corrected={(2*fb+wb)/1e9:8.3f} GB/launch")
+        traffic[k] = {"launches": nf, "fetch_bytes_raw": fb, "read_bytes_corrected": 2 * fb, "write_bytes": wb,
+                      "hbm_bytes_per_launch": 2 * fb + wb}
+        print(f"{k:34s} launches={nf:4d} FETCH={fb/1e9:8.3f} GB (x2 -> {2*fb/1e9:8.3f}) WRITE={wb/1e9:8.3f} GB "
+              f"traffic={(2*fb+wb)/1e9:8.3f} GB/launch")
+if len(sys.argv) > 2 and traffic:
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 "
+                         "--warmup 0 --no-cpu-baseline`; read side x2 (gfx950 FETCH_SIZE correction)",
+               "kernels": traffic}, open(sys.argv[2], "w"), indent=1)
