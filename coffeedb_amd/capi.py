@@ -20,7 +20,7 @@ EXPORTS = [
     "cdb_query", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
-    "cdb_debug_radix_sort",
+    "cdb_debug_radix_sort", "cdb_debug_verify",
 ]
 
 
@@ -90,6 +90,7 @@ def load_library():
     lib.cdb_release_cached_memory.restype = None
     lib.cdb_cached_memory_bytes.argtypes = []
     lib.cdb_cached_memory_bytes.restype = u64
+    lib.cdb_debug_verify.argtypes = [vp, C.POINTER(u64)]
     lib.cdb_debug_radix_sort.argtypes = [C.c_int, vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_int)]
     _LIB = lib
@@ -184,6 +185,13 @@ class GpuStringIndex:
         if n:
             self._check(self._lib.cdb_sa_copy(self._h, _ptr(out), out.nbytes))
         return out
+
+    def verify(self):
+        """GPU-side structural check of the suffix array (see cdb_debug_verify)."""
+        out = (C.c_uint64 * 5)()
+        self._check(self._lib.cdb_debug_verify(self._h, out))
+        return {"inversions": out[0], "tie_violations": out[1], "entry_sum": out[2], "invalid_entries": out[3],
+                "expected_entry_sum": out[4]}
 
     def set_option(self, name, value):
         self._check(self._lib.cdb_set_option(self._h, name.encode(), int(value)))

@@ -351,6 +351,17 @@ int cdb_profile_dump(cdb_index* h, char* buf, size_t cap) {
     return CDB_OK;
 }
 
+int cdb_debug_verify(cdb_index* h, uint64_t out[5]) {
+    if (!h || !out) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        if (ix.width == 0) throw Error("index has not been built");
+        verify_suffix_array(ix, out);
+    });
+}
+
 int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int val_bytes, int key_bits,
                          int variant, double* onesweep_ms, int* passes) {
     if (!d_keys || (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) || key_bits < 1 || key_bits > 64)

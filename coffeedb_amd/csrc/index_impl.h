@@ -77,6 +77,9 @@ struct Index {
 // sa_build.hip
 void build_suffix_array(Index& ix);
 
+// verify.hip — out = {inversions, tie-order violations, wrapped sum of entries, invalid entries, expected sum}
+void verify_suffix_array(Index& ix, uint64_t out[5]);
+
 // query.hip — patterns already on the device; leaves CSR results in ix.q_rowptr / q_ids / q_counts
 struct DeviceCsr {
     uint64_t npat = 0, nrows = 0, nhits = 0;

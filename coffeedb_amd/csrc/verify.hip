@@ -1,0 +1,90 @@
+// verify.hip — size-independent checks of a built suffix array, computed on the GPU by code that shares
+// nothing with the build (plain adjacent-suffix comparison).  Test hook behind cdb_debug_verify: lets
+// the full-size configurations (1 GiB and up, where no CPU oracle finishes) assert
+//   * sortedness        : suffix(sa[i-1]) <= suffix(sa[i]) in unsigned byte order, shorter first
+//   * canonical ties     : equal suffixes ascend by document index (SURVEY.md Q1 canonical form)
+//   * permutation        : every entry is a valid (doc, off) and the wrapped sum of all entries equals
+//                          the closed-form sum over all (doc, off) pairs — with strict tie order this
+//                          rules out duplicates and omissions.
+#include "index_impl.h"
+
+namespace cdb {
+namespace {
+
+template <typename V>
+__global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa, uint64_t n,
+                                                        const uint8_t* __restrict__ text,
+                                                        const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                        int bits, uint64_t mask, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s_acc[4];
+    if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long inv = 0, tie = 0, sum = 0, bad = 0;
+    if (i < n) {
+        const V eb = sa[i];
+        const uint64_t db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
+        sum = (unsigned long long)eb;
+        if (db >= ndocs || ob >= doc_start[db + 1] - doc_start[db]) {
+            bad = 1;
+        } else if (i > 0) {
+            const V ea = sa[i - 1];
+            const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits;
+            if (da < ndocs && oa < doc_start[da + 1] - doc_start[da]) {
+                const uint8_t* pa = text + doc_start[da] + oa;
+                const uint8_t* pb = text + doc_start[db] + ob;
+                const uint64_t la = doc_start[da + 1] - doc_start[da] - oa, lb = doc_start[db + 1] - doc_start[db] - ob;
+                const uint64_t len = la < lb ? la : lb;
+                int c = 0;
+                for (uint64_t k = 0; k < len; ++k) {
+                    const uint8_t x = pa[k], y = pb[k];
+                    if (x != y) {
+                        c = x < y ? -1 : 1;
+                        break;
+                    }
+                }
+                if (c == 0) c = la < lb ? -1 : (la > lb ? 1 : 0);
+                if (c > 0) inv = 1;
+                if (c == 0 && da >= db) tie = 1;
+            }
+        }
+    }
+    if (inv) atomicAdd(&s_acc[0], inv);
+    if (tie) atomicAdd(&s_acc[1], tie);
+    atomicAdd(&s_acc[2], sum);
+    if (bad) atomicAdd(&s_acc[3], bad);
+    __syncthreads();
+    if (threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+}  // namespace
+
+void verify_suffix_array(Index& ix, uint64_t out[5]) {
+    hipStream_t s = ix.stream;
+    DevBuf d_out;
+    d_out.alloc(4 * sizeof(uint64_t));
+    CDB_HIP(hipMemsetAsync(d_out.p, 0, 4 * sizeof(uint64_t), s));
+    if (ix.size) {
+        const unsigned grid = (unsigned)ceil_div(ix.size, 256);
+        if (ix.width == 4)
+            hipLaunchKernelGGL((sa_verify_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
+                               ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits,
+                               ix.mask, d_out.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL((sa_verify_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(),
+                               ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits,
+                               ix.mask, d_out.as<unsigned long long>());
+    }
+    CDB_HIP(hipMemcpyAsync(out, d_out.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    // closed-form wrapped sum of all (off << bits) | doc entries
+    uint64_t expect = 0;
+    for (uint64_t d = 0; d < ix.ndocs; ++d) {
+        const uint64_t len = ix.doc_start[d + 1] - ix.doc_start[d];
+        const uint64_t tri = (len & 1) ? len * ((len - 1) / 2) : (len / 2) * (len - 1);  // len(len-1)/2 mod 2^64
+        expect += (tri << ix.bits) + len * d;
+    }
+    out[4] = expect;
+}
+
+}  // namespace cdb

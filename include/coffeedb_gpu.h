@@ -141,6 +141,13 @@ void cdb_profile_reset(cdb_index* h);
 void cdb_release_cached_memory(void);
 uint64_t cdb_cached_memory_bytes(void);
 
+/* Test hook: size-independent checks of the built suffix array, computed on the GPU by plain adjacent-
+ * suffix comparison (verify.hip).  out[0] = adjacent pairs out of unsigned byte order, out[1] = equal
+ * suffixes not ascending by document, out[2] = wrapped sum of all entries, out[3] = entries that are not
+ * a valid (doc, off), out[4] = closed-form expected value of out[2].  (With reference_compat and bytes
+ * >= 0x80 the reference's order is not globally sorted, so out[0] > 0 is expected there.) */
+int cdb_debug_verify(cdb_index* h, uint64_t out[5]);
+
 /* Test hook for the radix-sort primitive (tests/test_gpu_sort.py, tools/sort_bench.py): stable sort of
  * n 64-bit keys (+ optional 4- or 8-byte values, val_bytes = 0/4/8) held in DEVICE memory by key bits
  * [0, key_bits), in place.  variant = kernel configuration (0 = default).  Reports the summed HIP-event
