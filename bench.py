@@ -39,7 +39,7 @@ class _DevArr:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def merge_on_device(torch, dist, shard, r, npat, world, device):
+def merge_on_device(torch, dist, shard, r, npat, world, device, coll_device):
     """Wraps the library's device-resident CSR of this shard and merges it across ranks over RCCL."""
     nrows = int(r.nrows)
     row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
@@ -48,7 +48,7 @@ def merge_on_device(torch, dist, shard, r, npat, world, device):
         cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
     else:
         ids = cnt = torch.empty(0, dtype=torch.int64, device=device)
-    return shard.merge_shard_results(torch, dist, row_ptr, ids, cnt, world)
+    return shard.merge_shard_results(torch, dist, row_ptr.to(coll_device), ids.to(coll_device), cnt.to(coll_device), world)
 
 
 def pmc_traffic(kernel):
@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-docs", type=int, default=1 << 15, help="docs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
+                         "exercise the N > 1 code path on a one-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,11 +127,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     ndocs, doclen, npat, mmin, mmax = WORKLOADS[args.workload]
     n = ndocs * doclen
@@ -143,17 +153,25 @@ def main():
         meta = torch.tensor([len(pb)], dtype=torch.int64, device=device)
     else:
         meta = torch.zeros(1, dtype=torch.int64, device=device)
-    if world > 1:
-        dist.broadcast(meta, 0)
+    def bcast(t):
+        if world == 1:
+            return
+        if coll_device == t.device:
+            dist.broadcast(t, 0)
+        else:
+            c = t.to(coll_device)
+            dist.broadcast(c, 0)
+            t.copy_(c)
+
+    bcast(meta)
     nbytes = int(meta.item())
     d_blob = torch.zeros(nbytes + 16, dtype=torch.uint8, device=device)
     d_offs = torch.zeros(npat + 1, dtype=torch.int64, device=device)
     if rank == 0:
         d_blob[:nbytes] = torch.from_numpy(pb).to(device)
         d_offs.copy_(torch.from_numpy(po.astype(np.int64)).to(device))
-    if world > 1:
-        dist.broadcast(d_blob, 0)
-        dist.broadcast(d_offs, 0)
+    bcast(d_blob)
+    bcast(d_offs)
 
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
@@ -164,7 +182,7 @@ def main():
         r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
         tq = g.stat("query_ms")
         if world > 1:
-            merge_on_device(torch, dist, shard, r, npat, world, device)
+            merge_on_device(torch, dist, shard, r, npat, world, device, coll_device)
         return tb, tq, int(r.nhits), int(r.nrows)
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
@@ -186,7 +204,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, build_ms, query_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, build_ms, query_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
 

@@ -22,6 +22,7 @@
 //                        stable and the initial order is text order they already ascend by document.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 
 #include "index_impl.h"
 #include "scan.h"
@@ -473,10 +474,25 @@ void build_typed(Index& ix) {
     const int symbits = std::max(1, bit_width64((uint64_t)sigma));
     CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
 
-    int passes = ix.initial_passes > 0 ? ix.initial_passes : (int)ceil_div(bit_width64(n) + 12, 8);
-    passes = std::min(std::max(passes, 1), 8);
-    int nsym = std::min((8 * passes) / symbits, 64 / symbits);
-    nsym = std::min(std::max(nsym, 1), KG_LOOK);
+    // Key width of the initial sort.  Every suffix left unresolved costs a refinement round (compaction,
+    // gathers, a further sort, inverse-array traffic for doubling) that is an order of magnitude more
+    // expensive per element than one more radix pass, so the key takes as many symbols as it needs for
+    // the expected unresolved share to drop below ~1/64 under an order-0 model of the text: a suffix
+    // shares its first k symbols with some other suffix with probability ~ n * pc^k, pc = sum_c p_c^2.
+    int nsym;
+    if (ix.initial_passes > 0) {
+        const int passes = std::min(ix.initial_passes, 8);
+        nsym = std::min((8 * passes) / symbits, 64 / symbits);
+    } else {
+        double pc = 0;
+        for (int b = 0; b < 256; ++b) {
+            const double p = (double)h_counts[b] / (double)n;
+            pc += p * p;
+        }
+        const double need = pc < 0.999 ? std::log(64.0 * (double)n) / -std::log(pc) : 1e9;
+        nsym = (int)std::min<double>(std::ceil(need), 64.0);
+    }
+    nsym = std::min(std::max(nsym, 1), std::min(64 / symbits, 32));
     const int key_bits = nsym * symbits;
     // digit width of the initial sort: whole symbols per digit when that costs no extra pass — the
     // digit then takes at most alphabet+1 values, which lengthens the per-digit runs of a tile

@@ -1,0 +1,28 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from coffeedb_amd import capi, workloads as W
+nd = int(sys.argv[1]); dl = int(sys.argv[2]); kind = sys.argv[3] if len(sys.argv) > 3 else "ascii"
+n = nd * dl
+if kind == "zipf":
+    w = 1.0 / torch.arange(1, 65, dtype=torch.float64, device="cuda"); cdf = torch.cumsum(w / w.sum(), 0)
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        u = torch.rand(e - s, dtype=torch.float64, device="cuda", generator=gen)
+        text[s:e] = (0x30 + torch.searchsorted(cdf, u).clamp_(0, 63)).to(torch.uint8)
+else:
+    text = W.random_bytes_torch(n, 12345, device="cuda")
+ds = W.uniform_docs(nd, dl); ids = np.arange(nd, dtype=np.int64)
+torch.cuda.synchronize()
+g = capi.GpuStringIndex(); g.set_option("profile", 1)
+for i in range(2):
+    g.profile_reset(); t = time.time(); g.build_device(text.data_ptr(), ds, ids); w_ = time.time() - t
+    print(f"{kind} n={n/2**30:.2f} GiB width={g.sa_width} build {w_*1e3:.1f} ms ({n/2**30/w_:.2f} GiB/s) rounds={g.stat('rounds'):.0f} ext={g.stat('ext_rounds'):.0f} dbl={g.stat('dbl_rounds'):.0f} "
+          f"unres0={g.stat('unresolved_after_initial'):.0f} passes={g.stat('sort_passes'):.0f} nsym={g.stat('key_symbols'):.0f} symbits={g.stat('symbol_bits'):.0f} fused={g.stat('fused_keygen'):.0f} depth={g.stat('final_depth'):.0f}", flush=True)
+for k, v in sorted(g.profile().items(), key=lambda kv: -kv[1]["ms"])[:8]:
+    print(f"   {k:32s} {v['ms']:9.3f} ms x{v['launches']}")
+t = time.time(); print(g.verify(), f"verify {time.time()-t:.2f}s")
+print("free/total GiB:", [x / 2**30 for x in torch.cuda.mem_get_info()])
