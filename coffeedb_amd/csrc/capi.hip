@@ -2,6 +2,7 @@
 // cdb_add, the reference's width rule, uploads/downloads and error translation.  All device work is in
 // sa_build.hip / query.hip / radix_sort.h.
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 
@@ -227,19 +228,93 @@ void cdb_result_free(cdb_result* r) {
     std::memset(r, 0, sizeof(*r));
 }
 
+// Single-keyword queries arrive from many host threads at once (the reference serves them from an
+// httplib pool under a shared lock, database.cpp:388) and one GPU round trip costs ~100 us, so
+// concurrent callers are coalesced: the first caller becomes the leader and resolves everything that
+// queued up as ONE batched GPU query, then the next batch, until the queue is empty; the others wait
+// for their slice of the result.  No artificial delay is added for a lone caller.
+namespace {
+struct PendingQuery {
+    const char* kw;
+    size_t len;
+    int64_t *ids = nullptr, *counts = nullptr;
+    size_t rows = 0;
+    int rc = CDB_OK;
+    bool done = false;
+};
+
+void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
+    std::string blob;
+    std::vector<uint64_t> offs{0};
+    for (auto* q : batch) {
+        blob.append(q->kw, q->len);
+        offs.push_back(blob.size());
+    }
+    cdb_result r;
+    const int rc = cdb_query_batch(h, blob.data(), offs.data(), batch.size(), &r);
+    for (size_t j = 0; j < batch.size(); ++j) {
+        PendingQuery* q = batch[j];
+        q->rc = rc;
+        if (rc != CDB_OK) continue;
+        const uint64_t a = r.row_ptr[j], b = r.row_ptr[j + 1];
+        q->rows = (size_t)(b - a);
+        q->ids = (int64_t*)std::malloc(std::max<size_t>(q->rows, 1) * 8);
+        q->counts = (int64_t*)std::malloc(std::max<size_t>(q->rows, 1) * 8);
+        if (!q->ids || !q->counts) {
+            q->rc = CDB_E_DEVICE;
+            continue;
+        }
+        std::memcpy(q->ids, r.ids + a, q->rows * 8);
+        std::memcpy(q->counts, r.counts + a, q->rows * 8);
+    }
+    if (rc == CDB_OK) cdb_result_free(&r);
+}
+}  // namespace
+
 int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows) {
     if (!h || !ids || !counts || !nrows) return CDB_E_INVALID;
     *ids = nullptr;
     *counts = nullptr;
     *nrows = 0;
-    const uint64_t offs[2] = {0, (uint64_t)len};
-    cdb_result r;
-    const int rc = cdb_query_batch(h, keyword, offs, 1, &r);
-    if (rc != CDB_OK) return rc;
-    *ids = r.ids;
-    *counts = r.counts;
-    *nrows = (size_t)r.nrows;
-    std::free(r.row_ptr);
+    Index& ix = h->ix;
+    if (len == 0) {  // index.cpp:239-241
+        std::lock_guard<std::mutex> g(ix.qmu);
+        ix.err = "Empty keywords are not allowed";
+        return CDB_E_INVALID;
+    }
+    PendingQuery me{keyword, len};
+    if (!ix.coalesce_queries) {
+        std::vector<PendingQuery*> one{&me};
+        run_coalesced(h, one);
+    } else {
+        std::unique_lock<std::mutex> lk(ix.qmu);
+        ix.qpending.push_back(&me);
+        if (!ix.qleader) {
+            ix.qleader = true;
+            while (!ix.qpending.empty()) {
+                std::vector<void*> taken;
+                taken.swap(ix.qpending);
+                lk.unlock();
+                std::vector<PendingQuery*> batch;
+                for (void* p : taken) batch.push_back(static_cast<PendingQuery*>(p));
+                run_coalesced(h, batch);
+                lk.lock();
+                for (auto* q : batch) q->done = true;
+                ix.qcv.notify_all();
+            }
+            ix.qleader = false;
+        } else {
+            ix.qcv.wait(lk, [&] { return me.done; });
+        }
+    }
+    if (me.rc != CDB_OK) {
+        std::free(me.ids);
+        std::free(me.counts);
+        return me.rc;
+    }
+    *ids = me.ids;
+    *counts = me.counts;
+    *nrows = me.rows;
     return CDB_OK;
 }
 
@@ -296,6 +371,9 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "sort_variant")) ix.sort_variant = (int)value;
     else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
+    else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
+        ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;
+    else if (!std::strcmp(name, "coalesce_queries")) ix.coalesce_queries = value != 0;
     else {
         ix.err = std::string("unknown option: ") + name;
         return CDB_E_INVALID;

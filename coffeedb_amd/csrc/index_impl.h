@@ -1,5 +1,6 @@
 // index_impl.h — state of one GPU string index (the object behind the opaque cdb_index handle).
 #pragma once
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -36,6 +37,12 @@ struct Index {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;  // serialises device work of one index (queries from several host threads)
+    // coalescing of concurrent single-keyword queries (capi.hip: cdb_query)
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::vector<void*> qpending;
+    bool qleader = false;
+    bool coalesce_queries = true;
 
     // ---- host staging (cdb_add)
     std::vector<int64_t> ids;
@@ -67,6 +74,7 @@ struct Index {
     int sort_variant = 0;
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;
+    uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 
     Profiler prof;
     BuildStats bstats;

@@ -90,23 +90,24 @@ struct HitsOut {
     }
 };
 
-// one thread per hit slot: find the owning pattern (binary search over the hit offsets), emit
-// (pattern << dbits) | doc
+// one thread per hit slot of the chunk [j0, j1) of patterns: find the owning pattern (binary search
+// over the hit offsets), emit ((pattern - j0) << dbits) | doc
 template <typename V>
 __global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa, uint64_t mask, int dbits,
                                                        const int64_t* __restrict__ left,
-                                                       const uint64_t* __restrict__ hoff, uint64_t npat, uint64_t H,
-                                                       uint64_t* __restrict__ keys) {
+                                                       const uint64_t* __restrict__ hoff, uint64_t j0, uint64_t j1,
+                                                       uint64_t H, uint64_t* __restrict__ keys) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= H) return;
-    uint64_t lo = 0, hi = npat - 1;  // largest j with hoff[j] <= t
+    const uint64_t slot = hoff[j0] + t;
+    uint64_t lo = j0, hi = j1 - 1;  // largest j with hoff[j] <= slot
     while (lo < hi) {
         const uint64_t mid = lo + (hi - lo + 1) / 2;
-        if (hoff[mid] <= t) lo = mid; else hi = mid - 1;
+        if (hoff[mid] <= slot) lo = mid; else hi = mid - 1;
     }
     const uint64_t j = lo;
-    const uint64_t i = (uint64_t)left[j] + (t - hoff[j]);
-    keys[t] = (j << dbits) | ((uint64_t)sa[i] & mask);
+    const uint64_t i = (uint64_t)left[j] + (slot - hoff[j]);
+    keys[t] = ((j - j0) << dbits) | ((uint64_t)sa[i] & mask);
 }
 
 struct RunIn {  // 1 at the first hit of every (pattern, doc) run
@@ -138,17 +139,28 @@ __global__ __launch_bounds__(256) void q_rows_kernel(const uint64_t* __restrict_
     out_counts[r] = (int64_t)(row_first[r + 1] - row_first[r]);
 }
 
-// row_ptr[j] = first row whose pattern id >= j  (rows are sorted by (pattern, doc))
+// row_ptr[j0 + k] = rows_base + first row of the chunk whose local pattern id >= k, k = 0 .. count-1
 __global__ __launch_bounds__(256) void q_rowptr_kernel(const uint64_t* __restrict__ row_key, uint64_t nrows, int dbits,
-                                                       uint64_t npat, uint64_t* __restrict__ row_ptr) {
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j > npat) return;
+                                                       uint64_t j0, uint64_t count, uint64_t rows_base,
+                                                       uint64_t* __restrict__ row_ptr) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
     uint64_t lo = 0, hi = nrows;
     while (lo < hi) {
         const uint64_t mid = lo + (hi - lo) / 2;
-        if ((row_key[mid] >> dbits) < j) lo = mid + 1; else hi = mid;
+        if ((row_key[mid] >> dbits) < k) lo = mid + 1; else hi = mid;
     }
-    row_ptr[j] = lo;
+    row_ptr[j0 + k] = rows_base + lo;
+}
+
+// grows a device buffer to `need` bytes, keeping its first `used` bytes
+void grow_keep(DevBuf& b, size_t need, size_t used, hipStream_t s) {
+    if (need <= b.bytes) return;
+    DevBuf nb;
+    nb.alloc(need + need / 2);
+    if (used) CDB_HIP(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
+    CDB_HIP(hipStreamSynchronize(s));  // the old block goes back to the shared cache
+    b = std::move(nb);
 }
 
 template <typename V>
@@ -187,34 +199,73 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         return out;
     }
     const int dbits = (int)ix.bits;
-    const int jbits = bit_width64(npat - 1);
-    if (dbits + jbits > 64) throw Error("pattern batch too large for one call");
-    ix.q_keys0.ensure(H * 8);
-    ix.q_keys1.ensure(H * 8);
-    t = ix.prof.begin(s);
-    hipLaunchKernelGGL((q_expand_kernel<V>), dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, s, sa, ix.mask, dbits,
-                       (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, H,
-                       ix.q_keys0.as<uint64_t>());
-    ix.prof.end(t, "q_expand", H * (sizeof(V) + 8), s);
-    // stable sort of the whole batch by (pattern ∘ doc); passes over constant digits are skipped
-    const int sel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(),
-                                                (NoVal*)nullptr, (NoVal*)nullptr, H, 0, dbits + jbits, nullptr);
-    const uint64_t* keys = sel == 0 ? ix.q_keys0.as<uint64_t>() : ix.q_keys1.as<uint64_t>();
-    uint64_t* spare = sel == 0 ? ix.q_keys1.as<uint64_t>() : ix.q_keys0.as<uint64_t>();
+    // Chunks of patterns whose hit lists fit the scratch budget (16 B of sort scratch per hit); almost
+    // always one chunk.  A short pattern over a big corpus can match a large share of the text, and a
+    // whole batch of them can exceed any buffer — they are then resolved chunk by chunk.
+    std::vector<uint64_t> cut{0, npat};
+    if (H > ix.query_hit_budget) {
+        std::vector<uint64_t> hoff(npat + 1);
+        CDB_HIP(hipMemcpyAsync(hoff.data(), ix.q_hoff.p, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        cut.assign(1, 0);
+        uint64_t start = 0;
+        for (uint64_t j = 1; j <= npat; ++j) {
+            if (hoff[j] - hoff[start] > ix.query_hit_budget && j - 1 > start) {
+                cut.push_back(j - 1);
+                start = j - 1;
+            }
+        }
+        cut.push_back(npat);
+    }
+    uint64_t rows_total = 0;
+    for (size_t c = 0; c + 1 < cut.size(); ++c) {
+        const uint64_t j0 = cut[c], j1 = cut[c + 1];
+        uint64_t Hc = H;
+        if (cut.size() > 2) {
+            uint64_t e[2];
+            CDB_HIP(hipMemcpyAsync(&e[0], ix.q_hoff.as<uint64_t>() + j0, 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(&e[1], ix.q_hoff.as<uint64_t>() + j1, 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            Hc = e[1] - e[0];
+        }
+        if (Hc == 0) {
+            hipLaunchKernelGGL(q_rowptr_kernel, dim3((unsigned)ceil_div(j1 - j0, 256)), dim3(256), 0, s,
+                               (const uint64_t*)nullptr, (uint64_t)0, dbits, j0, j1 - j0, rows_total, ix.q_rowptr.as<uint64_t>());
+            continue;
+        }
+        const int jbits = bit_width64(j1 - j0 - 1);
+        if (dbits + jbits > 64) throw Error("pattern batch too large for one call");
+        ix.q_keys0.ensure(Hc * 8);
+        ix.q_keys1.ensure(Hc * 8);
+        t = ix.prof.begin(s);
+        hipLaunchKernelGGL((q_expand_kernel<V>), dim3((unsigned)ceil_div(Hc, 256)), dim3(256), 0, s, sa, ix.mask, dbits,
+                           (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), j0, j1, Hc,
+                           ix.q_keys0.as<uint64_t>());
+        ix.prof.end(t, "q_expand", Hc * (sizeof(V) + 8), s);
+        // stable sort of the chunk by (pattern ∘ doc); passes over constant digits are skipped
+        const int sel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(),
+                                                    (NoVal*)nullptr, (NoVal*)nullptr, Hc, 0, dbits + jbits, nullptr);
+        const uint64_t* keys = sel == 0 ? ix.q_keys0.as<uint64_t>() : ix.q_keys1.as<uint64_t>();
+        uint64_t* spare = sel == 0 ? ix.q_keys1.as<uint64_t>() : ix.q_keys0.as<uint64_t>();
 
-    RunIn rin{keys};
-    const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, rin, H, OpAdd{}, (uint64_t)0);
-    out.nrows = nrows;
-    ix.q_flags.ensure((nrows + 1) * 8);  // row_first
-    // row keys go to the spare key buffer (nrows <= H)
-    scan_apply<uint64_t>(s, ix.scan_partials, rin, H, OpAdd{}, (uint64_t)0, RunOut{keys, ix.q_flags.as<uint64_t>(), spare, H});
-    ix.q_ids.ensure(nrows * 8);
-    ix.q_counts.ensure(nrows * 8);
-    hipLaunchKernelGGL(q_rows_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, s,
-                       (const uint64_t*)ix.q_flags.as<uint64_t>(), (const uint64_t*)spare, nrows, dbits,
-                       (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
-    hipLaunchKernelGGL(q_rowptr_kernel, dim3((unsigned)ceil_div(npat + 1, 256)), dim3(256), 0, s, (const uint64_t*)spare,
-                       nrows, dbits, npat, ix.q_rowptr.as<uint64_t>());
+        RunIn rin{keys};
+        const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0);
+        ix.q_flags.ensure((nrows + 1) * 8);  // row_first
+        // row keys go to the spare key buffer (nrows <= Hc)
+        scan_apply<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0,
+                             RunOut{keys, ix.q_flags.as<uint64_t>(), spare, Hc});
+        grow_keep(ix.q_ids, (rows_total + nrows) * 8, rows_total * 8, s);
+        grow_keep(ix.q_counts, (rows_total + nrows) * 8, rows_total * 8, s);
+        hipLaunchKernelGGL(q_rows_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, s,
+                           (const uint64_t*)ix.q_flags.as<uint64_t>(), (const uint64_t*)spare, nrows, dbits,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>() + rows_total,
+                           ix.q_counts.as<int64_t>() + rows_total);
+        hipLaunchKernelGGL(q_rowptr_kernel, dim3((unsigned)ceil_div(j1 - j0, 256)), dim3(256), 0, s, (const uint64_t*)spare,
+                           nrows, dbits, j0, j1 - j0, rows_total, ix.q_rowptr.as<uint64_t>());
+        rows_total += nrows;
+    }
+    out.nrows = rows_total;
+    CDB_HIP(hipMemcpyAsync(ix.q_rowptr.as<uint64_t>() + npat, &rows_total, 8, hipMemcpyHostToDevice, s));
     CDB_HIP(hipGetLastError());
     radix_check_error(s, ix.rws);
     CDB_HIP(hipStreamSynchronize(s));

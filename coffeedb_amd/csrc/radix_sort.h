@@ -623,6 +623,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
                const uint64_t* h_hist_in = nullptr, const TextGen* gen = nullptr) {
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     if constexpr (!HAS_V) {
+        if (n >= (1ull << 23))  // key-only: same 16 Ki-key tile as the pair sort
+            return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
         return radix_sort_cfg<K, V, RsCfg<16, false, false>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
     } else {
         // variant 0 picks by size: big tiles (16 Ki keys, one workgroup per CU) give the longest per-digit

@@ -194,6 +194,13 @@ def test_many_hits_single_char_patterns(G):
     po = np.array([0, 1, 2, 4, 6, 7], dtype=np.uint64)
     g, o = _check_parity(G, blob, ds, patterns=(pb, po))
     assert len(g.query(b"a")) == 3000
+    # the same batch resolved in several chunks (hit budget far below the batch's ~260k hits), and with
+    # a budget smaller than single patterns' hit lists
+    for budget in (100_000, 700, 1):
+        g.set_option("query_hit_budget", budget)
+        rp, gi, gc, hits = g.query_batch(pb, po)
+        orp, oi, oc, ohits = o.query_batch(pb, po)
+        assert hits == ohits and np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc)
 
 
 def test_high_bytes_native_order_matches_brute_force(G):
