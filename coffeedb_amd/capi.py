@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device",
-    "cdb_query", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_query", "cdb_query_or", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
     "cdb_debug_radix_sort", "cdb_debug_verify",
@@ -69,6 +69,8 @@ def load_library():
     lib.cdb_build_device.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                               C.POINTER(C.c_size_t)]
+    lib.cdb_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
+                                 C.POINTER(C.c_size_t)]
     lib.cdb_free.argtypes = [vp]
     lib.cdb_free.restype = None
     lib.cdb_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
@@ -145,6 +147,19 @@ class GpuStringIndex:
     def query(self, kw: bytes):
         ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
         self._check(self._lib.cdb_query(self._h, kw, len(kw), C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = [(ids[i], cnt[i]) for i in range(n.value)]
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return out
+
+    def query_or(self, keywords):
+        """Union over `keywords` by object id with summed counts, ascending id (interface.cpp:78-113)."""
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        self._check(self._lib.cdb_query_or(self._h, _ptr(blob) if len(blob) else None, _ptr(offs), len(keywords),
+                                           C.byref(ids), C.byref(cnt), C.byref(n)))
         out = [(ids[i], cnt[i]) for i in range(n.value)]
         self._lib.cdb_free(ids)
         self._lib.cdb_free(cnt)

@@ -220,6 +220,46 @@ int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uin
     });
 }
 
+int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                 size_t* nrows) {
+    if (!h || !ids || !counts || !nrows || (nkw && !offsets)) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        if (nkw == 0) throw Error("The constraint list cannot be empty");  // interface.cpp:75-77
+        for (uint64_t j = 0; j < nkw; ++j)
+            if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        hipStream_t s = ix.stream;
+        const uint64_t base = offsets[0], nbytes = offsets[nkw] - base;
+        ix.q_pat.ensure(nbytes + 16);
+        ix.q_offs.ensure((nkw + 1) * 8);
+        std::vector<uint64_t> rel(nkw + 1);
+        for (uint64_t j = 0; j <= nkw; ++j) rel[j] = offsets[j] - base;
+        CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
+        CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (nkw + 1) * 8, hipMemcpyHostToDevice, s));
+        const DeviceCsr r = query_or_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), nkw);
+        int64_t* hi = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
+        int64_t* hc = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
+        if (!hi || !hc) {
+            std::free(hi);
+            std::free(hc);
+            throw std::bad_alloc();
+        }
+        if (r.nrows) {
+            CDB_HIP(hipMemcpyAsync(hi, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(hc, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+        }
+        *ids = hi;
+        *counts = hc;
+        *nrows = (size_t)r.nrows;
+    });
+}
+
 void cdb_result_free(cdb_result* r) {
     if (!r) return;
     std::free(r->row_ptr);

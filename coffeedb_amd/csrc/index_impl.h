@@ -93,5 +93,7 @@ struct DeviceCsr {
     uint64_t npat = 0, nrows = 0, nhits = 0;
 };
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+// union over the patterns by object id with summed counts, rows ascending by id, in ix.q_ids / q_counts
+DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
 
 }  // namespace cdb

@@ -163,6 +163,48 @@ void grow_keep(DevBuf& b, size_t need, size_t used, hipStream_t s) {
     b = std::move(nb);
 }
 
+// ---- OR over the keywords of one key (interface.cpp:78-113): per-document totals by atomics ------
+template <typename V>
+__global__ __launch_bounds__(256) void q_count_docs_kernel(const V* __restrict__ sa, uint64_t mask,
+                                                           const int64_t* __restrict__ left,
+                                                           const uint64_t* __restrict__ hoff, uint64_t npat, uint64_t H,
+                                                           unsigned long long* __restrict__ doc_count) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < H; t += stride) {
+        uint64_t lo = 0, hi = npat - 1;  // largest j with hoff[j] <= t
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (hoff[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t i = (uint64_t)left[lo] + (t - hoff[lo]);
+        atomicAdd(&doc_count[(uint64_t)sa[i] & mask], 1ull);
+    }
+}
+
+struct NonZeroIn {
+    const unsigned long long* c;
+    __device__ __forceinline__ uint64_t operator()(uint64_t d) const { return c[d] ? 1ull : 0ull; }
+};
+struct IdRowsOut {  // row r of the union: key = id with the sign bit flipped (unsigned order == signed order)
+    const unsigned long long* c;
+    const int64_t* ids;
+    uint64_t* key;
+    uint64_t* val;
+    __device__ __forceinline__ void operator()(uint64_t d, uint64_t ex, uint64_t in) const {
+        if (in != ex) {
+            key[ex] = (uint64_t)ids[d] ^ (1ull << 63);
+            val[ex] = (uint64_t)c[d];
+        }
+    }
+};
+__global__ __launch_bounds__(256) void q_unflip_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ val,
+                                                       uint64_t n, int64_t* __restrict__ ids, int64_t* __restrict__ counts) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    ids[r] = (int64_t)(key[r] ^ (1ull << 63));
+    counts[r] = (int64_t)val[r];
+}
+
 template <typename V>
 DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     hipStream_t s = ix.stream;
@@ -272,11 +314,68 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
     return out;
 }
 
+template <typename V>
+DeviceCsr query_or_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    hipStream_t s = ix.stream;
+    DeviceCsr out;
+    out.npat = npat;
+    ix.q_ids.ensure(16);
+    ix.q_counts.ensure(16);
+    if (npat == 0 || ix.size == 0 || ix.width == 0) return out;
+    const V* sa = ix.d_sa.as<V>();
+    ix.q_left.ensure(npat * 8);
+    ix.q_right.ensure(npat * 8);
+    ix.q_hoff.ensure((npat + 1) * 8);
+    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                       (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, d_blob, d_offs, npat,
+                       ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    HitsIn hin{ix.q_right.as<uint64_t>()};
+    const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    out.nhits = H;
+    if (H == 0) {
+        CDB_HIP(hipStreamSynchronize(s));
+        return out;
+    }
+    DevBuf doc_count;
+    doc_count.alloc(ix.ndocs * 8);
+    CDB_HIP(hipMemsetAsync(doc_count.p, 0, ix.ndocs * 8, s));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(H, 256), 1u << 20);
+    hipLaunchKernelGGL((q_count_docs_kernel<V>), dim3(grid), dim3(256), 0, s, sa, ix.mask,
+                       (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, H,
+                       doc_count.as<unsigned long long>());
+    NonZeroIn nz{doc_count.as<unsigned long long>()};
+    const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, nz, ix.ndocs, OpAdd{}, (uint64_t)0);
+    out.nrows = nrows;
+    DevBuf k0, k1, v0, v1;
+    k0.alloc(nrows * 8); k1.alloc(nrows * 8); v0.alloc(nrows * 8); v1.alloc(nrows * 8);
+    scan_apply<uint64_t>(s, ix.scan_partials, nz, ix.ndocs, OpAdd{}, (uint64_t)0,
+                         IdRowsOut{doc_count.as<unsigned long long>(), ix.d_ids.as<int64_t>(), k0.as<uint64_t>(), v0.as<uint64_t>()});
+    const int sel = radix_sort<uint64_t, uint64_t>(s, ix.rws, ix.prof, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint64_t>(),
+                                                   v1.as<uint64_t>(), nrows, 0, 64, nullptr);
+    ix.q_ids.ensure(nrows * 8);
+    ix.q_counts.ensure(nrows * 8);
+    hipLaunchKernelGGL(q_unflip_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, s,
+                       (const uint64_t*)(sel ? k1 : k0).as<uint64_t>(), (const uint64_t*)(sel ? v1 : v0).as<uint64_t>(), nrows,
+                       ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+    CDB_HIP(hipGetLastError());
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    return out;
+}
+
 }  // namespace
 
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat)
                                 : query_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    ix.prof.resolve();
+    return r;
+}
+
+DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat)
+                                : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
     ix.prof.resolve();
     return r;
 }

@@ -119,3 +119,22 @@ std::vector<index::result_type> string_index::query_batch(const std::vector<std:
     cdb_result_free(&res);
     return out;
 }
+
+index::result_type string_index::query_any(const std::vector<std::string>& keywords) const {
+    std::string blob;
+    std::vector<uint64_t> offs{0};
+    for (const auto& k : keywords) {
+        blob += k;
+        offs.push_back(blob.size());
+    }
+    int64_t *ids = nullptr, *counts = nullptr;
+    size_t rows = 0;
+    const int rc = cdb_query_or(handle, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
+    if (rc != CDB_OK) rethrow(handle, rc);
+    result_type out;
+    out.reserve(rows);
+    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+    cdb_free(ids);
+    cdb_free(counts);
+    return out;
+}

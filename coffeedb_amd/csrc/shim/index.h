@@ -87,6 +87,9 @@ public:
     // Batched form used by callers that resolve many keywords at once (interface.cpp:79-113 loops
     // query() per keyword): one result list per keyword, same contents as query().
     std::vector<result_type> query_batch(const std::vector<std::string>& keywords) const;
+    // OR over the keywords of this key — what filter() computes per key before the AND across keys
+    // (interface.cpp:78-113): union by object id, counts summed, ascending id.  One GPU call.
+    result_type query_any(const std::vector<std::string>& keywords) const;
 
 private:
     cdb_index* handle = nullptr;

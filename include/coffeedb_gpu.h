@@ -94,6 +94,15 @@ void cdb_free(void* p);
 int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
 void cdb_result_free(cdb_result* r);
 
+/* OR over the keywords of ONE string key — replaces the per-key merge loop of interface.cpp:78-113
+ * (query each keyword, sort by id, merge lists by id summing the counts): returns the union of the
+ * matching objects with their summed $correlation, rows ascending by object id — exactly the list
+ * filter() holds for that key before the AND across keys, the $correlation range filter and the final
+ * ranking (which stay host-side in the shim: coffeedb_amd/csrc/shim/ranking.h).  Object ids are assumed
+ * unique (they are insertion timestamps, interface.cpp:151,178).  Release ids/counts with cdb_free. */
+int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                 size_t* nrows);
+
 /* Batched query with patterns and results left in device memory (multi-GPU merge over RCCL, HBM-
  * resident timing).  d_blob/d_offsets are device pointers.  On return the library-owned device arrays
  * d_row_ptr (npat+1 u64), d_ids (nrows i64), d_counts (nrows i64) stay valid until the next query on

@@ -402,6 +402,52 @@ int orc_query_batch(void* h, const char* blob, const uint64_t* offs, uint64_t np
     return 0;
 }
 
+// interface.cpp:78-113 — the per-key OR over a list of keywords: query each, sort the (id, count) pairs,
+// merge lists by id summing the counts.  Output ascends by id.  Returns the row count (first `cap`
+// rows are written).
+uint64_t orc_filter_or(void* h, const char* blob, const uint64_t* offs, uint64_t nkw, int64_t* ids, int64_t* counts,
+                       uint64_t cap) {
+    Oracle& ix = *(Oracle*)h;
+    using Row = std::pair<int64_t, int64_t>;
+    std::vector<Row> result;
+    for (uint64_t k = 0; k < nkw; ++k) {
+        std::vector<int64_t> qi, qc;
+        const uint64_t m = offs[k + 1] - offs[k];
+        if (ix.built && m) {
+            if (ix.width == 4) query_typed<uint32_t>(ix, ix.sa32.data(), blob + offs[k], m, qi, qc);
+            else query_typed<uint64_t>(ix, ix.sa64.data(), blob + offs[k], m, qi, qc);
+        }
+        std::vector<Row> now(qi.size());
+        for (size_t r = 0; r < qi.size(); ++r) now[r] = Row(qi[r], qc[r]);
+        std::sort(now.begin(), now.end());
+        if (k == 0) {
+            result.swap(now);
+            continue;
+        }
+        std::vector<Row> merged;
+        size_t i = 0, j = 0;
+        while (i < now.size() && j < result.size()) {
+            if (now[i].first == result[j].first) {
+                merged.push_back(Row(now[i].first, now[i].second + result[j].second));
+                ++i;
+                ++j;
+            } else if (now[i] < result[j]) {
+                merged.push_back(now[i++]);
+            } else {
+                merged.push_back(result[j++]);
+            }
+        }
+        while (i < now.size()) merged.push_back(now[i++]);
+        while (j < result.size()) merged.push_back(result[j++]);
+        result.swap(merged);
+    }
+    for (uint64_t r = 0; r < result.size() && r < cap; ++r) {
+        ids[r] = result[r].first;
+        counts[r] = result[r].second;
+    }
+    return result.size();
+}
+
 // SURVEY.md §8c tie canonicalisation; returns the number of runs that were reordered.
 uint64_t orc_canonicalize(void* h) {
     Oracle& ix = *(Oracle*)h;

@@ -42,6 +42,8 @@ def _lib():
         lib.orc_query_batch.restype = C.c_int
         lib.orc_query_batch.argtypes = [vp, vp, vp, u64, C.c_uint, vp, vp, vp, u64, C.POINTER(u64)]
         lib.orc_brute_count.argtypes = [vp, vp, u64, C.c_char_p, u64, vp]
+        lib.orc_filter_or.restype = u64
+        lib.orc_filter_or.argtypes = [vp, vp, vp, u64, vp, vp, u64]
         _LIB = lib
     return _LIB
 
@@ -105,6 +107,20 @@ class OracleIndex:
             if n.value <= cap:
                 return list(zip(ids[: n.value].tolist(), cnt[: n.value].tolist()))
             cap = n.value
+
+    def filter_or(self, keywords):
+        """interface.cpp:78-113: union over keywords by id with summed counts, ascending id."""
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        cap = 1 << 16
+        while True:
+            ids = np.empty(cap, dtype=np.int64)
+            cnt = np.empty(cap, dtype=np.int64)
+            n = _lib().orc_filter_or(self._h, _ptr(blob), _ptr(offs), len(keywords), _ptr(ids), _ptr(cnt), cap)
+            if n <= cap:
+                return list(zip(ids[:n].tolist(), cnt[:n].tolist()))
+            cap = n
 
     def query_batch(self, blob, offsets, nthreads=1, want_rows=True):
         """Returns (row_ptr, ids, counts, total_hits); ids/counts are None when want_rows is False."""

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "index.h"
+#include "ranking.h"
 
 static int failures = 0;
 #define CHECK(c)                                                   \
@@ -55,6 +56,18 @@ static void numeric() {
     try { bi.query("maybe"); } catch (const std::runtime_error&) { threw = true; }
     CHECK(threw);
 
+    // interface.cpp:114-146 restated in ranking.h
+    {
+        cdb_shim::rows_t a{{1, 2}, {3, 1}, {5, 4}, {9, 1}}, b{{3, 2}, {4, 7}, {5, 1}};
+        auto m = cdb_shim::and_merge(a, b);
+        CHECK((m == cdb_shim::rows_t{{3, 3}, {5, 5}}));
+        cdb_shim::rows_t c{{1, 1}, {2, 5}, {3, 2}, {4, 9}};
+        cdb_shim::correlation_filter(c, 2, 9);
+        CHECK((c == cdb_shim::rows_t{{2, 5}, {3, 2}}));
+        cdb_shim::rows_t r{{1, 1}, {2, 5}, {3, 2}, {4, 9}, {5, 3}};
+        cdb_shim::rank_by_correlation(r);
+        CHECK((r == cdb_shim::rows_t{{4, 9}, {2, 5}, {5, 3}, {3, 2}, {1, 1}}));
+    }
     index base;
     threw = false;
     try { base.build(); } catch (const std::logic_error&) { threw = true; }
@@ -80,6 +93,7 @@ static void gpu_string() {
     CHECK(threw);
     auto batch = sp->query_batch({"010", "0", "!"});
     CHECK(batch.size() == 3 && batch[0] == (R{{100, 2}, {101, 1}, {102, 2}}) && batch[1] == (R{{100, 3}, {101, 2}, {102, 4}}) && batch[2].empty());
+    CHECK((sp->query_any({"010", "3"}) == R{{100, 4}, {101, 2}, {102, 2}}));
     // rebuild-and-swap as database.cpp:170-281 does: new object built while the old one still answers
     auto fresh = std::make_unique<string_index>();
     fresh->add(1, "hello world");

@@ -251,6 +251,22 @@ def test_reference_compat_bit_parity_high_bytes(G):
     assert g.stat("compat_rotations") == 0 and o.inversions() == 0
 
 
+def test_or_merge_over_keywords_matches_reference_loop(G):
+    # interface.cpp:78-113 — per-key OR over a keyword list (union by id, counts summed)
+    blob, ds = W.ascii_corpus(4000, 200, seed=41, lo=0x61, hi=0x66)
+    ids = (np.arange(4000, dtype=np.int64)[::-1] * 7 - 9000)          # unsorted, partly negative ids
+    g = _gpu(G, blob, ds, ids)
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 40, 2, 5, seed=3, miss_byte=0x7A)
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(40)]
+    for group in (kws[:1], kws[:2], kws[2:7], kws[7:40], [b"zzzz"], [b"a", b"b", b"ab"], [kws[3], kws[3]]):
+        assert g.query_or(group) == o.filter_or(group), group
+    with pytest.raises(RuntimeError, match="Empty keywords are not allowed"):
+        g.query_or([b"ab", b""])
+    with pytest.raises(RuntimeError, match="cannot be empty"):
+        g.query_or([])
+
+
 def test_concurrent_queries_same_handle(G):
     blob, ds = W.ascii_corpus(2000, 128, seed=3)
     ids = np.arange(2000, dtype=np.int64)
