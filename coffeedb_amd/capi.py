@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device",
-    "cdb_query", "cdb_query_or", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
     "cdb_debug_radix_sort", "cdb_debug_verify",
@@ -27,6 +27,11 @@ EXPORTS = [
 class CdbResult(C.Structure):
     _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
                 ("row_ptr", C.POINTER(C.c_uint64)), ("ids", C.POINTER(C.c_int64)), ("counts", C.POINTER(C.c_int64))]
+
+
+class CdbSpans(C.Structure):
+    _fields_ = [("ndocs", C.c_uint64), ("nspans", C.c_uint64), ("ids", C.POINTER(C.c_int64)),
+                ("span_ptr", C.POINTER(C.c_uint64)), ("begin", C.POINTER(C.c_uint64)), ("end", C.POINTER(C.c_uint64))]
 
 
 class CdbDeviceResult(C.Structure):
@@ -71,6 +76,9 @@ def load_library():
                               C.POINTER(C.c_size_t)]
     lib.cdb_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                                  C.POINTER(C.c_size_t)]
+    lib.cdb_query_spans.argtypes = [vp, vp, vp, u64, C.POINTER(CdbSpans)]
+    lib.cdb_spans_free.argtypes = [C.POINTER(CdbSpans)]
+    lib.cdb_spans_free.restype = None
     lib.cdb_free.argtypes = [vp]
     lib.cdb_free.restype = None
     lib.cdb_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
@@ -164,6 +172,23 @@ class GpuStringIndex:
         self._lib.cdb_free(ids)
         self._lib.cdb_free(cnt)
         return out
+
+    def query_spans(self, keywords):
+        """{object id: [(begin, end_inclusive), ...]} — merged highlight spans (database.cpp:58-76)."""
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        r = CdbSpans()
+        self._check(self._lib.cdb_query_spans(self._h, _ptr(blob) if len(blob) else None, _ptr(offs), len(keywords),
+                                              C.byref(r)))
+        try:
+            out = []
+            for d in range(r.ndocs):
+                a, b = r.span_ptr[d], r.span_ptr[d + 1]
+                out.append((r.ids[d], [(r.begin[k], r.end[k]) for k in range(a, b)]))
+            return out
+        finally:
+            self._lib.cdb_spans_free(C.byref(r))
 
     # ---- batched
     def query_batch(self, blob, offsets):

@@ -260,6 +260,56 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
     });
 }
 
+int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {
+    if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::vector<uint64_t> rel{0};
+        std::string pat;
+        for (uint64_t j = 0; j < nkw; ++j) {  // empty highlight keywords never match (ac_automaton::insert)
+            if (offsets[j + 1] <= offsets[j]) continue;
+            pat.append(blob + offsets[j], offsets[j + 1] - offsets[j]);
+            rel.push_back(pat.size());
+        }
+        const uint64_t npat = rel.size() - 1;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        hipStream_t s = ix.stream;
+        SpanResult r;
+        if (npat) {
+            ix.q_pat.ensure(pat.size() + 16);
+            ix.q_offs.ensure((npat + 1) * 8);
+            CDB_HIP(hipMemcpyAsync(ix.q_pat.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s));
+            CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
+            r = query_spans_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+        }
+        out->ndocs = r.ndocs;
+        out->nspans = r.nspans;
+        out->ids = (int64_t*)std::malloc(std::max<uint64_t>(r.ndocs, 1) * 8);
+        out->span_ptr = (uint64_t*)std::calloc(r.ndocs + 1, 8);
+        out->begin = (uint64_t*)std::malloc(std::max<uint64_t>(r.nspans, 1) * 8);
+        out->end = (uint64_t*)std::malloc(std::max<uint64_t>(r.nspans, 1) * 8);
+        if (!out->ids || !out->span_ptr || !out->begin || !out->end) throw std::bad_alloc();
+        if (r.nspans) {
+            CDB_HIP(hipMemcpyAsync(out->ids, ix.q_ids.p, r.ndocs * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(out->span_ptr, ix.q_rowptr.p, (r.ndocs + 1) * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(out->begin, ix.q_keys0.p, r.nspans * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(out->end, ix.q_keys1.p, r.nspans * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+        }
+    });
+}
+
+void cdb_spans_free(cdb_spans* r) {
+    if (!r) return;
+    std::free(r->ids);
+    std::free(r->span_ptr);
+    std::free(r->begin);
+    std::free(r->end);
+    std::memset(r, 0, sizeof(*r));
+}
+
 void cdb_result_free(cdb_result* r) {
     if (!r) return;
     std::free(r->row_ptr);

@@ -93,6 +93,12 @@ struct DeviceCsr {
     uint64_t npat = 0, nrows = 0, nhits = 0;
 };
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+// highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
+// ix.q_keys0, inclusive span ends -> ix.q_keys1
+struct SpanResult {
+    uint64_t ndocs = 0, nspans = 0, nhits = 0;
+};
+SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
 // union over the patterns by object id with summed counts, rows ascending by id, in ix.q_ids / q_counts
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
 

@@ -205,6 +205,105 @@ __global__ __launch_bounds__(256) void q_unflip_kernel(const uint64_t* __restric
     counts[r] = (int64_t)val[r];
 }
 
+// ---- highlight spans (reference database.cpp:58-76) -----------------------------------
+// ac_automaton::render walks a document once and, for every position where a keyword ends, merges the
+// occurrence [begin, end] into a span list: earlier spans starting at or after `begin` are dropped, an
+// occurrence that begins inside the previous span extends it, anything else starts a new span.  The
+// outcome is the union of all keyword occurrences of the document with OVERLAPPING occurrences fused
+// and merely adjacent ones kept apart.  The suffix array already knows every occurrence (offset =
+// entry >> bits), so no document has to be re-scanned: occurrences are sorted by (doc, begin) and a
+// segmented running maximum of the ends decides where a new span starts.
+template <typename V>
+__global__ __launch_bounds__(256) void q_expand_occ_kernel(const V* __restrict__ sa, uint64_t mask, int bits, int obits,
+                                                           const int64_t* __restrict__ left,
+                                                           const uint64_t* __restrict__ hoff,
+                                                           const uint64_t* __restrict__ offs, uint64_t npat, uint64_t H,
+                                                           uint64_t* __restrict__ keys, uint64_t* __restrict__ ends) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < H; t += stride) {
+        uint64_t lo = 0, hi = npat - 1;  // largest j with hoff[j] <= t
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (hoff[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const V e = sa[(uint64_t)left[lo] + (t - hoff[lo])];
+        const uint64_t doc = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        keys[t] = (doc << obits) | off;
+        ends[t] = off + (offs[lo + 1] - offs[lo]);  // one past the last byte of the occurrence
+    }
+}
+
+struct DocMax {  // (document, running maximum of occurrence ends) — segmented max
+    uint64_t doc, mx;
+};
+struct OpDocMax {
+    __device__ __forceinline__ DocMax operator()(const DocMax& a, const DocMax& b) const {
+        return DocMax{b.doc, a.doc == b.doc ? (a.mx > b.mx ? a.mx : b.mx) : b.mx};
+    }
+};
+struct OccIn {
+    const uint64_t* keys;
+    const uint64_t* ends;
+    int obits;
+    __device__ __forceinline__ DocMax operator()(uint64_t i) const { return DocMax{keys[i] >> obits, ends[i]}; }
+};
+struct OccOut {  // head[i] = 1 where a new span starts; incl[i] = running max end inside the document
+    const uint64_t* keys;
+    int obits;
+    uint8_t* head;
+    uint64_t* incl;
+    __device__ __forceinline__ void operator()(uint64_t i, const DocMax& ex, const DocMax& in) const {
+        const uint64_t k = keys[i];
+        const uint64_t doc = k >> obits, begin = k & ((1ull << obits) - 1ull);
+        head[i] = (uint8_t)((i == 0 || ex.doc != doc || begin >= ex.mx) ? 1 : 0);  // begin >= max end+... : no overlap
+        incl[i] = in.mx;
+    }
+};
+struct HeadIn {
+    const uint8_t* head;
+    __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return head[i]; }
+};
+struct SpanOut {  // span k starts at occurrence i
+    const uint8_t* head;
+    const uint64_t* keys;
+    uint64_t* span_first;
+    uint64_t* span_key;
+    uint64_t m;
+    __device__ __forceinline__ void operator()(uint64_t i, uint64_t ex, uint64_t in) const {
+        if (in != ex) {
+            span_first[ex] = i;
+            span_key[ex] = keys[i];
+        }
+        if (i + 1 == m) span_first[in] = m;
+    }
+};
+__global__ __launch_bounds__(256) void q_span_rows_kernel(const uint64_t* __restrict__ span_first,
+                                                          const uint64_t* __restrict__ span_key,
+                                                          const uint64_t* __restrict__ incl, uint64_t nspans, int obits,
+                                                          uint64_t* __restrict__ begin, uint64_t* __restrict__ end,
+                                                          uint8_t* __restrict__ dochead) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nspans) return;
+    begin[k] = span_key[k] & ((1ull << obits) - 1ull);
+    end[k] = incl[span_first[k + 1] - 1] - 1;  // inclusive last byte, as ac_automaton's spans
+    dochead[k] = (uint8_t)((k == 0 || (span_key[k] >> obits) != (span_key[k - 1] >> obits)) ? 1 : 0);
+}
+struct DocRowOut {  // row r (document) starts at span k
+    const uint64_t* span_key;
+    const int64_t* ids;
+    int obits;
+    uint64_t nspans;
+    int64_t* out_ids;
+    uint64_t* span_ptr;
+    __device__ __forceinline__ void operator()(uint64_t k, uint64_t ex, uint64_t in) const {
+        if (in != ex) {
+            out_ids[ex] = ids[span_key[k] >> obits];
+            span_ptr[ex] = k;
+        }
+        if (k + 1 == nspans) span_ptr[in] = nspans;
+    }
+};
+
 template <typename V>
 DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     hipStream_t s = ix.stream;
@@ -364,6 +463,74 @@ DeviceCsr query_or_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_off
     return out;
 }
 
+template <typename V>
+SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    hipStream_t s = ix.stream;
+    SpanResult out;
+    if (npat == 0 || ix.size == 0 || ix.width == 0) return out;
+    const V* sa = ix.d_sa.as<V>();
+    ix.q_left.ensure(npat * 8);
+    ix.q_right.ensure(npat * 8);
+    ix.q_hoff.ensure((npat + 1) * 8);
+    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                       (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, d_blob, d_offs, npat,
+                       ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    HitsIn hin{ix.q_right.as<uint64_t>()};
+    const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    out.nhits = H;
+    if (H == 0) {
+        CDB_HIP(hipStreamSynchronize(s));
+        return out;
+    }
+    if (H > (1ull << 31)) throw Error("too many occurrences for one highlight request");
+    const int obits = ix.width * 8 - (int)ix.bits;  // offset bits of an entry
+    DevBuf k0, k1, e0, e1, head, incl;
+    k0.alloc(H * 8); k1.alloc(H * 8); e0.alloc(H * 8); e1.alloc(H * 8); head.alloc(H); incl.alloc(H * 8);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(H, 256), 1u << 20);
+    hipLaunchKernelGGL((q_expand_occ_kernel<V>), dim3(grid), dim3(256), 0, s, sa, ix.mask, (int)ix.bits, obits,
+                       (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), d_offs, npat, H,
+                       k0.as<uint64_t>(), e0.as<uint64_t>());
+    const int sel = radix_sort<uint64_t, uint64_t>(s, ix.rws, ix.prof, k0.as<uint64_t>(), k1.as<uint64_t>(), e0.as<uint64_t>(),
+                                                   e1.as<uint64_t>(), H, 0, std::min(64, obits + (int)ix.bits), nullptr);
+    const uint64_t* keys = (sel ? k1 : k0).as<uint64_t>();
+    const uint64_t* ends = (sel ? e1 : e0).as<uint64_t>();
+    uint64_t* spare_k = (sel ? k0 : k1).as<uint64_t>();
+    uint64_t* spare_e = (sel ? e0 : e1).as<uint64_t>();
+    // equal begins of one document: the stable sort keeps them in keyword order; the running maximum
+    // makes the order irrelevant
+    OccIn oin{keys, ends, obits};
+    const DocMax ident{~0ull, 0};
+    (void)scan_totals<DocMax>(s, ix.scan_partials, oin, H, OpDocMax{}, ident);
+    scan_apply<DocMax>(s, ix.scan_partials, oin, H, OpDocMax{}, ident, OccOut{keys, obits, head.as<uint8_t>(), incl.as<uint64_t>()});
+    HeadIn hd{head.as<uint8_t>()};
+    const uint64_t nspans = scan_totals<uint64_t>(s, ix.scan_partials, hd, H, OpAdd{}, (uint64_t)0);
+    out.nspans = nspans;
+    // span_first -> spare_e (nspans + 1 <= H + 1 entries: allocate separately), span_key -> spare_k
+    DevBuf span_first, dochead;
+    span_first.alloc((nspans + 1) * 8);
+    dochead.alloc(nspans);
+    scan_apply<uint64_t>(s, ix.scan_partials, hd, H, OpAdd{}, (uint64_t)0,
+                         SpanOut{head.as<uint8_t>(), keys, span_first.as<uint64_t>(), spare_k, H});
+    ix.q_keys0.ensure(nspans * 8);  // begin
+    ix.q_keys1.ensure(nspans * 8);  // end
+    hipLaunchKernelGGL(q_span_rows_kernel, dim3((unsigned)ceil_div(nspans, 256)), dim3(256), 0, s,
+                       (const uint64_t*)span_first.as<uint64_t>(), (const uint64_t*)spare_k, (const uint64_t*)incl.as<uint64_t>(),
+                       nspans, obits, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(), dochead.as<uint8_t>());
+    HeadIn dh{dochead.as<uint8_t>()};
+    const uint64_t ndocs = scan_totals<uint64_t>(s, ix.scan_partials, dh, nspans, OpAdd{}, (uint64_t)0);
+    out.ndocs = ndocs;
+    ix.q_ids.ensure(ndocs * 8);
+    ix.q_rowptr.ensure((ndocs + 1) * 8);
+    scan_apply<uint64_t>(s, ix.scan_partials, dh, nspans, OpAdd{}, (uint64_t)0,
+                         DocRowOut{spare_k, ix.d_ids.as<int64_t>(), obits, nspans, ix.q_ids.as<int64_t>(), ix.q_rowptr.as<uint64_t>()});
+    (void)spare_e;
+    CDB_HIP(hipGetLastError());
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    return out;
+}
+
 }  // namespace
 
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
@@ -376,6 +543,13 @@ DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat)
                                 : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    ix.prof.resolve();
+    return r;
+}
+
+SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    SpanResult r = ix.width == 8 ? query_spans_typed<uint64_t>(ix, d_blob, d_offs, npat)
+                                 : query_spans_typed<uint32_t>(ix, d_blob, d_offs, npat);
     ix.prof.resolve();
     return r;
 }

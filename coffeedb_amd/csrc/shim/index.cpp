@@ -138,3 +138,23 @@ index::result_type string_index::query_any(const std::vector<std::string>& keywo
     cdb_free(counts);
     return out;
 }
+
+std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> string_index::highlight_spans(
+    const std::vector<std::string>& keywords) const {
+    std::string blob;
+    std::vector<uint64_t> offs{0};
+    for (const auto& k : keywords) {
+        blob += k;
+        offs.push_back(blob.size());
+    }
+    cdb_spans sp;
+    const int rc = cdb_query_spans(handle, blob.data(), offs.data(), keywords.size(), &sp);
+    if (rc != CDB_OK) rethrow(handle, rc);
+    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> out(sp.ndocs);
+    for (uint64_t d = 0; d < sp.ndocs; ++d) {
+        out[d].first = sp.ids[d];
+        for (uint64_t k = sp.span_ptr[d]; k < sp.span_ptr[d + 1]; ++k) out[d].second.emplace_back(sp.begin[k], sp.end[k]);
+    }
+    cdb_spans_free(&sp);
+    return out;
+}

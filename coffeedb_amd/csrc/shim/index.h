@@ -90,6 +90,11 @@ public:
     // OR over the keywords of this key — what filter() computes per key before the AND across keys
     // (interface.cpp:78-113): union by object id, counts summed, ascending id.  One GPU call.
     result_type query_any(const std::vector<std::string>& keywords) const;
+    // Highlight spans of every document that contains one of the keywords: (object id, [begin, end]
+    // byte ranges, end inclusive) with the merge rule of ac_automaton::render (database.cpp:58-76).
+    // Render with cdb_shim::render_spans (highlight.h).
+    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> highlight_spans(
+        const std::vector<std::string>& keywords) const;
 
 private:
     cdb_index* handle = nullptr;

@@ -103,6 +103,22 @@ void cdb_result_free(cdb_result* r);
 int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
                  size_t* nrows);
 
+/* Highlight spans — replaces the per-document re-scan of ac_automaton::render (database.cpp:58-76) that
+ * select() runs for every returned object (database.cpp:394-441): for the keyword list of ONE string
+ * key, every matching document's merged highlight spans [begin, end] (byte offsets, end inclusive), with
+ * the reference's merge rule — overlapping keyword occurrences fuse, merely adjacent ones do not.
+ * Documents ascend by insertion index; document r owns spans [span_ptr[r], span_ptr[r+1]).  The
+ * occurrences come straight from the suffix-array ranges (offset = entry >> bits), no text is scanned. */
+typedef struct cdb_spans {
+    uint64_t ndocs, nspans;
+    int64_t* ids;        /* ndocs */
+    uint64_t* span_ptr;  /* ndocs + 1 */
+    uint64_t* begin;     /* nspans */
+    uint64_t* end;       /* nspans, inclusive */
+} cdb_spans;
+int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out);
+void cdb_spans_free(cdb_spans* r);
+
 /* Batched query with patterns and results left in device memory (multi-GPU merge over RCCL, HBM-
  * resident timing).  d_blob/d_offsets are device pointers.  On return the library-owned device arrays
  * d_row_ptr (npat+1 u64), d_ids (nrows i64), d_counts (nrows i64) stay valid until the next query on

@@ -24,6 +24,7 @@
 // are held as one concatenated byte buffer plus a doc_start[] offset table instead of a vector of
 // string_views; a suffix is therefore (doc_start[doc] + off, doc_start[doc+1]).
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -446,6 +447,78 @@ uint64_t orc_filter_or(void* h, const char* blob, const uint64_t* offs, uint64_t
         counts[r] = result[r].second;
     }
     return result.size();
+}
+
+// database.cpp:26-138 — multi-keyword automaton (dense goto table, failure links, longest keyword
+// ending at each state) and the span merging of ac_automaton::render (database.cpp:58-76), restated.
+// Writes the spans of every document that has at least one; returns the span count.
+// doc_of_span / begin / end (inclusive) have capacity cap.
+uint64_t orc_highlight_spans(void* h, const char* blob, const uint64_t* offs, uint64_t nkw, uint64_t* doc_of_span,
+                             uint64_t* begin, uint64_t* end, uint64_t cap) {
+    Oracle& ix = *(Oracle*)h;
+    std::vector<std::array<int32_t, 256>> go(1);
+    std::vector<int32_t> fail(1, 0), longest(1, 0);
+    go[0].fill(0);
+    for (uint64_t k = 0; k < nkw; ++k) {  // trie insertion
+        int32_t u = 0;
+        for (uint64_t i = offs[k]; i < offs[k + 1]; ++i) {
+            const unsigned c = (unsigned char)blob[i];
+            if (!go[u][c]) {
+                go[u][c] = (int32_t)go.size();
+                go.emplace_back();
+                go.back().fill(0);
+                fail.push_back(0);
+                longest.push_back(0);
+            }
+            u = go[u][c];
+        }
+        longest[u] = (int32_t)(offs[k + 1] - offs[k]);
+    }
+    std::deque<int32_t> bfs;  // failure links, breadth first
+    for (int c = 0; c < 256; ++c)
+        if (go[0][c]) bfs.push_back(go[0][c]);
+    while (!bfs.empty()) {
+        const int32_t r = bfs.front();
+        bfs.pop_front();
+        for (int c = 0; c < 256; ++c) {
+            const int32_t u = go[r][c];
+            if (!u) {
+                go[r][c] = go[fail[r]][c];
+                continue;
+            }
+            bfs.push_back(u);
+            int32_t v = fail[r];
+            while (v && !go[v][c]) v = fail[v];
+            fail[u] = go[v][c];
+            longest[u] = std::max(longest[u], longest[fail[u]]);
+        }
+    }
+    uint64_t total = 0;
+    const uint64_t ndocs = ix.ids.size();
+    for (uint64_t d = 0; d < ndocs; ++d) {
+        const unsigned char* t = (const unsigned char*)ix.text.data() + ix.doc_start[d];
+        const uint64_t len = ix.doc_start[d + 1] - ix.doc_start[d];
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
+        int32_t node = 0;
+        for (uint64_t i = 0; i < len; ++i) {
+            node = go[node][t[i]];
+            if (longest[node]) {
+                const uint64_t b = i - (uint64_t)longest[node] + 1;
+                while (!spans.empty() && b <= spans.back().first) spans.pop_back();
+                if (!spans.empty() && b <= spans.back().second) spans.back().second = i;
+                else spans.emplace_back(b, i);
+            }
+        }
+        for (auto& sp : spans) {
+            if (total < cap) {
+                doc_of_span[total] = d;
+                begin[total] = sp.first;
+                end[total] = sp.second;
+            }
+            ++total;
+        }
+    }
+    return total;
 }
 
 // SURVEY.md §8c tie canonicalisation; returns the number of runs that were reordered.

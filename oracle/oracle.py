@@ -42,6 +42,8 @@ def _lib():
         lib.orc_query_batch.restype = C.c_int
         lib.orc_query_batch.argtypes = [vp, vp, vp, u64, C.c_uint, vp, vp, vp, u64, C.POINTER(u64)]
         lib.orc_brute_count.argtypes = [vp, vp, u64, C.c_char_p, u64, vp]
+        lib.orc_highlight_spans.restype = u64
+        lib.orc_highlight_spans.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64]
         lib.orc_filter_or.restype = u64
         lib.orc_filter_or.argtypes = [vp, vp, vp, u64, vp, vp, u64]
         _LIB = lib
@@ -121,6 +123,27 @@ class OracleIndex:
             if n <= cap:
                 return list(zip(ids[:n].tolist(), cnt[:n].tolist()))
             cap = n
+
+    def highlight_spans(self, keywords, ids):
+        """[(object id, [(begin, end_inclusive), ...])] per document with a match, insertion order
+        (ac_automaton::render's spans, database.cpp:58-76)."""
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        cap = 1 << 16
+        while True:
+            dd = np.empty(cap, dtype=np.uint64); bb = np.empty(cap, dtype=np.uint64); ee = np.empty(cap, dtype=np.uint64)
+            n = _lib().orc_highlight_spans(self._h, _ptr(blob), _ptr(offs), len(keywords), _ptr(dd), _ptr(bb), _ptr(ee), cap)
+            if n <= cap:
+                break
+            cap = n
+        out = []
+        for k in range(n):
+            d = int(dd[k])
+            if not out or out[-1][0] != d:
+                out.append((d, []))
+            out[-1][1].append((int(bb[k]), int(ee[k])))
+        return [(int(ids[d]), sp) for d, sp in out]
 
     def query_batch(self, blob, offsets, nthreads=1, want_rows=True):
         """Returns (row_ptr, ids, counts, total_hits); ids/counts are None when want_rows is False."""

@@ -8,6 +8,7 @@
 #include <string>
 
 #include "index.h"
+#include "highlight.h"
 #include "ranking.h"
 
 static int failures = 0;
@@ -94,6 +95,12 @@ static void gpu_string() {
     auto batch = sp->query_batch({"010", "0", "!"});
     CHECK(batch.size() == 3 && batch[0] == (R{{100, 2}, {101, 1}, {102, 2}}) && batch[1] == (R{{100, 3}, {101, 2}, {102, 4}}) && batch[2].empty());
     CHECK((sp->query_any({"010", "3"}) == R{{100, 4}, {101, 2}, {102, 2}}));
+    {   // README.md:107-110: "010" highlighted in "3010103" gives "3<b>01010</b>3"
+        auto spans = sp->highlight_spans({"010"});
+        CHECK(spans.size() == 3 && spans[0].first == 100);
+        CHECK(cdb_shim::render_spans(docs[0], spans[0].second, "<b>", "</b>") == "3<b>01010</b>3");
+        CHECK(cdb_shim::render_spans(docs[2], spans[2].second, "[", "]") == "[010]11[010]");
+    }
     // rebuild-and-swap as database.cpp:170-281 does: new object built while the old one still answers
     auto fresh = std::make_unique<string_index>();
     fresh->add(1, "hello world");

@@ -267,6 +267,29 @@ def test_or_merge_over_keywords_matches_reference_loop(G):
         g.query_or([])
 
 
+def test_highlight_spans_match_aho_corasick_render(G):
+    # database.cpp:58-76 — overlapping occurrences fuse, adjacent ones do not
+    g = G()
+    docs = [b"3010103", b"301022", b"01011010", b"", b"abcabcabc", b"aaaaaa"]
+    for i, d in enumerate(docs):
+        g.add(100 + i, d)
+    g.build()
+    assert g.query_spans([b"010"]) == [(100, [(1, 5)]), (101, [(1, 3)]), (102, [(0, 2), (5, 7)])]  # README.md:107-110
+    assert g.query_spans([b"abc"])[0] == (104, [(0, 2), (3, 5), (6, 8)])       # adjacent -> separate spans
+    assert g.query_spans([b"abca"])[0] == (104, [(0, 6)])                       # overlapping -> fused
+    assert g.query_spans([b"aa", b"aaa"]) == [(105, [(0, 5)])]
+    assert g.query_spans([b"zzz", b""]) == []
+    # randomised against the restated automaton, incl. keywords that are prefixes/suffixes of each other
+    blob, ds = W.ascii_corpus(1500, 120, seed=8, lo=0x61, hi=0x63)
+    ids = np.arange(1500, dtype=np.int64) * 2 + 5
+    g = _gpu(G, blob, ds, ids)
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 60, 1, 6, seed=12, miss_byte=0x7A)
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(60)]
+    for group in (kws[:1], kws[1:4], kws[4:12], kws[12:60], [b"a", b"ab", b"abc", b"bc"], [b"zz"]):
+        assert g.query_spans(group) == o.highlight_spans(group, ids), group
+
+
 def test_concurrent_queries_same_handle(G):
     blob, ds = W.ascii_corpus(2000, 128, seed=3)
     ids = np.arange(2000, dtype=np.int64)
