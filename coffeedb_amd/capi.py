@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
 _LIB = None
 
 EXPORTS = [
-    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device",
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
@@ -70,6 +70,10 @@ def load_library():
     lib.cdb_last_error.restype = cp
     lib.cdb_add.argtypes = [vp, i64, cp, C.c_size_t]
     lib.cdb_add_bulk.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_raw_record_find_string.argtypes = [vp, C.c_size_t, cp, C.POINTER(i64), C.POINTER(cp), C.POINTER(C.c_size_t)]
+    lib.cdb_add_raw_record.argtypes = [vp, cp, vp, C.c_size_t]
+    lib.cdb_save.argtypes = [vp, cp]
+    lib.cdb_load.argtypes = [vp, cp]
     lib.cdb_build.argtypes = [vp]
     lib.cdb_build_device.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
@@ -146,6 +150,15 @@ class GpuStringIndex:
 
     def build(self):
         self._check(self._lib.cdb_build(self._h))
+
+    def add_raw_record(self, key: bytes, record: bytes):
+        self._check(self._lib.cdb_add_raw_record(self._h, key, record, len(record)))
+
+    def save(self, path):
+        self._check(self._lib.cdb_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        self._check(self._lib.cdb_load(self._h, os.fsencode(path)))
 
     def build_device(self, d_text_ptr, doc_start, ids):
         ids = np.ascontiguousarray(ids, dtype=np.int64)
@@ -264,3 +277,17 @@ def debug_radix_sort(d_keys_ptr, d_vals_ptr, n, val_bytes, key_bits, variant=0, 
     if rc != 0:
         raise RuntimeError(f"cdb_debug_radix_sort failed ({rc})")
     return ms.value, passes.value
+
+
+def raw_record_find_string(record: bytes, key: bytes):
+    """(id, value) of the string stored under `key` in one CoffeeDB raw record, or None."""
+    lib = load_library()
+    id_, val, n = C.c_int64(0), C.c_char_p(), C.c_size_t(0)
+    buf = C.create_string_buffer(record, len(record))
+    r = lib.cdb_raw_record_find_string(buf, len(record), key, C.byref(id_), C.byref(val), C.byref(n))
+    if r < 0:
+        raise ValueError("malformed raw record")
+    if r == 0:
+        return None
+    off = C.cast(val, C.c_void_p).value - C.addressof(buf)
+    return id_.value, record[off:off + n.value]

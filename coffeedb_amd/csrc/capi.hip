@@ -136,6 +136,144 @@ int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint6
     });
 }
 
+// ---- f3: raw-record ingest (reference on-disk record, database.cpp:182-271 reader / :334-378 writer) ----
+//   int64 id | int32 nfields | nfields x { int32 keylen | key | int8 type | value }
+//   value: type 0 bool = 1 byte, 1 integer = 8 bytes, 2 double = 8 bytes, 3 string = int32 len | bytes
+int cdb_raw_record_find_string(const void* record, size_t len, const char* key, int64_t* id, const char** value,
+                               size_t* value_len) {
+    if (!record || !key || !id || !value || !value_len) return -1;
+    const unsigned char* p = static_cast<const unsigned char*>(record);
+    const unsigned char* end = p + len;
+    auto take = [&](void* dst, size_t n) -> bool {
+        if ((size_t)(end - p) < n) return false;
+        std::memcpy(dst, p, n);
+        p += n;
+        return true;
+    };
+    int32_t nfields = 0;
+    if (!take(id, 8) || !take(&nfields, 4) || nfields <= 0) return -1;
+    const size_t klen = std::strlen(key);
+    int found = 0;
+    for (int32_t f = 0; f < nfields; ++f) {
+        int32_t kl = 0;
+        if (!take(&kl, 4) || kl <= 0 || (size_t)(end - p) < (size_t)kl + 1) return -1;
+        const bool match = (size_t)kl == klen && std::memcmp(p, key, klen) == 0;
+        p += kl;
+        const int8_t type = (int8_t)*p++;
+        if (type == 0) {
+            if (end - p < 1) return -1;
+            p += 1;
+        } else if (type == 1 || type == 2) {
+            if (end - p < 8) return -1;
+            p += 8;
+        } else if (type == 3) {
+            int32_t vl = 0;
+            if (!take(&vl, 4) || vl < 0 || (size_t)(end - p) < (size_t)vl) return -1;
+            if (match) {
+                *value = reinterpret_cast<const char*>(p);
+                *value_len = (size_t)vl;
+                found = 1;
+            }
+            p += vl;
+        } else {
+            return -1;
+        }
+    }
+    return found;
+}
+
+int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t len) {
+    if (!h) return CDB_E_INVALID;
+    int64_t id = 0;
+    const char* v = nullptr;
+    size_t vl = 0;
+    const int r = cdb_raw_record_find_string(record, len, key, &id, &v, &vl);
+    if (r < 0) {
+        h->ix.err = "malformed raw record";
+        return CDB_E_INVALID;
+    }
+    if (r == 0) return CDB_OK;  // the object has no string value under this key
+    return cdb_add(h, id, v, vl);
+}
+
+// ---- f4: persistence of a built index (the reference rebuilds every index at start, server.cpp:44) ----
+namespace {
+constexpr uint64_t SAVE_MAGIC = 0x3130584449424443ull;  // "CDBIDX01"
+struct SaveHeader {
+    uint64_t magic, size, ndocs, bits, mask, width, compat;
+};
+}  // namespace
+
+int cdb_save(cdb_index* h, const char* path) {
+    if (!h || !path) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        if (ix.width == 0) throw Error("index has not been built");
+        FILE* fp = std::fopen(path, "wb");
+        if (!fp) throw Error(std::string("Cannot open file: ") + path);
+        struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+        const SaveHeader hd{SAVE_MAGIC, ix.size, ix.ndocs, ix.bits, ix.mask, (uint64_t)ix.width, ix.reference_compat ? 1ull : 0ull};
+        bool ok = std::fwrite(&hd, sizeof(hd), 1, fp) == 1;
+        ok = ok && (ix.ndocs == 0 || std::fwrite(ix.ids.data(), 8, ix.ndocs, fp) == ix.ndocs);
+        ok = ok && std::fwrite(ix.doc_start.data(), 8, ix.ndocs + 1, fp) == ix.ndocs + 1;
+        std::vector<char> buf(std::min<uint64_t>(std::max<uint64_t>(ix.size * (uint64_t)ix.width, 1), 256ull << 20));
+        auto dump = [&](const void* dptr, uint64_t bytes) {
+            for (uint64_t o = 0; o < bytes && ok; o += buf.size()) {
+                const uint64_t c = std::min<uint64_t>(buf.size(), bytes - o);
+                CDB_HIP(hipMemcpyAsync(buf.data(), static_cast<const char*>(dptr) + o, c, hipMemcpyDeviceToHost, ix.stream));
+                CDB_HIP(hipStreamSynchronize(ix.stream));
+                ok = std::fwrite(buf.data(), 1, c, fp) == c;
+            }
+        };
+        dump(ix.d_text, ix.size);
+        dump(ix.d_sa.p, ix.size * (uint64_t)ix.width);
+        if (!ok) throw Error(std::string("Cannot write file: ") + path);
+    });
+}
+
+int cdb_load(cdb_index* h, const char* path) {
+    if (!h || !path) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        FILE* fp = std::fopen(path, "rb");
+        if (!fp) throw Error(std::string("Cannot open file: ") + path);
+        struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+        SaveHeader hd{};
+        if (std::fread(&hd, sizeof(hd), 1, fp) != 1 || hd.magic != SAVE_MAGIC || (hd.width != 4 && hd.width != 8))
+            throw Error(std::string("Not a saved index: ") + path);
+        ix.ids.resize(hd.ndocs);
+        ix.doc_start.resize(hd.ndocs + 1);
+        bool ok = hd.ndocs == 0 || std::fread(ix.ids.data(), 8, hd.ndocs, fp) == hd.ndocs;
+        ok = ok && std::fread(ix.doc_start.data(), 8, hd.ndocs + 1, fp) == hd.ndocs + 1;
+        if (!ok || ix.doc_start[hd.ndocs] != hd.size) throw Error(std::string("Truncated index file: ") + path);
+        ix.size = hd.size; ix.ndocs = hd.ndocs; ix.bits = hd.bits; ix.mask = hd.mask; ix.width = (int)hd.width;
+        ix.reference_compat = hd.compat != 0;
+        ix.host_text.clear();
+        ix.d_text_owned.alloc(ix.size + TEXT_PAD);
+        CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + ix.size, 0, TEXT_PAD, ix.stream));
+        ix.d_text = ix.d_text_owned.as<uint8_t>();
+        ix.text_padded = true;
+        ix.d_sa.alloc(std::max<uint64_t>(ix.size * hd.width, 16));
+        std::vector<char> buf(std::min<uint64_t>(std::max<uint64_t>(ix.size * hd.width, 1), 256ull << 20));
+        auto fill = [&](void* dptr, uint64_t bytes) {
+            for (uint64_t o = 0; o < bytes; o += buf.size()) {
+                const uint64_t c = std::min<uint64_t>(buf.size(), bytes - o);
+                if (std::fread(buf.data(), 1, c, fp) != c) throw Error(std::string("Truncated index file: ") + path);
+                CDB_HIP(hipMemcpyAsync(static_cast<char*>(dptr) + o, buf.data(), c, hipMemcpyHostToDevice, ix.stream));
+                CDB_HIP(hipStreamSynchronize(ix.stream));
+            }
+        };
+        fill(ix.d_text_owned.p, ix.size);
+        fill(ix.d_sa.p, ix.size * hd.width);
+        upload_tables(ix);
+        CDB_HIP(hipStreamSynchronize(ix.stream));
+    });
+}
+
 int cdb_build(cdb_index* h) {
     if (!h) return CDB_E_INVALID;
     return guarded(h, [&] {

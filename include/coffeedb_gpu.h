@@ -67,6 +67,23 @@ int cdb_add(cdb_index* h, int64_t id, const char* value, size_t len);
  * document d = blob[doc_start[d] .. doc_start[d+1]), ndocs documents. */
 int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
 
+/* Raw-record ingest — the step before add() in database.cpp:170-275: CoffeeDB keeps one
+ * binary file per object (writer database.cpp:334-378):
+ *   int64 id | int32 nfields | nfields x { int32 keylen | key | int8 type | value },
+ *   value = 1 byte (type 0 bool) | 8 bytes (1 integer, 2 double) | int32 len + bytes (3 string).
+ * cdb_raw_record_find_string locates the string value stored under `key` in one in-memory record
+ * (returns 1 found, 0 absent / not a string, -1 malformed; no handle or GPU needed);
+ * cdb_add_raw_record adds that value under the record's id (a record without the key is skipped). */
+int cdb_raw_record_find_string(const void* record, size_t len, const char* key, int64_t* id, const char** value,
+                               size_t* value_len);
+int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t len);
+
+/* Persistence of a built index (the reference has none and rebuilds every index at start,
+ * server.cpp:44): header + ids + doc_start + text + suffix array.  cdb_load restores a queryable index
+ * without rebuilding. */
+int cdb_save(cdb_index* h, const char* path);
+int cdb_load(cdb_index* h, const char* path);
+
 /* ---- build ----------------------------------------------------------------------------------- */
 
 /* replaces string_index::build() (src/index.cpp:178-236): computes bits/mask/size and the entry width

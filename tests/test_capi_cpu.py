@@ -48,3 +48,33 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def _raw_record(id_, fields):
+    """CoffeeDB's on-disk record (writer: reference src/database.cpp:334-378)."""
+    import struct
+    out = struct.pack("<qi", id_, len(fields))
+    for key, value in fields:
+        out += struct.pack("<i", len(key)) + key
+        if isinstance(value, bool):
+            out += struct.pack("<b?", 0, value)
+        elif isinstance(value, int):
+            out += struct.pack("<bq", 1, value)
+        elif isinstance(value, float):
+            out += struct.pack("<bd", 2, value)
+        else:
+            out += struct.pack("<bi", 3, len(value)) + value
+    return out
+
+
+def test_raw_record_parser(lib):
+    rec = _raw_record(1234567890123, [(b"number", 123), (b"name", b"sunkafei"), (b"flag", True), (b"pos", 1.7724),
+                                      (b"secret", b"3010103"), (b"empty", b"")])
+    assert capi.raw_record_find_string(rec, b"secret") == (1234567890123, b"3010103")
+    assert capi.raw_record_find_string(rec, b"name") == (1234567890123, b"sunkafei")
+    assert capi.raw_record_find_string(rec, b"empty") == (1234567890123, b"")
+    assert capi.raw_record_find_string(rec, b"number") is None      # not a string
+    assert capi.raw_record_find_string(rec, b"missing") is None
+    for cut in (3, 11, 20, len(rec) - 1):
+        with pytest.raises(ValueError):
+            capi.raw_record_find_string(rec[:cut], b"secret")

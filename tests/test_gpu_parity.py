@@ -290,6 +290,29 @@ def test_highlight_spans_match_aho_corasick_render(G):
         assert g.query_spans(group) == o.highlight_spans(group, ids), group
 
 
+def test_raw_record_ingest_and_persistence(G, tmp_path):
+    # f3: records in CoffeeDB's on-disk format feed add(); f4: save / load without rebuilding
+    from tests.test_capi_cpu import _raw_record
+    g = G()
+    docs = [(100, b"3010103"), (101, b"301022"), (102, b"01011010")]
+    for id_, text in docs:
+        g.add_raw_record(b"secret", _raw_record(id_, [(b"number", id_), (b"secret", text), (b"other", b"xyz")]))
+    g.add_raw_record(b"secret", _raw_record(103, [(b"number", 5)]))           # no such key: skipped
+    g.build()
+    assert g.query(b"010") == [(100, 2), (101, 1), (102, 2)]
+    path = tmp_path / "secret.idx"
+    g.save(path)
+    sa = g.sa()
+    h = G()
+    h.load(path)
+    assert (h.size, h.bits, h.mask, h.sa_width) == (g.size, g.bits, g.mask, g.sa_width)
+    assert np.array_equal(h.sa(), sa)
+    assert h.query(b"010") == [(100, 2), (101, 1), (102, 2)] and h.query_spans([b"010"])[0] == (100, [(1, 5)])
+    with pytest.raises(RuntimeError, match="Not a saved index"):
+        (tmp_path / "junk").write_bytes(b"x" * 100)
+        h.load(tmp_path / "junk")
+
+
 def test_concurrent_queries_same_handle(G):
     blob, ds = W.ascii_corpus(2000, 128, seed=3)
     ids = np.arange(2000, dtype=np.int64)
