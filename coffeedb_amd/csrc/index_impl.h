@@ -23,6 +23,7 @@ struct BuildStats {
     int sort_passes_skipped = 0;
     int isa_built = 0;
     int fused_keygen = 0;
+    int bucketed = 0;            // bucket-wise initial sort (corpora >= 2^32)
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
     uint64_t compat_rotations = 0, compat_depth = 0;  // reference_compat pass (bytes >= 0x80)
@@ -72,6 +73,7 @@ struct Index {
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;
+    bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)

@@ -427,10 +427,11 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-template <typename V>
-void build_typed(Index& ix) {
-    using I = uint32_t;
-    using R = uint32_t;
+// I = type of suffix-array slot numbers, R = type of ranks / extended text positions: u32 while
+// n + D < 2^32, u64 beyond.  `big` additionally selects the bucket-wise initial sort that keeps the
+// working set inside HBM for multi-GiB corpora with 8-byte entries.
+template <typename V, typename I, typename R>
+void build_typed(Index& ix, bool big) {
     hipStream_t s = ix.stream;
     const uint64_t n = ix.size, D = ix.ndocs;
     BuildStats& st = ix.bstats;
@@ -444,8 +445,7 @@ void build_typed(Index& ix) {
         ix.d_sa.alloc(16);
         return;
     }
-    if (n + D + 2 >= (1ull << 32))
-        throw Error("corpus too large for this build of the GPU index (text bytes + documents must stay below 2^32)");
+    if (sizeof(R) == 4 && n + D + 2 >= (1ull << 32)) throw Error("internal: 32-bit ranks selected for a corpus >= 2^32");
     const uint8_t* text = ix.d_text;
     const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
 
@@ -503,25 +503,24 @@ void build_typed(Index& ix) {
         if ((int)ceil_div(nsym, dsym) <= (int)ceil_div(key_bits, 8)) dbits = dsym * symbits;
     }
     if (ix.digit_bits > 0) dbits = ix.digit_bits;
+    if (big) {
+        // the bucket-wise sort partitions on whole symbols and generates its keys from the text
+        if (symbits > 8 || nsym > HC_MAXSYM)
+            throw Error("corpora of 4 GiB and more need an alphabet of at most 255 byte values");
+        dbits = symbits;
+    }
     st.digit_bits = dbits;
     st.key_symbols = nsym;
     st.symbol_bits = symbits;
     st.alphabet = sigma;
 
     // ---- 2 + 3. keys + entries, initial sort
-    DevBuf keys[2], vals[2], flags;
-    double ta = now_ms();
-    keys[0].alloc(n * sizeof(uint64_t));
-    keys[1].alloc(n * sizeof(uint64_t));
-    vals[0].alloc(n * sizeof(V));
-    vals[1].alloc(n * sizeof(V));
-    flags.alloc(n);
-    st.alloc_ms += now_ms() - ta;
+    DevBuf sorted_keys, sa_buf, flags;
     SortStats ss;
-    int sel;
-    const bool fused = ix.fuse_keygen && dbits == symbits && nsym <= HC_MAXSYM &&
-                       (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1);
+    const bool fused = big || (ix.fuse_keygen && dbits == symbits && nsym <= HC_MAXSYM &&
+                               (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1));
     st.fused_keygen = fused ? 1 : 0;
+    std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
     if (fused) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
@@ -544,7 +543,7 @@ void build_typed(Index& ix) {
         uint64_t code_count[257] = {0};
         for (int b = 0; b < 256; ++b)
             if (h_map[b]) code_count[h_map[b]] = h_counts[b];
-        std::vector<uint64_t> h_hist((size_t)nsym * 256, 0);
+        h_hist.assign((size_t)nsym * 256, 0);
         for (int p = 0; p < nsym; ++p) {
             const int k = nsym - 1 - p;  // LSD: pass 0 sorts on the last symbol of the key
             uint64_t* hp = &h_hist[(size_t)p * 256];
@@ -560,33 +559,84 @@ void build_typed(Index& ix) {
                 hp[c] = code_count[c] - head;
             }
         }
-        TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, symbits, nsym, ix.text_padded};
-        sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
-                                      vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
-    } else {
-        {
+    }
+    TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, symbits, nsym, ix.text_padded};
+    double ta = now_ms();
+    flags.alloc(n);
+    if (!big) {
+        DevBuf keys[2], vals[2];
+        keys[0].alloc(n * sizeof(uint64_t));
+        keys[1].alloc(n * sizeof(uint64_t));
+        vals[0].alloc(n * sizeof(V));
+        vals[1].alloc(n * sizeof(V));
+        st.alloc_ms += now_ms() - ta;
+        int sel;
+        if (fused) {
+            sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
+                                          vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+        } else {
             int t = ix.prof.begin(s);
             hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text,
                                doc_start, D, n, (int)ix.bits, d_symmap.as<uint16_t>(), symbits, nsym, ix.text_padded,
                                keys[0].as<uint64_t>(), vals[0].as<V>());
             ix.prof.end(t, "sa_keygen", n * (1 + sizeof(uint64_t) + sizeof(V)), s);
+            sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
+                                          vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits);
         }
-        sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
-                                      vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits);
+        CDB_HIP(hipStreamSynchronize(s));
+        sorted_keys = std::move(keys[sel]);
+        sa_buf = std::move(vals[sel]);
+    } else {
+        // Bucket-wise initial sort: a double-buffered LSD sort of (u64 key, u64 entry) pairs would need
+        // 32 n bytes — 256 GiB at n = 2^33 — so the pairs are first partitioned by their FIRST symbol (one
+        // generated pass straight from the text into single n-element arrays), then every first-symbol
+        // bucket is LSD-sorted on the remaining symbols with scratch the size of the largest bucket.
+        DevBuf K, E, KT, ET;
+        K.alloc(n * sizeof(uint64_t));
+        E.alloc(n * sizeof(V));
+        st.alloc_ms += now_ms() - ta;
+        const int top_shift = (nsym - 1) * symbits;
+        // histogram of the first symbol = p = nsym-1 row (k = 0: no head correction, no end code)
+        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, K.as<uint64_t>(), (V*)nullptr, E.as<V>(), n,
+                                      top_shift, key_bits, &ss, ix.sort_variant, dbits,
+                                      &h_hist[(size_t)(nsym - 1) * 256], &gen);
+        uint64_t maxb = 0;
+        for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_hist[(size_t)(nsym - 1) * 256 + c]);
+        if (nsym > 1) {
+            KT.alloc(maxb * sizeof(uint64_t));
+            ET.alloc(maxb * sizeof(V));
+            uint64_t start = 0;
+            for (int c = 1; c <= sigma; ++c) {
+                const uint64_t cnt = h_hist[(size_t)(nsym - 1) * 256 + c];
+                if (cnt > 1) {
+                    uint64_t* kb = K.as<uint64_t>() + start;
+                    V* eb = E.as<V>() + start;
+                    const int r = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, kb, KT.as<uint64_t>(), eb, ET.as<V>(), cnt, 0,
+                                                          top_shift, &ss, ix.sort_variant, dbits);
+                    if (r == 1) {  // result sits in the scratch: move it home
+                        CDB_HIP(hipMemcpyAsync(kb, KT.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+                        CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
+                    }
+                }
+                start += cnt;
+            }
+        }
+        CDB_HIP(hipStreamSynchronize(s));
+        st.bucketed = 1;
+        sorted_keys = std::move(K);
+        sa_buf = std::move(E);
     }
     {
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                           (const uint64_t*)keys[sel].as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>());
+                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>());
         ix.prof.end(t, "sa_initflags", n * 9, s);
     }
     CDB_HIP(hipStreamSynchronize(s));
     ta = now_ms();
-    keys[0].release();
-    keys[1].release();
-    vals[sel ^ 1].release();
+    sorted_keys.release();
     st.free_ms += now_ms() - ta;
-    V* sa = vals[sel].as<V>();
+    V* sa = sa_buf.as<V>();
 
     // ---- 4. refinement rounds
     DevBuf U, skey[2], sval[2], nh, rank;
@@ -687,7 +737,7 @@ void build_typed(Index& ix) {
     radix_check_error(s, ix.rws);
     CDB_HIP(hipStreamSynchronize(s));
     if (ix.reference_compat && high_bytes) apply_reference_order<V>(ix, sa);
-    ix.d_sa = std::move(vals[sel]);
+    ix.d_sa = std::move(sa_buf);
 }
 
 }  // namespace
@@ -695,8 +745,15 @@ void build_typed(Index& ix) {
 void build_suffix_array(Index& ix) {
     const double t0 = now_ms();
     try {
-        if (ix.width == 4) build_typed<uint32_t>(ix);
-        else build_typed<uint64_t>(ix);
+        const bool wide = ix.size + ix.ndocs + 2 >= (1ull << 32) || ix.force_big_path;
+        if (wide && ix.width != 8 && !ix.force_big_path) throw Error("internal: a corpus >= 2^32 bytes must have 8-byte entries");
+        if (!wide) {
+            if (ix.width == 4) build_typed<uint32_t, uint32_t, uint32_t>(ix, false);
+            else build_typed<uint64_t, uint32_t, uint32_t>(ix, false);
+        } else {
+            if (ix.width == 4) build_typed<uint32_t, uint64_t, uint64_t>(ix, true);  // only reachable through force_big_path
+            else build_typed<uint64_t, uint64_t, uint64_t>(ix, true);
+        }
     } catch (...) {
         // scratch buffers go back to the shared block cache when the stack unwinds: make sure no
         // kernel of this build is still using them

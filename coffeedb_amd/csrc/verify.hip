@@ -19,14 +19,14 @@ __global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa
     __shared__ unsigned long long s_acc[4];
     if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long inv = 0, tie = 0, sum = 0, bad = 0;
-    if (i < n) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;  // grid-stride: n may exceed 2^32 threads
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const V eb = sa[i];
         const uint64_t db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
-        sum = (unsigned long long)eb;
+        sum += (unsigned long long)eb;
         if (db >= ndocs || ob >= doc_start[db + 1] - doc_start[db]) {
-            bad = 1;
+            bad += 1;
         } else if (i > 0) {
             const V ea = sa[i - 1];
             const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa
                     }
                 }
                 if (c == 0) c = la < lb ? -1 : (la > lb ? 1 : 0);
-                if (c > 0) inv = 1;
-                if (c == 0 && da >= db) tie = 1;
+                if (c > 0) inv += 1;
+                if (c == 0 && da >= db) tie += 1;
             }
         }
     }
@@ -65,7 +65,7 @@ void verify_suffix_array(Index& ix, uint64_t out[5]) {
     d_out.alloc(4 * sizeof(uint64_t));
     CDB_HIP(hipMemsetAsync(d_out.p, 0, 4 * sizeof(uint64_t), s));
     if (ix.size) {
-        const unsigned grid = (unsigned)ceil_div(ix.size, 256);
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 22);
         if (ix.width == 4)
             hipLaunchKernelGGL((sa_verify_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
                                ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits,

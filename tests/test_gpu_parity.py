@@ -107,6 +107,32 @@ def test_fused_and_materialised_first_pass_agree(G, opts):
             assert g.stat("key_symbols") == {3: 3, 6: 6, 8: 9}[passes]
 
 
+@pytest.mark.parametrize("force_doubling", [0, 1])
+def test_big_corpus_code_path_at_small_size(G, force_doubling):
+    # the >= 2^32 path (u64 ranks/positions, bucket-wise initial sort) forced on small inputs
+    opts = dict(force_big_path=1, force_doubling=force_doubling)
+    blob, ds = W.ragged_corpus(20000, 90, seed=15, empty_every=13)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 300, 1, 6, seed=3, miss_byte=0x7B), **opts)
+    assert g.stat("bucketed") == 1
+    blob, ds = W.ascii_corpus(3000, 333, seed=2)
+    _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 200, 2, 9, seed=5), **opts)
+    blob, ds = W.zipf_corpus(2000, 256, seed=2)
+    _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 300, 2, 16, seed=8, miss_byte=0x2F), **opts)
+    # duplicates (groups that never resolve) and u64 entries
+    base, _ = W.ascii_corpus(1, 700, seed=9, lo=0x61, hi=0x64)
+    blob = np.concatenate([base] * 30)
+    ds = (np.arange(31) * 700).astype(np.uint64)
+    _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 100, 1, 12, seed=4), **opts)
+    lens = np.full(40000, 3, dtype=np.uint64)
+    lens[123] = 70000
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = W.random_bytes(int(ds[-1]), 17, 0x61, 0x63)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 200, 1, 8, seed=12, miss_byte=0x7A), **opts)
+    assert g.sa_width == 8
+    v = g.verify()
+    assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
+
+
 def test_test_string_shape_property(G):
     # test/test-string.py shape (a-z, 3-char keywords) scaled to 300 x 5000, brute-force oracle
     from oracle import brute_count
