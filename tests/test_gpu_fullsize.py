@@ -59,3 +59,46 @@ def test_c1_full_size_properties():
         got = {(int(i) - 7) // 3: int(c) for i, c in zip(ri[a:b], rc[a:b])}
         assert got == want, (j, bytes(kw))
     g.close()
+
+
+def test_beyond_4gib_on_one_gpu():
+    """A corpus of more than 2^32 bytes (README benchmark shape, reference README.md:226-232: documents of
+    128 KiB of a-z text; here 36864 of them = 4.5 GiB) on ONE GPU: 8-byte entries, 64-bit ranks, bucket-wise
+    initial sort.  Checked by the GPU-side verifier and brute-force scans of sampled keywords."""
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    nd, dl = 36864, 131072
+    n = nd * dl
+    assert n > 1 << 32
+    text = W.random_bytes_torch(n, 777, 0x61, 0x7A, device="cuda")
+    ds = W.uniform_docs(nd, dl)
+    ids = np.arange(nd, dtype=np.int64) + 1_000_000
+    torch.cuda.synchronize()
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), ds, ids)
+    assert (g.size, g.sa_width, g.bits) == (n, 8, 16) and g.stat("bucketed") == 1   # 16 + 18 bits -> u64 entries
+    v = g.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+    assert v["entry_sum"] == v["expected_entry_sum"]
+    pb = W.random_bytes(5 * 2000, 4242, 0x61, 0x7A)                       # test/benchmark.py: 5-char keywords
+    po = (np.arange(2001) * 5).astype(np.uint64)
+    rp, ri, rc, hits = g.query_batch(pb, po)
+    assert int(rc.sum()) == hits and hits > 2000 * 300                    # ~ n / 26^5 = 407 hits per keyword
+    for j in (0, 1234):
+        kw = torch.from_numpy(pb[5 * j:5 * j + 5].copy()).cuda()
+        per_doc = {}
+        step = 1 << 30
+        for s0 in range(0, n, step):
+            seg = text[s0:min(n, s0 + step + 4)]
+            ok = seg[: len(seg) - 4] == kw[0]
+            for k in range(1, 5):
+                ok &= seg[k: len(seg) - 4 + k] == kw[k]
+            pos = torch.nonzero(ok).flatten() + s0
+            pos = pos[((pos % dl) + 5 <= dl) & (pos < s0 + step)]
+            d, c = torch.unique(pos // dl, return_counts=True)
+            for a, b in zip(d.tolist(), c.tolist()):
+                per_doc[a] = per_doc.get(a, 0) + b
+        a, b = int(rp[j]), int(rp[j + 1])
+        assert {int(i) - 1_000_000: int(c) for i, c in zip(ri[a:b], rc[a:b])} == per_doc
+    g.close()
+    capi.load_library().cdb_release_cached_memory()
