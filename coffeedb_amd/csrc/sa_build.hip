@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "index_impl.h"
 #include "scan.h"
@@ -88,6 +89,55 @@ __global__ __launch_bounds__(256) void sa_headcorr_kernel(const uint8_t* __restr
     for (int i = threadIdx.x; i < HC_MAXSYM * 257; i += 256)
         if (s_first[i]) atomicAdd(&first[i], (unsigned long long)s_first[i]);
     if (threadIdx.x < HC_MAXSYM && s_len[threadIdx.x]) atomicAdd(&lencnt[threadIdx.x], (unsigned long long)s_len[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// key-width estimate by sampling: keys of `kmax` symbols for `S` pseudo-random suffixes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_sample_keys_kernel(const uint8_t* __restrict__ text,
+                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                             uint64_t n, const uint16_t* __restrict__ symmap, int symbits,
+                                                             int kmax, uint64_t S, uint64_t* __restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser -> position
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const uint64_t stride = n / S;               // stratified: one position per stride, all distinct
+    const uint64_t p = i * stride + z % stride;  // (a position drawn twice would count as a collision)
+    uint64_t lo = 0, hi = ndocs - 1;  // document of p
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo + 1) / 2;
+        if (doc_start[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t rem = doc_start[lo + 1] - p;
+    uint64_t key = 0;
+    for (int k = 0; k < kmax; ++k) key = (key << symbits) | ((uint64_t)k < rem ? (uint64_t)symmap[text[p + k]] : 0ull);
+    keys[i] = key;
+}
+
+// eq[k] = adjacent pairs of the sorted sample that agree on their first k symbols (k = 1 .. kmax)
+__global__ __launch_bounds__(256) void sa_sample_count_kernel(const uint64_t* __restrict__ keys, uint64_t S, int symbits,
+                                                              int kmax, unsigned long long* __restrict__ eq) {
+    __shared__ unsigned int s_eq[32];
+    if (threadIdx.x < 32) s_eq[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 < S) {
+        const uint64_t x = keys[i] ^ keys[i + 1];
+        // number of leading symbols that agree
+        int same = kmax;
+        if (x) same = (__clzll((long long)x) - (64 - kmax * symbits)) / symbits;
+        // a k-prefix that already contains the end-of-document code identifies the whole suffix: such
+        // pairs are equal suffixes (a final group), not unresolved ones — count only "live" prefixes
+        int live = 0;
+        while (live < kmax && ((keys[i] >> ((kmax - 1 - live) * symbits)) & ((1ull << symbits) - 1ull)) != 0) ++live;
+        if (live < same) same = live;
+        for (int k = 1; k <= same; ++k) atomicAdd(&s_eq[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 32 && s_eq[threadIdx.x]) atomicAdd(&eq[threadIdx.x], (unsigned long long)s_eq[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -477,12 +527,43 @@ void build_typed(Index& ix, bool big) {
     // Key width of the initial sort.  Every suffix left unresolved costs a refinement round (compaction,
     // gathers, a further sort, inverse-array traffic for doubling) that is an order of magnitude more
     // expensive per element than one more radix pass, so the key takes as many symbols as it needs for
-    // the expected unresolved share to drop below ~1/64 under an order-0 model of the text: a suffix
-    // shares its first k symbols with some other suffix with probability ~ n * pc^k, pc = sum_c p_c^2.
+    // the expected unresolved share to drop below ~1/64.  The share is estimated from the text itself:
+    // S pseudo-random suffixes are keyed with the maximal width and sorted, and the number of adjacent
+    // sample pairs agreeing on their first k symbols gives the pair-collision probability c_k, hence
+    // ~ n * c_k of all suffixes share their k-prefix with another one.  (An order-0 symbol model is far
+    // too optimistic for correlated text such as multi-byte UTF-8.)  Small corpora use the order-0 model.
     int nsym;
+    const int kmax = std::min(64 / symbits, 16);
     if (ix.initial_passes > 0) {
         const int passes = std::min(ix.initial_passes, 8);
         nsym = std::min((8 * passes) / symbits, 64 / symbits);
+    } else if (n >= (1ull << 24)) {
+        const uint64_t S = 1ull << 22;
+        DevBuf sk0, sk1, d_eq;
+        sk0.alloc(S * 8);
+        sk1.alloc(S * 8);
+        d_eq.alloc(32 * 8);
+        CDB_HIP(hipMemsetAsync(d_eq.p, 0, 32 * 8, s));
+        hipLaunchKernelGGL(sa_sample_keys_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, text, doc_start, D, n,
+                           (const uint16_t*)d_symmap.as<uint16_t>(), symbits, kmax, S, sk0.as<uint64_t>());
+        const int ssel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, sk0.as<uint64_t>(), sk1.as<uint64_t>(), (NoVal*)nullptr,
+                                                     (NoVal*)nullptr, S, 0, kmax * symbits, nullptr);
+        hipLaunchKernelGGL(sa_sample_count_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s,
+                           (const uint64_t*)(ssel ? sk1 : sk0).as<uint64_t>(), S, symbits, kmax, d_eq.as<unsigned long long>());
+        uint64_t h_eq[32];
+        CDB_HIP(hipMemcpyAsync(h_eq, d_eq.p, sizeof(h_eq), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        const double pairs = (double)S * (double)S / 2.0;
+        if (getenv("CDB_DEBUG_SAMPLE")) {
+            for (int k = 1; k <= kmax; ++k) std::fprintf(stderr, "[sample] k=%d adjacent-equal=%llu\n", k, (unsigned long long)h_eq[k]);
+        }
+        nsym = kmax;
+        for (int k = 1; k <= kmax; ++k) {
+            if ((double)n * ((double)h_eq[k] / pairs) <= 1.0 / 64.0) {
+                nsym = k;
+                break;
+            }
+        }
     } else {
         double pc = 0;
         for (int b = 0; b < 256; ++b) {
