@@ -299,6 +299,60 @@ struct CompactOut {
     }
 };
 
+// Compaction of the unresolved entries, specialised for the byte-flag array (the generic scan spends
+// most of its time carrying 16 (u64, u64) pairs per thread for entries that are almost all resolved):
+// one 16-byte load per thread, SWAR popcounts, a workgroup scan of one packed u32 (both tile-local counts
+// stay below 2^16), and the consumer functor only runs for threads that own unresolved entries.
+// Uses the tile partials produced by scan_totals<U2>(FlagIn) — same tile geometry (SC_TILE = 256 x 16).
+template <typename Out>
+__global__ __launch_bounds__(SC_NT) void sa_flag_compact_kernel(const uint8_t* __restrict__ flags, uint64_t n,
+                                                               const U2* __restrict__ partials, Out out) {
+    static_assert(SC_IPT == 16 && SC_NT == 256, "flag compaction assumes 256 x 16 tiles");
+    __shared__ uint32_t s_w[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+    uint32_t x[4] = {0, 0, 0, 0};
+    if (base + 16 <= n) {
+        const uint4 w = *reinterpret_cast<const uint4*>(flags + base);
+        x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+    } else if (base < n) {
+        for (int k = 0; k < 16 && base + k < n; ++k) x[k >> 2] |= (uint32_t)flags[base + k] << (8 * (k & 3));
+    }
+    uint32_t cu = 0, ch = 0;  // unresolved entries / unresolved group heads owned by this thread
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t u = (x[q] >> 1) & 0x01010101u;
+        cu += __popc(u);
+        ch += __popc(u & x[q] & 0x01010101u);
+    }
+    uint32_t v = cu | (ch << 16);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) pre += s_w[w];
+    if (cu == 0) return;
+    const uint32_t excl = pre + incl - v;
+    U2 run = partials[blockIdx.x];
+    run.a += excl & 0xFFFFu;
+    run.b += excl >> 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t f = (x[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        const uint64_t u = (f >> 1) & 1u;
+        const U2 nxt{run.a + u, run.b + (u & (f & 1u))};
+        if (u) out(base + k, run, nxt);
+        run = nxt;
+    }
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restrict__ skey, const I* __restrict__ U,
                                                          const uint8_t* __restrict__ flags, uint64_t m,
@@ -776,12 +830,14 @@ void build_typed(Index& ix, bool big) {
                 CompactOut<V, I, R, true> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
                                              doc_start, text, d_symmap.as<uint16_t>(), rank.as<R>(), (int)ix.bits,
                                              ix.mask, h, kbits, nsym2, symbits};
-                scan_apply<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0}, co);
+                hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
+                                   (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
             } else {
                 CompactOut<V, I, R, false> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
                                               doc_start, text, d_symmap.as<uint16_t>(), nullptr, (int)ix.bits,
                                               ix.mask, h, kbits, nsym2, symbits};
-                scan_apply<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0}, co);
+                hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
+                                   (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
             }
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
