@@ -650,6 +650,9 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 7: CDB_RS(12, true, true, 512, false, 1, 0, 1);
             case 11: CDB_RS(16, true, true, 1024, false, 1, 0, 1);
             case 12: CDB_RS(16, true, true, 512, false, 4, 0, 1);
+            case 13: CDB_RS(16, true, true, 512, false, 4, 0, 4);    // 8 Ki-key tile, 2 WG/CU
+            case 14: CDB_RS(12, true, true, 512, false, 1, 0, 4);    // 6 Ki-key tile, 2 WG/CU
+            case 15: CDB_RS(14, true, true, 1024, false, 1, 0, 4);   // 14 Ki-key tile
             case 22: CDB_RS(16, true, true, 1024, false, 1, 0, 8);
             case 23: CDB_RS(16, true, true, 1024, false, 1, 0, 16);
             case 24: CDB_RS(16, true, true, 1024, false, 1, 0, 2);
