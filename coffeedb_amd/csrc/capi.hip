@@ -252,6 +252,8 @@ int cdb_load(cdb_index* h, const char* path) {
         if (!ok || ix.doc_start[hd.ndocs] != hd.size) throw Error(std::string("Truncated index file: ") + path);
         ix.size = hd.size; ix.ndocs = hd.ndocs; ix.bits = hd.bits; ix.mask = hd.mask; ix.width = (int)hd.width;
         ix.reference_compat = hd.compat != 0;
+        ix.sa_sorted = false;  // unknown for a loaded array: queries take the reference's exact probe sequence
+        ix.pivot_levels = 0;
         ix.host_text.clear();
         ix.d_text_owned.alloc(ix.size + TEXT_PAD);
         CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + ix.size, 0, TEXT_PAD, ix.stream));
@@ -603,6 +605,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
         ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;
     else if (!std::strcmp(name, "coalesce_queries")) ix.coalesce_queries = value != 0;
+    else if (!std::strcmp(name, "fast_search")) ix.use_fast_search = value != 0;
     else {
         ix.err = std::string("unknown option: ") + name;
         return CDB_E_INVALID;

@@ -44,6 +44,7 @@ struct Index {
     std::vector<void*> qpending;
     bool qleader = false;
     bool coalesce_queries = true;
+    bool use_fast_search = true;  // pivot-table / galloping search on sorted arrays (query.hip)
 
     // ---- host staging (cdb_add)
     std::vector<int64_t> ids;
@@ -62,6 +63,10 @@ struct Index {
     DevBuf d_doc_start;               // ndocs + 1 u64
     DevBuf d_ids;                     // ndocs i64
     DevBuf d_sa;                      // size * width bytes
+    bool sa_sorted = false;           // SA is globally sorted in unsigned byte order (false only for
+                                      // reference_compat orderings of text with bytes >= 0x80)
+    DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
+    int pivot_levels = 0;
 
     // ---- scratch kept across calls
     RadixWorkspace rws;

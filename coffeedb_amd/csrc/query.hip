@@ -77,6 +77,132 @@ __global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa,
     hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
 }
 
+// ---- fast search for globally sorted suffix arrays ---------------------------------------------------
+// The reference's lower-bound loop visits the same midpoints for every keyword on its first levels
+// (L = 0, R = n-1, M = L + (R-L)/2, ...).  The first PIVOT_LEVELS levels of that tree — 2^levels - 1
+// suffixes — are summarised once per index as (first 16 bytes big-endian, suffix length) and staged in
+// LDS, so those levels cost no global memory access at all; only a keyword that agrees with a pivot on
+// all 16 bytes and is longer than 16 falls back to the text.  The prefix upper bound gallops from the
+// lower bound (1, 2, 4, ... then bisects) instead of bisecting [left-1, n-1]: hit ranges are short, so
+// this is a handful of probes instead of log2(n).  Both searches return exactly what the reference's
+// loops return whenever the array is sorted; the reference-compat orderings of text with bytes >= 0x80
+// are not, and keep using q_search_kernel (the reference's own probe sequence).
+constexpr int PIVOT_LEVELS = 11;
+constexpr int PIVOT_NODES = (1 << PIVOT_LEVELS) - 1;
+struct Pivot {
+    uint64_t hi, lo;  // bytes 0..7 and 8..15 of the suffix, big-endian, zero padded
+    uint64_t sl;      // suffix length
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void q_pivots_kernel(const V* __restrict__ sa, uint64_t n,
+                                                       const uint8_t* __restrict__ text,
+                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                       int levels, Pivot* __restrict__ piv) {
+    const uint32_t id = blockIdx.x * 256 + threadIdx.x + 1;  // heap order: root 1, children 2id (R = M), 2id+1 (L = M+1)
+    if (id >= (1u << levels)) return;
+    int depth = 31 - __clz(id);
+    int64_t L = 0, R = (int64_t)n - 1;
+    bool dead = false;
+    for (int b = depth - 1; b >= 0; --b) {
+        if (L >= R) { dead = true; break; }
+        const int64_t M = L + (R - L) / 2;
+        if ((id >> b) & 1u) L = M + 1; else R = M;
+    }
+    Pivot p{0, 0, 0};
+    if (!dead && L < R) {
+        const int64_t M = L + (R - L) / 2;
+        const V e = sa[M];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t b0 = doc_start[d] + off, sl = doc_start[d + 1] - b0;
+        uint64_t w[2] = {0, 0};
+        for (int k = 0; k < 16 && (uint64_t)k < sl; ++k) w[k >> 3] |= (uint64_t)text[b0 + k] << (56 - 8 * (k & 7));
+        p = Pivot{w[0], w[1], sl};
+    }
+    piv[id] = p;
+}
+
+// keyword <= suffix ?  decided from 16-byte prefixes when possible; returns 0 / 1, or 2 = undecided
+__device__ __forceinline__ int kw_le_pivot(uint64_t khi, uint64_t klo, uint64_t m, const Pivot& p) {
+    const uint64_t common = m < p.sl ? m : p.sl;
+    const uint64_t c16 = common < 16 ? common : 16;
+    // compare the first c16 bytes: mask both sides
+    uint64_t mh = ~0ull, ml = ~0ull;
+    if (c16 < 8) { mh = c16 ? ~0ull << (64 - 8 * c16) : 0ull; ml = 0; }
+    else if (c16 < 16) { ml = c16 > 8 ? ~0ull << (64 - 8 * (c16 - 8)) : 0ull; }
+    const uint64_t ah = khi & mh, bh = p.hi & mh, al = klo & ml, bl = p.lo & ml;
+    if (ah != bh) return ah < bh ? 1 : 0;
+    if (al != bl) return al < bl ? 1 : 0;
+    if (common <= 16) return m <= p.sl ? 1 : 0;  // equal on the whole common part
+    return 2;
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict__ sa, uint64_t n,
+                                                            const uint8_t* __restrict__ text,
+                                                            const uint64_t* __restrict__ doc_start, int bits,
+                                                            uint64_t mask, const uint8_t* __restrict__ blob,
+                                                            const uint64_t* __restrict__ offs, uint64_t npat,
+                                                            const Pivot* __restrict__ piv, int levels,
+                                                            int64_t* __restrict__ left_out,
+                                                            uint64_t* __restrict__ hits_out) {
+    __shared__ Pivot s_piv[PIVOT_NODES + 1];
+    for (int i = threadIdx.x; i < (1 << levels); i += 256) s_piv[i] = piv[i];
+    __syncthreads();
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= npat) return;
+    const uint8_t* k = blob + offs[j];
+    const uint64_t m = offs[j + 1] - offs[j];
+    uint64_t kw[2] = {0, 0};
+    for (int q = 0; q < 16 && (uint64_t)q < m; ++q) kw[q >> 3] |= (uint64_t)k[q] << (56 - 8 * (q & 7));
+    auto suffix_of = [&](int64_t M, const uint8_t*& sp, uint64_t& sl) {
+        const V e = sa[M];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t b = doc_start[d] + off;
+        sp = text + b;
+        sl = doc_start[d + 1] - b;
+    };
+    // ---- lower bound (index.cpp:260-274), first `levels` levels from LDS
+    int64_t L = 0, R = (int64_t)n - 1;
+    uint32_t id = 1;
+    while (L < R) {
+        const int64_t M = L + (R - L) / 2;
+        int le = 2;
+        if (id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
+        if (le == 2) {
+            const uint8_t* sp;
+            uint64_t sl;
+            suffix_of(M, sp, sl);
+            const int c = cmp_common(k, m, sp, sl);
+            le = (c < 0 || (c == 0 && m <= sl)) ? 1 : 0;
+        }
+        if (le) { R = M; id = 2 * id; } else { L = M + 1; id = 2 * id + 1; }
+    }
+    const int64_t left = L;
+    // ---- prefix upper bound (index.cpp:275-287) by galloping from `left`
+    auto is_prefix = [&](int64_t M) -> bool {
+        const uint8_t* sp;
+        uint64_t sl;
+        suffix_of(M, sp, sl);
+        return sl >= m && cmp_common(k, m, sp, sl) == 0;
+    };
+    int64_t right = left;  // first index >= left whose suffix does not start with the keyword
+    if (n > 0 && is_prefix(left)) {
+        int64_t good = left, step = 1, bad = (int64_t)n;
+        while (good + step < (int64_t)n) {
+            if (is_prefix(good + step)) { good += step; step <<= 1; }
+            else { bad = good + step; break; }
+        }
+        while (good + 1 < bad) {  // invariant: good is a prefix match, bad is not (or n)
+            const int64_t mid = good + (bad - good) / 2;
+            if (is_prefix(mid)) good = mid; else bad = mid;
+        }
+        right = good + 1;
+    }
+    left_out[j] = left;
+    hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
+}
+
 struct HitsIn {
     const uint64_t* hits;
     __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return hits[j]; }
@@ -161,6 +287,33 @@ void grow_keep(DevBuf& b, size_t need, size_t used, hipStream_t s) {
     if (used) CDB_HIP(hipMemcpyAsync(nb.p, b.p, used, hipMemcpyDeviceToDevice, s));
     CDB_HIP(hipStreamSynchronize(s));  // the old block goes back to the shared cache
     b = std::move(nb);
+}
+
+// runs the keyword search (fast path on sorted arrays, the reference's probe sequence otherwise)
+template <typename V>
+void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+    hipStream_t s = ix.stream;
+    const V* sa = ix.d_sa.as<V>();
+    const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
+    int t = ix.prof.begin(s);
+    if (ix.sa_sorted && ix.use_fast_search && ix.size >= 4096) {
+        if (ix.pivot_levels == 0) {
+            int levels = PIVOT_LEVELS;
+            while (levels > 1 && (1ull << levels) > ix.size / 2) --levels;
+            ix.d_pivots.alloc(((size_t)1 << levels) * sizeof(Pivot));
+            hipLaunchKernelGGL((q_pivots_kernel<V>), dim3((unsigned)ceil_div((1u << levels), 256)), dim3(256), 0, s, sa, ix.size,
+                               ix.d_text, doc_start, (int)ix.bits, ix.mask, levels, ix.d_pivots.as<Pivot>());
+            ix.pivot_levels = levels;
+        }
+        hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                           doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)ix.d_pivots.as<Pivot>(),
+                           ix.pivot_levels, ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    } else {
+        hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                           doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, ix.q_left.as<int64_t>(),
+                           ix.q_right.as<uint64_t>());
+    }
+    ix.prof.end(t, "q_search", npat * 2 * (uint64_t)bit_width64(ix.size) * 128, s);
 }
 
 // ---- OR over the keywords of one key (interface.cpp:78-113): per-document totals by atomics ------
@@ -318,15 +471,11 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         return out;
     }
     const V* sa = ix.d_sa.as<V>();
-    const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
     ix.q_left.ensure(npat * 8);
     ix.q_right.ensure(npat * 8);  // hit counts
     ix.q_hoff.ensure((npat + 1) * 8);
-    int t = ix.prof.begin(s);
-    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
-                       doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, ix.q_left.as<int64_t>(),
-                       ix.q_right.as<uint64_t>());
-    ix.prof.end(t, "q_search", npat * 2 * (uint64_t)bit_width64(ix.size) * 128, s);
+    int t = 0;
+    launch_search<V>(ix, d_blob, d_offs, npat);
 
     HitsIn hin{ix.q_right.as<uint64_t>()};
     const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
@@ -425,9 +574,7 @@ DeviceCsr query_or_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_off
     ix.q_left.ensure(npat * 8);
     ix.q_right.ensure(npat * 8);
     ix.q_hoff.ensure((npat + 1) * 8);
-    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
-                       (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, d_blob, d_offs, npat,
-                       ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    launch_search<V>(ix, d_blob, d_offs, npat);
     HitsIn hin{ix.q_right.as<uint64_t>()};
     const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
     scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
@@ -472,9 +619,7 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
     ix.q_left.ensure(npat * 8);
     ix.q_right.ensure(npat * 8);
     ix.q_hoff.ensure((npat + 1) * 8);
-    hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
-                       (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, d_blob, d_offs, npat,
-                       ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    launch_search<V>(ix, d_blob, d_offs, npat);
     HitsIn hin{ix.q_right.as<uint64_t>()};
     const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
     scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});

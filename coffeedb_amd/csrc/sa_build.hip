@@ -547,6 +547,8 @@ void build_typed(Index& ix, bool big) {
     }
     if (n == 0) {
         ix.d_sa.alloc(16);
+        ix.sa_sorted = true;
+        ix.pivot_levels = 0;
         return;
     }
     if (sizeof(R) == 4 && n + D + 2 >= (1ull << 32)) throw Error("internal: 32-bit ranks selected for a corpus >= 2^32");
@@ -873,6 +875,8 @@ void build_typed(Index& ix, bool big) {
     st.sort_passes_skipped = ss.passes_skipped;
     radix_check_error(s, ix.rws);
     CDB_HIP(hipStreamSynchronize(s));
+    ix.sa_sorted = !(ix.reference_compat && high_bytes);
+    ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
     if (ix.reference_compat && high_bytes) apply_reference_order<V>(ix, sa);
     ix.d_sa = std::move(sa_buf);
 }

@@ -213,6 +213,35 @@ def test_single_doc_and_tiny(G):
         _check_parity(G, blob, ds, patterns=(pb, po))
 
 
+def test_extreme_document_shapes(G):
+    # (a) hundreds of thousands of 1-3 byte documents: more documents per radix tile than the LDS
+    #     boundary table holds (global fallback of the generated first pass)
+    lens = (W._draws(300_000, 3, 5) % np.uint64(3) + np.uint64(1)).astype(np.uint64)
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = W.random_bytes(int(ds[-1]), 9, 0x61, 0x7A)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 300, 1, 3, seed=2, miss_byte=0x7B))
+    assert g.stat("fused_keygen") in (0, 1)
+    _check_parity(G, blob, ds, initial_passes=3, sort_variant=21)  # 7-bit... forced config: big tiles, many docs per tile
+    # (b) one single 3 MB document
+    blob = W.random_bytes(3_000_000, 4, 0x30, 0x39)
+    ds = np.array([0, 3_000_000], dtype=np.uint64)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 200, 1, 9, seed=3, miss_byte=0x41))
+    assert (g.bits, g.sa_width) == (1, 4)
+    # (c) only empty documents, then one non-empty one in the middle of empties
+    ds = np.zeros(1001, dtype=np.uint64)
+    g, o = _check_parity(G, np.zeros(0, dtype=np.uint8), ds, patterns=(np.frombuffer(b"a", dtype=np.uint8), np.array([0, 1], dtype=np.uint64)))
+    assert g.size == 0
+    ds = np.concatenate([np.zeros(500), np.full(501, 7)]).astype(np.uint64)
+    _check_parity(G, np.frombuffer(b"abcabca", dtype=np.uint8), ds,
+                  patterns=(np.frombuffer(b"a" + b"abc" + b"ca", dtype=np.uint8), np.array([0, 1, 4, 6], dtype=np.uint64)))
+    # (d) a single byte value everywhere (1-bit symbols), many documents of varying length
+    lens = (W._draws(3000, 8, 2) % np.uint64(200)).astype(np.uint64)
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = np.full(int(ds[-1]), 0x78, dtype=np.uint8)
+    pb = np.frombuffer(b"x" + b"xx" + b"x" * 150 + b"y", dtype=np.uint8)
+    _check_parity(G, blob, ds, patterns=(pb, np.array([0, 1, 3, 153, 154], dtype=np.uint64)))
+
+
 def test_many_hits_single_char_patterns(G):
     # short patterns with very large hit ranges (radix path of index.cpp:299-314 in the oracle)
     blob, ds = W.ascii_corpus(3000, 200, seed=14, lo=0x61, hi=0x64)
@@ -275,6 +304,24 @@ def test_reference_compat_bit_parity_high_bytes(G):
     blob, ds = W.ascii_corpus(40, 64, seed=21, lo=0x00, hi=0xFF)
     g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 50, 1, 2, seed=1, miss_frac=0))
     assert g.stat("compat_rotations") == 0 and o.inversions() == 0
+
+
+def test_fast_and_reference_search_agree(G):
+    # sorted arrays are searched through the LDS pivot table + galloping upper bound; both paths must
+    # give the rows of the reference's two binary searches (long keywords exercise the >16-byte fallback)
+    blob, ds = W.ascii_corpus(6000, 300, seed=77, lo=0x61, hi=0x64)
+    ids = np.arange(6000, dtype=np.int64)
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 3000, 1, 40, seed=5, miss_byte=0x7A)
+    orp, oi, oc, ohits = o.query_batch(pb, po)
+    for fast in (1, 0):
+        g = _gpu(G, blob, ds, ids, fast_search=fast)
+        rp, gi, gc, hits = g.query_batch(pb, po)
+        assert hits == ohits and np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc), fast
+    # keyword greater / smaller than every suffix, and the whole-document keyword
+    g = _gpu(G, blob, ds, ids)
+    for kw in (b"zzzz", b"\x01", bytes(blob[:300]), bytes(blob[-300:]), bytes(blob[-1:])):
+        assert g.query(kw) == o.query(kw)
 
 
 def test_or_merge_over_keywords_matches_reference_loop(G):
