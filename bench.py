@@ -228,7 +228,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 text / u64 sort keys / u32 suffix entries",
+            "dtype": "u64",  # sort keys; text is u8, suffix entries u32 (u64 for corpora the reference stores as u64)
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {ndocs} docs x {doclen} B printable ASCII per GPU ({n / 2**30:.3f} GiB), "
