@@ -18,19 +18,23 @@ index::result_type index::query(const std::string&) const { throw std::logic_err
 void index::build() { throw std::logic_error("Unimplemented method index::build"); }
 
 // ---- numeric indexes: sorted (value, id) pairs, half-open lower_bound window (index.cpp:63-74, 129-173)
-namespace {
-template <typename Pairs>
-index::result_type numeric_window(const Pairs& data, const std::string& range) {
-    using T = typename Pairs::value_type::first_type;
+template <typename T, int8_t Tag>
+void numeric_index<T, Tag>::build() {
+    std::sort(rows.begin(), rows.end());
+    rows.shrink_to_fit();
+}
+template <typename T, int8_t Tag>
+index::result_type numeric_index<T, Tag>::query(const std::string& range) const {
     const auto [lo, hi] = parse_range<T>(range);
-    const auto first = std::lower_bound(data.begin(), data.end(), lo);
-    const auto last = std::lower_bound(data.begin(), data.end(), hi);
-    index::result_type out;
+    const auto first = std::lower_bound(rows.begin(), rows.end(), lo);
+    const auto last = std::lower_bound(rows.begin(), rows.end(), hi);
+    result_type out;
     if (first < last) out.reserve((size_t)(last - first));
     for (auto it = first; it < last; ++it) out.emplace_back(it->second, 0);
     return out;
 }
-}  // namespace
+template class numeric_index<int64_t, 1>;
+template class numeric_index<double, 2>;
 
 void bool_index::add(int64_t id, bool value) { data[value ? 1 : 0].push_back(id); }
 void bool_index::build() {
@@ -47,20 +51,6 @@ index::result_type bool_index::query(const std::string& range) const {
     for (int64_t id : data[which]) out.emplace_back(id, 0);
     return out;
 }
-
-void integer_index::add(int64_t id, int64_t value) { data.emplace_back(value, id); }
-void integer_index::build() {
-    std::sort(data.begin(), data.end());
-    data.shrink_to_fit();
-}
-index::result_type integer_index::query(const std::string& range) const { return numeric_window(data, range); }
-
-void double_index::add(int64_t id, double value) { data.emplace_back(value, id); }
-void double_index::build() {
-    std::sort(data.begin(), data.end());
-    data.shrink_to_fit();
-}
-index::result_type double_index::query(const std::string& range) const { return numeric_window(data, range); }
 
 // ---- string index: forwards to the GPU library
 namespace {

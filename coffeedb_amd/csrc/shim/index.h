@@ -45,29 +45,22 @@ private:
     std::array<std::vector<int64_t>, 2> data;
 };
 
-class integer_index : public index {
+// integer and double columns share one implementation: (value, id) pairs sorted at build(), answered with
+// two lower_bound calls over the parsed range (reference index.cpp:63-74, 154-173)
+template <typename T, int8_t Tag>
+class numeric_index : public index {
 public:
-    using value_type = int64_t;
-    static constexpr int8_t number = 1;
-    void add(int64_t id, int64_t value);
+    using value_type = T;
+    static constexpr int8_t number = Tag;
+    void add(int64_t id, T value) { rows.emplace_back(value, id); }
     void build() override;
     result_type query(const std::string& range) const override;
 
-private:
-    std::vector<std::pair<value_type, int64_t>> data;
+protected:
+    std::vector<std::pair<T, int64_t>> rows;
 };
-
-class double_index : public index {
-public:
-    using value_type = double;
-    static constexpr int8_t number = 2;
-    void add(int64_t id, double value);
-    void build() override;
-    result_type query(const std::string& range) const override;
-
-private:
-    std::vector<std::pair<value_type, int64_t>> data;
-};
+class integer_index : public numeric_index<int64_t, 1> {};
+class double_index : public numeric_index<double, 2> {};
 
 class string_index : public index {
 public:
