@@ -19,7 +19,7 @@ EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
-    "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes",
+    "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify",
 ]
 
@@ -102,6 +102,8 @@ def load_library():
     lib.cdb_profile_reset.restype = None
     lib.cdb_release_cached_memory.argtypes = []
     lib.cdb_release_cached_memory.restype = None
+    lib.cdb_set_cache_limit.argtypes = [u64]
+    lib.cdb_set_cache_limit.restype = None
     lib.cdb_cached_memory_bytes.argtypes = []
     lib.cdb_cached_memory_bytes.restype = u64
     lib.cdb_debug_verify.argtypes = [vp, C.POINTER(u64)]

@@ -722,6 +722,8 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
 
 void cdb_release_cached_memory(void) { DevPool::get().trim(); }
 
+void cdb_set_cache_limit(uint64_t bytes) { DevPool::get().set_limit((size_t)bytes); }
+
 uint64_t cdb_cached_memory_bytes(void) { return (uint64_t)DevPool::get().cached_bytes(); }
 
 void cdb_profile_reset(cdb_index* h) {

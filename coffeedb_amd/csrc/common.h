@@ -70,9 +70,28 @@ public:
         return p;
     }
     void free(void* p, size_t bytes, int device) {
-        std::lock_guard<std::mutex> g(mu_);
-        free_.push_back(Block{p, bytes, device});
-        cached_ += bytes;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (cached_ + bytes <= limit_) {
+                free_.push_back(Block{p, bytes, device});
+                cached_ += bytes;
+                return;
+            }
+        }
+        // the cache is full: hand the block back to the driver
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipFree(p);
+        if (cur != device) (void)hipSetDevice(cur);
+    }
+    void set_limit(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            limit_ = bytes;
+            if (cached_ <= limit_) return;
+        }
+        trim();
     }
     void trim() {
         std::vector<Block> blocks;
@@ -99,6 +118,7 @@ private:
     std::mutex mu_;
     std::vector<Block> free_;
     size_t cached_ = 0;
+    size_t limit_ = (size_t)128 << 30;  // bytes kept for reuse; the rest of a 288 GB part stays with the driver
 };
 
 // Owning device allocation, served by DevPool.
