@@ -1,5 +1,5 @@
-// radix_sort.h — stable LSD radix sort for gfx950 (8-bit digits, one read + one write of the data per
-// pass: "onesweep" with chained-scan decoupled look-back).
+// radix_sort.h — stable LSD radix sort for gfx950 (digits of up to 8 bits, one read + one write of the
+// data per pass: "onesweep" with chained-scan decoupled look-back).
 //
 // This is the bandwidth-dominant primitive of the suffix-array build (replaces the reference's
 // multithreaded MSD radix + std::sort leaves, /root/reference/src/index.cpp:75-128) and of the
@@ -11,8 +11,9 @@
 // Hardware mapping:
 //   * 64-wide wavefronts: per-digit ranks inside a wave come from 8 ballots (one per digit bit) —
 //     lanes with equal digits find each other without LDS atomics, which keeps the sort stable;
-//   * LDS: keys (and values) of one tile are staged in sorted-by-digit order so that the global
-//     write-out has consecutive lanes writing consecutive addresses inside each digit run;
+//   * LDS: keys, then values, of one tile are staged in sorted-by-digit order so that the global
+//     write-out has consecutive lanes writing consecutive addresses inside each digit run; the
+//     production tile is 1024 threads x 16 keys (150 KB of the CU's 160 KB LDS, one workgroup per CU);
 //   * 8 XCDs with non-coherent L2s: tiles exchange {epoch,state,count} words only through agent-scope
 //     relaxed atomic loads/stores (one 8-byte granule is both flag and payload — MI355X guide §G16 R2),
 //     tile ids come from an atomic ticket so a tile only ever waits on tiles that already started, and
@@ -24,20 +25,16 @@
 
 namespace cdb {
 
-constexpr int RS_NT = 256;            // threads per workgroup (4 waves)
-constexpr int RS_NW = RS_NT / 64;
 constexpr int RS_MAX_PASSES = 16;
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 
 struct NoVal {};
 
+// keys per thread of the small 256-thread configurations (cases 1 and 4 of radix_sort)
 template <typename K, typename V> struct RsTraits { static constexpr int IPT = 12; };
-template <> struct RsTraits<uint64_t, uint32_t> { static constexpr int IPT = 15; };  // 46 KB tile -> 3 WG/CU
-template <> struct RsTraits<uint64_t, uint64_t> { static constexpr int IPT = 12; };  // 48 KB tile
-template <> struct RsTraits<uint64_t, NoVal> { static constexpr int IPT = 16; };
-template <> struct RsTraits<uint32_t, uint32_t> { static constexpr int IPT = 16; };
-template <> struct RsTraits<uint32_t, NoVal> { static constexpr int IPT = 16; };
+template <> struct RsTraits<uint64_t, uint32_t> { static constexpr int IPT = 15; };
+template <> struct RsTraits<uint64_t, uint64_t> { static constexpr int IPT = 12; };
 
 // ---------------------------------------------------------------------------------------------
 // upfront histogram of every pass's digit (one read of the keys)
