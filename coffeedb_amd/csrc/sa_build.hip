@@ -900,6 +900,9 @@ void build_suffix_array(Index& ix) {
         // kernel of this build is still using them
         (void)hipStreamSynchronize(ix.stream);
         ix.prof.resolve();
+        ix.d_sa.release();
+        ix.width = 0;  // back to "never built": queries answer {} instead of touching a half-built array
+        ix.size = 0;
         throw;
     }
     CDB_HIP(hipStreamSynchronize(ix.stream));

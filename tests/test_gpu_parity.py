@@ -408,6 +408,23 @@ def test_concurrent_queries_same_handle(G):
     assert not errs
 
 
+def test_failed_build_leaves_index_unbuilt(G):
+    # a build that cannot complete (here: >= 4 GiB path forced on a full 256-value alphabet) must leave a
+    # queryable "never built" index behind, not a half-built one
+    blob, ds = W.ascii_corpus(300, 64, seed=3, lo=0x00, hi=0xFF)
+    g = G()
+    g.add_bulk(np.arange(300, dtype=np.int64), blob, ds)
+    g.build()
+    assert g.query(bytes(blob[:2]))
+    g.set_option("force_big_path", 1)
+    with pytest.raises(RuntimeError, match="alphabet"):
+        g.build()
+    assert g.sa_width == 0 and g.query(bytes(blob[:2])) == []
+    g.set_option("force_big_path", 0)
+    g.build()
+    assert g.query(bytes(blob[:2]))
+
+
 def test_rebuild_after_more_adds(G):
     g = G()
     g.add(1, b"hello world")
