@@ -606,6 +606,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
         ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;
     else if (!std::strcmp(name, "coalesce_queries")) ix.coalesce_queries = value != 0;
     else if (!std::strcmp(name, "fast_search")) ix.use_fast_search = value != 0;
+    else if (!std::strcmp(name, "wave_rows")) ix.use_wave_rows = value != 0;
     else {
         ix.err = std::string("unknown option: ") + name;
         return CDB_E_INVALID;

@@ -44,6 +44,7 @@ struct Index {
     std::vector<void*> qpending;
     bool qleader = false;
     bool coalesce_queries = true;
+    bool use_wave_rows = true;    // wavefront-per-pattern row building when every hit list has <= 64 entries
     bool use_fast_search = true;  // pivot-table / galloping search on sorted arrays (query.hip)
 
     // ---- host staging (cdb_add)

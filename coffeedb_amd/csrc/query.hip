@@ -203,6 +203,87 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
 }
 
+struct OpSumMax {  // (a, b) = (sum, max)
+    __device__ __forceinline__ U2 operator()(const U2& x, const U2& y) const { return U2{x.a + y.a, x.b > y.b ? x.b : y.b}; }
+};
+struct HitsIn2 {
+    const uint64_t* hits;
+    __device__ __forceinline__ U2 operator()(uint64_t j) const { return U2{hits[j], hits[j]}; }
+};
+struct HitsOut2 {
+    uint64_t* hoff;
+    uint64_t npat;
+    __device__ __forceinline__ void operator()(uint64_t j, const U2& ex, const U2& in) const {
+        hoff[j] = ex.a;
+        if (j + 1 == npat) hoff[npat] = in.a;
+    }
+};
+
+// ---- rows of patterns with at most 64 hits: one wavefront per pattern ---------------------------------
+// The common case (keywords of a few characters or more) has short hit lists, for which a device-wide
+// radix sort of (pattern, doc) keys plus two scans is mostly launch and synchronisation latency.  Here a
+// wavefront loads its pattern's hits straight from the suffix array (one entry per lane), sorts the 64
+// document indices with a bitonic network of lane shuffles, and run-length encodes them with a ballot —
+// replaces index.cpp:288-322 for that pattern.  Phase 1 leaves compacted (doc, count) pairs at the
+// pattern's hit offset and its row count; after a scan of the row counts phase 2 moves the rows to
+// their CSR position and maps documents to object ids.
+template <typename V>
+__global__ __launch_bounds__(256) void q_wave_rows_kernel(const V* __restrict__ sa, uint64_t mask,
+                                                          const int64_t* __restrict__ left,
+                                                          const uint64_t* __restrict__ hits,
+                                                          const uint64_t* __restrict__ hoff, uint64_t npat,
+                                                          uint32_t* __restrict__ row_doc, uint32_t* __restrict__ row_cnt,
+                                                          uint64_t* __restrict__ nrows) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= npat) return;
+    const uint32_t h = (uint32_t)hits[j];
+    uint32_t v = 0xFFFFFFFFu;  // sentinel behind every document index
+    if ((uint32_t)lane < h) v = (uint32_t)((uint64_t)sa[(uint64_t)left[j] + lane] & mask);
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int q = k >> 1; q > 0; q >>= 1) {
+            const uint32_t o = __shfl_xor(v, q);
+            const bool up = (lane & k) == 0;          // ascending block
+            const bool lower = (lane & q) == 0;       // this lane keeps the smaller element of the pair
+            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    const uint32_t prev = __shfl_up(v, 1);
+    const bool head = (uint32_t)lane < h && (lane == 0 || v != prev);
+    const uint64_t heads = __ballot(head);
+    if (head) {
+        const uint32_t r = __popcll(heads & ((1ull << lane) - 1ull));
+        const uint64_t later = heads & ~((2ull << lane) - 1ull);       // heads behind this lane
+        const uint32_t next = later ? (uint32_t)(__ffsll((unsigned long long)later) - 1) : h;
+        row_doc[hoff[j] + r] = v;
+        row_cnt[hoff[j] + r] = next - (uint32_t)lane;
+    }
+    if (lane == 0) nrows[j] = (uint64_t)__popcll(heads);
+}
+
+__global__ __launch_bounds__(256) void q_wave_emit_kernel(const uint32_t* __restrict__ row_doc,
+                                                          const uint32_t* __restrict__ row_cnt,
+                                                          const uint64_t* __restrict__ hoff,
+                                                          const uint64_t* __restrict__ row_ptr, uint64_t npat,
+                                                          const int64_t* __restrict__ ids, int64_t* __restrict__ out_ids,
+                                                          int64_t* __restrict__ out_counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= npat) return;
+    const uint64_t a = row_ptr[j], nr = row_ptr[j + 1] - a;
+    if ((uint64_t)lane < nr) {
+        out_ids[a + lane] = ids[row_doc[hoff[j] + lane]];
+        out_counts[a + lane] = (int64_t)row_cnt[hoff[j] + lane];
+    }
+}
+struct NrowsIn {
+    const uint64_t* nrows;
+    __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return nrows[j]; }
+};
+
 struct HitsIn {
     const uint64_t* hits;
     __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return hits[j]; }
@@ -477,14 +558,40 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
     int t = 0;
     launch_search<V>(ix, d_blob, d_offs, npat);
 
-    HitsIn hin{ix.q_right.as<uint64_t>()};
-    const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
-    scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    HitsIn2 hin{ix.q_right.as<uint64_t>()};
+    const U2 tot = scan_totals<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0});
+    scan_apply<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0}, HitsOut2{ix.q_hoff.as<uint64_t>(), npat});
+    const uint64_t H = tot.a, maxh = tot.b;
     out.nhits = H;
     if (H == 0) {
         CDB_HIP(hipMemsetAsync(ix.q_rowptr.p, 0, (npat + 1) * 8, s));
         ix.q_ids.ensure(16);
         ix.q_counts.ensure(16);
+        CDB_HIP(hipStreamSynchronize(s));
+        return out;
+    }
+    if (maxh <= 64 && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && H <= (1ull << 31)) {
+        // every pattern's hit list fits one wavefront: sort + run-length encode per pattern in registers
+        ix.q_keys0.ensure(H * 4);   // row_doc
+        ix.q_keys1.ensure(H * 4);   // row_cnt
+        ix.q_flags.ensure(npat * 8);  // rows per pattern
+        t = ix.prof.begin(s);
+        hipLaunchKernelGGL((q_wave_rows_kernel<V>), dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s, sa, ix.mask,
+                           (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_right.as<uint64_t>(),
+                           (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, ix.q_keys0.as<uint32_t>(), ix.q_keys1.as<uint32_t>(),
+                           ix.q_flags.as<uint64_t>());
+        ix.prof.end(t, "q_wave_rows", H * (sizeof(V) + 8), s);
+        NrowsIn nin{ix.q_flags.as<uint64_t>()};
+        const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0);
+        scan_apply<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_rowptr.as<uint64_t>(), npat});
+        out.nrows = nrows;
+        ix.q_ids.ensure(std::max<uint64_t>(nrows, 2) * 8);
+        ix.q_counts.ensure(std::max<uint64_t>(nrows, 2) * 8);
+        hipLaunchKernelGGL(q_wave_emit_kernel, dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s,
+                           (const uint32_t*)ix.q_keys0.as<uint32_t>(), (const uint32_t*)ix.q_keys1.as<uint32_t>(),
+                           (const uint64_t*)ix.q_hoff.as<uint64_t>(), (const uint64_t*)ix.q_rowptr.as<uint64_t>(), npat,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+        CDB_HIP(hipGetLastError());
         CDB_HIP(hipStreamSynchronize(s));
         return out;
     }

@@ -318,6 +318,16 @@ def test_fast_and_reference_search_agree(G):
         g = _gpu(G, blob, ds, ids, fast_search=fast)
         rp, gi, gc, hits = g.query_batch(pb, po)
         assert hits == ohits and np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc), fast
+    # row building: one wavefront per pattern (all hit lists <= 64 entries) vs the device-wide sort
+    blob2, ds2 = W.ascii_corpus(20000, 128, seed=9)
+    ids2 = np.arange(20000, dtype=np.int64)[::-1].copy()
+    o2 = _oracle(blob2, ds2, ids2)
+    p2 = W.sample_patterns(blob2, ds2, 5000, 3, 12, seed=4)
+    want = o2.query_batch(*p2)
+    for wave in (1, 0):
+        g2 = _gpu(G, blob2, ds2, ids2, wave_rows=wave)
+        got = g2.query_batch(*p2)
+        assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])), wave
     # keyword greater / smaller than every suffix, and the whole-document keyword
     g = _gpu(G, blob, ds, ids)
     for kw in (b"zzzz", b"\x01", bytes(blob[:300]), bytes(blob[-300:]), bytes(blob[-1:])):
