@@ -254,6 +254,8 @@ int cdb_load(cdb_index* h, const char* path) {
         ix.reference_compat = hd.compat != 0;
         ix.sa_sorted = false;  // unknown for a loaded array: queries take the reference's exact probe sequence
         ix.pivot_levels = 0;
+        ix.d_keys.release();
+        ix.key_nsym = 0;
         ix.host_text.clear();
         ix.d_text_owned.alloc(ix.size + TEXT_PAD);
         CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + ix.size, 0, TEXT_PAD, ix.stream));
@@ -607,6 +609,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "coalesce_queries")) ix.coalesce_queries = value != 0;
     else if (!std::strcmp(name, "fast_search")) ix.use_fast_search = value != 0;
     else if (!std::strcmp(name, "wave_rows")) ix.use_wave_rows = value != 0;
+    else if (!std::strcmp(name, "keep_keys")) ix.keep_keys = value != 0;
     else {
         ix.err = std::string("unknown option: ") + name;
         return CDB_E_INVALID;

@@ -44,6 +44,7 @@ struct Index {
     std::vector<void*> qpending;
     bool qleader = false;
     bool coalesce_queries = true;
+    bool keep_keys = true;        // keep d_keys when it costs <= 16 GiB (8 bytes per suffix)
     bool use_wave_rows = true;    // wavefront-per-pattern row building when every hit list has <= 64 entries
     bool use_fast_search = true;  // pivot-table / galloping search on sorted arrays (query.hip)
 
@@ -66,6 +67,10 @@ struct Index {
     DevBuf d_sa;                      // size * width bytes
     bool sa_sorted = false;           // SA is globally sorted in unsigned byte order (false only for
                                       // reference_compat orderings of text with bytes >= 0x80)
+    DevBuf d_keys;                    // optional: the sorted initial keys (first key_nsym symbol codes of every
+                                      // suffix, packed) kept for the search: one load decides most probes
+    DevBuf d_symmap_q;                // byte -> symbol code (u16[256]) matching d_keys
+    int key_nsym = 0, key_symbits = 0;
     DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
     int pivot_levels = 0;
 

@@ -144,10 +144,14 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                                                             uint64_t mask, const uint8_t* __restrict__ blob,
                                                             const uint64_t* __restrict__ offs, uint64_t npat,
                                                             const Pivot* __restrict__ piv, int levels,
+                                                            const uint64_t* __restrict__ keys,
+                                                            const uint16_t* __restrict__ symmap, int nsym, int symbits,
                                                             int64_t* __restrict__ left_out,
                                                             uint64_t* __restrict__ hits_out) {
     __shared__ Pivot s_piv[PIVOT_NODES + 1];
+    __shared__ uint16_t s_code[256];
     for (int i = threadIdx.x; i < (1 << levels); i += 256) s_piv[i] = piv[i];
+    if (keys) s_code[threadIdx.x] = symmap[threadIdx.x];
     __syncthreads();
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= npat) return;
@@ -155,6 +159,30 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     const uint64_t m = offs[j + 1] - offs[j];
     uint64_t kw[2] = {0, 0};
     for (int q = 0; q < 16 && (uint64_t)q < m; ++q) kw[q >> 3] |= (uint64_t)k[q] << (56 - 8 * (q & 7));
+    // keyword in the key alphabet: its first min(m, nsym) symbol codes, packed like keys[]; a byte that
+    // does not occur in the text (code 0) means the keyword occurs nowhere
+    const int kc = keys ? (int)(m < (uint64_t)nsym ? m : (uint64_t)nsym) : 0;
+    uint64_t kwc = 0;
+    bool absent = false;
+    for (int q = 0; q < kc; ++q) {
+        const uint64_t c = s_code[k[q]];
+        absent |= c == 0;
+        kwc = (kwc << symbits) | c;
+    }
+    if (keys)
+        for (uint64_t q = kc; q < m; ++q) absent |= s_code[k[q]] == 0;
+    if (absent) {
+        left_out[j] = 0;
+        hits_out[j] = 0;
+        return;
+    }
+    const int kshift = keys ? (nsym - kc) * symbits : 0;
+    // three-way answer from the key of slot M alone: -1 suffix < keyword, +1 keyword < suffix,
+    // 0 = the suffix starts with the keyword's first kc symbols (decisive iff m <= nsym)
+    auto key_cmp = [&](int64_t M) -> int {
+        const uint64_t sk = keys[M] >> kshift;
+        return sk < kwc ? -1 : (sk > kwc ? 1 : 0);
+    };
     auto suffix_of = [&](int64_t M, const uint8_t*& sp, uint64_t& sl) {
         const V e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
@@ -169,6 +197,11 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
         const int64_t M = L + (R - L) / 2;
         int le = 2;
         if (id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
+        if (le == 2 && keys) {
+            const int c = key_cmp(M);
+            if (c != 0) le = c > 0 ? 1 : 0;
+            else if (m <= (uint64_t)nsym) le = 1;  // keyword is a prefix of the suffix: keyword <= suffix
+        }
         if (le == 2) {
             const uint8_t* sp;
             uint64_t sl;
@@ -181,6 +214,10 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     const int64_t left = L;
     // ---- prefix upper bound (index.cpp:275-287) by galloping from `left`
     auto is_prefix = [&](int64_t M) -> bool {
+        if (keys) {
+            if (key_cmp(M) != 0) return false;
+            if (m <= (uint64_t)nsym) return true;
+        }
         const uint8_t* sp;
         uint64_t sl;
         suffix_of(M, sp, sl);
@@ -388,7 +425,9 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
         }
         hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)ix.d_pivots.as<Pivot>(),
-                           ix.pivot_levels, ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+                           ix.pivot_levels, ix.key_nsym ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
+                           (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_symbits,
+                           ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
     } else {
         hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, ix.q_left.as<int64_t>(),

@@ -549,6 +549,8 @@ void build_typed(Index& ix, bool big) {
         ix.d_sa.alloc(16);
         ix.sa_sorted = true;
         ix.pivot_levels = 0;
+        ix.d_keys.release();
+        ix.key_nsym = 0;
         return;
     }
     if (sizeof(R) == 4 && n + D + 2 >= (1ull << 32)) throw Error("internal: 32-bit ranks selected for a corpus >= 2^32");
@@ -771,7 +773,17 @@ void build_typed(Index& ix, bool big) {
     }
     CDB_HIP(hipStreamSynchronize(s));
     ta = now_ms();
-    sorted_keys.release();
+    // The sorted keys stay valid for the finished array: refinement only permutes entries inside groups
+    // of equal keys.  They let a search probe decide on ONE load (query.hip) — kept when affordable.
+    ix.d_keys.release();
+    ix.key_nsym = 0;
+    if (ix.keep_keys && n * 8 <= (16ull << 30)) {
+        ix.d_keys = std::move(sorted_keys);
+        ix.key_nsym = nsym;
+        ix.key_symbits = symbits;
+    } else {
+        sorted_keys.release();
+    }
     st.free_ms += now_ms() - ta;
     V* sa = sa_buf.as<V>();
 
@@ -877,7 +889,12 @@ void build_typed(Index& ix, bool big) {
     CDB_HIP(hipStreamSynchronize(s));
     ix.sa_sorted = !(ix.reference_compat && high_bytes);
     ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
-    if (ix.reference_compat && high_bytes) apply_reference_order<V>(ix, sa);
+    if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
+    if (ix.reference_compat && high_bytes) {
+        apply_reference_order<V>(ix, sa);
+        ix.d_keys.release();  // the rotations moved the entries away from their keys
+        ix.key_nsym = 0;
+    }
     ix.d_sa = std::move(sa_buf);
 }
 
@@ -901,6 +918,8 @@ void build_suffix_array(Index& ix) {
         (void)hipStreamSynchronize(ix.stream);
         ix.prof.resolve();
         ix.d_sa.release();
+        ix.d_keys.release();
+        ix.key_nsym = 0;
         ix.width = 0;  // back to "never built": queries answer {} instead of touching a half-built array
         ix.size = 0;
         throw;
