@@ -198,9 +198,9 @@ int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t
 
 // ---- f4: persistence of a built index (the reference rebuilds every index at start, server.cpp:44) ----
 namespace {
-constexpr uint64_t SAVE_MAGIC = 0x3130584449424443ull;  // "CDBIDX01"
+constexpr uint64_t SAVE_MAGIC = 0x3230584449424443ull;  // "CDBIDX02"
 struct SaveHeader {
-    uint64_t magic, size, ndocs, bits, mask, width, compat;
+    uint64_t magic, size, ndocs, bits, mask, width, compat, sorted;
 };
 }  // namespace
 
@@ -214,7 +214,8 @@ int cdb_save(cdb_index* h, const char* path) {
         FILE* fp = std::fopen(path, "wb");
         if (!fp) throw Error(std::string("Cannot open file: ") + path);
         struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
-        const SaveHeader hd{SAVE_MAGIC, ix.size, ix.ndocs, ix.bits, ix.mask, (uint64_t)ix.width, ix.reference_compat ? 1ull : 0ull};
+        const SaveHeader hd{SAVE_MAGIC, ix.size, ix.ndocs, ix.bits, ix.mask, (uint64_t)ix.width, ix.reference_compat ? 1ull : 0ull,
+                            ix.sa_sorted ? 1ull : 0ull};
         bool ok = std::fwrite(&hd, sizeof(hd), 1, fp) == 1;
         ok = ok && (ix.ndocs == 0 || std::fwrite(ix.ids.data(), 8, ix.ndocs, fp) == ix.ndocs);
         ok = ok && std::fwrite(ix.doc_start.data(), 8, ix.ndocs + 1, fp) == ix.ndocs + 1;
@@ -252,7 +253,7 @@ int cdb_load(cdb_index* h, const char* path) {
         if (!ok || ix.doc_start[hd.ndocs] != hd.size) throw Error(std::string("Truncated index file: ") + path);
         ix.size = hd.size; ix.ndocs = hd.ndocs; ix.bits = hd.bits; ix.mask = hd.mask; ix.width = (int)hd.width;
         ix.reference_compat = hd.compat != 0;
-        ix.sa_sorted = false;  // unknown for a loaded array: queries take the reference's exact probe sequence
+        ix.sa_sorted = hd.sorted != 0;  // a reference-compat ordering keeps the reference's exact probe sequence
         ix.pivot_levels = 0;
         ix.d_keys.release();
         ix.key_nsym = 0;
