@@ -425,7 +425,7 @@ int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uin
             ix.q_offs.ensure((npat + 1) * 8);
             CDB_HIP(hipMemcpyAsync(ix.q_pat.p, pat.data(), pat.size(), hipMemcpyHostToDevice, s));
             CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
-            r = query_spans_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+            r = query_spans_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat, pat.size());
         }
         out->ndocs = r.ndocs;
         out->nspans = r.nspans;

@@ -111,7 +111,8 @@ DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t
 struct SpanResult {
     uint64_t ndocs = 0, nspans = 0, nhits = 0;
 };
-SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
+                                 uint64_t total_pattern_bytes);
 // union over the patterns by object id with summed counts, rows ascending by id, in ix.q_ids / q_counts
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
 

@@ -506,6 +506,59 @@ __global__ __launch_bounds__(256) void q_expand_occ_kernel(const V* __restrict__
     }
 }
 
+// Occurrences by scanning the text itself — used for highlight spans when the suffix array is a
+// reference-compat ordering of text with bytes >= 0x80: the reference's QUERY inherits the wrong ranges of
+// its binary search there (and so does ours), but its highlighter re-scans the document text with an
+// Aho-Corasick automaton (database.cpp:58-76) and therefore reports the true occurrences.  One thread
+// per text position, keywords in LDS, a 256-bit first-byte filter rejects almost every position at once.
+constexpr int SCAN_MAX_KW = 256;
+constexpr int SCAN_MAX_BYTES = 8192;
+template <bool FILL>
+__global__ __launch_bounds__(256) void q_scan_occ_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                         const uint64_t* __restrict__ doc_start, uint64_t ndocs, int obits,
+                                                         const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
+                                                         uint32_t npat, unsigned long long* __restrict__ counter,
+                                                         uint64_t* __restrict__ keys, uint64_t* __restrict__ ends) {
+    __shared__ uint8_t s_blob[SCAN_MAX_BYTES];
+    __shared__ uint32_t s_off[SCAN_MAX_KW + 1];
+    __shared__ uint32_t s_first[8];
+    if (threadIdx.x < 8) s_first[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i <= npat; i += 256) s_off[i] = (uint32_t)offs[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_off[npat]; i += 256) s_blob[i] = blob[i];
+    if (threadIdx.x < npat) atomicOr(&s_first[blob[s_off[threadIdx.x]] >> 5], 1u << (blob[s_off[threadIdx.x]] & 31));
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += stride) {
+        const uint8_t c = text[p];
+        if (!((s_first[c >> 5] >> (c & 31)) & 1u)) continue;
+        uint64_t d = ~0ull, dend = 0, ds = 0;
+        for (uint32_t k = 0; k < npat; ++k) {
+            const uint32_t a = s_off[k], m = s_off[k + 1] - a;
+            if (s_blob[a] != c || p + m > n) continue;
+            uint32_t q = 1;
+            while (q < m && text[p + q] == s_blob[a + q]) ++q;
+            if (q < m) continue;
+            if (d == ~0ull) {  // document of p (looked up once per matching position)
+                uint64_t lo = 0, hi = ndocs - 1;
+                while (lo < hi) {
+                    const uint64_t mid = lo + (hi - lo + 1) / 2;
+                    if (doc_start[mid] <= p) lo = mid; else hi = mid - 1;
+                }
+                d = lo;
+                ds = doc_start[d];
+                dend = doc_start[d + 1];
+            }
+            if (p + m > dend) continue;  // would run into the next document
+            const unsigned long long slot = atomicAdd(counter, 1ull);
+            if (FILL) {
+                keys[slot] = (d << obits) | (p - ds);
+                ends[slot] = (p - ds) + m;
+            }
+        }
+    }
+}
+
 struct DocMax {  // (document, running maximum of occurrence ends) — segmented max
     uint64_t doc, mx;
 };
@@ -757,31 +810,55 @@ DeviceCsr query_or_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_off
 }
 
 template <typename V>
-SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
+                             uint64_t total_pattern_bytes) {
     hipStream_t s = ix.stream;
     SpanResult out;
     if (npat == 0 || ix.size == 0 || ix.width == 0) return out;
     const V* sa = ix.d_sa.as<V>();
-    ix.q_left.ensure(npat * 8);
-    ix.q_right.ensure(npat * 8);
-    ix.q_hoff.ensure((npat + 1) * 8);
-    launch_search<V>(ix, d_blob, d_offs, npat);
-    HitsIn hin{ix.q_right.as<uint64_t>()};
-    const uint64_t H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
-    scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    const int obits = ix.width * 8 - (int)ix.bits;  // offset bits of an entry
+    const bool by_scan = !ix.sa_sorted;  // reference-compat ordering: occurrences come from the text itself
+    uint64_t H = 0;
+    DevBuf k0, k1, e0, e1, head, incl, d_cnt;
+    if (by_scan) {
+        if (npat > SCAN_MAX_KW || total_pattern_bytes > SCAN_MAX_BYTES)
+            throw Error("too many highlight keywords for one request on a reference-compatible index");
+        d_cnt.alloc(8);
+        CDB_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16);
+        hipLaunchKernelGGL((q_scan_occ_kernel<false>), dim3(grid), dim3(256), 0, s, ix.d_text, ix.size,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, obits, d_blob, d_offs, (uint32_t)npat,
+                           d_cnt.as<unsigned long long>(), (uint64_t*)nullptr, (uint64_t*)nullptr);
+        CDB_HIP(hipMemcpyAsync(&H, d_cnt.p, 8, hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+    } else {
+        ix.q_left.ensure(npat * 8);
+        ix.q_right.ensure(npat * 8);
+        ix.q_hoff.ensure((npat + 1) * 8);
+        launch_search<V>(ix, d_blob, d_offs, npat);
+        HitsIn hin{ix.q_right.as<uint64_t>()};
+        H = scan_totals<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0);
+        scan_apply<uint64_t>(s, ix.scan_partials, hin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_hoff.as<uint64_t>(), npat});
+    }
     out.nhits = H;
     if (H == 0) {
         CDB_HIP(hipStreamSynchronize(s));
         return out;
     }
     if (H > (1ull << 31)) throw Error("too many occurrences for one highlight request");
-    const int obits = ix.width * 8 - (int)ix.bits;  // offset bits of an entry
-    DevBuf k0, k1, e0, e1, head, incl;
     k0.alloc(H * 8); k1.alloc(H * 8); e0.alloc(H * 8); e1.alloc(H * 8); head.alloc(H); incl.alloc(H * 8);
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(H, 256), 1u << 20);
-    hipLaunchKernelGGL((q_expand_occ_kernel<V>), dim3(grid), dim3(256), 0, s, sa, ix.mask, (int)ix.bits, obits,
-                       (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), d_offs, npat, H,
-                       k0.as<uint64_t>(), e0.as<uint64_t>());
+    if (by_scan) {
+        CDB_HIP(hipMemsetAsync(d_cnt.p, 0, 8, s));
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16);
+        hipLaunchKernelGGL((q_scan_occ_kernel<true>), dim3(grid), dim3(256), 0, s, ix.d_text, ix.size,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, obits, d_blob, d_offs, (uint32_t)npat,
+                           d_cnt.as<unsigned long long>(), k0.as<uint64_t>(), e0.as<uint64_t>());
+    } else {
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(H, 256), 1u << 20);
+        hipLaunchKernelGGL((q_expand_occ_kernel<V>), dim3(grid), dim3(256), 0, s, sa, ix.mask, (int)ix.bits, obits,
+                           (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), d_offs, npat, H,
+                           k0.as<uint64_t>(), e0.as<uint64_t>());
+    }
     const int sel = radix_sort<uint64_t, uint64_t>(s, ix.rws, ix.prof, k0.as<uint64_t>(), k1.as<uint64_t>(), e0.as<uint64_t>(),
                                                    e1.as<uint64_t>(), H, 0, std::min(64, obits + (int)ix.bits), nullptr);
     const uint64_t* keys = (sel ? k1 : k0).as<uint64_t>();
@@ -838,9 +915,10 @@ DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d
     return r;
 }
 
-SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
-    SpanResult r = ix.width == 8 ? query_spans_typed<uint64_t>(ix, d_blob, d_offs, npat)
-                                 : query_spans_typed<uint32_t>(ix, d_blob, d_offs, npat);
+SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
+                                 uint64_t total_pattern_bytes) {
+    SpanResult r = ix.width == 8 ? query_spans_typed<uint64_t>(ix, d_blob, d_offs, npat, total_pattern_bytes)
+                                 : query_spans_typed<uint32_t>(ix, d_blob, d_offs, npat, total_pattern_bytes);
     ix.prof.resolve();
     return r;
 }

@@ -1,0 +1,78 @@
+"""Seeded fuzz parity: random corpus shapes x build options against the CPU oracle (suffix array
+bit-exact after tie canonicalisation, batched query rows, OR-merge and highlight spans)."""
+import numpy as np
+import pytest
+
+from coffeedb_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(rng):
+    kind = rng.integers(0, 6)
+    nd = int(rng.integers(1, 4000))
+    if kind == 0:      # uniform, random alphabet range (sometimes with bytes >= 0x80)
+        lo = int(rng.integers(0, 200)); hi = int(min(255, lo + rng.integers(0, 120)))
+        blob, ds = W.ragged_corpus(nd, int(rng.integers(1, 120)), seed=int(rng.integers(1 << 30)), lo=lo, hi=hi,
+                                   empty_every=int(rng.integers(0, 9)))
+    elif kind == 1:    # tiny alphabet -> deep repeats
+        blob, ds = W.ragged_corpus(nd, int(rng.integers(1, 200)), seed=int(rng.integers(1 << 30)), lo=0x61,
+                                   hi=0x61 + int(rng.integers(0, 3)))
+    elif kind == 2:    # duplicated documents
+        base, _ = W.ascii_corpus(1, int(rng.integers(1, 300)), seed=int(rng.integers(1 << 30)), lo=0x61, hi=0x66)
+        reps = int(rng.integers(2, 40))
+        blob = np.concatenate([base] * reps)
+        ds = (np.arange(reps + 1) * len(base)).astype(np.uint64)
+    elif kind == 3:    # zipf
+        blob, ds = W.zipf_corpus(max(1, nd // 4), int(rng.integers(8, 300)), seed=int(rng.integers(1 << 30)))
+    elif kind == 4:    # valid UTF-8
+        blob, ds = W.utf8_corpus(max(1, nd // 20), int(rng.integers(10, 200)), seed=int(rng.integers(1 << 30)))
+    else:              # one long document among short ones (u64 entries when long enough)
+        lens = rng.integers(0, 6, size=nd).astype(np.uint64)
+        lens[int(rng.integers(0, nd))] = int(rng.integers(1000, 90000))
+        ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        blob = W.random_bytes(int(ds[-1]), int(rng.integers(1 << 30)), 0x41, 0x44)
+    return blob, ds
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_N", "24"))))
+def test_fuzz_parity(seed):
+    from coffeedb_amd import capi
+    from oracle import OracleIndex
+    rng = np.random.default_rng(1000 + seed)
+    blob, ds = _corpus(rng)
+    nd = len(ds) - 1
+    if int(ds[-1]) == 0:
+        pytest.skip("empty corpus drawn")
+    ids = rng.permutation(nd).astype(np.int64) * 3 - 50
+    opts = {}
+    if rng.random() < 0.3: opts["force_doubling"] = 1
+    if rng.random() < 0.3: opts["fuse_keygen"] = 0
+    if rng.random() < 0.25: opts["force_big_path"] = 1
+    if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
+    if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26]))
+    if rng.random() < 0.2: opts["keep_keys"] = 0
+    if rng.random() < 0.2: opts["fast_search"] = 0
+    if rng.random() < 0.2: opts["wave_rows"] = 0
+    o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
+    g = capi.GpuStringIndex()
+    for k, v in opts.items():
+        g.set_option(k, v)
+    g.add_bulk(ids, blob, ds)
+    try:
+        g.build()
+    except RuntimeError as e:   # the >= 4 GiB path refuses 256-value alphabets: a documented limit
+        assert "alphabet" in str(e) and opts.get("force_big_path"), (seed, opts, e)
+        return
+    assert (g.size, g.bits, g.mask, g.sa_width) == (o.size, o.bits, o.mask, o.sa_width), (seed, opts)
+    assert np.array_equal(g.sa(), o.sa()), (seed, opts)
+    npat = int(rng.integers(1, 400))
+    pb, po = W.sample_patterns(blob, ds, npat, 1, int(rng.integers(1, 24)), seed=seed, miss_frac=0.2, miss_byte=int(blob[0]))
+    rp, gi, gc, hits = g.query_batch(pb, po)
+    orp, oi, oc, ohits = o.query_batch(pb, po, nthreads=2)
+    assert hits == ohits and np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc), (seed, opts)
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(min(npat, 12))]
+    if len(set(ids.tolist())) == nd:
+        assert g.query_or(kws) == o.filter_or(kws), (seed, opts)
+    assert g.query_spans(kws) == o.highlight_spans(kws, ids), (seed, opts)
+    g.close()

@@ -371,6 +371,17 @@ def test_highlight_spans_match_aho_corasick_render(G):
     kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(60)]
     for group in (kws[:1], kws[1:4], kws[4:12], kws[12:60], [b"a", b"ab", b"abc", b"bc"], [b"zz"]):
         assert g.query_spans(group) == o.highlight_spans(group, ids), group
+    # bytes >= 0x80 under reference_compat: the reference's QUERY misses occurrences (Q2) but its
+    # highlighter re-scans the text and finds them all — spans then come from a text scan, not the SA
+    blob, ds = W.utf8_corpus(200, 150, seed=4)
+    ids = np.arange(200, dtype=np.int64)
+    g = _gpu(G, blob, ds, ids)
+    o = _oracle(blob, ds, ids)
+    assert o.inversions() > 0
+    pb, po = W.sample_patterns(blob, ds, 40, 1, 4, seed=2, miss_frac=0)
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(40)]
+    for group in (kws[:1], kws[1:6], kws[6:40], [b"\xc3", b"\xe2\x82"]):
+        assert g.query_spans(group) == o.highlight_spans(group, ids), group
 
 
 def test_raw_record_ingest_and_persistence(G, tmp_path):
