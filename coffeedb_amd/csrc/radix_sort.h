@@ -94,11 +94,12 @@ __device__ __forceinline__ void rs_st_status(uint64_t* p, uint64_t v) {
 // LDS staging buffer (two write-out phases, smaller footprint -> more workgroups per CU); EARLYV =
 // values are fetched together with the keys instead of after the look-back.
 template <int IPT_, bool REUSE_, bool EARLYV_, int NT_ = 256, bool NONTEMP_ = false, int MINW_ = 1, int ABL_ = 0,
-          int LB_ = 1>
+          int LB_ = 1, bool DMA_ = false>
 struct RsCfg {
+    static constexpr bool DMA = DMA_;         // keys/values reach the registers through LDS by 16-byte global->LDS DMA
     static constexpr int LB = LB_;            // look-back window: predecessors polled per round trip
     static constexpr int ABL = ABL_;          // timing-only ablations (WRONG results): 1 = no look-back,
-                                              // 2 = linear (unscattered) write-out, 4 = no ranking
+                                              // 2 = linear (unscattered) write-out, 8 = look-back depth counters
     static constexpr int MINW = MINW_;        // min waves per SIMD the register allocator must allow
     static constexpr int IPT = IPT_;
     static constexpr bool REUSE = REUSE_;
@@ -279,6 +280,37 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         __syncthreads();  // the staging buffer is reused for the sorted keys below
+    } else if constexpr (Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
+        // Keys and values travel global -> LDS by 16-byte-per-lane DMA (global_load_lds: full-rate 1 KiB
+        // per wave instruction, no staging registers) into this wave's slice of the still unused
+        // staging buffer, and are read back striped.  The value DMA overlaps the ranking below.
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        unsigned char* wdst = s_stage + (size_t)wave * WCHUNK * sizeof(K);
+        // clamp to the last 16-byte vector that holds a real element (device blocks are padded to 256 B)
+        const uint64_t last_pair = (n - 1) & ~1ull;
+#pragma unroll
+        for (int i = 0; i < IPT / 2; ++i) {
+            uint64_t e = base + (uint64_t)wave * WCHUNK + i * 128 + 2 * lane;
+            e = e < last_pair ? e : last_pair;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kin + e), (lptr_t)(wdst + i * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            const K kk = reinterpret_cast<const K*>(wdst)[j * 64 + lane];
+            key[j] = li < valid ? kk : (K)~(K)0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slice is free again: reuse it for the values
+        constexpr int VPL = 16 / (int)sizeof(VS);             // values per lane per DMA
+        const uint64_t last_vec = (n - 1) & ~(uint64_t)(VPL - 1);
+#pragma unroll
+        for (int i = 0; i < IPT / VPL; ++i) {
+            uint64_t e = base + (uint64_t)wave * WCHUNK + i * (64 * VPL) + VPL * lane;
+            e = e < last_vec ? e : last_vec;
+            __builtin_amdgcn_global_load_lds((gptr_t)(vin + e), (lptr_t)(wdst + i * 1024), 16, 0, 0);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
-        for (int b = 0; b < ((Cfg::ABL & 4) ? 0 : 8); ++b) {
+        for (int b = 0; b < 8; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             m &= bit ? bal : ~bal;
@@ -318,6 +350,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         }
         old = __shfl(old, __ffsll((unsigned long long)m) - 1);
         rank[j] = old + below;
+    }
+    if constexpr (!GEN && Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
+        // the value DMA issued before the ranking has had the whole loop to land
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const VS* wv = reinterpret_cast<const VS*>(s_stage + (size_t)wave * WCHUNK * sizeof(K));
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) val[j] = wv[j * 64 + lane];
     }
     __syncthreads();
 
@@ -647,6 +686,9 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 7: CDB_RS(12, true, true, 512, false, 1, 0, 1);
             case 11: CDB_RS(16, true, true, 1024, false, 1, 0, 1);
             case 12: CDB_RS(16, true, true, 512, false, 4, 0, 1);
+            case 41: CDB_RS(16, true, true, 1024, false, 1, 0, 4, true);   // 16 Ki tile, LDS-DMA loads
+            case 42: CDB_RS(16, true, true, 512, false, 4, 0, 4, true);    // 8 Ki tile, LDS-DMA loads
+            case 43: CDB_RS(12, true, true, 256, false, 1, 0, 4, true);    // 3 Ki tile, LDS-DMA loads
             case 13: CDB_RS(16, true, true, 512, false, 4, 0, 4);    // 8 Ki-key tile, 2 WG/CU
             case 14: CDB_RS(12, true, true, 512, false, 1, 0, 4);    // 6 Ki-key tile, 2 WG/CU
             case 15: CDB_RS(14, true, true, 1024, false, 1, 0, 4);   // 14 Ki-key tile

@@ -4,7 +4,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [0, 21, 26, 1, 4, 3, 7, 11, 12, 22, 10, 23, 24])
+@pytest.mark.parametrize("variant", [0, 21, 26, 1, 4, 3, 7, 11, 12, 22, 10, 23, 24, 41, 42, 43])
 @pytest.mark.parametrize("val_bytes", [4, 8, 0])
 def test_radix_sort_matches_stable_sort(variant, val_bytes):
     import torch
