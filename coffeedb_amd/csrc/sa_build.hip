@@ -8,11 +8,15 @@
 // arbitrary tie order.
 //
 // Algorithm (GPU-first; none of the reference's task queue survives):
-//   1. alphabet scan   : which byte values occur -> dense order-preserving codes, `symbits` per symbol
-//   2. key generation  : every suffix's first `nsym` symbols packed big-endian into one 64-bit key
-//                        (code 0 = end of document, so shorter suffixes sort first); the value is the
-//                        reference entry (off << bits) | doc.  Text is read once, coalesced, through LDS.
-//   3. initial sort    : stable LSD radix sort of (key, entry)  (radix_sort.h)
+//   1. alphabet        : byte histogram -> dense order-preserving symbol codes, `symbits` per symbol
+//   2. key width       : `nsym` symbols per 64-bit key, chosen from a sorted sample of the text so that
+//                        few suffixes stay unresolved (code 0 = end of document: shorter suffixes first)
+//   3. initial sort    : stable LSD radix sort of (key, entry) pairs, entry = (off << bits) | doc
+//                        (radix_sort.h).  With one symbol per digit the first pass GENERATES its pairs
+//                        from the text (TextGen) and the digit histograms come from the byte histogram,
+//                        so keys are never materialised beforehand; otherwise sa_keygen_kernel writes them.
+//                        Corpora of 2^32 bytes and more are first partitioned by their first symbol and
+//                        sorted bucket by bucket (memory).
 //   4. refinement      : only groups of still-equal keys are touched again.  While few suffixes are
 //                        unresolved they are re-keyed straight from the text (next symbols);
 //                        otherwise an inverse array (rank per text position) is built and classic
@@ -20,6 +24,8 @@
 //                        suffix h symbols further on).  A group whose members end inside the compared
 //                        prefix is final: its members are identical suffixes, and because every sort is
 //                        stable and the initial order is text order they already ascend by document.
+//   5. reference order : for text with bytes >= 0x80 the reference's signed-bucket order is reproduced by
+//                        block rotations (apply_reference_order) unless reference_compat is switched off.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
