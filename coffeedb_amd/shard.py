@@ -46,18 +46,27 @@ def merge_shard_results(torch, dist, row_ptr, ids, counts, world):
         pad[1, :nrows] = counts
     pad_list = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(pad_list, pad)                       # all-gatherv via padding to the longest list
+    # one vectorised placement for all shards: rows are enumerated shard-major (shard q, its rows in
+    # order); row i of shard q belongs to pattern pat[i] and lands behind the rows that earlier shards
+    # contribute to the same pattern
     total = all_cnt.sum(0)
     g_row_ptr = torch.zeros(npat + 1, dtype=torch.int64, device=device)
     torch.cumsum(total, 0, out=g_row_ptr[1:])
-    before = torch.cumsum(all_cnt, 0) - all_cnt          # rows of earlier shards, per pattern
-    out = torch.empty(2, int(g_row_ptr[-1].item()), dtype=torch.int64, device=device)
-    pats = torch.arange(npat, device=device)
-    for q in range(world):
-        nq = int(rows_per_rank[q].item())
-        if nq == 0:
-            continue
-        pat = torch.repeat_interleave(pats, all_cnt[q])
-        rp_q = torch.cumsum(all_cnt[q], 0) - all_cnt[q]
-        dest = g_row_ptr[pat] + before[q][pat] + (torch.arange(nq, device=device) - rp_q[pat])
-        out[:, dest] = pad_list[q][:, :nq]
+    before = torch.cumsum(all_cnt, 0) - all_cnt            # [world, npat] rows of earlier shards per pattern
+    flat_cnt = all_cnt.reshape(-1)                         # (shard, pattern) group sizes, shard-major
+    nrows_total = int(g_row_ptr[-1].item())
+    out = torch.empty(2, nrows_total, dtype=torch.int64, device=device)
+    if nrows_total:
+        group = torch.repeat_interleave(torch.arange(world * npat, device=device), flat_cnt)
+        group_start = torch.cumsum(flat_cnt, 0) - flat_cnt
+        pos = torch.arange(nrows_total, device=device)
+        within = pos - group_start[group]
+        q = group // npat
+        pat = group - q * npat
+        dest = g_row_ptr[pat] + before.reshape(-1)[group] + within
+        rank_start = torch.cumsum(rows_per_rank, 0) - rows_per_rank
+        src = q * maxrows + (pos - rank_start[q])
+        allrows = torch.stack(pad_list)                    # [world, 2, maxrows]
+        out[0, dest] = allrows[:, 0, :].reshape(-1)[src]
+        out[1, dest] = allrows[:, 1, :].reshape(-1)[src]
     return g_row_ptr, out[0], out[1]
