@@ -266,44 +266,51 @@ struct FlagIn {
 };
 
 // compaction of the unresolved entries + construction of their sort keys
-template <typename V, typename I, typename R, bool USE_ISA>
+// compaction of the unresolved entries: slot number, entry and group id of every unresolved entry
+// (the sort key's minor part is filled in by sa_round_keys_kernel, one dense thread per entry)
+template <typename V, typename I>
 struct CompactOut {
-    const uint8_t* flags;
     const V* sa;
     I* U;
     uint64_t* skey;
     V* sval;
-    const uint64_t* doc_start;
-    const uint8_t* text;
-    const uint16_t* symmap;
-    const R* rank;
-    int bits;
-    uint64_t mask;
-    uint64_t h;
-    int kbits, nsym2, symbits;
+    int kbits;
     __device__ __forceinline__ void operator()(uint64_t i, const U2& ex, const U2& in) const {
         if (in.a == ex.a) return;  // not an unresolved entry
         const uint64_t j = ex.a;
-        const uint64_t gid = in.b - 1;
-        const V v = sa[i];
-        const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
-        const uint64_t ds = doc_start[d];
-        uint64_t key2 = 0;
-        if constexpr (USE_ISA) {
-            key2 = (uint64_t)rank[ds + d + off + h];  // extended position: one end slot per document
-        } else {
-            const uint64_t rem = doc_start[d + 1] - ds - off - h;  // >= 0: unresolved => length >= h
-            const uint8_t* p = text + ds + off + h;
-            for (int k = 0; k < nsym2; ++k) {
-                const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[p[k]] : 0ull;
-                key2 = (key2 << symbits) | sym;
-            }
-        }
         U[j] = (I)i;
-        skey[j] = (gid << kbits) | key2;
-        sval[j] = v;
+        skey[j] = (in.b - 1) << kbits;  // group id
+        sval[j] = sa[i];
     }
 };
+
+// minor sort key of every compacted entry: the rank of the suffix h symbols further on (prefix
+// doubling) or the next nsym2 symbols read from the text (text extension)
+template <typename V, typename R, bool USE_ISA>
+__global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict__ sval, uint64_t m,
+                                                            const uint64_t* __restrict__ doc_start,
+                                                            const uint8_t* __restrict__ text,
+                                                            const uint16_t* __restrict__ symmap,
+                                                            const R* __restrict__ rank, int bits, uint64_t mask, uint64_t h,
+                                                            int nsym2, int symbits, uint64_t* __restrict__ skey) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const V v = sval[j];
+    const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
+    const uint64_t ds = doc_start[d];
+    uint64_t key2 = 0;
+    if constexpr (USE_ISA) {
+        key2 = (uint64_t)rank[ds + d + off + h];  // extended position: one end slot per document
+    } else {
+        const uint64_t rem = doc_start[d + 1] - ds - off - h;  // >= 0: unresolved => length >= h
+        const uint8_t* p = text + ds + off + h;
+        for (int k = 0; k < nsym2; ++k) {
+            const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[p[k]] : 0ull;
+            key2 = (key2 << symbits) | sym;
+        }
+    }
+    skey[j] |= key2;
+}
 
 // Compaction of the unresolved entries, specialised for the byte-flag array (the generic scan spends
 // most of its time carrying 16 (u64, u64) pairs per thread for entries that are almost all resolved):
@@ -846,19 +853,17 @@ void build_typed(Index& ix, bool big) {
         }
         {
             int t = ix.prof.begin(s);
-            if (isa) {
-                CompactOut<V, I, R, true> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
-                                             doc_start, text, d_symmap.as<uint16_t>(), rank.as<R>(), (int)ix.bits,
-                                             ix.mask, h, kbits, nsym2, symbits};
-                hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
-                                   (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
-            } else {
-                CompactOut<V, I, R, false> co{flags.as<uint8_t>(), sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(),
-                                              doc_start, text, d_symmap.as<uint16_t>(), nullptr, (int)ix.bits,
-                                              ix.mask, h, kbits, nsym2, symbits};
-                hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
-                                   (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
-            }
+            CompactOut<V, I> co{sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
+            hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
+                               (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
+            if (isa)
+                hipLaunchKernelGGL((sa_round_keys_kernel<V, R, true>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
+                                   (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
+                                   (const R*)rank.as<R>(), (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>());
+            else
+                hipLaunchKernelGGL((sa_round_keys_kernel<V, R, false>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
+                                   (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
+                                   (const R*)nullptr, (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>());
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
         const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
