@@ -84,12 +84,15 @@ __global__ __launch_bounds__(SC_NT) void scan_reduce_kernel(In in, uint64_t n, O
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-// in-place exclusive scan of the tile partials by one workgroup; partials[nb] receives the grand total
+// in-place exclusive scan of the tile partials by ONE workgroup of 1024 threads (16 Ki partials per
+// sweep); partials[nb] receives the grand total
+constexpr int SP_NT = 1024;
 template <typename T, typename Op>
-__global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint64_t nb, Op op, T identity) {
-    __shared__ T s_buf[8];
+__global__ __launch_bounds__(SP_NT) void scan_partials_kernel(T* partials, uint64_t nb, Op op, T identity) {
+    __shared__ T s_w[SP_NT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T carry = identity;
-    for (uint64_t c = 0; c < nb; c += SC_TILE) {
+    for (uint64_t c = 0; c < nb; c += (uint64_t)SP_NT * SC_IPT) {
         const uint64_t base = c + (uint64_t)threadIdx.x * SC_IPT;
         T v[SC_IPT];
         T acc = identity;
@@ -98,23 +101,30 @@ __global__ __launch_bounds__(SC_NT) void scan_partials_kernel(T* partials, uint6
             v[k] = base + k < nb ? partials[base + k] : identity;
             acc = op(acc, v[k]);
         }
-        T total;
-        const T incl = block_scan_incl(acc, op, s_buf, total);
-        // exclusive start of this thread = carry ∘ (inclusive of the previous thread)
-        T prev = shfl_up_any(incl, 1);
+        T incl = acc;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const T x = shfl_up_any(incl, off);
+            if (lane >= off) incl = op(x, incl);
+        }
+        T prev = shfl_up_any(incl, 1);  // inclusive value of the previous lane
+        __syncthreads();                // s_w of the previous sweep is consumed
+        if (lane == 63) s_w[wave] = incl;
         __syncthreads();
-        if ((threadIdx.x & 63) == 63) s_buf[4 + (threadIdx.x >> 6)] = incl;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0 && threadIdx.x > 0) prev = s_buf[4 + (threadIdx.x >> 6) - 1];
-        T run = carry;
-        if (threadIdx.x > 0) run = op(carry, prev);
+        T run = carry;                  // everything before this thread
+        T total = identity;
+#pragma unroll
+        for (int w = 0; w < SP_NT / 64; ++w) {
+            if (w < wave) run = op(run, s_w[w]);
+            total = op(total, s_w[w]);
+        }
+        if (lane > 0) run = op(run, prev);
 #pragma unroll
         for (int k = 0; k < SC_IPT; ++k) {
             if (base + k < nb) partials[base + k] = run;
             run = op(run, v[k]);
         }
         carry = op(carry, total);
-        __syncthreads();
     }
     if (threadIdx.x == 0) partials[nb] = carry;
 }
@@ -159,7 +169,7 @@ T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T ident
     partials.ensure((nb + 1) * sizeof(T));
     T* d_part = partials.as<T>();
     if (nb) hipLaunchKernelGGL((scan_reduce_kernel<T, In, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity, d_part);
-    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SC_NT), 0, s, d_part, nb, op, identity);
+    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part, nb, op, identity);
     T total;
     CDB_HIP(hipMemcpyAsync(&total, d_part + nb, sizeof(T), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
