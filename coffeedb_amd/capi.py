@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
-    "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify",
@@ -32,6 +32,10 @@ class CdbResult(C.Structure):
 class CdbSpans(C.Structure):
     _fields_ = [("ndocs", C.c_uint64), ("nspans", C.c_uint64), ("ids", C.POINTER(C.c_int64)),
                 ("span_ptr", C.POINTER(C.c_uint64)), ("begin", C.POINTER(C.c_uint64)), ("end", C.POINTER(C.c_uint64))]
+
+
+class CdbHits(C.Structure):
+    _fields_ = [("hit_ptr", C.POINTER(C.c_uint64)), ("offsets", C.POINTER(C.c_uint64))]
 
 
 class CdbDeviceResult(C.Structure):
@@ -86,6 +90,9 @@ def load_library():
     lib.cdb_free.argtypes = [vp]
     lib.cdb_free.restype = None
     lib.cdb_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
+    lib.cdb_query_batch_offsets.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult), C.POINTER(CdbHits)]
+    lib.cdb_hits_free.argtypes = [C.POINTER(CdbHits)]
+    lib.cdb_hits_free.restype = None
     lib.cdb_result_free.argtypes = [C.POINTER(CdbResult)]
     lib.cdb_result_free.restype = None
     lib.cdb_query_batch_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(CdbDeviceResult)]
@@ -221,6 +228,25 @@ class GpuStringIndex:
             return row_ptr, ids, cnt, int(r.nhits)
         finally:
             self._lib.cdb_result_free(C.byref(r))
+
+    def query_batch_offsets(self, blob, offsets):
+        """query_batch plus (hit_ptr uint64[nrows+1], occurrence offsets uint64[nhits])."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        npat = len(offsets) - 1
+        r, hx = CdbResult(), CdbHits()
+        self._check(self._lib.cdb_query_batch_offsets(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r), C.byref(hx)))
+        try:
+            nrows, nhits = int(r.nrows), int(r.nhits)
+            row_ptr = np.ctypeslib.as_array(r.row_ptr, shape=(npat + 1,)).copy()
+            ids = np.ctypeslib.as_array(r.ids, shape=(max(nrows, 1),))[:nrows].copy()
+            cnt = np.ctypeslib.as_array(r.counts, shape=(max(nrows, 1),))[:nrows].copy()
+            hit_ptr = np.ctypeslib.as_array(hx.hit_ptr, shape=(nrows + 1,)).copy()
+            offs = np.ctypeslib.as_array(hx.offsets, shape=(max(nhits, 1),))[:nhits].copy()
+            return row_ptr, ids, cnt, hit_ptr, offs
+        finally:
+            self._lib.cdb_result_free(C.byref(r))
+            self._lib.cdb_hits_free(C.byref(hx))
 
     def query_batch_device(self, d_blob_ptr, d_offsets_ptr, npat, blob_bytes):
         r = CdbDeviceResult()

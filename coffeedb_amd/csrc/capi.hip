@@ -324,9 +324,12 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
 
 void cdb_free(void* p) { std::free(p); }
 
-int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+namespace {
+int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
+                     cdb_hits* hits) {
     if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
+    if (hits) std::memset(hits, 0, sizeof(*hits));
     return guarded(h, [&] {
         Index& ix = h->ix;
         for (uint64_t j = 0; j < npat; ++j)
@@ -343,7 +346,7 @@ int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uin
         for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
         if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
         CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
-        const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+        const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat, hits != nullptr);
         out->npat = npat;
         out->nrows = r.nrows;
         out->nhits = r.nhits;
@@ -351,16 +354,43 @@ int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uin
         out->ids = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
         out->counts = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
         if (!out->row_ptr || !out->ids || !out->counts) throw std::bad_alloc();
+        if (hits) {
+            hits->hit_ptr = (uint64_t*)std::calloc(r.nrows + 1, 8);
+            hits->offsets = (uint64_t*)std::malloc(std::max<uint64_t>(r.nhits, 1) * 8);
+            if (!hits->hit_ptr || !hits->offsets) throw std::bad_alloc();
+        }
         CDB_HIP(hipMemcpyAsync(out->row_ptr, ix.q_rowptr.p, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
         if (r.nrows) {
             CDB_HIP(hipMemcpyAsync(out->ids, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
             CDB_HIP(hipMemcpyAsync(out->counts, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+            if (hits) {
+                CDB_HIP(hipMemcpyAsync(hits->hit_ptr, ix.q_hitptr.p, (r.nrows + 1) * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipMemcpyAsync(hits->offsets, ix.q_hitoff.p, r.nhits * 8, hipMemcpyDeviceToHost, s));
+            }
         }
         CDB_HIP(hipStreamSynchronize(s));
         ix.qstats.query_ms = wall_ms() - t0;
         ix.qstats.nhits = r.nhits;
         ix.qstats.nrows = r.nrows;
     });
+}
+}  // namespace
+
+int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+    return query_batch_impl(h, blob, offsets, npat, out, nullptr);
+}
+
+int cdb_query_batch_offsets(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
+                            cdb_hits* hits) {
+    if (!hits) return CDB_E_INVALID;
+    return query_batch_impl(h, blob, offsets, npat, out, hits);
+}
+
+void cdb_hits_free(cdb_hits* x) {
+    if (!x) return;
+    std::free(x->hit_ptr);
+    std::free(x->offsets);
+    std::memset(x, 0, sizeof(*x));
 }
 
 int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,

@@ -77,7 +77,7 @@ struct Index {
     // ---- scratch kept across calls
     RadixWorkspace rws;
     DevBuf scan_partials;
-    DevBuf q_pat, q_offs, q_left, q_right, q_hoff, q_keys0, q_keys1, q_flags, q_rowptr, q_ids, q_counts;
+    DevBuf q_pat, q_offs, q_left, q_right, q_hoff, q_keys0, q_keys1, q_flags, q_rowptr, q_ids, q_counts, q_hitptr, q_hitoff;
 
     // ---- options
     bool reference_compat = true;   // bit-parity with the reference also for bytes >= 0x80
@@ -105,7 +105,10 @@ void verify_suffix_array(Index& ix, uint64_t out[5]);
 struct DeviceCsr {
     uint64_t npat = 0, nrows = 0, nhits = 0;
 };
-DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+// with_offsets: additionally ix.q_hitptr[nrows+1] / ix.q_hitoff[nhits] = byte offsets of every occurrence,
+// grouped by result row, ascending
+DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
+                                bool with_offsets = false);
 // highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
 // ix.q_keys0, inclusive span ends -> ix.q_keys1
 struct SpanResult {

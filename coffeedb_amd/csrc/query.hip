@@ -337,8 +337,8 @@ struct HitsOut {
 // one thread per hit slot of the chunk [j0, j1) of patterns: find the owning pattern (binary search
 // over the hit offsets), emit ((pattern - j0) << dbits) | doc
 template <typename V>
-__global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa, uint64_t mask, int dbits,
-                                                       const int64_t* __restrict__ left,
+__global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa, uint64_t mask, int dbits, int bits,
+                                                       int obits, const int64_t* __restrict__ left,
                                                        const uint64_t* __restrict__ hoff, uint64_t j0, uint64_t j1,
                                                        uint64_t H, uint64_t* __restrict__ keys) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -351,23 +351,33 @@ __global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa,
     }
     const uint64_t j = lo;
     const uint64_t i = (uint64_t)left[j] + (slot - hoff[j]);
-    keys[t] = ((j - j0) << dbits) | ((uint64_t)sa[i] & mask);
+    // obits > 0: the occurrence offset rides along as the least significant field (offset emission)
+    const V e = sa[i];
+    const uint64_t pd = ((j - j0) << dbits) | ((uint64_t)e & mask);
+    keys[t] = obits ? (pd << obits) | ((uint64_t)e >> bits) : pd;
 }
 
 struct RunIn {  // 1 at the first hit of every (pattern, doc) run
     const uint64_t* keys;
-    __device__ __forceinline__ uint64_t operator()(uint64_t t) const { return (t == 0 || keys[t] != keys[t - 1]) ? 1ull : 0ull; }
+    int obits;
+    __device__ __forceinline__ uint64_t operator()(uint64_t t) const {
+        return (t == 0 || (keys[t] >> obits) != (keys[t - 1] >> obits)) ? 1ull : 0ull;
+    }
 };
 struct RunOut {  // row r starts at hit slot t: remember t, decode the doc
     const uint64_t* keys;
     uint64_t* row_first;  // [nrows + 1] first hit slot of each row
     uint64_t* row_key;
     uint64_t H;
+    int obits;
+    uint64_t* hit_off;  // optional: occurrence offset of every hit slot, in sorted order
     __device__ __forceinline__ void operator()(uint64_t t, uint64_t ex, uint64_t in) const {
+        const uint64_t k = keys[t];
         if (in != ex) {
             row_first[ex] = t;
-            row_key[ex] = keys[t];
+            row_key[ex] = k >> obits;
         }
+        if (hit_off) hit_off[t] = k & ((1ull << obits) - 1ull);
         if (t + 1 == H) row_first[in] = H;
     }
 };
@@ -375,12 +385,14 @@ struct RunOut {  // row r starts at hit slot t: remember t, decode the doc
 __global__ __launch_bounds__(256) void q_rows_kernel(const uint64_t* __restrict__ row_first,
                                                      const uint64_t* __restrict__ row_key, uint64_t nrows, int dbits,
                                                      const int64_t* __restrict__ ids, int64_t* __restrict__ out_ids,
-                                                     int64_t* __restrict__ out_counts) {
+                                                     int64_t* __restrict__ out_counts, uint64_t hits_base,
+                                                     uint64_t* __restrict__ hit_ptr) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrows) return;
     const uint64_t doc = row_key[r] & ((1ull << dbits) - 1ull);
     out_ids[r] = ids[doc];
     out_counts[r] = (int64_t)(row_first[r + 1] - row_first[r]);
+    if (hit_ptr) hit_ptr[r] = hits_base + row_first[r];  // the row's occurrences are hit slots [hit_ptr[r], hit_ptr[r+1])
 }
 
 // row_ptr[j0 + k] = rows_base + first row of the chunk whose local pattern id >= k, k = 0 .. count-1
@@ -631,7 +643,7 @@ struct DocRowOut {  // row r (document) starts at span k
 };
 
 template <typename V>
-DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
+DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, bool with_offsets) {
     hipStream_t s = ix.stream;
     DeviceCsr out;
     out.npat = npat;
@@ -662,7 +674,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         CDB_HIP(hipStreamSynchronize(s));
         return out;
     }
-    if (maxh <= 64 && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && H <= (1ull << 31)) {
+    if (!with_offsets && maxh <= 64 && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && H <= (1ull << 31)) {
         // every pattern's hit list fits one wavefront: sort + run-length encode per pattern in registers
         ix.q_keys0.ensure(H * 4);   // row_doc
         ix.q_keys1.ensure(H * 4);   // row_cnt
@@ -688,6 +700,8 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         return out;
     }
     const int dbits = (int)ix.bits;
+    const int obits = with_offsets ? ix.width * 8 - dbits : 0;  // offset field of the sort key (offset emission)
+    if (with_offsets) ix.q_hitoff.ensure(H * 8);
     // Chunks of patterns whose hit lists fit the scratch budget (16 B of sort scratch per hit); almost
     // always one chunk.  A short pattern over a big corpus can match a large share of the text, and a
     // whole batch of them can exceed any buffer — they are then resolved chunk by chunk.
@@ -706,7 +720,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         }
         cut.push_back(npat);
     }
-    uint64_t rows_total = 0;
+    uint64_t rows_total = 0, hits_done = 0;
     for (size_t c = 0; c + 1 < cut.size(); ++c) {
         const uint64_t j0 = cut[c], j1 = cut[c + 1];
         uint64_t Hc = H;
@@ -723,37 +737,45 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
             continue;
         }
         const int jbits = bit_width64(j1 - j0 - 1);
-        if (dbits + jbits > 64) throw Error("pattern batch too large for one call");
+        if (dbits + jbits + obits > 64) throw Error("pattern batch too large for one call");
         ix.q_keys0.ensure(Hc * 8);
         ix.q_keys1.ensure(Hc * 8);
         t = ix.prof.begin(s);
         hipLaunchKernelGGL((q_expand_kernel<V>), dim3((unsigned)ceil_div(Hc, 256)), dim3(256), 0, s, sa, ix.mask, dbits,
-                           (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), j0, j1, Hc,
+                           (int)ix.bits, obits, (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), j0, j1, Hc,
                            ix.q_keys0.as<uint64_t>());
         ix.prof.end(t, "q_expand", Hc * (sizeof(V) + 8), s);
         // stable sort of the chunk by (pattern ∘ doc); passes over constant digits are skipped
         const int sel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(),
-                                                    (NoVal*)nullptr, (NoVal*)nullptr, Hc, 0, dbits + jbits, nullptr);
+                                                    (NoVal*)nullptr, (NoVal*)nullptr, Hc, 0, dbits + jbits + obits, nullptr);
         const uint64_t* keys = sel == 0 ? ix.q_keys0.as<uint64_t>() : ix.q_keys1.as<uint64_t>();
         uint64_t* spare = sel == 0 ? ix.q_keys1.as<uint64_t>() : ix.q_keys0.as<uint64_t>();
 
-        RunIn rin{keys};
+        RunIn rin{keys, obits};
         const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0);
         ix.q_flags.ensure((nrows + 1) * 8);  // row_first
         // row keys go to the spare key buffer (nrows <= Hc)
         scan_apply<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0,
-                             RunOut{keys, ix.q_flags.as<uint64_t>(), spare, Hc});
+                             RunOut{keys, ix.q_flags.as<uint64_t>(), spare, Hc, obits,
+                                    with_offsets ? ix.q_hitoff.as<uint64_t>() + hits_done : (uint64_t*)nullptr});
         grow_keep(ix.q_ids, (rows_total + nrows) * 8, rows_total * 8, s);
         grow_keep(ix.q_counts, (rows_total + nrows) * 8, rows_total * 8, s);
+        if (with_offsets) grow_keep(ix.q_hitptr, (rows_total + nrows + 1) * 8, rows_total * 8, s);
         hipLaunchKernelGGL(q_rows_kernel, dim3((unsigned)ceil_div(nrows, 256)), dim3(256), 0, s,
                            (const uint64_t*)ix.q_flags.as<uint64_t>(), (const uint64_t*)spare, nrows, dbits,
                            (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>() + rows_total,
-                           ix.q_counts.as<int64_t>() + rows_total);
+                           ix.q_counts.as<int64_t>() + rows_total, hits_done,
+                           with_offsets ? ix.q_hitptr.as<uint64_t>() + rows_total : (uint64_t*)nullptr);
         hipLaunchKernelGGL(q_rowptr_kernel, dim3((unsigned)ceil_div(j1 - j0, 256)), dim3(256), 0, s, (const uint64_t*)spare,
                            nrows, dbits, j0, j1 - j0, rows_total, ix.q_rowptr.as<uint64_t>());
         rows_total += nrows;
+        hits_done += Hc;
     }
     out.nrows = rows_total;
+    if (with_offsets) {
+        ix.q_hitptr.ensure((rows_total + 1) * 8);
+        CDB_HIP(hipMemcpyAsync(ix.q_hitptr.as<uint64_t>() + rows_total, &hits_done, 8, hipMemcpyHostToDevice, s));
+    }
     CDB_HIP(hipMemcpyAsync(ix.q_rowptr.as<uint64_t>() + npat, &rows_total, 8, hipMemcpyHostToDevice, s));
     CDB_HIP(hipGetLastError());
     radix_check_error(s, ix.rws);
@@ -901,9 +923,9 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
 
 }  // namespace
 
-DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
-    DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat)
-                                : query_typed<uint32_t>(ix, d_blob, d_offs, npat);
+DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, bool with_offsets) {
+    DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat, with_offsets)
+                                : query_typed<uint32_t>(ix, d_blob, d_offs, npat, with_offsets);
     ix.prof.resolve();
     return r;
 }

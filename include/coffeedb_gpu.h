@@ -111,6 +111,18 @@ void cdb_free(void* p);
 int cdb_query_batch(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
 void cdb_result_free(cdb_result* r);
 
+/* Batched query that also emits WHERE every occurrence sits (BASELINE config 2: "highlight offset
+ * emission"): row r of the CSR result owns occurrences [hit_ptr[r], hit_ptr[r+1]) of `offsets`, the byte
+ * offsets of the keyword inside that row's document, ascending.  The offsets are the `entry >> bits`
+ * fields of the matched suffix-array range, sorted along with (pattern, document). */
+typedef struct cdb_hits {
+    uint64_t* hit_ptr;  /* nrows + 1 */
+    uint64_t* offsets;  /* nhits */
+} cdb_hits;
+int cdb_query_batch_offsets(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
+                            cdb_hits* hits);
+void cdb_hits_free(cdb_hits* x);
+
 /* OR over the keywords of ONE string key — replaces the per-key merge loop of interface.cpp:78-113
  * (query each keyword, sort by id, merge lists by id summing the counts): returns the union of the
  * matching objects with their summed $correlation, rows ascending by object id — exactly the list

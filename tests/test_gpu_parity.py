@@ -407,6 +407,29 @@ def test_raw_record_ingest_and_persistence(G, tmp_path):
         h.load(tmp_path / "junk")
 
 
+def test_batched_query_with_occurrence_offsets(G):
+    # BASELINE config 2 "highlight offset emission": every row also lists where the keyword occurs
+    blob, ds = W.ascii_corpus(1500, 200, seed=6, lo=0x61, hi=0x64)
+    ids = np.arange(1500, dtype=np.int64) * 2 + 1
+    g = _gpu(G, blob, ds, ids)
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 120, 1, 7, seed=3, miss_byte=0x7A)
+    for budget in (1 << 31, 5000):       # single chunk / several chunks of patterns
+        g.set_option("query_hit_budget", budget)
+        rp, gi, gc, hp, off = g.query_batch_offsets(pb, po)
+        orp, oi, oc, ohits = o.query_batch(pb, po)
+        assert np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc)
+        assert hp[0] == 0 and hp[-1] == ohits == len(off) and np.array_equal(np.diff(hp.astype(np.int64)), gc)
+        txt = blob.tobytes()
+        for j in range(0, 120, 7):
+            kw = bytes(pb[int(po[j]):int(po[j + 1])])
+            for r in range(int(rp[j]), int(rp[j + 1])):
+                d = (int(gi[r]) - 1) // 2
+                doc = txt[int(ds[d]):int(ds[d + 1])]
+                want = [i for i in range(len(doc) - len(kw) + 1) if doc[i:i + len(kw)] == kw]
+                assert off[int(hp[r]):int(hp[r + 1])].tolist() == want, (j, r)
+
+
 def test_concurrent_queries_same_handle(G):
     blob, ds = W.ascii_corpus(2000, 128, seed=3)
     ids = np.arange(2000, dtype=np.int64)
