@@ -58,6 +58,7 @@ void compute_layout(Index& ix) {
     ix.mask = mask1;
     ix.bits = (uint64_t)bits1;
     ix.width = bits1 + bits2 <= 32 ? 4 : 8;
+    ix.off_bits = bits2;
     ix.ndocs = ndocs;
 }
 
@@ -253,6 +254,12 @@ int cdb_load(cdb_index* h, const char* path) {
         if (!ok || ix.doc_start[hd.ndocs] != hd.size) throw Error(std::string("Truncated index file: ") + path);
         ix.size = hd.size; ix.ndocs = hd.ndocs; ix.bits = hd.bits; ix.mask = hd.mask; ix.width = (int)hd.width;
         ix.reference_compat = hd.compat != 0;
+        {
+            uint64_t mask2 = 1;
+            for (uint64_t d = 0; d < hd.ndocs; ++d)
+                while (mask2 < ix.doc_start[d + 1] - ix.doc_start[d]) mask2 = (mask2 << 1) + 1;
+            ix.off_bits = __builtin_popcountll(mask2);
+        }
         ix.sa_sorted = hd.sorted != 0;  // a reference-compat ordering keeps the reference's exact probe sequence
         ix.pivot_levels = 0;
         ix.d_keys.release();

@@ -118,7 +118,8 @@ private:
     std::mutex mu_;
     std::vector<Block> free_;
     size_t cached_ = 0;
-    size_t limit_ = (size_t)128 << 30;  // bytes kept for reuse; the rest of a 288 GB part stays with the driver
+    size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
+                                 // the working set of a multi-GiB build costs more than the build itself
 };
 
 // Owning device allocation, served by DevPool.

@@ -55,6 +55,7 @@ struct Index {
 
     // ---- reference-visible parameters (src/index.h:56-57)
     uint64_t bits = 1, mask = 1, size = 0;
+    int off_bits = 1;  // bits of the largest document length (the offset field really in use)
     int width = 0;  // 4 / 8, 0 = never built
     uint64_t ndocs = 0;
 

@@ -700,7 +700,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         return out;
     }
     const int dbits = (int)ix.bits;
-    const int obits = with_offsets ? ix.width * 8 - dbits : 0;  // offset field of the sort key (offset emission)
+    const int obits = with_offsets ? ix.off_bits : 0;  // offset field of the sort key (offset emission)
     if (with_offsets) ix.q_hitoff.ensure(H * 8);
     // Chunks of patterns whose hit lists fit the scratch budget (16 B of sort scratch per hit); almost
     // always one chunk.  A short pattern over a big corpus can match a large share of the text, and a

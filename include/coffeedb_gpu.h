@@ -194,7 +194,7 @@ void cdb_profile_reset(cdb_index* h);
  * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size. */
 void cdb_release_cached_memory(void);
 uint64_t cdb_cached_memory_bytes(void);
-/* upper bound of the block cache (default 128 GiB); blocks released beyond it go back to the driver */
+/* upper bound of the block cache (default: unlimited); blocks released beyond it go back to the driver */
 void cdb_set_cache_limit(uint64_t bytes);
 
 /* Test hook: size-independent checks of the built suffix array, computed on the GPU by plain adjacent-

@@ -26,3 +26,21 @@ for k, v in sorted(g.profile().items(), key=lambda kv: -kv[1]["ms"])[:8]:
     print(f"   {k:32s} {v['ms']:9.3f} ms x{v['launches']}")
 t = time.time(); print(g.verify(), f"verify {time.time()-t:.2f}s")
 print("free/total GiB:", [x / 2**30 for x in torch.cuda.mem_get_info()])
+if len(sys.argv) > 4:   # query stage: N patterns of length lo-hi sampled from a 256 MiB host prefix, with offsets
+    npat, lo, hi = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    host = text[: 1 << 28].cpu().numpy()
+    pb, po = W.sample_patterns(host, W.uniform_docs((1 << 28) // dl, dl), npat, lo, hi, seed=99)
+    for rep in range(2):
+        t = time.time(); rp, ri, rc, hits = g.query_batch(pb, po); tq = time.time() - t
+    print(f"query_batch {npat} patterns len {lo}-{hi}: {tq*1e3:.1f} ms ({npat/tq/1e6:.1f} M/s) hits={hits} rows={len(ri)}")
+    t = time.time(); rp2, ri2, rc2, hp, off = g.query_batch_offsets(pb, po); tq = time.time() - t
+    assert np.array_equal(ri, ri2) and np.array_equal(rc, rc2) and len(off) == hits
+    # spot-check a few rows against the text
+    for r in np.random.default_rng(1).choice(len(ri2), 20, replace=False):
+        j = int(np.searchsorted(rp2, r, side="right") - 1)
+        kw = pb[int(po[j]):int(po[j + 1])]
+        d = int(ri2[r])
+        doc = text[d * dl:(d + 1) * dl].cpu().numpy()
+        for o_ in off[int(hp[r]):int(hp[r + 1])]:
+            assert np.array_equal(doc[int(o_):int(o_) + len(kw)], kw)
+    print(f"query_batch_offsets: {tq*1e3:.1f} ms, {len(off)} occurrence offsets, spot checks ok")
