@@ -23,7 +23,7 @@ struct BuildStats {
     int sort_passes_skipped = 0;
     int isa_built = 0;
     int fused_keygen = 0;
-    int bucketed = 0;            // bucket-wise initial sort (corpora >= 2^32)
+    int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
     uint64_t compat_rotations = 0, compat_depth = 0;  // reference_compat pass (bytes >= 0x80)

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const K k = s_keys[i];
                 const uint32_t dd = (uint32_t)(k >> shift) & dmask;
                 const uint64_t dst = s_gbase[dd] + i;
-                rs_store<NTM>(kout + dst, k);
+                if (!GEN || kout) rs_store<NTM>(kout + dst, k);  // generated pass: kout may be null (entries only)
                 if constexpr (HAS_V) rs_store<NTM>(vout + dst, (V)s_vals[i]);
             }
         }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const K k = s_keys[i];
                 const uint32_t dd = (uint32_t)(k >> shift) & dmask;
                 dig[j] = (uint8_t)dd;
-                rs_store<NTM>(kout + s_gbase[dd] + i, k);
+                if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
             }
         }
         __syncthreads();
@@ -633,7 +633,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                    ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), g2);
             }
             prof.end(t, (std::string("rs_onesweep_textgen_t") + std::to_string(TILE)).c_str(),
-                     n * (1 + sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+                     n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0)), s);
             materialised = true;
         } else {
             hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen>), dim3(tiles), dim3(Cfg::NT), 0, s,

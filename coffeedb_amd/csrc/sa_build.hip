@@ -210,8 +210,10 @@ __global__ __launch_bounds__(256) void sa_keygen_kernel(const uint8_t* __restric
 // group flags: bit0 = first entry of a group of equal prefixes, bit1 = still unresolved
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                           uint64_t symmask, uint8_t* __restrict__ flags) {
-    // four consecutive keys per thread (two 16-byte loads), four flag bytes in one store
+                                                           uint64_t symmask, uint8_t* __restrict__ flags,
+                                                           bool flags_aligned) {
+    // four consecutive keys per thread (two 16-byte loads), four flag bytes in one store (bytewise when the
+    // flag range of a bucket does not start on a 4-byte boundary)
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     uint64_t k[6];  // k[0] = predecessor, k[1..4] = own, k[5] = successor
@@ -235,11 +237,58 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
         const bool exhausted = (k[q + 1] & symmask) == 0;  // an end-of-document code inside the key
         out |= (uint32_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0)) << (8 * q);
     }
-    if (i0 + 4 <= n) {
+    if (flags_aligned && i0 + 4 <= n) {
         *reinterpret_cast<uint32_t*>(flags + i0) = out;
     } else {
         for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
     }
+}
+
+// keys of one first-symbol bucket, gathered from the text for entries that already sit in text order
+// (streamed bucket-wise sort: the n keys are never materialised together)
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;  // gfx950 global loads need no alignment
+template <typename V>
+__global__ __launch_bounds__(256) void sa_bucket_keys_kernel(const V* __restrict__ ent, uint64_t cnt,
+                                                             const uint8_t* __restrict__ text, uint64_t n,
+                                                             const uint64_t* __restrict__ doc_start,
+                                                             const uint16_t* __restrict__ symmap, int bits, uint64_t mask,
+                                                             int nsym, int symbits, uint64_t* __restrict__ keys) {
+    __shared__ uint16_t s_map[256];
+    s_map[threadIdx.x] = symmap[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    const uint64_t e = (uint64_t)ent[i];
+    const uint64_t d = e & mask;
+    const uint64_t pos = doc_start[d] + (e >> bits);
+    const uint64_t rem = doc_start[d + 1] - pos;
+    uint64_t key = 0;
+    if (pos + 16 <= n) {  // two 8-byte windows instead of nsym byte loads
+        uint64_t w = *reinterpret_cast<const u64_unaligned*>(text + pos);
+        if (nsym > 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                key = (key << symbits) | ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                w >>= 8;
+            }
+            w = *reinterpret_cast<const u64_unaligned*>(text + pos + 8);
+            for (int k = 8; k < nsym; ++k) {
+                key = (key << symbits) | ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                w >>= 8;
+            }
+        } else {
+            for (int k = 0; k < nsym; ++k) {
+                key = (key << symbits) | ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                w >>= 8;
+            }
+        }
+    } else {
+        for (int k = 0; k < nsym; ++k) {
+            const uint64_t sym = (uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull;
+            key = (key << symbits) | sym;
+        }
+    }
+    keys[i] = key;
 }
 
 struct FlagIn {
@@ -739,49 +788,54 @@ void build_typed(Index& ix, bool big) {
         sorted_keys = std::move(keys[sel]);
         sa_buf = std::move(vals[sel]);
     } else {
-        // Bucket-wise initial sort: a double-buffered LSD sort of (u64 key, u64 entry) pairs would need
-        // 32 n bytes — 256 GiB at n = 2^33 — so the pairs are first partitioned by their FIRST symbol (one
-        // generated pass straight from the text into single n-element arrays), then every first-symbol
-        // bucket is LSD-sorted on the remaining symbols with scratch the size of the largest bucket.
-        DevBuf K, E, KT, ET;
-        K.alloc(n * sizeof(uint64_t));
+        // Streamed bucket-wise sort (a double-buffered LSD sort of (u64 key, u64 entry) pairs would need 32 n
+        // bytes — 256 GiB at n = 2^33): ONE generated pass partitions the ENTRIES by first symbol — its keys exist only
+        // inside the tile — and every bucket then gathers its keys from the text (its entries are still in
+        // text order, so the gather walks the text front to back), LSD-sorts (key, entry) on the remaining
+        // symbols and writes its group flags.  Peak = 8 n (entries) + 24 x the largest bucket.
+        DevBuf E, KT[2], ET;
         E.alloc(n * sizeof(V));
         st.alloc_ms += now_ms() - ta;
         const int top_shift = (nsym - 1) * symbits;
-        // histogram of the first symbol = p = nsym-1 row (k = 0: no head correction, no end code)
-        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, K.as<uint64_t>(), (V*)nullptr, E.as<V>(), n,
-                                      top_shift, key_bits, &ss, ix.sort_variant, dbits,
-                                      &h_hist[(size_t)(nsym - 1) * 256], &gen);
+        const uint64_t* h_first = &h_hist[(size_t)(nsym - 1) * 256];
+        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n,
+                                      top_shift, key_bits, &ss, ix.sort_variant, dbits, h_first, &gen);
         uint64_t maxb = 0;
-        for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_hist[(size_t)(nsym - 1) * 256 + c]);
-        if (nsym > 1) {
-            KT.alloc(maxb * sizeof(uint64_t));
+        for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
+        KT[0].alloc(maxb * sizeof(uint64_t));
+        if (nsym > 1 && maxb > 1) {
+            KT[1].alloc(maxb * sizeof(uint64_t));
             ET.alloc(maxb * sizeof(V));
-            uint64_t start = 0;
-            for (int c = 1; c <= sigma; ++c) {
-                const uint64_t cnt = h_hist[(size_t)(nsym - 1) * 256 + c];
-                if (cnt > 1) {
-                    uint64_t* kb = K.as<uint64_t>() + start;
-                    V* eb = E.as<V>() + start;
-                    const int r = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, kb, KT.as<uint64_t>(), eb, ET.as<V>(), cnt, 0,
-                                                          top_shift, &ss, ix.sort_variant, dbits);
-                    if (r == 1) {  // result sits in the scratch: move it home
-                        CDB_HIP(hipMemcpyAsync(kb, KT.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
-                        CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
-                    }
-                }
-                start += cnt;
+        }
+        uint64_t start = 0;
+        for (int c = 1; c <= sigma; ++c) {
+            const uint64_t cnt = h_first[c];
+            if (!cnt) continue;
+            V* eb = E.as<V>() + start;
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL((sa_bucket_keys_kernel<V>), dim3((unsigned)ceil_div(cnt, 256)), dim3(256), 0, s, (const V*)eb, cnt,
+                               text, n, doc_start, (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, symbits,
+                               KT[0].as<uint64_t>());
+            ix.prof.end(t, "sa_bucket_keys", cnt * ((uint64_t)nsym + 8 + sizeof(V)), s);
+            int r = 0;
+            if (nsym > 1 && cnt > 1) {
+                r = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, KT[0].as<uint64_t>(), KT[1].as<uint64_t>(), eb, ET.as<V>(), cnt, 0,
+                                            top_shift, &ss, ix.sort_variant, dbits);
+                if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
             }
+            hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                               (const uint64_t*)KT[r].as<uint64_t>(), cnt, (1ull << symbits) - 1ull, flags.as<uint8_t>() + start,
+                               (start & 3) == 0);
+            start += cnt;
         }
         CDB_HIP(hipStreamSynchronize(s));
         st.bucketed = 1;
-        sorted_keys = std::move(K);
         sa_buf = std::move(E);
     }
-    {
+    if (!big) {  // (the bucket-wise sort writes the flags bucket by bucket)
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>());
+                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>(), true);
         ix.prof.end(t, "sa_initflags", n * 9, s);
     }
     CDB_HIP(hipStreamSynchronize(s));
@@ -790,7 +844,7 @@ void build_typed(Index& ix, bool big) {
     // of equal keys.  They let a search probe decide on ONE load (query.hip) — kept when affordable.
     ix.d_keys.release();
     ix.key_nsym = 0;
-    if (ix.keep_keys && n * 8 <= (16ull << 30)) {
+    if (ix.keep_keys && !big && n * 8 <= (16ull << 30)) {
         ix.d_keys = std::move(sorted_keys);
         ix.key_nsym = nsym;
         ix.key_symbits = symbits;

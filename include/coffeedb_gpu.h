@@ -175,7 +175,7 @@ int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes);
  * array and the (then partly wrong) counts are bit-identical to the reference's; 0 = plain unsigned
  * order with true counts; no effect and no cost on pure-ASCII text), "initial_passes" (radix
  * passes of the initial key sort, 0 = automatic), "force_doubling" (0/1), "sort_variant" (radix kernel
- * configuration, 0 = default). */
+ * configuration, 0 = default); further tuning and test hooks are listed in DESIGN.md. */
 int cdb_set_option(cdb_index* h, const char* name, int64_t value);
 
 /* statistic by name: "build_ms", "rounds", "unresolved_after_initial", "sort_passes", "isa_built",

@@ -109,7 +109,7 @@ def test_fused_and_materialised_first_pass_agree(G, opts):
 
 @pytest.mark.parametrize("force_doubling", [0, 1])
 def test_big_corpus_code_path_at_small_size(G, force_doubling):
-    # the >= 2^32 path (u64 ranks/positions, bucket-wise initial sort) forced on small inputs
+    # the >= 2^32 path (u64 ranks/positions, streamed bucket-wise initial sort) forced on small inputs
     opts = dict(force_big_path=1, force_doubling=force_doubling)
     blob, ds = W.ragged_corpus(20000, 90, seed=15, empty_every=13)
     g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 300, 1, 6, seed=3, miss_byte=0x7B), **opts)

@@ -16,8 +16,10 @@ if kind == "zipf":
 else:
     text = W.random_bytes_torch(n, 12345, device="cuda")
 ds = W.uniform_docs(nd, dl); ids = np.arange(nd, dtype=np.int64)
-torch.cuda.synchronize()
+torch.cuda.synchronize(); torch.cuda.empty_cache()
 g = capi.GpuStringIndex(); g.set_option("profile", 1)
+for kv in os.environ.get("CDB_OPTS", "").split(","):   # e.g. CDB_OPTS=streamed_build=1
+    if kv: g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for i in range(2):
     g.profile_reset(); t = time.time(); g.build_device(text.data_ptr(), ds, ids); w_ = time.time() - t
     print(f"{kind} n={n/2**30:.2f} GiB width={g.sa_width} build {w_*1e3:.1f} ms ({n/2**30/w_:.2f} GiB/s) rounds={g.stat('rounds'):.0f} ext={g.stat('ext_rounds'):.0f} dbl={g.stat('dbl_rounds'):.0f} "
