@@ -541,6 +541,17 @@ __global__ __launch_bounds__(320) void compat_bounds_kernel(const V* __restrict_
     bounds[(uint64_t)blockIdx.x * 258 + c] = lo;
 }
 
+// in-place reversal of x[0, len): [A|B] -> [B|A] is reverse(A), reverse(B), reverse(A|B) — the same traffic as
+// a round trip through a scratch copy, but without the scratch (up to n entries at the root bucket)
+template <typename V>
+__global__ __launch_bounds__(256) void compat_reverse_kernel(V* __restrict__ x, uint64_t len) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len / 2) return;
+    const V a = x[i], b = x[len - 1 - i];
+    x[i] = b;
+    x[len - 1 - i] = a;
+}
+
 template <typename V>
 void apply_reference_order(Index& ix, V* sa) {
     hipStream_t s = ix.stream;
@@ -548,8 +559,12 @@ void apply_reference_order(Index& ix, V* sa) {
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
     std::vector<CompatBucket> level{{0ull, (unsigned long long)n}};
     if (n <= chuck) return;
-    DevBuf d_buckets, d_bounds, tmp;
+    DevBuf d_buckets, d_bounds;
     uint64_t depth = 0;
+    auto reverse = [&](uint64_t at, uint64_t len) {
+        if (len > 1)
+            hipLaunchKernelGGL((compat_reverse_kernel<V>), dim3((unsigned)ceil_div(len / 2, 256)), dim3(256), 0, s, sa + at, len);
+    };
     while (!level.empty()) {
         const size_t nb = level.size();
         d_buckets.ensure(nb * sizeof(CompatBucket));
@@ -568,10 +583,9 @@ void apply_reference_order(Index& ix, V* sa) {
             const uint64_t a0 = bd[1], b0 = bd[129], end = bd[257];  // [a0,b0) = 0x00..0x7F, [b0,end) = 0x80..0xFF
             const uint64_t lenA = b0 - a0, lenB = end - b0;
             if (lenA && lenB) {
-                tmp.ensure((lenA + lenB) * sizeof(V));
-                CDB_HIP(hipMemcpyAsync(tmp.p, sa + a0, (lenA + lenB) * sizeof(V), hipMemcpyDeviceToDevice, s));
-                CDB_HIP(hipMemcpyAsync(sa + a0, tmp.as<V>() + lenA, lenB * sizeof(V), hipMemcpyDeviceToDevice, s));
-                CDB_HIP(hipMemcpyAsync(sa + a0 + lenB, tmp.p, lenA * sizeof(V), hipMemcpyDeviceToDevice, s));
+                reverse(a0, lenA);
+                reverse(b0, lenB);
+                reverse(a0, lenA + lenB);
                 ix.bstats.compat_rotations++;
             }
             for (int v = 0; v < 256; ++v) {

@@ -9,9 +9,10 @@ from coffeedb_amd import capi
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 ncp = int(gib * 2**30 / 1.7)
 g_ = torch.Generator(device="cuda").manual_seed(4)
-parts = []
+cuts = []
 step = 1 << 27
 total = 0
+text_buf = torch.empty(int(ncp * 1.72) + (1 << 20), dtype=torch.uint8, device="cuda")
 for s in range(0, ncp, step):
     m = min(step, ncp - s)
     cls = torch.randint(0, 10, (m,), device="cuda", generator=g_)
@@ -20,21 +21,25 @@ for s in range(0, ncp, step):
     ln = torch.where(cp < 0x80, 1, torch.where(cp < 0x800, 2, 3))
     off = torch.cumsum(ln, 0) - ln
     nb = int((off[-1] + ln[-1]).item())
-    out = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    out = text_buf[total:total + nb]
+    out.zero_()
     one, two, three = cp < 0x80, (cp >= 0x80) & (cp < 0x800), cp >= 0x800
     out[off[one]] = cp[one].to(torch.uint8)
     out[off[two]] = (0xC0 | (cp[two] >> 6)).to(torch.uint8); out[off[two] + 1] = (0x80 | (cp[two] & 0x3F)).to(torch.uint8)
     out[off[three]] = (0xE0 | (cp[three] >> 12)).to(torch.uint8); out[off[three] + 1] = (0x80 | ((cp[three] >> 6) & 0x3F)).to(torch.uint8)
     out[off[three] + 2] = (0x80 | (cp[three] & 0x3F)).to(torch.uint8)
-    # document cuts at code-point boundaries, one about every 1024 bytes
-    starts = off.cpu().numpy() + total
-    parts.append((out, starts))
+    # document cuts at code-point boundaries, one about every 1024 bytes (first code point at or after k * 1024)
+    first = (total + 1023) // 1024 * 1024
+    tg = torch.arange(first, total + nb, 1024, device="cuda") - total
+    idx = torch.searchsorted(off, tg).clamp_(max=m - 1)
+    cuts.append((off[idx] + total).cpu().numpy())
     total += nb
+    del cls, val, cp, ln, off, one, two, three, tg, idx
 n16 = (total // 16) * 16
-text = torch.cat([p[0] for p in parts])[:n16].contiguous()
-cp_starts = np.concatenate([p[1] for p in parts]); cp_starts = cp_starts[cp_starts < n16]
-cuts = cp_starts[np.searchsorted(cp_starts, np.arange(0, n16, 1024))]
-ds = np.unique(np.concatenate([cuts, [n16]])).astype(np.uint64); ds[0] = 0
+text = text_buf[:n16]
+cuts = np.concatenate(cuts); cuts = cuts[cuts < n16]
+ds = np.unique(np.concatenate([[0], cuts, [n16]])).astype(np.uint64)
+torch.cuda.empty_cache()
 nd = len(ds) - 1
 n = int(ds[-1])
 print(f"UTF-8 corpus: {n/2**30:.2f} GiB, {nd} docs, max doc {int((ds[1:]-ds[:-1]).max())} B", flush=True)
