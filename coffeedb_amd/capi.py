@@ -213,6 +213,28 @@ class GpuStringIndex:
             self._lib.cdb_spans_free(C.byref(r))
 
     # ---- batched
+    @staticmethod
+    def _adopt(ptr, n, dtype, owner):
+        """numpy view of a C result array of n elements; large arrays are adopted without a copy (the view
+        keeps `owner` alive, whose finaliser hands the pinned blocks back to the library)."""
+        n = int(n)
+        if n == 0:
+            return np.empty(0, dtype=dtype)
+        nbytes = n * np.dtype(dtype).itemsize
+        buf = (C.c_uint8 * nbytes).from_address(C.addressof(ptr.contents))
+        if nbytes < (1 << 20):
+            return np.frombuffer(buf, dtype=dtype).copy()
+        buf._owner = owner
+        return np.frombuffer(buf, dtype=dtype)
+
+    class _Owner:
+        def __init__(self, lib, *frees):
+            self._frees = [(getattr(lib, fn), C.byref(obj), obj) for fn, obj in frees]
+
+        def __del__(self):
+            for fn, ref, _obj in self._frees:
+                fn(ref)
+
     def query_batch(self, blob, offsets):
         """Returns (row_ptr uint64[npat+1], ids int64[nrows], counts int64[nrows], nhits)."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -220,14 +242,10 @@ class GpuStringIndex:
         npat = len(offsets) - 1
         r = CdbResult()
         self._check(self._lib.cdb_query_batch(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r)))
-        try:
-            row_ptr = np.ctypeslib.as_array(r.row_ptr, shape=(npat + 1,)).copy()
-            nrows = int(r.nrows)
-            ids = np.ctypeslib.as_array(r.ids, shape=(max(nrows, 1),))[:nrows].copy()
-            cnt = np.ctypeslib.as_array(r.counts, shape=(max(nrows, 1),))[:nrows].copy()
-            return row_ptr, ids, cnt, int(r.nhits)
-        finally:
-            self._lib.cdb_result_free(C.byref(r))
+        own = self._Owner(self._lib, ("cdb_result_free", r))
+        nrows = int(r.nrows)
+        return (self._adopt(r.row_ptr, npat + 1, np.uint64, own), self._adopt(r.ids, nrows, np.int64, own),
+                self._adopt(r.counts, nrows, np.int64, own), int(r.nhits))
 
     def query_batch_offsets(self, blob, offsets):
         """query_batch plus (hit_ptr uint64[nrows+1], occurrence offsets uint64[nhits])."""
@@ -236,17 +254,11 @@ class GpuStringIndex:
         npat = len(offsets) - 1
         r, hx = CdbResult(), CdbHits()
         self._check(self._lib.cdb_query_batch_offsets(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r), C.byref(hx)))
-        try:
-            nrows, nhits = int(r.nrows), int(r.nhits)
-            row_ptr = np.ctypeslib.as_array(r.row_ptr, shape=(npat + 1,)).copy()
-            ids = np.ctypeslib.as_array(r.ids, shape=(max(nrows, 1),))[:nrows].copy()
-            cnt = np.ctypeslib.as_array(r.counts, shape=(max(nrows, 1),))[:nrows].copy()
-            hit_ptr = np.ctypeslib.as_array(hx.hit_ptr, shape=(nrows + 1,)).copy()
-            offs = np.ctypeslib.as_array(hx.offsets, shape=(max(nhits, 1),))[:nhits].copy()
-            return row_ptr, ids, cnt, hit_ptr, offs
-        finally:
-            self._lib.cdb_result_free(C.byref(r))
-            self._lib.cdb_hits_free(C.byref(hx))
+        own = self._Owner(self._lib, ("cdb_result_free", r), ("cdb_hits_free", hx))
+        nrows, nhits = int(r.nrows), int(r.nhits)
+        return (self._adopt(r.row_ptr, npat + 1, np.uint64, own), self._adopt(r.ids, nrows, np.int64, own),
+                self._adopt(r.counts, nrows, np.int64, own), self._adopt(hx.hit_ptr, nrows + 1, np.uint64, own),
+                self._adopt(hx.offsets, nhits, np.uint64, own))
 
     def query_batch_device(self, d_blob_ptr, d_offsets_ptr, npat, blob_bytes):
         r = CdbDeviceResult()

@@ -329,7 +329,7 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
     });
 }
 
-void cdb_free(void* p) { std::free(p); }
+void cdb_free(void* p) { host_free(p); }
 
 namespace {
 int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
@@ -353,18 +353,20 @@ int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, ui
         for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
         if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
         CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        const double t1 = wall_ms();
         const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat, hits != nullptr);
+        CDB_HIP(hipStreamSynchronize(s));
+        const double t2 = wall_ms();
         out->npat = npat;
         out->nrows = r.nrows;
         out->nhits = r.nhits;
-        out->row_ptr = (uint64_t*)std::malloc((npat + 1) * 8);
-        out->ids = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
-        out->counts = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
-        if (!out->row_ptr || !out->ids || !out->counts) throw std::bad_alloc();
+        out->row_ptr = (uint64_t*)host_alloc((npat + 1) * 8);
+        out->ids = (int64_t*)host_alloc(r.nrows * 8);
+        out->counts = (int64_t*)host_alloc(r.nrows * 8);
         if (hits) {
-            hits->hit_ptr = (uint64_t*)std::calloc(r.nrows + 1, 8);
-            hits->offsets = (uint64_t*)std::malloc(std::max<uint64_t>(r.nhits, 1) * 8);
-            if (!hits->hit_ptr || !hits->offsets) throw std::bad_alloc();
+            hits->hit_ptr = (uint64_t*)host_alloc((r.nrows + 1) * 8, true);
+            hits->offsets = (uint64_t*)host_alloc(r.nhits * 8);
         }
         CDB_HIP(hipMemcpyAsync(out->row_ptr, ix.q_rowptr.p, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
         if (r.nrows) {
@@ -377,6 +379,9 @@ int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, ui
         }
         CDB_HIP(hipStreamSynchronize(s));
         ix.qstats.query_ms = wall_ms() - t0;
+        ix.qstats.upload_ms = t1 - t0;
+        ix.qstats.device_ms = t2 - t1;
+        ix.qstats.download_ms = wall_ms() - t2;
         ix.qstats.nhits = r.nhits;
         ix.qstats.nrows = r.nrows;
     });
@@ -395,8 +400,8 @@ int cdb_query_batch_offsets(cdb_index* h, const char* blob, const uint64_t* offs
 
 void cdb_hits_free(cdb_hits* x) {
     if (!x) return;
-    std::free(x->hit_ptr);
-    std::free(x->offsets);
+    host_free(x->hit_ptr);
+    host_free(x->offsets);
     std::memset(x, 0, sizeof(*x));
 }
 
@@ -422,12 +427,13 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
         CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
         CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (nkw + 1) * 8, hipMemcpyHostToDevice, s));
         const DeviceCsr r = query_or_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), nkw);
-        int64_t* hi = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
-        int64_t* hc = (int64_t*)std::malloc(std::max<uint64_t>(r.nrows, 1) * 8);
-        if (!hi || !hc) {
-            std::free(hi);
-            std::free(hc);
-            throw std::bad_alloc();
+        int64_t* hi = (int64_t*)host_alloc(r.nrows * 8);
+        int64_t* hc = nullptr;
+        try {
+            hc = (int64_t*)host_alloc(r.nrows * 8);
+        } catch (...) {
+            host_free(hi);
+            throw;
         }
         if (r.nrows) {
             CDB_HIP(hipMemcpyAsync(hi, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
@@ -466,11 +472,10 @@ int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uin
         }
         out->ndocs = r.ndocs;
         out->nspans = r.nspans;
-        out->ids = (int64_t*)std::malloc(std::max<uint64_t>(r.ndocs, 1) * 8);
-        out->span_ptr = (uint64_t*)std::calloc(r.ndocs + 1, 8);
-        out->begin = (uint64_t*)std::malloc(std::max<uint64_t>(r.nspans, 1) * 8);
-        out->end = (uint64_t*)std::malloc(std::max<uint64_t>(r.nspans, 1) * 8);
-        if (!out->ids || !out->span_ptr || !out->begin || !out->end) throw std::bad_alloc();
+        out->ids = (int64_t*)host_alloc(r.ndocs * 8);
+        out->span_ptr = (uint64_t*)host_alloc((r.ndocs + 1) * 8, true);
+        out->begin = (uint64_t*)host_alloc(r.nspans * 8);
+        out->end = (uint64_t*)host_alloc(r.nspans * 8);
         if (r.nspans) {
             CDB_HIP(hipMemcpyAsync(out->ids, ix.q_ids.p, r.ndocs * 8, hipMemcpyDeviceToHost, s));
             CDB_HIP(hipMemcpyAsync(out->span_ptr, ix.q_rowptr.p, (r.ndocs + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -483,18 +488,18 @@ int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uin
 
 void cdb_spans_free(cdb_spans* r) {
     if (!r) return;
-    std::free(r->ids);
-    std::free(r->span_ptr);
-    std::free(r->begin);
-    std::free(r->end);
+    host_free(r->ids);
+    host_free(r->span_ptr);
+    host_free(r->begin);
+    host_free(r->end);
     std::memset(r, 0, sizeof(*r));
 }
 
 void cdb_result_free(cdb_result* r) {
     if (!r) return;
-    std::free(r->row_ptr);
-    std::free(r->ids);
-    std::free(r->counts);
+    host_free(r->row_ptr);
+    host_free(r->ids);
+    host_free(r->counts);
     std::memset(r, 0, sizeof(*r));
 }
 
@@ -667,7 +672,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
-        {"query_ms", q.query_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
+        {"query_ms", q.query_ms}, {"query_upload_ms", q.upload_ms}, {"query_device_ms", q.device_ms}, {"query_download_ms", q.download_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
     };
     for (auto& e : tab)
         if (!std::strcmp(e.n, name)) {
@@ -762,7 +767,10 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
     }
 }
 
-void cdb_release_cached_memory(void) { DevPool::get().trim(); }
+void cdb_release_cached_memory(void) {
+    DevPool::get().trim();
+    HostPool::get().trim();
+}
 
 void cdb_set_cache_limit(uint64_t bytes) { DevPool::get().set_limit((size_t)bytes); }
 

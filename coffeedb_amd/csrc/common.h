@@ -4,6 +4,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -150,6 +152,99 @@ struct DevBuf {
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// Result arrays handed to the caller.  A fresh malloc() block is pageable and untouched: a multi-GB
+// device-to-host copy into it runs at a few GB/s (page faults + the driver's staging copies).  Large results
+// therefore come from a process-wide cache of PINNED blocks (hipHostMalloc; page-locking is paid once per
+// block, later batches reuse it); small ones stay plain malloc.  host_free() tells the two apart.
+class HostPool {
+public:
+    static HostPool& get() {
+        static HostPool p;
+        return p;
+    }
+    static constexpr size_t kMinPinned = 1u << 20;
+    void* alloc(size_t bytes) {
+        const size_t need = (bytes + 4095) / 4096 * 4096;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            int best = -1;
+            for (int i = 0; i < (int)free_.size(); ++i) {
+                if (free_[i].bytes < need || free_[i].bytes > 2 * need + (8u << 20)) continue;
+                if (best < 0 || free_[i].bytes < free_[best].bytes) best = i;
+            }
+            if (best >= 0) {
+                Block b = free_[best];
+                free_.erase(free_.begin() + best);
+                cached_ -= b.bytes;
+                live_[b.p] = b.bytes;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            trim();
+            if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        live_[p] = need;
+        return p;
+    }
+    bool release(void* p) {  // false: not one of ours
+        size_t bytes;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = live_.find(p);
+            if (it == live_.end()) return false;
+            bytes = it->second;
+            live_.erase(it);
+            if (cached_ + bytes <= limit_) {
+                free_.push_back(Block{p, bytes});
+                cached_ += bytes;
+                return true;
+            }
+        }
+        (void)hipHostFree(p);
+        return true;
+    }
+    void trim() {
+        std::vector<Block> blocks;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            blocks.swap(free_);
+            cached_ = 0;
+        }
+        for (auto& b : blocks) (void)hipHostFree(b.p);
+    }
+    size_t cached_bytes() {
+        std::lock_guard<std::mutex> g(mu_);
+        return cached_;
+    }
+
+private:
+    struct Block { void* p; size_t bytes; };
+    std::mutex mu_;
+    std::vector<Block> free_;
+    std::map<void*, size_t> live_;
+    size_t cached_ = 0;
+    size_t limit_ = 8ull << 30;  // pinned bytes kept for the next batch
+};
+
+inline void* host_alloc(size_t bytes, bool zero = false) {
+    if (bytes == 0) bytes = 8;
+    void* p = bytes >= HostPool::kMinPinned ? HostPool::get().alloc(bytes) : nullptr;
+    if (!p) p = std::malloc(bytes);
+    if (!p) throw std::bad_alloc();
+    if (zero) std::memset(p, 0, bytes);
+    return p;
+}
+inline void host_free(void* p) {
+    if (p && !HostPool::get().release(p)) std::free(p);
+}
 
 // Per-kernel timing with HIP events recorded on the launching stream (bench.py's roofline leg reads
 // these through cdb_profile_get).  Events are resolved lazily after a stream synchronise.

@@ -31,6 +31,7 @@ struct BuildStats {
 
 struct QueryStats {
     double query_ms = 0;
+    double upload_ms = 0, device_ms = 0, download_ms = 0;  // host batches: patterns in, search + rows, results out
     uint64_t nhits = 0, nrows = 0;
 };
 

@@ -191,7 +191,10 @@ void cdb_profile_reset(cdb_index* h);
 
 /* Device blocks released by builds/queries are cached process-wide for the next build (hipMalloc of the
  * ~30 GiB working set of a 1 GiB build costs ~1 s on MI355X — the driver maps and clears VRAM).  This
- * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size. */
+ * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size.  Result
+ * arrays of 1 MiB and more (cdb_query_batch*, cdb_query_or, cdb_query_spans) are pinned host blocks from a
+ * similar cache (up to 8 GiB kept; device-to-host copies into fresh pageable memory run at a few GB/s);
+ * always release them through cdb_result_free / cdb_hits_free / cdb_spans_free / cdb_free. */
 void cdb_release_cached_memory(void);
 uint64_t cdb_cached_memory_bytes(void);
 /* upper bound of the block cache (default: unlimited); blocks released beyond it go back to the driver */

@@ -32,9 +32,13 @@ if len(sys.argv) > 4:   # query stage: N patterns of length lo-hi sampled from a
     npat, lo, hi = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
     host = text[: 1 << 28].cpu().numpy()
     pb, po = W.sample_patterns(host, W.uniform_docs((1 << 28) // dl, dl), npat, lo, hi, seed=99)
-    for rep in range(2):
+    for rep in range(3):   # results are released before the next batch, whose pinned blocks are then reused
+        rp = ri = rc = None
         t = time.time(); rp, ri, rc, hits = g.query_batch(pb, po); tq = time.time() - t
-    print(f"query_batch {npat} patterns len {lo}-{hi}: {tq*1e3:.1f} ms ({npat/tq/1e6:.1f} M/s) hits={hits} rows={len(ri)}")
+    print(f"query_batch {npat} patterns len {lo}-{hi}: {tq*1e3:.1f} ms ({npat/tq/1e6:.1f} M/s) hits={hits} rows={len(ri)} library {g.stat('query_ms'):.1f} ms = upload {g.stat('query_upload_ms'):.1f} + device {g.stat('query_device_ms'):.1f} + download {g.stat('query_download_ms'):.1f}")
+    g.profile_reset(); g.query_batch(pb, po)
+    for k, v in sorted(g.profile().items(), key=lambda kv: -kv[1]["ms"])[:10]:
+        print(f"   {k:32s} {v['ms']:9.3f} ms x{v['launches']}")
     t = time.time(); rp2, ri2, rc2, hp, off = g.query_batch_offsets(pb, po); tq = time.time() - t
     assert np.array_equal(ri, ri2) and np.array_equal(rc, rc2) and len(off) == hits
     # spot-check a few rows against the text
