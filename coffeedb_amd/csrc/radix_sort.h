@@ -210,21 +210,24 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         if (docs_in_lds)
             for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
         for (int i = tid; i < 256; i += NT) s_map[i] = gen.symmap[i];
+        __syncthreads();
+        // bytes -> symbol codes on their way into LDS: one table lookup per text byte instead of one per
+        // (suffix, symbol)
         for (uint32_t i = tid * 16; i < (uint32_t)TILE + RS_GEN_LOOK; i += NT * 16) {
             const uint64_t g = base + i;
+            uint32_t x[4];
             if (gen.padded ? (g < n + RS_GEN_LOOK) : (g + 16 <= n)) {
-                *reinterpret_cast<uint4*>(&s_text[i]) = *reinterpret_cast<const uint4*>(gen.text + g);
+                const uint4 w = *reinterpret_cast<const uint4*>(gen.text + g);
+                x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
             } else {
 #pragma unroll
-                for (int b = 0; b < 16; ++b) s_text[i + b] = (g + b < n) ? gen.text[g + b] : (uint8_t)0;
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        x[q] |= (uint32_t)((g + 4 * q + b < n) ? gen.text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+                }
             }
-        }
-        __syncthreads();
-        // translate the staged bytes to symbol codes in place: one table lookup per text byte instead
-        // of one per (suffix, symbol)
-        for (uint32_t i = tid * 16; i < (uint32_t)TILE + RS_GEN_LOOK; i += NT * 16) {
-            uint4 w = *reinterpret_cast<const uint4*>(&s_text[i]);
-            uint32_t x[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 x[q] = (uint32_t)s_map[x[q] & 0xFF] | ((uint32_t)s_map[(x[q] >> 8) & 0xFF] << 8) |
@@ -255,20 +258,23 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 }
                 const uint64_t ds = docs_in_lds ? s_docs[d - dlo] : gen.doc_start[d];
                 const uint64_t rem = dend - p;
-                // the codes of positions li .. li+15 as two 64-bit windows (aligned dword reads)
-                const uint32_t wi = li >> 2, sh = (li & 3u) * 8u;
+                // the codes of positions li .. li+7 (li+15) from aligned dword reads; four byte codes are packed
+                // into 4*symbits bits with 32-bit operations (first symbol most significant)
+                const uint32_t wi = li >> 2, sel = li & 3u;
                 const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-                uint64_t lo8 = ((uint64_t)w1 << 32) | w0, hi8 = 0;  // codes of li&~3 .. +7
-                if (nsym > 8) {
+                const uint32_t s1 = (uint32_t)symbits, s2 = 2u * s1, s3 = 3u * s1;
+                auto pack4 = [&](uint32_t x) -> uint32_t {
+                    return ((x & 0xFFu) << s3) | (((x >> 8) & 0xFFu) << s2) | (((x >> 16) & 0xFFu) << s1) | (x >> 24);
+                };
+                const uint32_t c0 = __builtin_amdgcn_alignbyte(w1, w0, sel), c1 = __builtin_amdgcn_alignbyte(w2, w1, sel);
+                uint64_t kk = ((uint64_t)pack4(c0) << (4u * s1)) | pack4(c1);  // 8 symbols
+                if (nsym <= 8) {
+                    kk >>= (uint32_t)(8 - nsym) * s1;
+                } else {
                     const uint32_t w3 = s_words[wi + 3], w4 = s_words[wi + 4];
-                    hi8 = ((uint64_t)w3 << 32) | w2;
-                    if (sh) hi8 = (hi8 >> sh) | ((uint64_t)w4 << (64 - sh));
-                }
-                if (sh) lo8 = (lo8 >> sh) | ((uint64_t)w2 << (64 - sh));  // drop li&3 bytes, refill from the next word
-                uint64_t kk = 0;
-                for (int q = 0; q < nsym; ++q) {
-                    const uint64_t c = q < 8 ? (lo8 >> (8 * q)) & 0xFF : (hi8 >> (8 * (q - 8))) & 0xFF;
-                    kk = (kk << symbits) | c;
+                    const uint32_t c2 = __builtin_amdgcn_alignbyte(w3, w2, sel), c3 = __builtin_amdgcn_alignbyte(w4, w3, sel);
+                    const uint64_t k2 = ((uint64_t)pack4(c2) << (4u * s1)) | pack4(c3);
+                    kk = (kk << ((uint32_t)(nsym - 8) * s1)) | (k2 >> ((uint32_t)(16 - nsym) * s1));
                 }
                 // symbols at or behind the end of the document count as 0 ("end"): clear them
                 if (rem < (uint64_t)nsym) {

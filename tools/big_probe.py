@@ -24,7 +24,7 @@ for i in range(2):
     g.profile_reset(); t = time.time(); g.build_device(text.data_ptr(), ds, ids); w_ = time.time() - t
     print(f"{kind} n={n/2**30:.2f} GiB width={g.sa_width} build {w_*1e3:.1f} ms ({n/2**30/w_:.2f} GiB/s) rounds={g.stat('rounds'):.0f} ext={g.stat('ext_rounds'):.0f} dbl={g.stat('dbl_rounds'):.0f} "
           f"unres0={g.stat('unresolved_after_initial'):.0f} passes={g.stat('sort_passes'):.0f} nsym={g.stat('key_symbols'):.0f} symbits={g.stat('symbol_bits'):.0f} fused={g.stat('fused_keygen'):.0f} depth={g.stat('final_depth'):.0f}", flush=True)
-for k, v in sorted(g.profile().items(), key=lambda kv: -kv[1]["ms"])[:8]:
+for k, v in sorted(g.profile().items(), key=lambda kv: -kv[1]["ms"])[:16]:
     print(f"   {k:32s} {v['ms']:9.3f} ms x{v['launches']}")
 t = time.time(); print(g.verify(), f"verify {time.time()-t:.2f}s")
 print("free/total GiB:", [x / 2**30 for x in torch.cuda.mem_get_info()])

@@ -21,8 +21,9 @@ for rnd in range(3):
         p = g.profile()
         names = [k for k in p if k.startswith("rs_onesweep_k64_v32")]
         os_ = {"ms": sum(p[k]["ms"] for k in names), "bytes": sum(p[k]["bytes"] for k in names)}
-        res.setdefault((v, db), []).append((g.stat("build_ms"), os_["ms"], os_["bytes"], g.stat("sort_passes"), g.stat("digit_bits"), g.stat("unresolved_after_initial")))
+        tg = sum(p[k]["ms"] for k in p if k.startswith("rs_onesweep_textgen"))
+        res.setdefault((v, db), []).append((g.stat("build_ms"), os_["ms"], os_["bytes"], g.stat("sort_passes"), g.stat("digit_bits"), g.stat("unresolved_after_initial"), tg))
 for k, r in res.items():
     b = sorted(x[0] for x in r[1:])[0]
     o = min(r[1:], key=lambda x: x[1])
-    print(f"variant {k[0]:2d} digit_bits {k[1]} (used {o[4]:.0f}): build {b:7.2f} ms = {nd*dl/2**30/(b*1e-3):6.2f} GiB/s | onesweep {o[1]:7.2f} ms {o[2]/(o[1]*1e-3)/1e9:6.0f} GB/s passes {o[3]:.0f} unres0 {o[5]:.0f}")
+    print(f"variant {k[0]:2d} digit_bits {k[1]} (used {o[4]:.0f}): build {b:7.2f} ms = {nd*dl/2**30/(b*1e-3):6.2f} GiB/s | onesweep {o[1]:7.2f} ms {o[2]/(o[1]*1e-3)/1e9:6.0f} GB/s passes {o[3]:.0f} unres0 {o[5]:.0f} | textgen pass {min(x[6] for x in r[1:]):.2f} ms")
