@@ -23,6 +23,7 @@ struct BuildStats {
     int sort_passes_skipped = 0;
     int isa_built = 0;
     int fused_keygen = 0;
+    int dense_keys = 0;          // initial keys in base (alphabet + 1) instead of bit-aligned symbols
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
@@ -72,7 +73,8 @@ struct Index {
     DevBuf d_keys;                    // optional: the sorted initial keys (first key_nsym symbol codes of every
                                       // suffix, packed) kept for the search: one load decides most probes
     DevBuf d_symmap_q;                // byte -> symbol code (u16[256]) matching d_keys
-    int key_nsym = 0, key_symbits = 0;
+    int key_nsym = 0;
+    uint32_t key_base = 0;            // d_keys[i] = the first key_nsym symbol codes as a number in this base
     DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
     int pivot_levels = 0;
 
@@ -89,6 +91,7 @@ struct Index {
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;
+    int key_coding = 0;           // initial sort keys: 0 = dense when that saves a pass, 1 = bit-aligned symbols, 2 = dense
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 
     Profiler prof;

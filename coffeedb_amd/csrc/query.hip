@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                                                             const uint64_t* __restrict__ offs, uint64_t npat,
                                                             const Pivot* __restrict__ piv, int levels,
                                                             const uint64_t* __restrict__ keys,
-                                                            const uint16_t* __restrict__ symmap, int nsym, int symbits,
+                                                            const uint16_t* __restrict__ symmap, int nsym, uint32_t kbase,
                                                             int64_t* __restrict__ left_out,
                                                             uint64_t* __restrict__ hits_out) {
     __shared__ Pivot s_piv[PIVOT_NODES + 1];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     for (int q = 0; q < kc; ++q) {
         const uint64_t c = s_code[k[q]];
         absent |= c == 0;
-        kwc = (kwc << symbits) | c;
+        kwc = kwc * kbase + c;
     }
     if (keys)
         for (uint64_t q = kc; q < m; ++q) absent |= s_code[k[q]] == 0;
@@ -176,12 +176,16 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
         hits_out[j] = 0;
         return;
     }
-    const int kshift = keys ? (nsym - kc) * symbits : 0;
+    // keys are numbers in base kbase: the suffixes starting with the keyword's first kc symbols are exactly
+    // those with key in [klo, klo + kpw)
+    uint64_t kpw = 1;
+    for (int q = kc; q < nsym; ++q) kpw *= kbase;
+    const uint64_t klo = kwc * kpw;
     // three-way answer from the key of slot M alone: -1 suffix < keyword, +1 keyword < suffix,
     // 0 = the suffix starts with the keyword's first kc symbols (decisive iff m <= nsym)
     auto key_cmp = [&](int64_t M) -> int {
-        const uint64_t sk = keys[M] >> kshift;
-        return sk < kwc ? -1 : (sk > kwc ? 1 : 0);
+        const uint64_t sk = keys[M];
+        return sk < klo ? -1 : (sk - klo >= kpw ? 1 : 0);
     };
     auto suffix_of = [&](int64_t M, const uint8_t*& sp, uint64_t& sl) {
         const V e = sa[M];
@@ -438,7 +442,7 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
         hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)ix.d_pivots.as<Pivot>(),
                            ix.pivot_levels, ix.key_nsym ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
-                           (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_symbits,
+                           (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
                            ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
     } else {
         hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,

@@ -119,7 +119,8 @@ template <bool NT_, typename T> __device__ __forceinline__ void rs_store(T* p, T
 
 // Optional producer for the FIRST pass of the suffix-array sort: instead of reading (key, entry) pairs
 // that a separate kernel would have to write first, the pass computes them from the text on the fly —
-// key = the suffix's first `nsym` symbol codes (0 = end of document), entry = (off << bits) | doc.
+// key = the suffix's first `nsym` symbol codes (0 = end of document) as a number in base `base`, entry =
+// (off << bits) | doc.  base = 2^symbits gives bit-aligned symbols; base = alphabet + 1 the densest key.
 // Saves one write and one read of 8+w bytes per suffix plus the key read of the histogram kernel.
 struct NoGen {};
 struct TextGen {
@@ -127,11 +128,42 @@ struct TextGen {
     const uint64_t* doc_start;
     const uint16_t* symmap;
     uint64_t ndocs;
-    int bits, symbits, nsym;
+    int bits;
+    uint32_t base;
+    int nsym;
     bool padded;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
+
+// Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
+// in byte i): Horner over the first nsym (<= 16) codes in base `base`, first symbol most significant; codes
+// at or behind the end of the document (rem symbols left) count as 0.  Four codes at a time are combined
+// with 32-bit operations (base <= 256, so four of them stay below 2^32).
+__device__ __forceinline__ uint64_t rs_pack_key(const uint32_t* __restrict__ s_words, uint32_t li, int nsym, uint32_t base,
+                                                uint64_t rem) {
+    const uint32_t wi = li >> 2, sel = li & 3u;
+    const uint32_t b2 = base * base, b3 = b2 * base;
+    const uint32_t pw[5] = {1u, base, b2, b3, b3 * base};  // pw[4] wraps to 0 for base = 256: handled below
+    uint64_t kk = 0;
+    uint32_t lo = s_words[wi];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int q = 4 * w;
+        if (q >= nsym) break;                           // uniform
+        const int r = nsym - q < 4 ? nsym - q : 4;      // symbols taken from this window (uniform)
+        const uint32_t hi = s_words[wi + w + 1];
+        uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, sel);  // codes of li + q .. li + q + 3
+        lo = hi;
+        if (rem < (uint64_t)(q + 4)) x = rem <= (uint64_t)q ? 0u : (x & ((1u << (8u * (uint32_t)(rem - q))) - 1u));
+        uint32_t v = x & 0xFFu;
+        if (r > 1) v = v * base + ((x >> 8) & 0xFFu);
+        if (r > 2) v = v * base + ((x >> 16) & 0xFFu);
+        if (r > 3) v = v * base + (x >> 24);
+        kk = (r == 4 && pw[4] == 0u) ? ((kk << 32) | v) : kk * pw[r] + v;
+    }
+    return kk;
+}
 
 __device__ __forceinline__ uint64_t rs_doc_upper(const uint64_t* __restrict__ doc_start, uint64_t lo, uint64_t hi,
                                                  uint64_t p) {
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         __syncthreads();
         uint64_t d = dlo;
         uint64_t dend = 0;  // doc_start[d + 1] of the current document (0 = not looked up yet)
-        const int nsym = gen.nsym, symbits = gen.symbits;
+        const int nsym = gen.nsym;
         const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
@@ -258,29 +290,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 }
                 const uint64_t ds = docs_in_lds ? s_docs[d - dlo] : gen.doc_start[d];
                 const uint64_t rem = dend - p;
-                // the codes of positions li .. li+7 (li+15) from aligned dword reads; four byte codes are packed
-                // into 4*symbits bits with 32-bit operations (first symbol most significant)
-                const uint32_t wi = li >> 2, sel = li & 3u;
-                const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-                const uint32_t s1 = (uint32_t)symbits, s2 = 2u * s1, s3 = 3u * s1;
-                auto pack4 = [&](uint32_t x) -> uint32_t {
-                    return ((x & 0xFFu) << s3) | (((x >> 8) & 0xFFu) << s2) | (((x >> 16) & 0xFFu) << s1) | (x >> 24);
-                };
-                const uint32_t c0 = __builtin_amdgcn_alignbyte(w1, w0, sel), c1 = __builtin_amdgcn_alignbyte(w2, w1, sel);
-                uint64_t kk = ((uint64_t)pack4(c0) << (4u * s1)) | pack4(c1);  // 8 symbols
-                if (nsym <= 8) {
-                    kk >>= (uint32_t)(8 - nsym) * s1;
-                } else {
-                    const uint32_t w3 = s_words[wi + 3], w4 = s_words[wi + 4];
-                    const uint32_t c2 = __builtin_amdgcn_alignbyte(w3, w2, sel), c3 = __builtin_amdgcn_alignbyte(w4, w3, sel);
-                    const uint64_t k2 = ((uint64_t)pack4(c2) << (4u * s1)) | pack4(c3);
-                    kk = (kk << ((uint32_t)(nsym - 8) * s1)) | (k2 >> ((uint32_t)(16 - nsym) * s1));
-                }
-                // symbols at or behind the end of the document count as 0 ("end"): clear them
-                if (rem < (uint64_t)nsym) {
-                    const int drop = (nsym - (int)rem) * symbits;
-                    kk = (kk >> drop) << drop;
-                }
+                const uint64_t kk = rs_pack_key(s_words, li, nsym, gen.base, rem);
                 key[j] = (K)kk;
                 val[j] = (VS)(((p - ds) << gen.bits) | d);
             }

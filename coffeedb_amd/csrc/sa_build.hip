@@ -164,7 +164,7 @@ template <typename V>
 __global__ __launch_bounds__(256) void sa_keygen_kernel(const uint8_t* __restrict__ text,
                                                         const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                         uint64_t n, int bits, const uint16_t* __restrict__ symmap,
-                                                        int symbits, int nsym, bool padded,
+                                                        uint32_t kbase, int nsym, bool padded,
                                                         uint64_t* __restrict__ keys, V* __restrict__ vals) {
     __shared__ __attribute__((aligned(16))) uint8_t s_text[KG_TILE + KG_LOOK];
     __shared__ uint16_t s_map[256];
@@ -199,19 +199,101 @@ __global__ __launch_bounds__(256) void sa_keygen_kernel(const uint8_t* __restric
         uint64_t key = 0;
         for (int k = 0; k < nsym; ++k) {
             const uint64_t sym = (uint64_t)k < rem ? (uint64_t)s_map[s_text[li + k]] : 0ull;
-            key = (key << symbits) | sym;
+            key = key * kbase + sym;
         }
         keys[p] = key;
         vals[p] = (V)(((p - ds) << bits) | d);
     }
 }
 
+// Digit histograms of all LSD passes for keys whose digits are not whole symbols (dense base-(alphabet+1)
+// keys): the keys are generated from the text exactly like the first radix pass generates them, counted
+// and thrown away.  hist[pass][256], 8-bit digits.
+constexpr int KH_TILE = 8192;
+constexpr int KH_CHUNK = KH_TILE / 256;  // consecutive positions per thread
+__global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restrict__ text,
+                                                         const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                         uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
+                                                         int nsym, int npass, bool padded,
+                                                         unsigned long long* __restrict__ hist) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_code[KH_TILE + KG_LOOK];
+    __shared__ uint16_t s_map[256];
+    __shared__ uint64_t s_drange[2];
+    __shared__ uint32_t s_hist[8][256];  // <= 8 digits of 8 bits in a 64-bit key
+    const int tid = threadIdx.x;
+    s_map[tid] = symmap[tid];
+    for (int p = 0; p < npass; ++p) s_hist[p][tid] = 0;
+    uint64_t top = 1;  // base^(nsym-1): weight of the symbol that leaves the window
+    for (int q = 1; q < nsym; ++q) top *= kbase;
+    const uint64_t tiles = (n + KH_TILE - 1) / KH_TILE;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * KH_TILE;
+        const uint32_t cnt = (uint32_t)((n - p0) < (uint64_t)KH_TILE ? (n - p0) : (uint64_t)KH_TILE);
+        __syncthreads();  // s_map ready / previous tile consumed
+        if (tid == 0) s_drange[0] = doc_upper(doc_start, 0, ndocs - 1, p0);
+        if (tid == 64) s_drange[1] = doc_upper(doc_start, 0, ndocs - 1, p0 + cnt - 1);
+        for (uint32_t i = tid * 16; i < KH_TILE + KG_LOOK; i += 256 * 16) {
+            const uint64_t g = p0 + i;
+            uint32_t x[4];
+            if (padded ? (g < n + KG_LOOK) : (g + 16 <= n)) {
+                const uint4 w = *reinterpret_cast<const uint4*>(text + g);
+                x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        x[q] |= (uint32_t)((g + 4 * q + b < n) ? text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                x[q] = (uint32_t)s_map[x[q] & 0xFF] | ((uint32_t)s_map[(x[q] >> 8) & 0xFF] << 8) |
+                       ((uint32_t)s_map[(x[q] >> 16) & 0xFF] << 16) | ((uint32_t)s_map[x[q] >> 24] << 24);
+            *reinterpret_cast<uint4*>(&s_code[i]) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        __syncthreads();
+        // Each thread walks KH_CHUNK consecutive positions with a rolling key: inside one document
+        //   key(p + 1) = (key(p) - code(p) * base^(nsym-1)) * base + code(p + nsym)   [0 behind the document end]
+        // so only the first position of a chunk or of a document pays for a full Horner evaluation.
+        const uint64_t dhi = s_drange[1];
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_code);
+        const uint32_t q0 = tid * KH_CHUNK;
+        if (q0 < cnt) {
+            uint64_t d = doc_upper(doc_start, s_drange[0], dhi, p0 + q0);
+            uint64_t dend = doc_start[d + 1];
+            uint64_t key = 0;
+            bool fresh = true;
+            const uint32_t qe = q0 + KH_CHUNK < cnt ? q0 + KH_CHUNK : cnt;
+            for (uint32_t li = q0; li < qe; ++li) {
+                const uint64_t p = p0 + li;
+                if (p >= dend) {  // next non-empty document
+                    do { ++d; dend = doc_start[d + 1]; } while (p >= dend);
+                    fresh = true;
+                }
+                if (fresh) {
+                    key = rs_pack_key(s_words, li, nsym, kbase, dend - p);
+                    fresh = false;
+                } else {
+                    const uint64_t cin = p + (uint64_t)nsym <= dend ? (uint64_t)s_code[li + nsym - 1] : 0ull;
+                    key = (key - (uint64_t)s_code[li - 1] * top) * kbase + cin;
+                }
+                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; ++p)
+        if (s_hist[p][tid]) atomicAdd(&hist[p * 256 + tid], (unsigned long long)s_hist[p][tid]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // group flags: bit0 = first entry of a group of equal prefixes, bit1 = still unresolved
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __restrict__ keys, uint64_t n,
-                                                           uint64_t symmask, uint8_t* __restrict__ flags,
-                                                           bool flags_aligned) {
+                                                           uint32_t kbase, uint64_t kmagic,
+                                                           uint8_t* __restrict__ flags, bool flags_aligned) {
     // four consecutive keys per thread (two 16-byte loads), four flag bytes in one store (bytewise when the
     // flag range of a bucket does not start on a 4-byte boundary)
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -234,7 +316,10 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
         if (i >= n) break;
         const bool head = i == 0 || k[q] != k[q + 1];
         const bool tail = i + 1 == n || k[q + 2] != k[q + 1];
-        const bool exhausted = (k[q + 1] & symmask) == 0;  // an end-of-document code inside the key
+        // an end-of-document code (0) as the last symbol: key = 0 mod base.  kmagic = floor(2^64 / base) + 1
+        // makes the quotient one multiply (exact for keys < 2^56); 0 for a power-of-two base
+        const uint64_t kq = k[q + 1];
+        const bool exhausted = kmagic ? (kq - __umul64hi(kq, kmagic) * kbase) == 0 : (kq & (uint64_t)(kbase - 1u)) == 0;
         out |= (uint32_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0)) << (8 * q);
     }
     if (flags_aligned && i0 + 4 <= n) {
@@ -708,14 +793,13 @@ void build_typed(Index& ix, bool big) {
         nsym = (int)std::min<double>(std::ceil(need), 64.0);
     }
     nsym = std::min(std::max(nsym, 1), std::min(64 / symbits, 32));
-    const int key_bits = nsym * symbits;
     // digit width of the initial sort: whole symbols per digit when that costs no extra pass — the
     // digit then takes at most alphabet+1 values, which lengthens the per-digit runs of a tile
     // (better write coalescing) for small alphabets such as ASCII text
     int dbits = 8;
     if (symbits <= 8) {
         const int dsym = 8 / symbits;
-        if ((int)ceil_div(nsym, dsym) <= (int)ceil_div(key_bits, 8)) dbits = dsym * symbits;
+        if ((int)ceil_div(nsym, dsym) <= (int)ceil_div(nsym * symbits, 8)) dbits = dsym * symbits;
     }
     if (ix.digit_bits > 0) dbits = ix.digit_bits;
     if (big) {
@@ -724,6 +808,35 @@ void build_typed(Index& ix, bool big) {
             throw Error("corpora of 4 GiB and more need an alphabet of at most 255 byte values");
         dbits = symbits;
     }
+    // Key coding.  Bit-aligned symbols (base 2^symbits) waste log2(2^symbits / (alphabet + 1)) bits per
+    // symbol; the dense base-(alphabet + 1) number is used when it saves a whole radix pass (95-symbol
+    // ASCII: 6 symbols = 40 bits = 5 passes instead of 42 bits = 6).  Its digits are not whole symbols, so
+    // the per-pass histograms come from a counting pre-pass over the text instead of the byte counts.
+    int key_bits = nsym * symbits;
+    uint32_t kbase = 1u << symbits;
+    bool dense = false;
+    if (!big && ix.digit_bits == 0 && ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255) {
+        const unsigned __int128 B = (unsigned)sigma + 1u;
+        auto bits_of = [&](int k) {  // bits of B^k - 1; 999 when beyond 56 bits
+            unsigned __int128 v = 1;
+            for (int i = 0; i < k; ++i) {
+                v *= B;
+                if (v > ((unsigned __int128)1 << 56)) return 999;
+            }
+            return bit_width64((uint64_t)(v - 1));
+        };
+        const int bd = bits_of(nsym);
+        const int passes_dense = (int)ceil_div(bd, 8), passes_aligned = (int)ceil_div(key_bits, dbits);
+        if (bd <= 56 && (passes_dense < passes_aligned || ix.key_coding == 2)) {
+            dense = true;
+            while (nsym < HC_MAXSYM && bits_of(nsym + 1) <= 8 * passes_dense) ++nsym;  // symbols that ride along for free
+            key_bits = bits_of(nsym);
+            kbase = (uint32_t)sigma + 1u;
+            dbits = 8;
+        }
+    }
+    const uint64_t kmagic = (kbase & (kbase - 1u)) ? (uint64_t)(~0ull / kbase) + 1ull : 0ull;
+    st.dense_keys = dense ? 1 : 0;
     st.digit_bits = dbits;
     st.key_symbols = nsym;
     st.symbol_bits = symbits;
@@ -732,11 +845,25 @@ void build_typed(Index& ix, bool big) {
     // ---- 2 + 3. keys + entries, initial sort
     DevBuf sorted_keys, sa_buf, flags;
     SortStats ss;
-    const bool fused = big || (ix.fuse_keygen && dbits == symbits && nsym <= HC_MAXSYM &&
+    const bool fused = big || (ix.fuse_keygen && (dense || dbits == symbits) && nsym <= HC_MAXSYM &&
                                (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1));
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
-    if (fused) {
+    if (fused && dense) {
+        const int npass = (int)ceil_div(key_bits, 8);
+        DevBuf d_kh;
+        d_kh.alloc((size_t)npass * 256 * sizeof(uint64_t));
+        CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
+        const int grid = (int)std::min<uint64_t>(ceil_div(n, KH_TILE), 256 * 8);
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
+                           (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
+                           d_kh.as<unsigned long long>());
+        ix.prof.end(t, "sa_keyhist", n, s);
+        h_hist.assign((size_t)npass * 256, 0);
+        CDB_HIP(hipMemcpyAsync(h_hist.data(), d_kh.p, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+    } else if (fused) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
         const size_t corr_words = (size_t)HC_MAXSYM * 257 + HC_MAXSYM;
@@ -775,7 +902,7 @@ void build_typed(Index& ix, bool big) {
             }
         }
     }
-    TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, symbits, nsym, ix.text_padded};
+    TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, kbase, nsym, ix.text_padded};
     double ta = now_ms();
     flags.alloc(n);
     if (!big) {
@@ -792,7 +919,7 @@ void build_typed(Index& ix, bool big) {
         } else {
             int t = ix.prof.begin(s);
             hipLaunchKernelGGL((sa_keygen_kernel<V>), dim3((unsigned)ceil_div(n, KG_TILE)), dim3(256), 0, s, text,
-                               doc_start, D, n, (int)ix.bits, d_symmap.as<uint16_t>(), symbits, nsym, ix.text_padded,
+                               doc_start, D, n, (int)ix.bits, d_symmap.as<uint16_t>(), kbase, nsym, ix.text_padded,
                                keys[0].as<uint64_t>(), vals[0].as<V>());
             ix.prof.end(t, "sa_keygen", n * (1 + sizeof(uint64_t) + sizeof(V)), s);
             sel = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, keys[0].as<uint64_t>(), keys[1].as<uint64_t>(), vals[0].as<V>(),
@@ -838,7 +965,7 @@ void build_typed(Index& ix, bool big) {
                 if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
             }
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
-                               (const uint64_t*)KT[r].as<uint64_t>(), cnt, (1ull << symbits) - 1ull, flags.as<uint8_t>() + start,
+                               (const uint64_t*)KT[r].as<uint64_t>(), cnt, kbase, kmagic, flags.as<uint8_t>() + start,
                                (start & 3) == 0);
             start += cnt;
         }
@@ -849,7 +976,7 @@ void build_typed(Index& ix, bool big) {
     if (!big) {  // (the bucket-wise sort writes the flags bucket by bucket)
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, (1ull << symbits) - 1ull, flags.as<uint8_t>(), true);
+                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, kbase, kmagic, flags.as<uint8_t>(), true);
         ix.prof.end(t, "sa_initflags", n * 9, s);
     }
     CDB_HIP(hipStreamSynchronize(s));
@@ -861,7 +988,7 @@ void build_typed(Index& ix, bool big) {
     if (ix.keep_keys && !big && n * 8 <= (16ull << 30)) {
         ix.d_keys = std::move(sorted_keys);
         ix.key_nsym = nsym;
-        ix.key_symbits = symbits;
+        ix.key_base = kbase;
     } else {
         sorted_keys.release();
     }

@@ -50,6 +50,7 @@ def test_fuzz_parity(seed):
     if rng.random() < 0.3: opts["fuse_keygen"] = 0
     if rng.random() < 0.25: opts["force_big_path"] = 1
     if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
+    elif rng.random() < 0.5: opts["key_coding"] = int(rng.choice([1, 2]))
     if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26]))
     if rng.random() < 0.2: opts["keep_keys"] = 0
     if rng.random() < 0.2: opts["fast_search"] = 0

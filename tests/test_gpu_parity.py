@@ -107,6 +107,30 @@ def test_fused_and_materialised_first_pass_agree(G, opts):
             assert g.stat("key_symbols") == {3: 3, 6: 6, 8: 9}[passes]
 
 
+@pytest.mark.parametrize("coding", [1, 2])
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_key_coding_dense_and_bit_aligned(G, coding, fuse):
+    # initial sort keys either pack symbols bit-aligned (digit histograms from byte counts) or as a number in
+    # base alphabet+1 (one pass fewer for e.g. 95-symbol ASCII; histograms from a counting pre-pass); the
+    # kept keys also drive the one-load search probes, so queries of every length class are compared
+    opts = dict(key_coding=coding, fuse_keygen=fuse)
+    for blob, ds, miss in ((W.ascii_corpus(3000, 333, seed=2) + (0x7F,)),                     # 95 symbols
+                           (W.ragged_corpus(20000, 90, seed=15, empty_every=13) + (0x7B,)),     # a-z, ragged, empty docs
+                           (W.zipf_corpus(2000, 256, seed=2) + (0x2F,)),                          # skewed
+                           (W.ascii_corpus(500, 2000, seed=4, lo=0x41, hi=0x43) + (0x5A,))):      # 3 symbols: 16-symbol keys
+        pats = W.sample_patterns(blob, ds, 400, 1, 24, seed=11, miss_byte=miss)
+        g, o = _check_parity(G, blob, ds, patterns=pats, **opts)
+        assert g.stat("dense_keys") == (1 if coding == 2 else 0)
+        if coding == 2 and g.stat("key_symbols") <= 16:   # (bit-aligned keys are generated in the first pass
+            assert g.stat("fused_keygen") == fuse          #  only when digits are whole symbols)
+        for kw in (bytes(blob[:1]), bytes(blob[5:9]), bytes([miss]), bytes(blob[:3]) + bytes([miss]), bytes(blob[-7:])):
+            assert g.query(kw) == o.query(kw), kw
+    # auto: dense exactly when it saves a pass (4 symbols, 13-symbol keys: 39 bits = 5 passes, but 5^13 < 2^31 = 4)
+    blob, ds = W.ascii_corpus(1000, 1000, seed=3, lo=0x41, hi=0x44)
+    g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 500, 2, 20, seed=6), fuse_keygen=fuse)
+    assert g.stat("key_symbols") == 13 and g.stat("dense_keys") == 1
+
+
 @pytest.mark.parametrize("force_doubling", [0, 1])
 def test_big_corpus_code_path_at_small_size(G, force_doubling):
     # the >= 2^32 path (u64 ranks/positions, streamed bucket-wise initial sort) forced on small inputs
