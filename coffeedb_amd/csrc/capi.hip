@@ -262,8 +262,7 @@ int cdb_load(cdb_index* h, const char* path) {
         }
         ix.sa_sorted = hd.sorted != 0;  // a reference-compat ordering keeps the reference's exact probe sequence
         ix.pivot_levels = 0;
-        ix.d_keys.release();
-        ix.key_nsym = 0;
+        ix.drop_keys();
         ix.host_text.clear();
         ix.d_text_owned.alloc(ix.size + TEXT_PAD);
         CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + ix.size, 0, TEXT_PAD, ix.stream));
@@ -648,6 +647,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
+    else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
     else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
         ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;
     else if (!std::strcmp(name, "coalesce_queries")) ix.coalesce_queries = value != 0;
@@ -669,7 +669,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"bucketed", (double)b.bucketed},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

@@ -23,6 +23,7 @@ struct BuildStats {
     int sort_passes_skipped = 0;
     int isa_built = 0;
     int fused_keygen = 0;
+    int key_layout = 0;          // sort records: 0 = (u64 key, entry), 1 = (u32 key, entry), 2 = (u32 key, entry, u8 low digit)
     int dense_keys = 0;          // initial keys in base (alphabet + 1) instead of bit-aligned symbols
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -73,8 +74,17 @@ struct Index {
     DevBuf d_keys;                    // optional: the sorted initial keys (first key_nsym symbol codes of every
                                       // suffix, packed) kept for the search: one load decides most probes
     DevBuf d_symmap_q;                // byte -> symbol code (u16[256]) matching d_keys
+    DevBuf d_keys32, d_keylow;        // ... or, after a narrow / split sort, key >> key_low_bits as u32 and (split) the
+    int key_low_bits = 0;             // low digit as one byte per suffix: 5 instead of 8 bytes per suffix
     int key_nsym = 0;
-    uint32_t key_base = 0;            // d_keys[i] = the first key_nsym symbol codes as a number in this base
+    uint32_t key_base = 0;            // key = the first key_nsym symbol codes as a number in this base
+    void drop_keys() {
+        d_keys.release();
+        d_keys32.release();
+        d_keylow.release();
+        key_nsym = 0;
+        key_low_bits = 0;
+    }
     DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
     int pivot_levels = 0;
 
@@ -91,6 +101,7 @@ struct Index {
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;
+    bool narrow_keys = true;      // 32-bit sort keys (+ a byte for the dropped low digit) when the key width allows
     int key_coding = 0;           // initial sort keys: 0 = dense when that saves a pass, 1 = bit-aligned symbols, 2 = dense
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 

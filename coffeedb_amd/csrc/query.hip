@@ -144,12 +144,15 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                                                             uint64_t mask, const uint8_t* __restrict__ blob,
                                                             const uint64_t* __restrict__ offs, uint64_t npat,
                                                             const Pivot* __restrict__ piv, int levels,
-                                                            const uint64_t* __restrict__ keys,
+                                                            const uint64_t* __restrict__ keys64,
+                                                            const uint32_t* __restrict__ keys32,
+                                                            const uint8_t* __restrict__ keylow, int low_bits,
                                                             const uint16_t* __restrict__ symmap, int nsym, uint32_t kbase,
                                                             int64_t* __restrict__ left_out,
                                                             uint64_t* __restrict__ hits_out) {
     __shared__ Pivot s_piv[PIVOT_NODES + 1];
     __shared__ uint16_t s_code[256];
+    const bool keys = keys64 != nullptr || keys32 != nullptr;  // sorted initial keys available
     for (int i = threadIdx.x; i < (1 << levels); i += 256) s_piv[i] = piv[i];
     if (keys) s_code[threadIdx.x] = symmap[threadIdx.x];
     __syncthreads();
@@ -183,9 +186,26 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     const uint64_t klo = kwc * kpw;
     // three-way answer from the key of slot M alone: -1 suffix < keyword, +1 keyword < suffix,
     // 0 = the suffix starts with the keyword's first kc symbols (decisive iff m <= nsym)
+    // (split keys: key = (keys32 << low_bits) | keylow; the 32-bit part alone decides unless it equals the
+    //  truncated range end it is compared with)
+    const uint64_t khi = klo + (kpw - 1);  // last key of the range
     auto key_cmp = [&](int64_t M) -> int {
-        const uint64_t sk = keys[M];
-        return sk < klo ? -1 : (sk - klo >= kpw ? 1 : 0);
+        uint64_t sk;
+        if (keys64) {
+            sk = keys64[M];
+        } else {
+            const uint64_t h = keys32[M];
+            if (keylow) {
+                const uint64_t a = klo >> low_bits, b = khi >> low_bits;
+                if (h < a) return -1;
+                if (h > b) return 1;
+                if (h > a && h < b) return 0;
+                sk = (h << low_bits) | (uint64_t)keylow[M];
+            } else {
+                sk = h;
+            }
+        }
+        return sk < klo ? -1 : (sk > khi ? 1 : 0);
     };
     auto suffix_of = [&](int64_t M, const uint8_t*& sp, uint64_t& sl) {
         const V e = sa[M];
@@ -441,8 +461,11 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
         }
         hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)ix.d_pivots.as<Pivot>(),
-                           ix.pivot_levels, ix.key_nsym ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
-                           (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
+                           ix.pivot_levels,
+                           ix.key_nsym && ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
+                           ix.key_nsym && ix.d_keys32.p ? (const uint32_t*)ix.d_keys32.as<uint32_t>() : (const uint32_t*)nullptr,
+                           ix.key_nsym && ix.d_keylow.p ? (const uint8_t*)ix.d_keylow.as<uint8_t>() : (const uint8_t*)nullptr,
+                           ix.key_low_bits, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
                            ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
     } else {
         hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,

@@ -94,8 +94,11 @@ __device__ __forceinline__ void rs_st_status(uint64_t* p, uint64_t v) {
 // LDS staging buffer (two write-out phases, smaller footprint -> more workgroups per CU); EARLYV =
 // values are fetched together with the keys instead of after the look-back.
 template <int IPT_, bool REUSE_, bool EARLYV_, int NT_ = 256, bool NONTEMP_ = false, int MINW_ = 1, int ABL_ = 0,
-          int LB_ = 1, bool DMA_ = false>
+          int LB_ = 1, bool DMA_ = false, bool ATOMRANK_ = false>
 struct RsCfg {
+    static constexpr bool ATOMRANK = ATOMRANK_;  // rank inside the wave with one returning LDS atomic per element
+                                              // instead of 8 ballots (relies on same-address LDS atomics of one
+                                              // instruction completing in lane order — checked by a self-test)
     static constexpr bool DMA = DMA_;         // keys/values reach the registers through LDS by 16-byte global->LDS DMA
     static constexpr int LB = LB_;            // look-back window: predecessors polled per round trip
     static constexpr int ABL = ABL_;          // timing-only ablations (WRONG results): 1 = no look-back,
@@ -131,7 +134,9 @@ struct TextGen {
     int bits;
     uint32_t base;
     int nsym;
-    bool padded;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
+    int low_bits = 0;  // split keys: the generated pass sorts on the key's low_bits lowest bits, which then travel
+                       // as a separate byte per element; the remaining passes see key >> low_bits (32-bit keys)
+    bool padded = false;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
@@ -185,13 +190,20 @@ static __global__ __launch_bounds__(256) void rs_tiledoc_kernel(const uint64_t* 
     tile_doc[t] = rs_doc_upper(doc_start, 0, ndocs - 1, p);
 }
 
-template <typename K, typename V, typename Cfg, typename Gen = NoGen>
+// W (optional) = one auxiliary byte per element that travels with the pair (the already sorted low digit of
+// a split key, see TextGen::low_bits); in the generated pass it IS the digit being sorted.
+template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
-    uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen()) {
+    uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen(),
+    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr) {
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
+    constexpr bool DIGW = GEN && HAS_W;  // the digit of this pass is the auxiliary byte
+    using WS = typename std::conditional<HAS_W, W, uint8_t>::type;
+    static_assert(!HAS_W || (Cfg::REUSE && HAS_V && !Cfg::DMA), "the auxiliary byte needs the shared-staging configuration");
     constexpr int IPT = Cfg::IPT;
     constexpr bool REUSE = Cfg::REUSE && HAS_V;
     constexpr bool EARLYV = (Cfg::EARLYV || REUSE) && HAS_V;
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     constexpr size_t STAGE_BYTES = REUSE ? (STAGE_K > STAGE_V ? STAGE_K : STAGE_V) : STAGE_K + STAGE_V;
 
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
+    __shared__ WS s_aux[HAS_W ? TILE : 1];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint32_t s_tstart[256];
@@ -225,9 +238,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
     K key[IPT];
     VS val[EARLYV ? IPT : 1];
+    WS aux[HAS_W ? IPT : 1];
     const uint32_t wbase = wave * WCHUNK + lane;
     if constexpr (GEN) {
-        static_assert(!GEN || (EARLYV && sizeof(K) == 8), "generator pass needs early values and 64-bit keys");
+        static_assert(!GEN || EARLYV, "generator pass needs early values");
         static_assert(!GEN || STAGE_BYTES >= (size_t)TILE + RS_GEN_LOOK + 2048, "staging buffer too small for the text tile");
         // stage the text of this tile (+ look-ahead) in the still unused LDS staging buffer
         uint8_t* s_text = s_stage;
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             const uint32_t li = wbase + j * 64;
             key[j] = (K)~(K)0;
             val[j] = VS(0);
+            if constexpr (HAS_W) aux[j] = WS(0);
             if (li < valid) {
                 const uint64_t p = base + li;
                 // positions of one thread ascend by 64: usually the same or the next document
@@ -291,7 +306,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const uint64_t ds = docs_in_lds ? s_docs[d - dlo] : gen.doc_start[d];
                 const uint64_t rem = dend - p;
                 const uint64_t kk = rs_pack_key(s_words, li, nsym, gen.base, rem);
-                key[j] = (K)kk;
+                if constexpr (HAS_W) {
+                    aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
+                    key[j] = (K)(kk >> gen.low_bits);
+                } else {
+                    key[j] = (K)kk;
+                }
                 val[j] = (VS)(((p - ds) << gen.bits) | d);
             }
         }
@@ -340,17 +360,33 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 val[j] = li < valid ? rs_load<NTM>(vin + base + li) : VS(0);
             }
         }
+        if constexpr (HAS_W) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                aux[j] = li < valid ? rs_load<NTM>(win + base + li) : WS(0);
+            }
+        }
     }
 
-    // ---- rank inside the wave: lanes with the same digit find each other with 8 ballots
+    // ---- rank inside the wave: lanes with the same digit find each other with 8 ballots, or (ATOMRANK) one
+    // returning atomic on the wave's private counter hands every element its rank directly
     uint32_t rank[IPT];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if constexpr (Cfg::ATOMRANK) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            const uint32_t d = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
+            rank[j] = atomicAdd(&s_whist[wave][d], 1u);
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
         // out-of-range slots take digit 255: they have the largest indices of the tile, so they end
         // up behind every real element and are simply not written out.
-        const uint32_t d = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
+        const uint32_t d = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -366,6 +402,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         }
         old = __shfl(old, __ffsll((unsigned long long)m) - 1);
         rank[j] = old + below;
+    }
     }
     if constexpr (!GEN && Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
         // the value DMA issued before the ranking has had the whole loop to land
@@ -420,10 +457,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
-        const uint32_t dd = li < valid ? ((uint32_t)(key[j] >> shift) & dmask) : 255u;
+        const uint32_t dd = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
+        if constexpr (HAS_W) s_aux[pos] = aux[j];
     }
     if constexpr (HAS_V && !REUSE) {
 #pragma unroll
@@ -506,9 +544,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             dig[j] = 0;
             if (i < valid) {
                 const K k = s_keys[i];
-                const uint32_t dd = (uint32_t)(k >> shift) & dmask;
+                const uint32_t dd = DIGW ? (uint32_t)s_aux[i] : ((uint32_t)(k >> shift) & dmask);
                 dig[j] = (uint8_t)dd;
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
+                if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
             }
         }
         __syncthreads();
@@ -521,6 +560,75 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// self-test behind the ATOMRANK configurations
+// ---------------------------------------------------------------------------------------------
+// The one-atomic ranking is only a stable rank if same-address LDS atomics issued by ONE wave instruction
+// complete in ascending lane order.  gfx950 does that (the LDS resolves a conflict lowest lane first), but
+// it is observed behaviour, not an ISA guarantee — so every process checks it once per device against the
+// ballot ranking on conflict patterns from "all 64 lanes on one counter" to "256 counters", and the sorts
+// fall back to the ballot configurations if a single return value differs.
+static __global__ __launch_bounds__(256) void rs_lane_order_probe_kernel(uint32_t* __restrict__ bad) {
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t ref[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += 256) {
+        (&cnt[0][0])[i] = 0;
+        (&ref[0][0])[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t wrong = 0;
+    for (uint32_t r = 0; r < 64; ++r) {
+        uint32_t h = (blockIdx.x * 64u + r) * 256u + (uint32_t)tid;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        const uint32_t mode = blockIdx.x & 3u;
+        const uint32_t d = mode == 0 ? 7u : mode == 1 ? (h & 1u) * 64u : mode == 2 ? (h & 15u) * 4u : (h & 255u);
+        const uint32_t got = atomicAdd(&cnt[wave][d], 1u);
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t below = __popcll(m & lt_mask);
+        uint32_t old = 0;
+        if (below == 0) {
+            old = ref[wave][d];
+            ref[wave][d] = old + __popcll(m);
+        }
+        old = __shfl(old, __ffsll((unsigned long long)m) - 1);
+        wrong += got != old + below ? 1u : 0u;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+// true when the device passed the probe (cached per device; CDB_RANK=ballot forces the ballot ranking)
+inline bool rs_atomic_rank_ok(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<int, bool> cache;
+    int dev = 0;
+    CDB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    bool ok = false;
+    const char* env = std::getenv("CDB_RANK");
+    if (!(env && std::string(env) == "ballot")) {
+        DevBuf d_bad;
+        d_bad.alloc(sizeof(uint32_t));
+        CDB_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(rs_lane_order_probe_kernel, dim3(512), dim3(256), 0, s, d_bad.as<uint32_t>());
+        uint32_t bad = 1;
+        CDB_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(bad), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        ok = bad == 0;
+    }
+    cache[dev] = ok;
+    return ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,20 +690,26 @@ struct SortPlan {
 // One sort.  `h_hist_in` (optional, host, [npass][256]) supplies the per-pass digit histograms when the
 // caller can derive them more cheaply than by reading the keys; `gen` (optional) makes the first pass
 // produce its (key, value) input on the fly (buffers 0 are then never read).
-template <typename K, typename V, typename Cfg, typename Gen = NoGen>
+template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal>
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                    int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
-                   const Gen* gen = nullptr) {
+                   const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
-    if (n == 0 || end_bit <= begin_bit) return 0;
+    // split keys: pass 0 is generated and sorts on the auxiliary byte (the key's lowest digit); the passes
+    // over the key bits [begin_bit, end_bit) follow.  h_hist_in then has one leading row for that digit.
+    constexpr int LEAD = (GEN && HAS_W) ? 1 : 0;
+    static_assert(!HAS_W || GEN, "auxiliary bytes only exist behind a generated split pass");
+    if (n == 0 || end_bit < begin_bit || (!LEAD && end_bit == begin_bit)) return 0;
     const int nbits = end_bit - begin_bit;
     if (dbits < 1 || dbits > 8) dbits = 8;
-    const int npass = (int)ceil_div(nbits, dbits);
+    const int kpass = (int)ceil_div(nbits, dbits);  // passes over the key proper
+    const int npass = kpass + LEAD;
     if (npass > RS_MAX_PASSES) throw Error("radix_sort: too many passes requested");
-    const int last_bits = nbits - dbits * (npass - 1);
+    const int last_bits = kpass ? nbits - dbits * (kpass - 1) : dbits;
     const uint32_t last_mask = (1u << last_bits) - 1u;
     ws.prepare(n, TILE, s);
 
@@ -622,19 +736,23 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
 
     K* kb[2] = {k0, k1};
     V* vb[2] = {v0, v1};
+    W* wb[2] = {w0, w1};
     int cur = 0;
     bool materialised = !GEN;  // with a generator the input exists only after the first executed pass
     const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
+    const size_t pair_bytes = sizeof(K) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0);
     for (int p = 0; p < npass; ++p) {
         bool trivial = false;
         for (int d = 0; d < 256; ++d)
             if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
-        if (trivial && (materialised || p + 1 < npass)) {
+        // (the leading pass of a split sort always runs: it is the one that produces the auxiliary bytes)
+        if (trivial && (materialised || p + 1 < npass) && !(LEAD && p == 0)) {
             if (stats) stats->passes_skipped++;
             continue;
         }
         const uint32_t e = ws.next_epoch(s);
-        const uint32_t dmask = p == npass - 1 ? last_mask : ((1u << dbits) - 1u);
+        const uint32_t dmask = p == npass - 1 && kpass ? last_mask : ((1u << dbits) - 1u);
+        const int shift = begin_bit + dbits * (p - LEAD);  // (unused by the leading pass of a split sort)
         int t = prof.begin(s);
         if (!materialised) {
             if constexpr (GEN) {
@@ -643,21 +761,21 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                 hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles + 1, 256)), dim3(256), 0, s,
                                    g2.doc_start, g2.ndocs, n, (uint64_t)TILE, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
                 g2.tile_doc = ws.tile_doc.as<uint64_t>();
-                hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen>), dim3(tiles), dim3(Cfg::NT), 0, s,
-                                   (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vb[cur ^ 1], n,
-                                   begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
-                                   ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), g2);
+                hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
+                                   (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vb[cur ^ 1], n, shift, dmask,
+                                   (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
+                                   ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1]);
             }
-            prof.end(t, (std::string("rs_onesweep_textgen_t") + std::to_string(TILE)).c_str(),
-                     n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0)), s);
+            prof.end(t, (std::string("rs_onesweep_textgen") + (HAS_W ? "_split" : "") + "_t" + std::to_string(TILE)).c_str(),
+                     n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0)), s);
             materialised = true;
         } else {
-            hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen>), dim3(tiles), dim3(Cfg::NT), 0, s,
-                               (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n,
-                               begin_bit + dbits * p, dmask, (const unsigned long long*)(d_start + p * 256),
-                               ws.status.as<uint64_t>(), ws.ticket_ptr(e), e, ws.err_ptr(), NoGen());
-            prof.end(t, (std::string(rs_kernel_name<K, V>()) + "_t" + std::to_string(TILE)).c_str(),
-                     2 * n * (sizeof(K) + (HAS_V ? sizeof(V) : 0)), s);
+            hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
+                               (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, shift, dmask,
+                               (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(), ws.ticket_ptr(e), e,
+                               ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1]);
+            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? "_w8" : "") + "_t" + std::to_string(TILE)).c_str(),
+                     2 * n * pair_bytes, s);
         }
         cur ^= 1;
         if (stats) stats->passes_run++;
@@ -674,21 +792,31 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
                int begin_bit, int end_bit, SortStats* stats = nullptr, int variant = 0, int dbits = 8,
                const uint64_t* h_hist_in = nullptr, const TextGen* gen = nullptr) {
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
+    const bool atomrank = rs_atomic_rank_ok(s);
     if constexpr (!HAS_V) {
-        if (n >= (1ull << 23))  // key-only: same 16 Ki-key tile as the pair sort
+        if (n >= (1ull << 23)) {  // key-only: same 16 Ki-key tile as the pair sort
+            if (atomrank && variant != 21)
+                return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4, false, true>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
             return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
+        }
+        if (atomrank && variant != 21)
+            return radix_sort_cfg<K, V, RsCfg<16, false, false, 256, false, 1, 0, 1, false, true>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
         return radix_sort_cfg<K, V, RsCfg<16, false, false>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
     } else {
         // variant 0 picks by size: big tiles (16 Ki keys, one workgroup per CU) give the longest per-digit
-        // runs and therefore the best-coalesced scatter, but need >= a few hundred tiles to fill 256 CUs
-        if (variant == 0) variant = n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1);
+        // runs and therefore the best-coalesced scatter, but need >= a few hundred tiles to fill 256 CUs;
+        // 31/36/32 = the same tiles with one-atomic ranking (when the device passed rs_atomic_rank_ok)
+        if (variant == 0)
+            variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
+                               : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
+        if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
 #define CDB_RS(...) return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in)
 #define CDB_RS_GEN(...)                                                                                               \
     if (gen)                                                                                                          \
         return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
                                                                  stats, dbits, h_hist_in, gen);                       \
     CDB_RS(__VA_ARGS__)
-        if (gen && variant != 21 && variant != 26 && variant != 1)
+        if (gen && variant != 21 && variant != 26 && variant != 1 && variant != 31 && variant != 36 && variant != 32)
             throw Error("radix_sort: this kernel configuration has no generated first pass (internal)");
         switch (variant) {
             // production configurations: IPT, REUSE, EARLYV, NT, NONTEMP, MINW, ABL, LB
@@ -696,6 +824,10 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 21: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4);   // 16 Ki-key tile, 1 WG/CU
             case 26: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4);    // 4.5 Ki-key tile, 3 WG/CU
             case 1: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1);     // 3.75 Ki-key tile, 4 WG/CU
+            // the same three with LDS-atomic ranking
+            case 31: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true);
+            case 36: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4, false, true);
+            case 32: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1, false, true);
             // kept for A/B measurements (tools/sort_bench.py, profiles/): earlier design points
             case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);   // round-1 first version
             case 3: CDB_RS(18, true, true, 256, false, 1, 0, 1);
@@ -735,6 +867,33 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
         CDB_HIP(hipMemcpy(c, ws.err_ptr(), sizeof(c), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[lookback] consumed=%u round_trips=%u\n", c[1], c[2]);
     }
+}
+
+// Split sort for keys of up to 32 + low_bits bits whose lowest digit the generated first pass sorts on and
+// then drops from the key: the remaining passes move (u32 key >> low_bits, value, u8 low digit) = 9 bytes
+// per element instead of 12 for a (u64, u32) pair.  h_hist = [1 + passes over hi_bits][256].
+template <typename V>
+int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
+                     uint8_t* w0, uint8_t* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
+                     const uint64_t* h_hist, const TextGen* gen) {
+    const bool atomrank = rs_atomic_rank_ok(s);
+    if (variant == 0)
+        variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
+                           : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
+    if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
+#define CDB_RS_SPLIT(...)                                                                                              \
+    return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, uint8_t>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits, \
+                                                                             stats, dbits, h_hist, gen, w0, w1)
+    switch (variant) {
+        default:
+        case 21: CDB_RS_SPLIT(16, true, true, 1024, false, 1, 0, 4);
+        case 26: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4);
+        case 1: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1);
+        case 31: CDB_RS_SPLIT(16, true, true, 1024, false, 1, 0, 4, false, true);
+        case 36: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4, false, true);
+        case 32: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1, false, true);
+    }
+#undef CDB_RS_SPLIT
 }
 
 }  // namespace cdb

@@ -291,6 +291,25 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
 // ---------------------------------------------------------------------------------------------
 // group flags: bit0 = first entry of a group of equal prefixes, bit1 = still unresolved
 // ---------------------------------------------------------------------------------------------
+// k[0] = predecessor, k[1..4] = the four keys of slots i0..i0+3, k[5] = successor -> four flag bytes
+__device__ __forceinline__ uint32_t sa_flags_of(const uint64_t (&k)[6], uint64_t i0, uint64_t n, uint32_t kbase,
+                                                uint64_t kmagic) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t i = i0 + q;
+        if (i >= n) break;
+        const bool head = i == 0 || k[q] != k[q + 1];
+        const bool tail = i + 1 == n || k[q + 2] != k[q + 1];
+        // an end-of-document code (0) as the last symbol: key = 0 mod base.  kmagic = floor(2^64 / base) + 1
+        // makes the quotient one multiply (exact for keys < 2^56); 0 for a power-of-two base
+        const uint64_t kq = k[q + 1];
+        const bool exhausted = kmagic ? (kq - __umul64hi(kq, kmagic) * kbase) == 0 : (kq & (uint64_t)(kbase - 1u)) == 0;
+        out |= (uint32_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0)) << (8 * q);
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __restrict__ keys, uint64_t n,
                                                            uint32_t kbase, uint64_t kmagic,
                                                            uint8_t* __restrict__ flags, bool flags_aligned) {
@@ -309,20 +328,40 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
     }
     k[0] = i0 > 0 ? keys[i0 - 1] : ~k[1];
     k[5] = i0 + 4 < n ? keys[i0 + 4] : 0;
-    uint32_t out = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint64_t i = i0 + q;
-        if (i >= n) break;
-        const bool head = i == 0 || k[q] != k[q + 1];
-        const bool tail = i + 1 == n || k[q + 2] != k[q + 1];
-        // an end-of-document code (0) as the last symbol: key = 0 mod base.  kmagic = floor(2^64 / base) + 1
-        // makes the quotient one multiply (exact for keys < 2^56); 0 for a power-of-two base
-        const uint64_t kq = k[q + 1];
-        const bool exhausted = kmagic ? (kq - __umul64hi(kq, kmagic) * kbase) == 0 : (kq & (uint64_t)(kbase - 1u)) == 0;
-        out |= (uint32_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0)) << (8 * q);
-    }
+    const uint32_t out = sa_flags_of(k, i0, n, kbase, kmagic);
     if (flags_aligned && i0 + 4 <= n) {
+        *reinterpret_cast<uint32_t*>(flags + i0) = out;
+    } else {
+        for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
+    }
+}
+
+// the same for 32-bit keys, optionally extended by the separately stored low digit (split sort):
+// key = (k32 << low_bits) | low
+__global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __restrict__ k32,
+                                                             const uint8_t* __restrict__ low, int low_bits, uint64_t n,
+                                                             uint32_t kbase, uint64_t kmagic, uint8_t* __restrict__ flags) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    auto full = [&](uint64_t i) -> uint64_t {
+        return low ? (((uint64_t)k32[i] << low_bits) | (uint64_t)low[i]) : (uint64_t)k32[i];
+    };
+    uint64_t k[6];
+    if (i0 + 4 <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(k32 + i0);
+        const uint32_t hi[4] = {a.x, a.y, a.z, a.w};
+        const uint32_t l4 = low ? *reinterpret_cast<const uint32_t*>(low + i0) : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | (uint64_t)((l4 >> (8 * q)) & 0xFFu)) : (uint64_t)hi[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? full(i0 + q) : 0;
+    }
+    k[0] = i0 > 0 ? full(i0 - 1) : ~k[1];
+    k[5] = i0 + 4 < n ? full(i0 + 4) : 0;
+    const uint32_t out = sa_flags_of(k, i0, n, kbase, kmagic);
+    if (i0 + 4 <= n) {
         *reinterpret_cast<uint32_t*>(flags + i0) = out;
     } else {
         for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
@@ -710,8 +749,7 @@ void build_typed(Index& ix, bool big) {
         ix.d_sa.alloc(16);
         ix.sa_sorted = true;
         ix.pivot_levels = 0;
-        ix.d_keys.release();
-        ix.key_nsym = 0;
+        ix.drop_keys();
         return;
     }
     if (sizeof(R) == 4 && n + D + 2 >= (1ull << 32)) throw Error("internal: 32-bit ranks selected for a corpus >= 2^32");
@@ -846,7 +884,8 @@ void build_typed(Index& ix, bool big) {
     DevBuf sorted_keys, sa_buf, flags;
     SortStats ss;
     const bool fused = big || (ix.fuse_keygen && (dense || dbits == symbits) && nsym <= HC_MAXSYM &&
-                               (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1));
+                               (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1 ||
+                                ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32));
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
     if (fused && dense) {
@@ -902,10 +941,48 @@ void build_typed(Index& ix, bool big) {
             }
         }
     }
-    TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, kbase, nsym, ix.text_padded};
+    TextGen gen{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, kbase, nsym, 0, ix.text_padded};
     double ta = now_ms();
     flags.alloc(n);
-    if (!big) {
+    // Layout of the sort records.  WIDE: (u64 key, entry).  When the generated first pass can drop the digit it
+    // sorts on (it travels as one byte per element) and the rest of the key fits 32 bits, the other passes
+    // move 9 instead of 12 bytes per suffix (SPLIT); keys of <= 32 bits need no extra byte at all (NARROW).
+    enum { WIDE, NARROW, SPLIT } layout = WIDE;
+    if (fused && !big && sizeof(V) == 4 && ix.narrow_keys) {
+        if (key_bits <= 32) layout = NARROW;
+        else if (key_bits - dbits <= 32) layout = SPLIT;
+    }
+    st.key_layout = (int)layout;
+    DevBuf sorted_k32, sorted_low;
+    const int low_bits = layout == SPLIT ? dbits : 0;
+    if (!big && layout != WIDE) {
+        if constexpr (sizeof(V) == 4) {
+            DevBuf k32[2], vals[2], low[2];
+            k32[0].alloc(n * sizeof(uint32_t));
+            k32[1].alloc(n * sizeof(uint32_t));
+            vals[0].alloc(n * sizeof(V));
+            vals[1].alloc(n * sizeof(V));
+            if (layout == SPLIT) {
+                low[0].alloc(n);
+                low[1].alloc(n);
+            }
+            st.alloc_ms += now_ms() - ta;
+            int sel;
+            if (layout == SPLIT) {
+                gen.low_bits = low_bits;
+                sel = radix_sort_split<V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
+                                          vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n, key_bits - low_bits,
+                                          &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+                sorted_low = std::move(low[sel]);
+            } else {
+                sel = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
+                                              vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+            }
+            CDB_HIP(hipStreamSynchronize(s));
+            sorted_k32 = std::move(k32[sel]);
+            sa_buf = std::move(vals[sel]);
+        }
+    } else if (!big) {
         DevBuf keys[2], vals[2];
         keys[0].alloc(n * sizeof(uint64_t));
         keys[1].alloc(n * sizeof(uint64_t));
@@ -975,22 +1052,32 @@ void build_typed(Index& ix, bool big) {
     }
     if (!big) {  // (the bucket-wise sort writes the flags bucket by bucket)
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                           (const uint64_t*)sorted_keys.as<uint64_t>(), n, kbase, kmagic, flags.as<uint8_t>(), true);
-        ix.prof.end(t, "sa_initflags", n * 9, s);
+        if (layout == WIDE)
+            hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+                               (const uint64_t*)sorted_keys.as<uint64_t>(), n, kbase, kmagic, flags.as<uint8_t>(), true);
+        else
+            hipLaunchKernelGGL(sa_initflags32_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+                               (const uint32_t*)sorted_k32.as<uint32_t>(),
+                               layout == SPLIT ? (const uint8_t*)sorted_low.as<uint8_t>() : (const uint8_t*)nullptr, low_bits, n,
+                               kbase, kmagic, flags.as<uint8_t>());
+        ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : (layout == SPLIT ? 6 : 5)), s);
     }
     CDB_HIP(hipStreamSynchronize(s));
     ta = now_ms();
     // The sorted keys stay valid for the finished array: refinement only permutes entries inside groups
     // of equal keys.  They let a search probe decide on ONE load (query.hip) — kept when affordable.
-    ix.d_keys.release();
-    ix.key_nsym = 0;
+    ix.drop_keys();
     if (ix.keep_keys && !big && n * 8 <= (16ull << 30)) {
         ix.d_keys = std::move(sorted_keys);
+        ix.d_keys32 = std::move(sorted_k32);
+        ix.d_keylow = std::move(sorted_low);
+        ix.key_low_bits = low_bits;
         ix.key_nsym = nsym;
         ix.key_base = kbase;
     } else {
         sorted_keys.release();
+        sorted_k32.release();
+        sorted_low.release();
     }
     st.free_ms += now_ms() - ta;
     V* sa = sa_buf.as<V>();
@@ -1098,8 +1185,7 @@ void build_typed(Index& ix, bool big) {
     if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
     if (ix.reference_compat && high_bytes) {
         apply_reference_order<V>(ix, sa);
-        ix.d_keys.release();  // the rotations moved the entries away from their keys
-        ix.key_nsym = 0;
+        ix.drop_keys();  // the rotations moved the entries away from their keys
     }
     ix.d_sa = std::move(sa_buf);
 }
@@ -1124,8 +1210,7 @@ void build_suffix_array(Index& ix) {
         (void)hipStreamSynchronize(ix.stream);
         ix.prof.resolve();
         ix.d_sa.release();
-        ix.d_keys.release();
-        ix.key_nsym = 0;
+        ix.drop_keys();
         ix.width = 0;  // back to "never built": queries answer {} instead of touching a half-built array
         ix.size = 0;
         throw;

@@ -53,6 +53,7 @@ def test_fuzz_parity(seed):
     elif rng.random() < 0.5: opts["key_coding"] = int(rng.choice([1, 2]))
     if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26]))
     if rng.random() < 0.2: opts["keep_keys"] = 0
+    if rng.random() < 0.3: opts["narrow_keys"] = 0
     if rng.random() < 0.2: opts["fast_search"] = 0
     if rng.random() < 0.2: opts["wave_rows"] = 0
     o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
