@@ -25,12 +25,16 @@ def find(sub, pat):
 
 def family(name):
     """rocprof kernel name -> the library profiler's name for the same instantiation."""
-    m = re.search(r"rs_onesweep_kernel<unsigned long, (unsigned int|unsigned long|cdb::NoVal), cdb::RsCfg<(\d+), \w+, \w+, (\d+)", name)
+    m = re.search(r"rs_onesweep_kernel<(unsigned int|unsigned long), (unsigned int|unsigned long|cdb::NoVal), "
+                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|cdb::NoVal)>", name)
     if m:
-        v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(1)]
-        tile = int(m.group(2)) * int(m.group(3))
-        gen = "textgen" if "TextGen" in name else "k64" + v
-        return f"rs_onesweep_{gen}_t{tile}"
+        k = {"unsigned int": "k32", "unsigned long": "k64"}[m.group(1)]
+        v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(2)]
+        tile = int(m.group(3)) * int(m.group(4))
+        split = m.group(6) == "unsigned char"
+        if m.group(5) == "TextGen":
+            return f"rs_onesweep_textgen{'_split' if split else ''}_t{tile}"
+        return f"rs_onesweep_{k}{v}{'_w8' if split else ''}_t{tile}"
     m = re.search(r"(?:cdb::(?:\(anonymous namespace\)::)?)(\w+?)(?:_kernel)?[<(]", name)
     return m.group(1) if m and "cdb::" in name else name.split("(")[0][:48]
 
