@@ -795,7 +795,7 @@ void build_typed(Index& ix, bool big) {
         const int passes = std::min(ix.initial_passes, 8);
         nsym = std::min((8 * passes) / symbits, 64 / symbits);
     } else if (n >= (1ull << 24)) {
-        const uint64_t S = 1ull << 22;
+        const uint64_t S = n >= (1ull << 32) ? 1ull << 22 : 1ull << 21;  // S^2 / 2 sample pairs must resolve 1 / (64 n)
         DevBuf sk0, sk1, d_eq;
         sk0.alloc(S * 8);
         sk1.alloc(S * 8);
