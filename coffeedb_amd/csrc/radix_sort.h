@@ -828,27 +828,11 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 31: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true);
             case 36: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4, false, true);
             case 32: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1, false, true);
-            // kept for A/B measurements (tools/sort_bench.py, profiles/): earlier design points
-            case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);   // round-1 first version
-            case 3: CDB_RS(18, true, true, 256, false, 1, 0, 1);
-            case 7: CDB_RS(12, true, true, 512, false, 1, 0, 1);
-            case 11: CDB_RS(16, true, true, 1024, false, 1, 0, 1);
-            case 12: CDB_RS(16, true, true, 512, false, 4, 0, 1);
-            case 41: CDB_RS(16, true, true, 1024, false, 1, 0, 4, true);   // 16 Ki tile, LDS-DMA loads
-            case 42: CDB_RS(16, true, true, 512, false, 4, 0, 4, true);    // 8 Ki tile, LDS-DMA loads
-            case 43: CDB_RS(12, true, true, 256, false, 1, 0, 4, true);    // 3 Ki tile, LDS-DMA loads
-            case 13: CDB_RS(16, true, true, 512, false, 4, 0, 4);    // 8 Ki-key tile, 2 WG/CU
-            case 14: CDB_RS(12, true, true, 512, false, 1, 0, 4);    // 6 Ki-key tile, 2 WG/CU
-            case 15: CDB_RS(14, true, true, 1024, false, 1, 0, 4);   // 14 Ki-key tile
-            case 22: CDB_RS(16, true, true, 1024, false, 1, 0, 8);
-            case 23: CDB_RS(16, true, true, 1024, false, 1, 0, 16);
-            case 24: CDB_RS(16, true, true, 1024, false, 1, 0, 2);
-            case 10: CDB_RS(18, true, true, 256, true, 1, 0, 1);     // non-temporal loads/stores
-            // timing-only ablations (results are WRONG by construction; never used by the product path)
-            case 101: CDB_RS(16, true, true, 1024, false, 1, 1, 1);  // no look-back
-            case 102: CDB_RS(16, true, true, 1024, false, 1, 2, 1);  // linear write-out
-            case 103: CDB_RS(16, true, true, 1024, false, 1, 3, 1);  // both
-            case 114: CDB_RS(16, true, true, 1024, false, 1, 8, 4);  // look-back depth counters
+            // kept for A/B measurements (tools/sort_bench.py): the first version and the LDS-DMA load path; the other
+            // design points that were measured (tile shapes, look-back depths, non-temporal accesses, timing
+            // ablations) are recorded in DESIGN.md §4.1
+            case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);        // round-1 first version
+            case 41: CDB_RS(16, true, true, 1024, false, 1, 0, 4, true);  // 16 Ki tile, LDS-DMA loads, ballot ranking
         }
 #undef CDB_RS
 #undef CDB_RS_GEN

@@ -4,7 +4,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [0, 21, 26, 1, 4, 3, 7, 11, 12, 22, 10, 23, 24, 41, 42, 43])
+@pytest.mark.parametrize("variant", [0, 21, 26, 1, 31, 36, 32, 4, 41])
 @pytest.mark.parametrize("val_bytes", [4, 8, 0])
 def test_radix_sort_matches_stable_sort(variant, val_bytes):
     import torch
@@ -12,7 +12,10 @@ def test_radix_sort_matches_stable_sort(variant, val_bytes):
     if val_bytes == 0 and variant != 0:
         pytest.skip("key-only sort has one configuration")
     g = torch.Generator(device="cuda").manual_seed(1234 + variant)
-    for n, bits in ((1, 8), (255, 13), (4097, 40), (100_003, 61), (1_000_000, 24), (300_000, 64)):
+    # (bits 3 / 1: eight values / one value — every lane of a wave lands on the same few counters, the
+    #  worst case for the one-atomic ranking, whose stability rests on lane-ordered LDS atomics)
+    for n, bits in ((1, 8), (255, 13), (4097, 40), (100_003, 61), (1_000_000, 24), (300_000, 64), (500_000, 3),
+                    (200_000, 1)):
         hi = (1 << min(bits, 62)) - 1
         keys = torch.randint(0, hi, (n,), dtype=torch.int64, device="cuda", generator=g)
         if bits == 24:
