@@ -23,7 +23,7 @@ struct BuildStats {
     int sort_passes_skipped = 0;
     int isa_built = 0;
     int fused_keygen = 0;
-    int key_layout = 0;          // sort records: 0 = (u64 key, entry), 1 = (u32 key, entry), 2 = (u32 key, entry, u8 low digit)
+    int key_layout = 0;          // sort records: 0 = (u64 key, entry), 1 = (u32 key, entry), 2 / 3 = (u32 key, entry, u8 / u16 low digits)
     int dense_keys = 0;          // initial keys in base (alphabet + 1) instead of bit-aligned symbols
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -75,7 +75,8 @@ struct Index {
                                       // suffix, packed) kept for the search: one load decides most probes
     DevBuf d_symmap_q;                // byte -> symbol code (u16[256]) matching d_keys
     DevBuf d_keys32, d_keylow;        // ... or, after a narrow / split sort, key >> key_low_bits as u32 and (split) the
-    int key_low_bits = 0;             // low digit as one byte per suffix: 5 instead of 8 bytes per suffix
+    int key_low_bits = 0;             // low digit(s) in one or two bytes per suffix: 5-6 instead of 8 bytes per suffix
+    int key_low_bytes = 0;
     int key_nsym = 0;
     uint32_t key_base = 0;            // key = the first key_nsym symbol codes as a number in this base
     void drop_keys() {
@@ -84,6 +85,7 @@ struct Index {
         d_keylow.release();
         key_nsym = 0;
         key_low_bits = 0;
+        key_low_bytes = 0;
     }
     DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
     int pivot_levels = 0;

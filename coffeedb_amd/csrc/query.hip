@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                                                             const Pivot* __restrict__ piv, int levels,
                                                             const uint64_t* __restrict__ keys64,
                                                             const uint32_t* __restrict__ keys32,
-                                                            const uint8_t* __restrict__ keylow, int low_bits,
+                                                            const void* __restrict__ keylow, int low_bits, int low_bytes,
                                                             const uint16_t* __restrict__ symmap, int nsym, uint32_t kbase,
                                                             int64_t* __restrict__ left_out,
                                                             uint64_t* __restrict__ hits_out) {
@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                 if (h < a) return -1;
                 if (h > b) return 1;
                 if (h > a && h < b) return 0;
-                sk = (h << low_bits) | (uint64_t)keylow[M];
+                sk = (h << low_bits) | (low_bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(keylow)[M]
+                                                        : (uint64_t)static_cast<const uint16_t*>(keylow)[M]);
             } else {
                 sk = h;
             }
@@ -464,8 +465,8 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
                            ix.pivot_levels,
                            ix.key_nsym && ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
                            ix.key_nsym && ix.d_keys32.p ? (const uint32_t*)ix.d_keys32.as<uint32_t>() : (const uint32_t*)nullptr,
-                           ix.key_nsym && ix.d_keylow.p ? (const uint8_t*)ix.d_keylow.as<uint8_t>() : (const uint8_t*)nullptr,
-                           ix.key_low_bits, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
+                           ix.key_nsym && ix.d_keylow.p ? (const void*)ix.d_keylow.p : (const void*)nullptr, ix.key_low_bits,
+                           ix.key_low_bytes, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
                            ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
     } else {
         hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,

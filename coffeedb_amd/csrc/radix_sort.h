@@ -190,18 +190,18 @@ static __global__ __launch_bounds__(256) void rs_tiledoc_kernel(const uint64_t* 
     tile_doc[t] = rs_doc_upper(doc_start, 0, ndocs - 1, p);
 }
 
-// W (optional) = one auxiliary byte per element that travels with the pair (the already sorted low digit of
-// a split key, see TextGen::low_bits); in the generated pass it IS the digit being sorted.
+// W (optional, u8 or u16) = auxiliary low digits of a split key that travel with the pair (TextGen::low_bits);
+// aux_shift >= 0 makes this pass sort on (aux >> aux_shift) & dmask instead of a key digit (the leading
+// passes of a split sort: the first, generated one, and for two low digits the one after it).
 template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
     uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen(),
-    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr) {
+    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr, int aux_shift = -1) {
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
-    constexpr bool DIGW = GEN && HAS_W;  // the digit of this pass is the auxiliary byte
     using WS = typename std::conditional<HAS_W, W, uint8_t>::type;
     static_assert(!HAS_W || (Cfg::REUSE && HAS_V && !Cfg::DMA), "the auxiliary byte needs the shared-staging configuration");
     constexpr int IPT = Cfg::IPT;
@@ -238,7 +238,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
     K key[IPT];
     VS val[EARLYV ? IPT : 1];
-    WS aux[HAS_W ? IPT : 1];
+    WS aux[HAS_W ? IPT : 1] = {};
+    auto digit_of = [&](K k, WS a) -> uint32_t {
+        if constexpr (HAS_W) {
+            if (aux_shift >= 0) return ((uint32_t)a >> aux_shift) & dmask;
+        }
+        return (uint32_t)(k >> shift) & dmask;
+    };
     const uint32_t wbase = wave * WCHUNK + lane;
     if constexpr (GEN) {
         static_assert(!GEN || EARLYV, "generator pass needs early values");
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
-            const uint32_t d = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
+            const uint32_t d = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
             rank[j] = atomicAdd(&s_whist[wave][d], 1u);
         }
     } else {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         const uint32_t li = wbase + j * 64;
         // out-of-range slots take digit 255: they have the largest indices of the tile, so they end
         // up behind every real element and are simply not written out.
-        const uint32_t d = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
+        const uint32_t d = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
-        const uint32_t dd = li < valid ? (DIGW ? (uint32_t)aux[j] : ((uint32_t)(key[j] >> shift) & dmask)) : 255u;
+        const uint32_t dd = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             dig[j] = 0;
             if (i < valid) {
                 const K k = s_keys[i];
-                const uint32_t dd = DIGW ? (uint32_t)s_aux[i] : ((uint32_t)(k >> shift) & dmask);
+                const uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
                 dig[j] = (uint8_t)dd;
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
                 if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
@@ -699,13 +705,15 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
-    // split keys: pass 0 is generated and sorts on the auxiliary byte (the key's lowest digit); the passes
-    // over the key bits [begin_bit, end_bit) follow.  h_hist_in then has one leading row for that digit.
-    constexpr int LEAD = (GEN && HAS_W) ? 1 : 0;
-    static_assert(!HAS_W || GEN, "auxiliary bytes only exist behind a generated split pass");
+    // split keys: the first `lead` passes (the generated one first) sort on the auxiliary low digits; the
+    // passes over the key bits [begin_bit, end_bit) follow.  h_hist_in then has `lead` leading rows.
+    static_assert(!HAS_W || GEN, "auxiliary digits only exist behind a generated split pass");
+    if (dbits < 1 || dbits > 8) dbits = 8;
+    int lead = 0;
+    if constexpr (GEN && HAS_W) lead = gen->low_bits / dbits;
+    const int LEAD = lead;
     if (n == 0 || end_bit < begin_bit || (!LEAD && end_bit == begin_bit)) return 0;
     const int nbits = end_bit - begin_bit;
-    if (dbits < 1 || dbits > 8) dbits = 8;
     const int kpass = (int)ceil_div(nbits, dbits);  // passes over the key proper
     const int npass = kpass + LEAD;
     if (npass > RS_MAX_PASSES) throw Error("radix_sort: too many passes requested");
@@ -746,13 +754,14 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
         for (int d = 0; d < 256; ++d)
             if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
         // (the leading pass of a split sort always runs: it is the one that produces the auxiliary bytes)
-        if (trivial && (materialised || p + 1 < npass) && !(LEAD && p == 0)) {
+        if (trivial && (materialised || p + 1 < npass) && !(LEAD > 0 && p == 0)) {
             if (stats) stats->passes_skipped++;
             continue;
         }
         const uint32_t e = ws.next_epoch(s);
         const uint32_t dmask = p == npass - 1 && kpass ? last_mask : ((1u << dbits) - 1u);
-        const int shift = begin_bit + dbits * (p - LEAD);  // (unused by the leading pass of a split sort)
+        const int shift = begin_bit + dbits * (p - LEAD);  // (unused by the leading passes of a split sort)
+        const int aux_shift = p < LEAD ? dbits * p : -1;
         int t = prof.begin(s);
         if (!materialised) {
             if constexpr (GEN) {
@@ -764,7 +773,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                 hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
                                    (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vb[cur ^ 1], n, shift, dmask,
                                    (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
-                                   ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1]);
+                                   ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift);
             }
             prof.end(t, (std::string("rs_onesweep_textgen") + (HAS_W ? "_split" : "") + "_t" + std::to_string(TILE)).c_str(),
                      n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0)), s);
@@ -773,8 +782,8 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
             hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
                                (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, shift, dmask,
                                (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(), ws.ticket_ptr(e), e,
-                               ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1]);
-            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? "_w8" : "") + "_t" + std::to_string(TILE)).c_str(),
+                               ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift);
+            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : "_w16") : "") + "_t" + std::to_string(TILE)).c_str(),
                      2 * n * pair_bytes, s);
         }
         cur ^= 1;
@@ -853,12 +862,13 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
     }
 }
 
-// Split sort for keys of up to 32 + low_bits bits whose lowest digit the generated first pass sorts on and
-// then drops from the key: the remaining passes move (u32 key >> low_bits, value, u8 low digit) = 9 bytes
-// per element instead of 12 for a (u64, u32) pair.  h_hist = [1 + passes over hi_bits][256].
-template <typename V>
+// Split sort for keys of up to 32 + low_bits bits: the lowest one or two digits (W = u8 / u16, gen->low_bits =
+// digits x dbits) are sorted first — the generated pass takes the lowest — and dropped from the key, so the
+// remaining passes move (u32 key >> low_bits, value, W) = 9 or 10 bytes per element instead of 12 for a
+// (u64, u32) pair.  h_hist = [all passes][256], lowest digit first.
+template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
-                     uint8_t* w0, uint8_t* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
+                     W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
                      const uint64_t* h_hist, const TextGen* gen) {
     const bool atomrank = rs_atomic_rank_ok(s);
     if (variant == 0)
@@ -866,7 +876,7 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
                            : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
     if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
 #define CDB_RS_SPLIT(...)                                                                                              \
-    return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, uint8_t>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits, \
+    return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits,       \
                                                                              stats, dbits, h_hist, gen, w0, w1)
     switch (variant) {
         default:

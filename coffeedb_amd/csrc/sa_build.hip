@@ -338,8 +338,9 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
 
 // the same for 32-bit keys, optionally extended by the separately stored low digit (split sort):
 // key = (k32 << low_bits) | low
+template <typename W>
 __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __restrict__ k32,
-                                                             const uint8_t* __restrict__ low, int low_bits, uint64_t n,
+                                                             const W* __restrict__ low, int low_bits, uint64_t n,
                                                              uint32_t kbase, uint64_t kmagic, uint8_t* __restrict__ flags) {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
@@ -350,10 +351,13 @@ __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __r
     if (i0 + 4 <= n) {
         const uint4 a = *reinterpret_cast<const uint4*>(k32 + i0);
         const uint32_t hi[4] = {a.x, a.y, a.z, a.w};
-        const uint32_t l4 = low ? *reinterpret_cast<const uint32_t*>(low + i0) : 0u;
+        W l4[4] = {};
+        if (low) {
+            if constexpr (sizeof(W) == 1) *reinterpret_cast<uint32_t*>(l4) = *reinterpret_cast<const uint32_t*>(low + i0);
+            else *reinterpret_cast<uint2*>(l4) = *reinterpret_cast<const uint2*>(low + i0);
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | (uint64_t)((l4 >> (8 * q)) & 0xFFu)) : (uint64_t)hi[q];
+        for (int q = 0; q < 4; ++q) k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | (uint64_t)l4[q]) : (uint64_t)hi[q];
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? full(i0 + q) : 0;
@@ -947,14 +951,16 @@ void build_typed(Index& ix, bool big) {
     // Layout of the sort records.  WIDE: (u64 key, entry).  When the generated first pass can drop the digit it
     // sorts on (it travels as one byte per element) and the rest of the key fits 32 bits, the other passes
     // move 9 instead of 12 bytes per suffix (SPLIT); keys of <= 32 bits need no extra byte at all (NARROW).
-    enum { WIDE, NARROW, SPLIT } layout = WIDE;
+    enum { WIDE, NARROW, SPLIT, SPLIT2 } layout = WIDE;
     if (fused && !big && sizeof(V) == 4 && ix.narrow_keys) {
         if (key_bits <= 32) layout = NARROW;
         else if (key_bits - dbits <= 32) layout = SPLIT;
+        else if (key_bits - 2 * dbits <= 32) layout = SPLIT2;  // two low digits in a u16: 10 bytes per suffix
     }
     st.key_layout = (int)layout;
     DevBuf sorted_k32, sorted_low;
-    const int low_bits = layout == SPLIT ? dbits : 0;
+    const int low_bits = layout == SPLIT ? dbits : (layout == SPLIT2 ? 2 * dbits : 0);
+    const int low_bytes = layout == SPLIT ? 1 : (layout == SPLIT2 ? 2 : 0);
     if (!big && layout != WIDE) {
         if constexpr (sizeof(V) == 4) {
             DevBuf k32[2], vals[2], low[2];
@@ -962,17 +968,23 @@ void build_typed(Index& ix, bool big) {
             k32[1].alloc(n * sizeof(uint32_t));
             vals[0].alloc(n * sizeof(V));
             vals[1].alloc(n * sizeof(V));
-            if (layout == SPLIT) {
-                low[0].alloc(n);
-                low[1].alloc(n);
+            if (low_bytes) {
+                low[0].alloc(n * low_bytes);
+                low[1].alloc(n * low_bytes);
             }
             st.alloc_ms += now_ms() - ta;
             int sel;
             if (layout == SPLIT) {
                 gen.low_bits = low_bits;
-                sel = radix_sort_split<V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
-                                          vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n, key_bits - low_bits,
-                                          &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+                sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
+                                                   vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n,
+                                                   key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+                sorted_low = std::move(low[sel]);
+            } else if (layout == SPLIT2) {
+                gen.low_bits = low_bits;
+                sel = radix_sort_split<V, uint16_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
+                                                    vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint16_t>(), low[1].as<uint16_t>(),
+                                                    n, key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
                 sorted_low = std::move(low[sel]);
             } else {
                 sel = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
@@ -1055,12 +1067,16 @@ void build_typed(Index& ix, bool big) {
         if (layout == WIDE)
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                                (const uint64_t*)sorted_keys.as<uint64_t>(), n, kbase, kmagic, flags.as<uint8_t>(), true);
+        else if (layout == SPLIT2)
+            hipLaunchKernelGGL(sa_initflags32_kernel<uint16_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+                               (const uint32_t*)sorted_k32.as<uint32_t>(), (const uint16_t*)sorted_low.as<uint16_t>(), low_bits, n,
+                               kbase, kmagic, flags.as<uint8_t>());
         else
-            hipLaunchKernelGGL(sa_initflags32_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+            hipLaunchKernelGGL(sa_initflags32_kernel<uint8_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                                (const uint32_t*)sorted_k32.as<uint32_t>(),
                                layout == SPLIT ? (const uint8_t*)sorted_low.as<uint8_t>() : (const uint8_t*)nullptr, low_bits, n,
                                kbase, kmagic, flags.as<uint8_t>());
-        ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : (layout == SPLIT ? 6 : 5)), s);
+        ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : 5 + low_bytes), s);
     }
     CDB_HIP(hipStreamSynchronize(s));
     ta = now_ms();
@@ -1072,6 +1088,7 @@ void build_typed(Index& ix, bool big) {
         ix.d_keys32 = std::move(sorted_k32);
         ix.d_keylow = std::move(sorted_low);
         ix.key_low_bits = low_bits;
+        ix.key_low_bytes = low_bytes;
         ix.key_nsym = nsym;
         ix.key_base = kbase;
     } else {

@@ -109,13 +109,14 @@ def test_fused_and_materialised_first_pass_agree(G, opts):
 
 @pytest.mark.parametrize("narrow", [1, 0])
 def test_sort_record_layouts(G, narrow):
-    # (u64 key, entry) records, or — when the generated first pass may drop the digit it sorts on — (u32 key,
-    # entry, u8 low digit) / plain (u32 key, entry); the kept keys (search probes) follow the layout
+    # (u64 key, entry) records, or — when the leading passes may drop the digits they sort on — (u32 key,
+    # entry, u8 / u16 low digits) / plain (u32 key, entry); the kept keys (search probes) follow the layout
     seen = set()
     for blob, ds, miss, opts in ((W.ascii_corpus(6000, 350, seed=21) + (0x7F, dict(key_coding=2))),         # dense, 6 symbols = 40 bits: split
                                  (W.ascii_corpus(3000, 333, seed=2) + (0x7F, dict(key_coding=2))),          # dense, <= 32 bits: narrow
                                  (W.ascii_corpus(3000, 333, seed=2) + (0x7F, dict(initial_passes=5))),      # 5 x 7 bits, digit 7: split
-                                 (W.ascii_corpus(3000, 333, seed=2) + (0x7F, dict(initial_passes=6))),      # 6 x 7 bits: wide
+                                 (W.ascii_corpus(3000, 333, seed=2) + (0x7F, dict(initial_passes=6))),      # 6 x 7 bits: two low digits in a u16
+                                 (W.ascii_corpus(3000, 333, seed=2) + (0x7F, dict(initial_passes=8))),      # 9 x 7 bits: wide
                                  (W.ascii_corpus(300, 333, seed=2) + (0x7F, dict(key_coding=1))),
                                  (W.ragged_corpus(20000, 90, seed=15, empty_every=13) + (0x7B, dict(key_coding=2))),
                                  (W.zipf_corpus(2000, 256, seed=2) + (0x2F, dict(key_coding=2))),
@@ -127,7 +128,7 @@ def test_sort_record_layouts(G, narrow):
             assert g.query(kw) == o.query(kw), kw
         v = g.verify()
         assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0
-    assert {l for l, _ in seen} == ({0, 1, 2} if narrow else {0}), seen
+    assert {l for l, _ in seen} == ({0, 1, 2, 3} if narrow else {0}), seen
     assert not narrow or (2, 1) in seen, seen   # a dense split sort is among the cases
 
 

@@ -48,8 +48,9 @@ ids = np.arange(nd, dtype=np.int64)
 torch.cuda.synchronize()
 for compat in (0, 1):
     g = capi.GpuStringIndex(); g.set_option("profile", 1); g.set_option("reference_compat", compat)
-    for rep in range(2):
+    for rep in range(4):
         g.profile_reset(); t = time.time(); g.build_device(text.data_ptr(), ds, ids); w = time.time() - t
+        print(f"   rep {rep}: {w*1e3:.1f} ms", flush=True)
     print(f"compat={compat}: build {w*1e3:.1f} ms = {n/2**30/w:.2f} GiB/s width={g.sa_width} nsym={g.stat('key_symbols'):.0f} symbits={g.stat('symbol_bits'):.0f} alphabet={g.stat('alphabet'):.0f} "
           f"fused={g.stat('fused_keygen'):.0f} bucketed={g.stat('bucketed'):.0f} rounds={g.stat('rounds'):.0f} ext={g.stat('ext_rounds'):.0f} dbl={g.stat('dbl_rounds'):.0f} unres0={g.stat('unresolved_after_initial'):.0f} "
           f"passes={g.stat('sort_passes'):.0f} rotations={g.stat('compat_rotations'):.0f} depth={g.stat('compat_depth'):.0f}", flush=True)
