@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
 _LIB = None
 
 EXPORTS = [
-    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
@@ -80,6 +80,7 @@ def load_library():
     lib.cdb_load.argtypes = [vp, cp]
     lib.cdb_build.argtypes = [vp]
     lib.cdb_build_device.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_build_resident.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                               C.POINTER(C.c_size_t)]
     lib.cdb_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
@@ -173,6 +174,11 @@ class GpuStringIndex:
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
         self._check(self._lib.cdb_build_device(self._h, C.c_void_p(d_text_ptr), _ptr(doc_start), _ptr(ids), len(ids)))
+
+    def build_resident(self, d_text_ptr, d_doc_start_ptr, d_ids_ptr, ndocs):
+        """Build over text AND document tables that already live in device memory (u64[ndocs+1], i64[ndocs])."""
+        self._check(self._lib.cdb_build_resident(self._h, C.c_void_p(d_text_ptr), C.c_void_p(d_doc_start_ptr),
+                                                 C.c_void_p(d_ids_ptr), int(ndocs)))
 
     def query(self, kw: bytes):
         ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)

@@ -74,7 +74,53 @@ void upload_tables(Index& ix) {
 
 void set_device(Index& ix) { CDB_HIP(hipSetDevice(ix.device)); }
 
+// resident build: longest document, order check and re-basing of the caller's device tables
+__global__ __launch_bounds__(256) void layout_kernel(const uint64_t* __restrict__ src_start,
+                                                     const int64_t* __restrict__ src_ids, uint64_t ndocs,
+                                                     uint64_t* __restrict__ dst_start, int64_t* __restrict__ dst_ids,
+                                                     unsigned long long* __restrict__ out /*[2]: max len, disorder*/) {
+    __shared__ unsigned long long s_max[4];
+    const uint64_t base = src_start[0];
+    uint64_t mx = 0, bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d <= ndocs; d += stride) {
+        const uint64_t a = src_start[d];
+        dst_start[d] = a - base;
+        if (d < ndocs) {
+            const uint64_t b = src_start[d + 1];
+            if (b < a) bad = 1;
+            else mx = b - a > mx ? b - a : mx;
+            dst_ids[d] = src_ids[d];
+        }
+    }
+    for (int off = 32; off; off >>= 1) {
+        const uint64_t o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+        bad |= __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+    if (bad && (threadIdx.x & 63) == 0) atomicExch(out + 1, 1ull);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) mx = s_max[w] > mx ? s_max[w] : mx;
+        atomicMax(out, (unsigned long long)mx);
+    }
+}
+
 }  // namespace
+
+namespace cdb {
+void ensure_host_tables(Index& ix) {
+    if (ix.host_tables_valid) return;
+    hipStream_t s = ix.stream;
+    ix.ids.resize(ix.ndocs);
+    ix.doc_start.resize(ix.ndocs + 1);
+    if (ix.ndocs) CDB_HIP(hipMemcpyAsync(ix.ids.data(), ix.d_ids.p, ix.ndocs * 8, hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipMemcpyAsync(ix.doc_start.data(), ix.d_doc_start.p, (ix.ndocs + 1) * 8, hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    ix.host_tables_valid = true;
+}
+}  // namespace cdb
 
 extern "C" {
 
@@ -212,6 +258,7 @@ int cdb_save(cdb_index* h, const char* path) {
         std::lock_guard<std::mutex> g(ix.mu);
         set_device(ix);
         if (ix.width == 0) throw Error("index has not been built");
+        ensure_host_tables(ix);
         FILE* fp = std::fopen(path, "wb");
         if (!fp) throw Error(std::string("Cannot open file: ") + path);
         struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
@@ -324,6 +371,56 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
         if (doc_start[0] & 15u) throw Error("first document must start 16-byte aligned");
         ix.text_padded = false;
         upload_tables(ix);
+        build_suffix_array(ix);
+    });
+}
+
+int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_start, const int64_t* d_ids,
+                       uint64_t ndocs) {
+    if (!h || !d_doc_start || (ndocs && !d_ids)) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        set_device(ix);
+        if (((uintptr_t)d_text & 15u) != 0) throw Error("device text must be 16-byte aligned");
+        hipStream_t s = ix.stream;
+        DevBuf d_start, d_id, d_out;
+        d_start.alloc((ndocs + 1) * sizeof(uint64_t));
+        d_id.alloc(std::max<uint64_t>(ndocs, 1) * sizeof(int64_t));
+        d_out.alloc(2 * sizeof(uint64_t));
+        CDB_HIP(hipMemsetAsync(d_out.p, 0, 2 * sizeof(uint64_t), s));
+        const int grid = (int)std::min<uint64_t>(ceil_div(ndocs + 1, 256), 1024);
+        hipLaunchKernelGGL(layout_kernel, dim3(grid), dim3(256), 0, s, d_doc_start, d_ids, ndocs, d_start.as<uint64_t>(),
+                           d_id.as<int64_t>(), d_out.as<unsigned long long>());
+        uint64_t out[2] = {0, 0}, first = 0, total = 0;
+        CDB_HIP(hipMemcpyAsync(out, d_out.p, sizeof(out), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipMemcpyAsync(&first, d_doc_start, 8, hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipMemcpyAsync(&total, d_start.as<uint64_t>() + ndocs, 8, hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        if (out[1]) throw Error("doc_start must be non-decreasing");
+        if (first != 0) throw Error("d_doc_start[0] must be 0");
+        // bits / mask / size / entry width exactly as index.cpp:182-208
+        uint64_t mask1 = 1, mask2 = 1;
+        while (mask1 < ndocs) mask1 = (mask1 << 1) + 1;
+        while (mask2 < out[0]) mask2 = (mask2 << 1) + 1;
+        const int bits1 = __builtin_popcountll(mask1), bits2 = __builtin_popcountll(mask2);
+        if (bits1 + bits2 > 64) throw Error("The amount of data exceeds the maximum range that CoffeeDB can handle");
+        if (bits1 > 32) throw Error("The number of objects exceeds the maximum range that CoffeeDB can handle");
+        ix.size = total;
+        ix.mask = mask1;
+        ix.bits = (uint64_t)bits1;
+        ix.width = bits1 + bits2 <= 32 ? 4 : 8;
+        ix.off_bits = bits2;
+        ix.ndocs = ndocs;
+        ix.ids.clear();
+        ix.doc_start.assign(1, 0);
+        ix.host_text.clear();
+        ix.host_tables_valid = false;
+        ix.d_text_owned.release();
+        ix.d_text = static_cast<const uint8_t*>(d_text);
+        ix.text_padded = false;
+        ix.d_doc_start = std::move(d_start);
+        ix.d_ids = std::move(d_id);
         build_suffix_array(ix);
     });
 }

@@ -55,6 +55,7 @@ struct Index {
     std::vector<int64_t> ids;
     std::vector<uint64_t> doc_start{0};
     std::string host_text;
+    bool host_tables_valid = true;  // false after cdb_build_resident until ids / doc_start are fetched back
 
     // ---- reference-visible parameters (src/index.h:56-57)
     uint64_t bits = 1, mask = 1, size = 0;
@@ -112,6 +113,9 @@ struct Index {
     QueryStats qstats;
     std::string err;
 };
+
+// capi.hip — ids / doc_start on the host (fetched from the device after a resident build)
+void ensure_host_tables(Index& ix);
 
 // sa_build.hip
 void build_suffix_array(Index& ix);

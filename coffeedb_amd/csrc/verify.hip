@@ -78,6 +78,7 @@ void verify_suffix_array(Index& ix, uint64_t out[5]) {
     CDB_HIP(hipMemcpyAsync(out, d_out.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
     // closed-form wrapped sum of all (off << bits) | doc entries
+    ensure_host_tables(ix);
     uint64_t expect = 0;
     for (uint64_t d = 0; d < ix.ndocs; ++d) {
         const uint64_t len = ix.doc_start[d + 1] - ix.doc_start[d];

@@ -97,6 +97,12 @@ int cdb_build(cdb_index* h);
 int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start, const int64_t* ids,
                      uint64_t ndocs);
 
+/* The same with the document table resident as well: d_doc_start (ndocs + 1 offsets into d_text, d_doc_start[0]
+ * = 0) and d_ids are DEVICE arrays; they are validated and copied on the device, nothing but a few scalars
+ * crosses PCIe.  (Host copies of the tables are fetched lazily if cdb_save / cdb_add* need them later.) */
+int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_start, const int64_t* d_ids,
+                       uint64_t ndocs);
+
 /* ---- query ----------------------------------------------------------------------------------- */
 
 /* replaces string_index::query(const std::string& keyword) (src/index.cpp:237-326).  On success

@@ -526,3 +526,39 @@ def test_rebuild_after_more_adds(G):
     g.add(2, b"foo")
     g.build()
     assert g.query(b"o") == [(1, 2), (2, 2)]
+
+
+def test_resident_build_equals_host_table_build(G, tmp_path):
+    # cdb_build_resident: text, doc_start and ids all in device memory; same index as cdb_build_device,
+    # host copies of the tables come back lazily (verify / save)
+    import torch
+    blob, ds = W.ragged_corpus(5000, 200, seed=31, empty_every=7)
+    ids = np.arange(len(ds) - 1, dtype=np.int64) * 7 - 3
+    o = _oracle(blob, ds, ids)
+    pad = np.zeros(16, dtype=np.uint8)
+    d_text = torch.from_numpy(np.concatenate([blob, pad])).cuda()
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_ids = torch.from_numpy(ids).cuda()
+    torch.cuda.synchronize()
+    g = G()
+    g.build_resident(d_text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), len(ids))
+    assert (g.size, g.bits, g.mask, g.sa_width) == (o.size, o.bits, o.mask, o.sa_width)
+    assert np.array_equal(g.sa(), o.sa())
+    pats = W.sample_patterns(blob, ds, 300, 1, 9, seed=2, miss_byte=0x7B)
+    got, want = g.query_batch(*pats), o.query_batch(*pats)
+    assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3]))
+    v = g.verify()
+    assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
+    path = tmp_path / "resident.cdb"
+    g.save(path)
+    g2 = G()
+    g2.load(path)
+    assert np.array_equal(g2.sa(), o.sa()) and g2.query(bytes(blob[3:6])) == o.query(bytes(blob[3:6]))
+    # a table that runs backwards is refused, and the handle stays usable
+    bad = d_ds.clone()
+    bad[5] = bad[6] + 1
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="non-decreasing"):
+        g.build_resident(d_text.data_ptr(), bad.data_ptr(), d_ids.data_ptr(), len(ids))
+    g.build_resident(d_text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), len(ids))
+    assert np.array_equal(g.sa(), o.sa())
