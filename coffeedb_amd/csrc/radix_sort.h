@@ -146,7 +146,7 @@ constexpr int RS_GEN_LOOK = 64;
 // at or behind the end of the document (rem symbols left) count as 0.  Four codes at a time are combined
 // with 32-bit operations (base <= 256, so four of them stay below 2^32).
 __device__ __forceinline__ uint64_t rs_pack_key(const uint32_t* __restrict__ s_words, uint32_t li, int nsym, uint32_t base,
-                                                uint64_t rem) {
+                                                uint32_t rem) {
     const uint32_t wi = li >> 2, sel = li & 3u;
     const uint32_t b2 = base * base, b3 = b2 * base;
     const uint32_t pw[5] = {1u, base, b2, b3, b3 * base};  // pw[4] wraps to 0 for base = 256: handled below
@@ -160,7 +160,7 @@ __device__ __forceinline__ uint64_t rs_pack_key(const uint32_t* __restrict__ s_w
         const uint32_t hi = s_words[wi + w + 1];
         uint32_t x = __builtin_amdgcn_alignbyte(hi, lo, sel);  // codes of li + q .. li + q + 3
         lo = hi;
-        if (rem < (uint64_t)(q + 4)) x = rem <= (uint64_t)q ? 0u : (x & ((1u << (8u * (uint32_t)(rem - q))) - 1u));
+        if (rem < (uint32_t)(q + 4)) x = rem <= (uint32_t)q ? 0u : (x & ((1u << (8u * (rem - (uint32_t)q))) - 1u));
         uint32_t v = x & 0xFFu;
         if (r > 1) v = v * base + ((x >> 8) & 0xFFu);
         if (r > 2) v = v * base + ((x >> 16) & 0xFFu);
@@ -287,8 +287,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             *reinterpret_cast<uint4*>(&s_text[i]) = make_uint4(x[0], x[1], x[2], x[3]);
         }
         __syncthreads();
+        // Per-document state lives in registers and changes only when a thread's positions (ascending by 64)
+        // leave the document: its end in tile-local 32-bit coordinates (clamped — only "fewer than nsym symbols
+        // left" matters) and ebase = doc - (doc_start << bits), so that entry = (position << bits) + ebase.
         uint64_t d = dlo;
-        uint64_t dend = 0;  // doc_start[d + 1] of the current document (0 = not looked up yet)
+        uint32_t dend_l = 0;  // tile-local end of the current document (0 = not looked up yet)
+        uint64_t ebase = 0;
         const int nsym = gen.nsym;
         const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
 #pragma unroll
@@ -298,27 +302,31 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             val[j] = VS(0);
             if constexpr (HAS_W) aux[j] = WS(0);
             if (li < valid) {
-                const uint64_t p = base + li;
-                // positions of one thread ascend by 64: usually the same or the next document
-                if (dend == 0 || p >= dend) {
+                if (li >= dend_l) {  // (also the first element: dend_l = 0)
+                    const uint64_t p = base + li;
+                    uint64_t ds, de;
                     if (docs_in_lds) {
                         d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
-                        dend = s_docs[d - dlo + 1];
+                        ds = s_docs[d - dlo];
+                        de = s_docs[d - dlo + 1];
                     } else {
                         d = rs_doc_upper(gen.doc_start, d, dhi, p);
-                        dend = gen.doc_start[d + 1];
+                        ds = gen.doc_start[d];
+                        de = gen.doc_start[d + 1];
                     }
+                    const uint64_t rel = de - base;
+                    dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
+                    ebase = d - (ds << gen.bits);
                 }
-                const uint64_t ds = docs_in_lds ? s_docs[d - dlo] : gen.doc_start[d];
-                const uint64_t rem = dend - p;
-                const uint64_t kk = rs_pack_key(s_words, li, nsym, gen.base, rem);
+                const uint64_t kk = rs_pack_key(s_words, li, nsym, gen.base, dend_l - li);
                 if constexpr (HAS_W) {
                     aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
                     key[j] = (K)(kk >> gen.low_bits);
                 } else {
                     key[j] = (K)kk;
                 }
-                val[j] = (VS)(((p - ds) << gen.bits) | d);
+                if constexpr (sizeof(VS) == 4) val[j] = (VS)((((uint32_t)base + li) << gen.bits) + (uint32_t)ebase);
+                else val[j] = (VS)(((base + li) << gen.bits) + ebase);
             }
         }
         __syncthreads();  // the staging buffer is reused for the sorted keys below

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                     fresh = true;
                 }
                 if (fresh) {
-                    key = rs_pack_key(s_words, li, nsym, kbase, dend - p);
+                    key = rs_pack_key(s_words, li, nsym, kbase, dend - p < (1ull << 30) ? (uint32_t)(dend - p) : (1u << 30));
                     fresh = false;
                 } else {
                     const uint64_t cin = p + (uint64_t)nsym <= dend ? (uint64_t)s_code[li + nsym - 1] : 0ull;
