@@ -9,14 +9,17 @@
 //
 // Algorithm (GPU-first; none of the reference's task queue survives):
 //   1. alphabet        : byte histogram -> dense order-preserving symbol codes, `symbits` per symbol
-//   2. key width       : `nsym` symbols per 64-bit key, chosen from a sorted sample of the text so that
-//                        few suffixes stay unresolved (code 0 = end of document: shorter suffixes first)
-//   3. initial sort    : stable LSD radix sort of (key, entry) pairs, entry = (off << bits) | doc
-//                        (radix_sort.h).  With one symbol per digit the first pass GENERATES its pairs
-//                        from the text (TextGen) and the digit histograms come from the byte histogram,
-//                        so keys are never materialised beforehand; otherwise sa_keygen_kernel writes them.
-//                        Corpora of 2^32 bytes and more are first partitioned by their first symbol and
-//                        sorted bucket by bucket (memory).
+//   2. key width       : `nsym` symbols per key, chosen from a sorted sample of the text so that few suffixes
+//                        stay unresolved (code 0 = end of document: shorter suffixes first)
+//   3. initial sort    : stable LSD radix sort of (key, entry) records, entry = (off << bits) | doc
+//                        (radix_sort.h).  The key is the symbol codes as a number in base alphabet+1 when that
+//                        saves a pass over bit-aligned symbols (digit histograms: sa_keyhist_kernel, rolling
+//                        keys over the text), else bit-aligned (histograms from the byte counts).  The first
+//                        pass GENERATES its records from the text (TextGen) and drops the digit(s) it sorts on
+//                        into a byte (two bytes) per suffix, so later passes move (u32 key, entry, u8/u16)
+//                        when the rest of the key fits 32 bits; sa_keygen_kernel + (u64 key, entry) otherwise.
+//                        Corpora of 2^32 bytes and more are first partitioned by their first symbol (entries
+//                        only) and sorted bucket by bucket with keys gathered per bucket (memory).
 //   4. refinement      : only groups of still-equal keys are touched again.  While few suffixes are
 //                        unresolved they are re-keyed straight from the text (next symbols);
 //                        otherwise an inverse array (rank per text position) is built and classic
