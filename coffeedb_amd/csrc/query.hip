@@ -702,7 +702,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         CDB_HIP(hipStreamSynchronize(s));
         return out;
     }
-    if (!with_offsets && maxh <= 64 && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && H <= (1ull << 31)) {
+    if (!with_offsets && maxh <= 64 && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && H <= (1ull << 28)) {
         // every pattern's hit list fits one wavefront: sort + run-length encode per pattern in registers
         ix.q_keys0.ensure(H * 4);   // row_doc
         ix.q_keys1.ensure(H * 4);   // row_cnt
@@ -714,17 +714,21 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
                            ix.q_flags.as<uint64_t>());
         ix.prof.end(t, "q_wave_rows", H * (sizeof(V) + 8), s);
         NrowsIn nin{ix.q_flags.as<uint64_t>()};
-        const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0);
+        // rows <= hits, so the result arrays are sized by H and the number of rows is fetched together with
+        // the final synchronisation instead of costing a round trip of its own
+        ix.q_ids.ensure(std::max<uint64_t>(H, 2) * 8);
+        ix.q_counts.ensure(std::max<uint64_t>(H, 2) * 8);
+        scan_totals_device<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0);
         scan_apply<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_rowptr.as<uint64_t>(), npat});
-        out.nrows = nrows;
-        ix.q_ids.ensure(std::max<uint64_t>(nrows, 2) * 8);
-        ix.q_counts.ensure(std::max<uint64_t>(nrows, 2) * 8);
         hipLaunchKernelGGL(q_wave_emit_kernel, dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s,
                            (const uint32_t*)ix.q_keys0.as<uint32_t>(), (const uint32_t*)ix.q_keys1.as<uint32_t>(),
                            (const uint64_t*)ix.q_hoff.as<uint64_t>(), (const uint64_t*)ix.q_rowptr.as<uint64_t>(), npat,
                            (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+        uint64_t nrows = 0;
+        CDB_HIP(hipMemcpyAsync(&nrows, ix.q_rowptr.as<uint64_t>() + npat, 8, hipMemcpyDeviceToHost, s));
         CDB_HIP(hipGetLastError());
         CDB_HIP(hipStreamSynchronize(s));
+        out.nrows = nrows;
         return out;
     }
     const int dbits = (int)ix.bits;

@@ -176,6 +176,16 @@ T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T ident
     return total;
 }
 
+// Phase 1 without the host round trip: partials[nb] holds the grand total on the device only.
+template <typename T, typename In, typename Op>
+void scan_totals_device(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity) {
+    const uint64_t nb = ceil_div(n, SC_TILE);
+    partials.ensure((nb + 1) * sizeof(T));
+    T* d_part = partials.as<T>();
+    if (nb) hipLaunchKernelGGL((scan_reduce_kernel<T, In, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity, d_part);
+    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part, nb, op, identity);
+}
+
 // Phase 2: apply (uses the partials left by scan_totals for the same `in`, n, op).
 template <typename T, typename In, typename Out, typename Op>
 void scan_apply(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity, Out out) {
