@@ -689,6 +689,7 @@ template <> inline const char* rs_kernel_name<uint64_t, uint32_t>() { return "rs
 template <> inline const char* rs_kernel_name<uint64_t, uint64_t>() { return "rs_onesweep_k64_v64"; }
 template <> inline const char* rs_kernel_name<uint64_t, NoVal>() { return "rs_onesweep_k64"; }
 template <> inline const char* rs_kernel_name<uint32_t, uint32_t>() { return "rs_onesweep_k32_v32"; }
+template <> inline const char* rs_kernel_name<uint32_t, uint64_t>() { return "rs_onesweep_k32_v64"; }
 template <> inline const char* rs_kernel_name<uint32_t, NoVal>() { return "rs_onesweep_k32"; }
 
 struct SortStats {
@@ -707,18 +708,20 @@ struct SortPlan {
 template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal>
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                    int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
-                   const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr) {
+                   const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr, int lead_in = 0) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
-    // split keys: the first `lead` passes (the generated one first) sort on the auxiliary low digits; the
-    // passes over the key bits [begin_bit, end_bit) follow.  h_hist_in then has `lead` leading rows.
-    static_assert(!HAS_W || GEN, "auxiliary digits only exist behind a generated split pass");
+    // split keys: the first `lead` passes sort on the auxiliary low digits (a generated first pass produces
+    // them: lead = low_bits / dbits; materialised records say how many digits their auxiliary array holds:
+    // lead_in); the passes over the key bits [begin_bit, end_bit) follow.  h_hist_in has `lead` leading rows.
     if (dbits < 1 || dbits > 8) dbits = 8;
     int lead = 0;
     if constexpr (GEN && HAS_W) lead = gen->low_bits / dbits;
+    else if constexpr (HAS_W) lead = lead_in;
+    if (HAS_W && !GEN && !h_hist_in) throw Error("radix_sort: split records need caller-supplied histograms (internal)");
     const int LEAD = lead;
     if (n == 0 || end_bit < begin_bit || (!LEAD && end_bit == begin_bit)) return 0;
     const int nbits = end_bit - begin_bit;
@@ -874,24 +877,31 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
 // digits x dbits) are sorted first — the generated pass takes the lowest — and dropped from the key, so the
 // remaining passes move (u32 key >> low_bits, value, W) = 9 or 10 bytes per element instead of 12 for a
 // (u64, u32) pair.  h_hist = [all passes][256], lowest digit first.
+// gen == nullptr: the records already exist in buffers 0 (their auxiliary array holds sizeof(W) digits).
 template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
                      W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
                      const uint64_t* h_hist, const TextGen* gen) {
     const bool atomrank = rs_atomic_rank_ok(s);
+    // 8-byte values: a 12 Ki-key tile keeps staging + auxiliary bytes inside the 160 KB of LDS
+    constexpr int IPT_BIG = sizeof(V) == 8 ? 12 : 16;
     if (variant == 0)
         variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
                            : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
     if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
 #define CDB_RS_SPLIT(...)                                                                                              \
-    return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits,       \
-                                                                             stats, dbits, h_hist, gen, w0, w1)
+    if (gen)                                                                                                           \
+        return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits,   \
+                                                                           stats, dbits, h_hist, gen, w0, w1);           \
+    return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, 0, hi_bits, stats,  \
+                                                                     dbits, h_hist, (const NoGen*)nullptr, w0, w1,       \
+                                                                     (int)sizeof(W))
     switch (variant) {
         default:
-        case 21: CDB_RS_SPLIT(16, true, true, 1024, false, 1, 0, 4);
+        case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);
         case 26: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4);
         case 1: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1);
-        case 31: CDB_RS_SPLIT(16, true, true, 1024, false, 1, 0, 4, false, true);
+        case 31: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true);
         case 36: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4, false, true);
         case 32: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1, false, true);
     }

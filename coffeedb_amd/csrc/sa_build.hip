@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void sa_initflags_kernel(const uint64_t* __res
 template <typename W>
 __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __restrict__ k32,
                                                              const W* __restrict__ low, int low_bits, uint64_t n,
-                                                             uint32_t kbase, uint64_t kmagic, uint8_t* __restrict__ flags) {
+                                                             uint32_t kbase, uint64_t kmagic, uint8_t* __restrict__ flags,
+                                                             bool flags_aligned) {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     auto full = [&](uint64_t i) -> uint64_t {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __r
     k[0] = i0 > 0 ? full(i0 - 1) : ~k[1];
     k[5] = i0 + 4 < n ? full(i0 + 4) : 0;
     const uint32_t out = sa_flags_of(k, i0, n, kbase, kmagic);
-    if (i0 + 4 <= n) {
+    if (flags_aligned && i0 + 4 <= n) {
         *reinterpret_cast<uint32_t*>(flags + i0) = out;
     } else {
         for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
@@ -420,6 +421,54 @@ __global__ __launch_bounds__(256) void sa_bucket_keys_kernel(const V* __restrict
         }
     }
     keys[i] = key;
+}
+
+// The same gather, but producing the bucket's sort records directly: key = the symbols BEHIND the (constant)
+// first one as a number in base kbase, split into (u32 key >> low_bits, low digits) like the records of the
+// single-sort path, plus the digit histograms of all passes — so no key is read again for a histogram.
+template <typename V, typename W>
+__global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restrict__ ent, uint64_t cnt,
+                                                                const uint8_t* __restrict__ text, uint64_t n,
+                                                                const uint64_t* __restrict__ doc_start,
+                                                                const uint16_t* __restrict__ symmap, int bits, uint64_t mask,
+                                                                int nsym, uint32_t kbase, int low_bits, int npass,
+                                                                uint32_t* __restrict__ k32, W* __restrict__ low,
+                                                                unsigned long long* __restrict__ hist) {
+    __shared__ uint16_t s_map[256];
+    __shared__ uint32_t s_hist[8][256];
+    s_map[threadIdx.x] = symmap[threadIdx.x];
+    for (int p = 0; p < npass; ++p) s_hist[p][threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += stride) {
+        const uint64_t e = (uint64_t)ent[i];
+        const uint64_t d = e & mask;
+        const uint64_t pos = doc_start[d] + (e >> bits);
+        const uint64_t rem = doc_start[d + 1] - pos;
+        uint64_t key = 0;
+        if (pos + 24 <= n) {  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
+            uint64_t w = *reinterpret_cast<const u64_unaligned*>(text + pos + 1);
+            for (int k = 1; k < nsym && k <= 8; ++k) {
+                key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                w >>= 8;
+            }
+            if (nsym > 9) {
+                w = *reinterpret_cast<const u64_unaligned*>(text + pos + 9);
+                for (int k = 9; k < nsym; ++k) {
+                    key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                    w >>= 8;
+                }
+            }
+        } else {
+            for (int k = 1; k < nsym; ++k) key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull);
+        }
+        k32[i] = (uint32_t)(key >> low_bits);
+        if constexpr (!std::is_same<W, NoVal>::value) low[i] = (W)(key & ((1ull << low_bits) - 1ull));
+        for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; ++p)
+        if (s_hist[p][threadIdx.x]) atomicAdd(&hist[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
 }
 
 struct FlagIn {
@@ -1035,6 +1084,74 @@ void build_typed(Index& ix, bool big) {
                                       top_shift, key_bits, &ss, ix.sort_variant, dbits, h_first, &gen);
         uint64_t maxb = 0;
         for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
+        // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
+        // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort
+        // path when it fits 32 bits + one or two low digits: (u32, entry, u8 / u16) instead of (u64, entry).
+        const uint32_t bbase = (uint32_t)sigma + 1u;
+        int bbits = 0;  // bits of bbase^(nsym-1) - 1; 999 beyond 56 bits
+        {
+            unsigned __int128 v = 1;
+            for (int i = 0; i + 1 < nsym && bbits != 999; ++i) {
+                v *= bbase;
+                if (v > ((unsigned __int128)1 << 56)) bbits = 999;
+            }
+            if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
+        }
+        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : -1));
+        const bool brecords = ix.narrow_keys && sigma < 255 && blow >= 0;
+        st.key_layout = brecords ? (blow == 0 ? 1 : (blow == 8 ? 2 : 3)) : 0;
+        if (brecords) {
+            const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
+            const int bpass = (int)ceil_div(bbits, 8);
+            DevBuf k32[2], low[2], ET, d_bh;
+            k32[0].alloc(maxb * 4);
+            k32[1].alloc(maxb * 4);
+            if (blow) {
+                low[0].alloc(maxb * (blow / 8));
+                low[1].alloc(maxb * (blow / 8));
+            }
+            ET.alloc(maxb * sizeof(V));
+            d_bh.alloc(8 * 256 * sizeof(uint64_t));
+            std::vector<uint64_t> bh((size_t)std::max(bpass, 1) * 256);
+            auto run_bucket = [&](auto wtag, V* eb, uint64_t cnt, uint64_t start) {
+                using W = decltype(wtag);
+                constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
+                CDB_HIP(hipMemsetAsync(d_bh.p, 0, 8 * 256 * sizeof(uint64_t), s));
+                int t = ix.prof.begin(s);
+                hipLaunchKernelGGL((sa_bucket_records_kernel<V, W>), dim3((unsigned)std::min<uint64_t>(ceil_div(cnt, 256), 8192)),
+                                   dim3(256), 0, s, (const V*)eb, cnt, text, n, doc_start, (const uint16_t*)d_symmap.as<uint16_t>(),
+                                   (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, k32[0].as<uint32_t>(), low[0].as<W>(),
+                                   d_bh.as<unsigned long long>());
+                ix.prof.end(t, "sa_bucket_records", cnt * ((uint64_t)nsym + 4 + blow / 8 + sizeof(V)), s);
+                int r = 0;
+                if (bpass > 0 && cnt > 1) {
+                    CDB_HIP(hipMemcpyAsync(bh.data(), d_bh.p, (size_t)bpass * 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                    CDB_HIP(hipStreamSynchronize(s));
+                    if constexpr (HAS_W)
+                        r = radix_sort_split<V, W>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), eb, ET.as<V>(),
+                                                   low[0].as<W>(), low[1].as<W>(), cnt, bbits - blow, &ss, ix.sort_variant, 8,
+                                                   bh.data(), (const TextGen*)nullptr);
+                    else
+                        r = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), eb, ET.as<V>(),
+                                                    cnt, 0, bbits, &ss, ix.sort_variant, 8, bh.data());
+                    if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
+                }
+                using FW = typename std::conditional<HAS_W, W, uint8_t>::type;
+                hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                                   (const uint32_t*)k32[r].as<uint32_t>(), HAS_W ? (const FW*)low[r].as<FW>() : (const FW*)nullptr, blow,
+                                   cnt, bbase, bmagic, flags.as<uint8_t>() + start, (start & 3) == 0);
+            };
+            uint64_t start = 0;
+            for (int c = 1; c <= sigma; ++c) {
+                const uint64_t cnt = h_first[c];
+                if (!cnt) continue;
+                V* eb = E.as<V>() + start;
+                if (blow == 0) run_bucket(NoVal{}, eb, cnt, start);
+                else if (blow == 8) run_bucket(uint8_t{}, eb, cnt, start);
+                else run_bucket(uint16_t{}, eb, cnt, start);
+                start += cnt;
+            }
+        } else {
         KT[0].alloc(maxb * sizeof(uint64_t));
         if (nsym > 1 && maxb > 1) {
             KT[1].alloc(maxb * sizeof(uint64_t));
@@ -1061,6 +1178,7 @@ void build_typed(Index& ix, bool big) {
                                (start & 3) == 0);
             start += cnt;
         }
+        }
         CDB_HIP(hipStreamSynchronize(s));
         st.bucketed = 1;
         sa_buf = std::move(E);
@@ -1073,12 +1191,12 @@ void build_typed(Index& ix, bool big) {
         else if (layout == SPLIT2)
             hipLaunchKernelGGL(sa_initflags32_kernel<uint16_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                                (const uint32_t*)sorted_k32.as<uint32_t>(), (const uint16_t*)sorted_low.as<uint16_t>(), low_bits, n,
-                               kbase, kmagic, flags.as<uint8_t>());
+                               kbase, kmagic, flags.as<uint8_t>(), true);
         else
             hipLaunchKernelGGL(sa_initflags32_kernel<uint8_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                                (const uint32_t*)sorted_k32.as<uint32_t>(),
                                layout == SPLIT ? (const uint8_t*)sorted_low.as<uint8_t>() : (const uint8_t*)nullptr, low_bits, n,
-                               kbase, kmagic, flags.as<uint8_t>());
+                               kbase, kmagic, flags.as<uint8_t>(), true);
         ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : 5 + low_bytes), s);
     }
     CDB_HIP(hipStreamSynchronize(s));
