@@ -26,6 +26,8 @@ struct BuildStats {
     int key_layout = 0;          // sort records: 0 = (u64 key, entry), 1 = (u32 key, entry), 2 / 3 = (u32 key, entry, u8 / u16 low digits)
     int dense_keys = 0;          // initial keys in base (alphabet + 1) instead of bit-aligned symbols
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
+    int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
+    uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
     uint64_t compat_rotations = 0, compat_depth = 0;  // reference_compat pass (bytes >= 0x80)
@@ -101,6 +103,7 @@ struct Index {
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;
+    uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;

@@ -423,24 +423,58 @@ __global__ __launch_bounds__(256) void sa_bucket_keys_kernel(const V* __restrict
     keys[i] = key;
 }
 
-// The same gather, but producing the bucket's sort records directly: key = the symbols BEHIND the (constant)
-// first one as a number in base kbase, split into (u32 key >> low_bits, low digits) like the records of the
-// single-sort path, plus the digit histograms of all passes — so no key is read again for a histogram.
+// Bucket records for the bucket-wise sort of big corpora.  Inside a first-symbol bucket the sort key is the
+// symbols BEHIND the first one as a number in base kbase, split into (u32 key >> low_bits, low digits) like
+// the records of the single-sort path.  Gathering them bucket by bucket would sweep the whole text once per
+// bucket (every 64-byte line holds suffixes of ~50 different buckets: 64 n bytes of traffic), so the gather
+// runs over GROUPS of buckets and in text order: a work item is (bucket, <= BR_ITEM consecutive entries of
+// it) and the items are sorted by text chunk first — all buckets walk one 32 MiB stretch of text (which
+// then sits in the Infinity Cache) before anybody moves on.  The per-bucket digit histograms of all sort
+// passes fall out of the same kernel.
+constexpr uint32_t BR_ITEM = 4096;
+struct BucketItem {
+    unsigned long long begin;  // index into the entry array
+    uint32_t count, bucket;
+};
+
+// bounds[b * (nch + 1) + x] = first index in bucket b's entry range whose text position is >= x * chunk
+template <typename V>
+__global__ __launch_bounds__(256) void sa_bucket_bounds_kernel(const V* __restrict__ ent,
+                                                               const unsigned long long* __restrict__ bstart /*[nb + 1]*/,
+                                                               uint32_t nb, uint32_t nch, uint64_t chunk,
+                                                               const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                               unsigned long long* __restrict__ bounds) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint64_t)nb * (nch + 1)) return;
+    const uint32_t b = (uint32_t)(t / (nch + 1)), x = (uint32_t)(t % (nch + 1));
+    uint64_t lo = bstart[b], hi = bstart[b + 1];
+    const uint64_t target = (uint64_t)x * chunk;
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        const uint64_t e = (uint64_t)ent[mid];
+        const uint64_t pos = doc_start[e & mask] + (e >> bits);
+        if (pos < target) lo = mid + 1; else hi = mid;
+    }
+    bounds[t] = lo;
+}
+
 template <typename V, typename W>
-__global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restrict__ ent, uint64_t cnt,
+__global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restrict__ ent,
+                                                                const BucketItem* __restrict__ items,
                                                                 const uint8_t* __restrict__ text, uint64_t n,
                                                                 const uint64_t* __restrict__ doc_start,
                                                                 const uint16_t* __restrict__ symmap, int bits, uint64_t mask,
                                                                 int nsym, uint32_t kbase, int low_bits, int npass,
-                                                                uint32_t* __restrict__ k32, W* __restrict__ low,
-                                                                unsigned long long* __restrict__ hist) {
+                                                                uint64_t gstart, uint32_t bucket0, uint32_t* __restrict__ k32,
+                                                                W* __restrict__ low, unsigned long long* __restrict__ hist) {
     __shared__ uint16_t s_map[256];
     __shared__ uint32_t s_hist[8][256];
     s_map[threadIdx.x] = symmap[threadIdx.x];
     for (int p = 0; p < npass; ++p) s_hist[p][threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += stride) {
+    const BucketItem it = items[blockIdx.x];
+    for (uint32_t r = threadIdx.x; r < it.count; r += 256) {
+        const uint64_t i = it.begin + r;
         const uint64_t e = (uint64_t)ent[i];
         const uint64_t d = e & mask;
         const uint64_t pos = doc_start[d] + (e >> bits);
@@ -462,13 +496,14 @@ __global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restr
         } else {
             for (int k = 1; k < nsym; ++k) key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull);
         }
-        k32[i] = (uint32_t)(key >> low_bits);
-        if constexpr (!std::is_same<W, NoVal>::value) low[i] = (W)(key & ((1ull << low_bits) - 1ull));
+        k32[i - gstart] = (uint32_t)(key >> low_bits);
+        if constexpr (!std::is_same<W, NoVal>::value) low[i - gstart] = (W)(key & ((1ull << low_bits) - 1ull));
         for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
     }
     __syncthreads();
+    unsigned long long* h = hist + (size_t)(it.bucket - bucket0) * 8 * 256;
     for (int p = 0; p < npass; ++p)
-        if (s_hist[p][threadIdx.x]) atomicAdd(&hist[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
+        if (s_hist[p][threadIdx.x]) atomicAdd(&h[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
 }
 
 struct FlagIn {
@@ -1098,58 +1133,118 @@ void build_typed(Index& ix, bool big) {
             if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
         }
         const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : -1));
-        const bool brecords = ix.narrow_keys && sigma < 255 && blow >= 0;
+        // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
+        //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
+        const bool brecords = ix.narrow_keys && sigma < 255 && blow >= 0 && nsym > 1;
         st.key_layout = brecords ? (blow == 0 ? 1 : (blow == 8 ? 2 : 3)) : 0;
         if (brecords) {
             const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
             const int bpass = (int)ceil_div(bbits, 8);
-            DevBuf k32[2], low[2], ET, d_bh;
-            k32[0].alloc(maxb * 4);
-            k32[1].alloc(maxb * 4);
-            if (blow) {
-                low[0].alloc(maxb * (blow / 8));
-                low[1].alloc(maxb * (blow / 8));
+            const int lowb = blow / 8;
+            // non-empty buckets and their entry ranges
+            std::vector<uint64_t> bstart;  // [nb + 1]
+            for (int c = 1; c <= sigma; ++c)
+                if (h_first[c]) bstart.push_back(0);
+            const uint32_t nb = (uint32_t)bstart.size();
+            bstart.push_back(0);
+            {
+                uint64_t acc = 0;
+                uint32_t b = 0;
+                for (int c = 1; c <= sigma; ++c)
+                    if (h_first[c]) {
+                        bstart[b++] = acc;
+                        acc += h_first[c];
+                    }
+                bstart[nb] = acc;
             }
+            // where every bucket crosses the 32 MiB text chunks
+            const uint64_t chunk = 32ull << 20;
+            const uint32_t nch = (uint32_t)ceil_div(n, chunk);
+            DevBuf d_bstart, d_bounds;
+            d_bstart.alloc((nb + 1) * 8);
+            d_bounds.alloc((size_t)nb * (nch + 1) * 8);
+            CDB_HIP(hipMemcpyAsync(d_bstart.p, bstart.data(), (nb + 1) * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((sa_bucket_bounds_kernel<V>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
+                               (const V*)E.as<V>(), (const unsigned long long*)d_bstart.as<unsigned long long>(), nb, nch, chunk,
+                               doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
+            std::vector<uint64_t> bounds((size_t)nb * (nch + 1));
+            CDB_HIP(hipMemcpyAsync(bounds.data(), d_bounds.p, bounds.size() * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            // groups of consecutive buckets whose records (4 + lowb bytes per suffix) fit the memory left
+            size_t fre = 0, tot = 0;
+            CDB_HIP(hipMemGetInfo(&fre, &tot));
+            const double avail = (double)fre + (double)DevPool::get().cached_bytes();
+            const double scratch = (double)maxb * (4 + lowb + sizeof(V)) + (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1);
+            uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (4 + lowb));
+            if (ix.bucket_group_limit) gcap = std::min<uint64_t>(gcap, ix.bucket_group_limit);
+            gcap = std::max<uint64_t>(std::min<uint64_t>(gcap, n), maxb);
+            DevBuf k32g, lowg, k32t, lowt, ET, d_bh, d_items;
+            k32g.alloc(gcap * 4);
+            if (lowb) lowg.alloc(gcap * lowb);
+            k32t.alloc(maxb * 4);
+            if (lowb) lowt.alloc(maxb * lowb);
             ET.alloc(maxb * sizeof(V));
-            d_bh.alloc(8 * 256 * sizeof(uint64_t));
-            std::vector<uint64_t> bh((size_t)std::max(bpass, 1) * 256);
-            auto run_bucket = [&](auto wtag, V* eb, uint64_t cnt, uint64_t start) {
+            std::vector<uint64_t> bh;
+            std::vector<BucketItem> items;
+            auto run_group = [&](auto wtag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
                 using W = decltype(wtag);
                 constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
-                CDB_HIP(hipMemsetAsync(d_bh.p, 0, 8 * 256 * sizeof(uint64_t), s));
-                int t = ix.prof.begin(s);
-                hipLaunchKernelGGL((sa_bucket_records_kernel<V, W>), dim3((unsigned)std::min<uint64_t>(ceil_div(cnt, 256), 8192)),
-                                   dim3(256), 0, s, (const V*)eb, cnt, text, n, doc_start, (const uint16_t*)d_symmap.as<uint16_t>(),
-                                   (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, k32[0].as<uint32_t>(), low[0].as<W>(),
-                                   d_bh.as<unsigned long long>());
-                ix.prof.end(t, "sa_bucket_records", cnt * ((uint64_t)nsym + 4 + blow / 8 + sizeof(V)), s);
-                int r = 0;
-                if (bpass > 0 && cnt > 1) {
-                    CDB_HIP(hipMemcpyAsync(bh.data(), d_bh.p, (size_t)bpass * 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-                    CDB_HIP(hipStreamSynchronize(s));
-                    if constexpr (HAS_W)
-                        r = radix_sort_split<V, W>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), eb, ET.as<V>(),
-                                                   low[0].as<W>(), low[1].as<W>(), cnt, bbits - blow, &ss, ix.sort_variant, 8,
-                                                   bh.data(), (const TextGen*)nullptr);
-                    else
-                        r = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), eb, ET.as<V>(),
-                                                    cnt, 0, bbits, &ss, ix.sort_variant, 8, bh.data());
-                    if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
-                }
                 using FW = typename std::conditional<HAS_W, W, uint8_t>::type;
-                hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
-                                   (const uint32_t*)k32[r].as<uint32_t>(), HAS_W ? (const FW*)low[r].as<FW>() : (const FW*)nullptr, blow,
-                                   cnt, bbase, bmagic, flags.as<uint8_t>() + start, (start & 3) == 0);
+                const uint64_t gstart = bstart[b0];
+                const uint32_t gb = b1 - b0;
+                d_bh.ensure((size_t)gb * 8 * 256 * sizeof(uint64_t));
+                CDB_HIP(hipMemsetAsync(d_bh.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
+                items.clear();
+                for (uint32_t x = 0; x < nch; ++x)      // text chunk major: the group's buckets share the cached text
+                    for (uint32_t b = b0; b < b1; ++b) {
+                        const uint64_t lo = bounds[(size_t)b * (nch + 1) + x], hi = bounds[(size_t)b * (nch + 1) + x + 1];
+                        for (uint64_t o = lo; o < hi; o += BR_ITEM)
+                            items.push_back(BucketItem{(unsigned long long)o, (uint32_t)std::min<uint64_t>(BR_ITEM, hi - o), b});
+                    }
+                st.gather_items += items.size();
+                if (!items.empty()) {
+                    d_items.ensure(items.size() * sizeof(BucketItem));
+                    CDB_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, s));
+                    int t = ix.prof.begin(s);
+                    hipLaunchKernelGGL((sa_bucket_records_kernel<V, W>), dim3((unsigned)items.size()), dim3(256), 0, s,
+                                       (const V*)E.as<V>(), (const BucketItem*)d_items.as<BucketItem>(), text, n, doc_start,
+                                       (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass,
+                                       gstart, b0, k32g.as<uint32_t>(), lowg.as<W>(), d_bh.as<unsigned long long>());
+                    ix.prof.end(t, "sa_bucket_records", (bstart[b1] - gstart) * ((uint64_t)nsym + 4 + lowb + sizeof(V)), s);
+                }
+                bh.resize((size_t)gb * 8 * 256);
+                CDB_HIP(hipMemcpyAsync(bh.data(), d_bh.p, bh.size() * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipStreamSynchronize(s));  // (also: `items` may be rebuilt for the next group)
+                for (uint32_t b = b0; b < b1; ++b) {
+                    const uint64_t start = bstart[b], cnt = bstart[b + 1] - start;
+                    V* eb = E.as<V>() + start;
+                    uint32_t* kb = k32g.as<uint32_t>() + (start - gstart);
+                    FW* lb = HAS_W ? lowg.as<FW>() + (start - gstart) : (FW*)nullptr;
+                    int r = 0;
+                    if (bpass > 0 && cnt > 1) {
+                        const uint64_t* hb = &bh[(size_t)(b - b0) * 8 * 256];
+                        if constexpr (HAS_W)
+                            r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
+                                                       bbits - blow, &ss, ix.sort_variant, 8, hb, (const TextGen*)nullptr);
+                        else
+                            r = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
+                                                        ix.sort_variant, 8, hb);
+                        if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
+                    }
+                    hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                                       (const uint32_t*)(r ? k32t.as<uint32_t>() : kb),
+                                       HAS_W ? (const FW*)(r ? lowt.as<FW>() : lb) : (const FW*)nullptr, blow, cnt, bbase, bmagic,
+                                       flags.as<uint8_t>() + start, (start & 3) == 0);
+                }
             };
-            uint64_t start = 0;
-            for (int c = 1; c <= sigma; ++c) {
-                const uint64_t cnt = h_first[c];
-                if (!cnt) continue;
-                V* eb = E.as<V>() + start;
-                if (blow == 0) run_bucket(NoVal{}, eb, cnt, start);
-                else if (blow == 8) run_bucket(uint8_t{}, eb, cnt, start);
-                else run_bucket(uint16_t{}, eb, cnt, start);
-                start += cnt;
+            for (uint32_t b0 = 0; b0 < nb;) {
+                uint32_t b1 = b0 + 1;
+                while (b1 < nb && bstart[b1 + 1] - bstart[b0] <= gcap) ++b1;
+                if (blow == 0) run_group(NoVal{}, b0, b1);
+                else if (blow == 8) run_group(uint8_t{}, b0, b1);
+                else run_group(uint16_t{}, b0, b1);
+                st.bucket_groups++;
+                b0 = b1;
             }
         } else {
         KT[0].alloc(maxb * sizeof(uint64_t));

@@ -48,7 +48,9 @@ def test_fuzz_parity(seed):
     opts = {}
     if rng.random() < 0.3: opts["force_doubling"] = 1
     if rng.random() < 0.3: opts["fuse_keygen"] = 0
-    if rng.random() < 0.25: opts["force_big_path"] = 1
+    if rng.random() < 0.25:
+        opts["force_big_path"] = 1
+        if rng.random() < 0.5: opts["bucket_group_limit"] = int(rng.integers(1, 5000))
     if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
     elif rng.random() < 0.5: opts["key_coding"] = int(rng.choice([1, 2]))
     if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26]))

@@ -156,13 +156,15 @@ def test_key_coding_dense_and_bit_aligned(G, coding, fuse):
     assert g.stat("key_symbols") == 13 and g.stat("dense_keys") == 1
 
 
+@pytest.mark.parametrize("group_limit", [0, 20000])
 @pytest.mark.parametrize("force_doubling", [0, 1])
-def test_big_corpus_code_path_at_small_size(G, force_doubling):
-    # the >= 2^32 path (u64 ranks/positions, streamed bucket-wise initial sort) forced on small inputs
-    opts = dict(force_big_path=1, force_doubling=force_doubling)
+def test_big_corpus_code_path_at_small_size(G, force_doubling, group_limit):
+    # the >= 2^32 path (u64 ranks/positions, streamed bucket-wise initial sort; group_limit: the bucket records
+    # are gathered for several groups of buckets instead of all at once) forced on small inputs
+    opts = dict(force_big_path=1, force_doubling=force_doubling, bucket_group_limit=group_limit)
     blob, ds = W.ragged_corpus(20000, 90, seed=15, empty_every=13)
     g, o = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 300, 1, 6, seed=3, miss_byte=0x7B), **opts)
-    assert g.stat("bucketed") == 1
+    assert g.stat("bucketed") == 1 and (g.stat("bucket_groups") > 1) == (group_limit > 0)
     blob, ds = W.ascii_corpus(3000, 333, seed=2)
     _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 200, 2, 9, seed=5), **opts)
     blob, ds = W.zipf_corpus(2000, 256, seed=2)
