@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void sa_bucket_keys_kernel(const V* __restrict
 // the records of the single-sort path.  Gathering them bucket by bucket would sweep the whole text once per
 // bucket (every 64-byte line holds suffixes of ~50 different buckets: 64 n bytes of traffic), so the gather
 // runs over GROUPS of buckets and in text order: a work item is (bucket, <= BR_ITEM consecutive entries of
-// it) and the items are sorted by text chunk first — all buckets walk one 32 MiB stretch of text (which
-// then sits in the Infinity Cache) before anybody moves on.  The per-bucket digit histograms of all sort
+// it) and the items are sorted by text chunk first — all buckets walk one 2 MiB stretch of text (which
+// then sits in every XCD's L2) before anybody moves on.  The per-bucket digit histograms of all sort
 // passes fall out of the same kernel.
 constexpr uint32_t BR_ITEM = 4096;
 struct BucketItem {
@@ -1157,8 +1157,9 @@ void build_typed(Index& ix, bool big) {
                     }
                 bstart[nb] = acc;
             }
-            // where every bucket crosses the 32 MiB text chunks
-            const uint64_t chunk = 32ull << 20;
+            // where every bucket crosses the text chunks: 2 MiB, so that the chunk all concurrent work items read
+            // fits every XCD's 4 MB L2
+            const uint64_t chunk = 2ull << 20;  // (measured at 8 GiB: 1 MiB 61 ms, 2 MiB 60, 4 MiB 62, 16 MiB 88, 32 MiB 97)
             const uint32_t nch = (uint32_t)ceil_div(n, chunk);
             DevBuf d_bstart, d_bounds;
             d_bstart.alloc((nb + 1) * 8);
