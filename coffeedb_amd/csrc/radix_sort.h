@@ -653,6 +653,11 @@ struct RadixWorkspace {
     DevBuf status;   // [tiles][256] u64
     DevBuf tickets;  // [256] u32 tickets (indexed by epoch) + [1] u32 error flag
     DevBuf tile_doc; // [tiles + 1] u64, generated first pass only
+    // optional third value buffer for the NEXT sort (cleared by it): with it an odd number of passes still ends
+    // with the values in buffer 0 (v0 -> spare -> v1 -> spare ... -> v0) instead of needing a copy back;
+    // value_result says where the values ended up (0 = v0, 1 = v1)
+    void* value_spare = nullptr;
+    int value_result = 0;
     uint32_t epoch = 0;
     uint64_t min_tile = 0;
 
@@ -754,21 +759,42 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     }
 
     K* kb[2] = {k0, k1};
-    V* vb[2] = {v0, v1};
     W* wb[2] = {w0, w1};
     int cur = 0;
     bool materialised = !GEN;  // with a generator the input exists only after the first executed pass
     const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
     const size_t pair_bytes = sizeof(K) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0);
-    for (int p = 0; p < npass; ++p) {
-        bool trivial = false;
-        for (int d = 0; d < 256; ++d)
-            if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
-        // (the leading pass of a split sort always runs: it is the one that produces the auxiliary bytes)
-        if (trivial && (materialised || p + 1 < npass) && !(LEAD > 0 && p == 0)) {
-            if (stats) stats->passes_skipped++;
-            continue;
+    // which passes run (a constant digit is skipped; the leading pass of a generated sort always runs: it
+    // produces the records) and through which value buffers
+    std::vector<int> run;
+    {
+        bool mat = materialised;
+        for (int p = 0; p < npass; ++p) {
+            bool trivial = false;
+            for (int d = 0; d < 256; ++d)
+                if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
+            if (trivial && (mat || p + 1 < npass) && !(GEN && LEAD > 0 && p == 0)) {
+                if (stats) stats->passes_skipped++;
+                continue;
+            }
+            run.push_back(p);
+            mat = true;
         }
+    }
+    V* spare = static_cast<V*>(ws.value_spare);
+    ws.value_spare = nullptr;
+    const size_t k = run.size();
+    std::vector<V*> vseq(k + 1);
+    for (size_t i = 0; i <= k; ++i) vseq[i] = (i & 1) ? v1 : v0;
+    if (HAS_V && !GEN && spare && (k & 1) && k >= 3) {
+        for (size_t i = 1; i < k; ++i) vseq[i] = (i & 1) ? spare : v1;
+        vseq[k] = v0;
+    }
+    ws.value_result = vseq[k] == v0 ? 0 : 1;
+    for (size_t ri = 0; ri < k; ++ri) {
+        const int p = run[ri];
+        V* const vin_p = vseq[ri];
+        V* const vout_p = vseq[ri + 1];
         const uint32_t e = ws.next_epoch(s);
         const uint32_t dmask = p == npass - 1 && kpass ? last_mask : ((1u << dbits) - 1u);
         const int shift = begin_bit + dbits * (p - LEAD);  // (unused by the leading passes of a split sort)
@@ -782,7 +808,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                    g2.doc_start, g2.ndocs, n, (uint64_t)TILE, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
                 g2.tile_doc = ws.tile_doc.as<uint64_t>();
                 hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
-                                   (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vb[cur ^ 1], n, shift, dmask,
+                                   (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vout_p, n, shift, dmask,
                                    (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
                                    ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift);
             }
@@ -791,7 +817,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
             materialised = true;
         } else {
             hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
-                               (const K*)kb[cur], kb[cur ^ 1], (const V*)vb[cur], vb[cur ^ 1], n, shift, dmask,
+                               (const K*)kb[cur], kb[cur ^ 1], (const V*)vin_p, vout_p, n, shift, dmask,
                                (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(), ws.ticket_ptr(e), e,
                                ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift);
             prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : "_w16") : "") + "_t" + std::to_string(TILE)).c_str(),

@@ -1179,12 +1179,13 @@ void build_typed(Index& ix, bool big) {
             uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (4 + lowb));
             if (ix.bucket_group_limit) gcap = std::min<uint64_t>(gcap, ix.bucket_group_limit);
             gcap = std::max<uint64_t>(std::min<uint64_t>(gcap, n), maxb);
-            DevBuf k32g, lowg, k32t, lowt, ET, d_bh, d_items;
+            DevBuf k32g, lowg, k32t, lowt, ET, EX, d_bh, d_items;
             k32g.alloc(gcap * 4);
             if (lowb) lowg.alloc(gcap * lowb);
             k32t.alloc(maxb * 4);
             if (lowb) lowt.alloc(maxb * lowb);
             ET.alloc(maxb * sizeof(V));
+            EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
             std::vector<uint64_t> bh;
             std::vector<BucketItem> items;
             auto run_group = [&](auto wtag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
@@ -1224,13 +1225,14 @@ void build_typed(Index& ix, bool big) {
                     int r = 0;
                     if (bpass > 0 && cnt > 1) {
                         const uint64_t* hb = &bh[(size_t)(b - b0) * 8 * 256];
+                        ix.rws.value_spare = EX.p;
                         if constexpr (HAS_W)
                             r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
                                                        bbits - blow, &ss, ix.sort_variant, 8, hb, (const TextGen*)nullptr);
                         else
                             r = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
                                                         ix.sort_variant, 8, hb);
-                        if (r == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
+                        if (ix.rws.value_result == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
                     }
                     hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
                                        (const uint32_t*)(r ? k32t.as<uint32_t>() : kb),
