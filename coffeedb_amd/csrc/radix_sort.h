@@ -137,6 +137,7 @@ struct TextGen {
     int low_bits = 0;  // split keys: the generated pass sorts on the key's low_bits lowest bits, which then travel
                        // as a separate byte per element; the remaining passes see key >> low_bits (32-bit keys)
     bool padded = false;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
+    bool first_only = false;  // entries-only partition by the first symbol: the key is just that symbol's digit
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
                     ebase = d - (ds << gen.bits);
                 }
-                const uint64_t kk = rs_pack_key(s_words, li, nsym, gen.base, dend_l - li);
+                const uint64_t kk = gen.first_only ? ((uint64_t)s_text[li] << shift)
+                                                   : rs_pack_key(s_words, li, nsym, gen.base, dend_l - li);
                 if constexpr (HAS_W) {
                     aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
                     key[j] = (K)(kk >> gen.low_bits);

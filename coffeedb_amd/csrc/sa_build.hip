@@ -1115,6 +1115,7 @@ void build_typed(Index& ix, bool big) {
         st.alloc_ms += now_ms() - ta;
         const int top_shift = (nsym - 1) * symbits;
         const uint64_t* h_first = &h_hist[(size_t)(nsym - 1) * 256];
+        gen.first_only = true;
         (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n,
                                       top_shift, key_bits, &ss, ix.sort_variant, dbits, h_first, &gen);
         uint64_t maxb = 0;
