@@ -104,8 +104,8 @@ def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-docs", type=int, default=1 << 15, help="docs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -199,10 +199,12 @@ def main():
     t0 = time.perf_counter()
     build_ms = query_ms = 0.0
     hits = rows = 0
+    step_build_ms = []
     for _ in range(args.steps):
         tb, tq, hits, rows = step()
         build_ms += tb
         query_ms += tq
+        step_build_ms.append(round(tb, 3))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -244,6 +246,7 @@ def main():
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
             "query_hits_per_batch": hits,
             "query_rows_per_batch": rows,
+            "build_ms_per_step": step_build_ms,
             "build_stats": {k: g.stat(k) for k in ("rounds", "ext_rounds", "dbl_rounds", "unresolved_after_initial",
                                                    "sort_passes", "sort_passes_skipped", "key_symbols", "symbol_bits",
                                                    "isa_built")},

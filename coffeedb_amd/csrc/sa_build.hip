@@ -832,8 +832,13 @@ void build_typed(Index& ix, bool big) {
     BuildStats& st = ix.bstats;
     st = BuildStats{};
     {
+        // the previous suffix array and kept keys go back to the block cache first: a rebuild of the same
+        // corpus shape then finds every buffer it needs there instead of asking the driver for fresh memory
         const double tf = now_ms();
         ix.d_sa.release();
+        ix.drop_keys();
+        ix.d_pivots.release();
+        ix.pivot_levels = 0;
         st.free_ms += now_ms() - tf;
     }
     if (n == 0) {
