@@ -1348,7 +1348,12 @@ void build_typed(Index& ix, bool big) {
         const int gbits = bit_width64(G - 1);
         int nsym2 = std::min((64 - gbits) / symbits, KG_LOOK);
         if (!isa) {
-            const bool use_text = !ix.force_doubling && m <= n / 32 && st.ext_rounds < 4 && nsym2 >= 1;
+            // Re-keying m suffixes from the text costs ~ m x (one random line + a sort); the inverse array of prefix
+            // doubling costs n random writes before its first round.  Text extension therefore gets up to four
+            // rounds while few suffixes are open, and two rounds even for a larger share (e.g. Zipf text, 5 % open
+            // after the initial sort, resolved by 2 x 5 more symbols); only then the inverse array is built.
+            const bool use_text = !ix.force_doubling && nsym2 >= 1 &&
+                                  ((m <= n / 32 && st.ext_rounds < 4) || (m <= n / 8 && st.ext_rounds < 2));
             if (!use_text) {
                 rank.alloc((n + D + 1) * sizeof(R));
                 CDB_HIP(hipMemsetAsync(rank.p, 0, (n + D + 1) * sizeof(R), s));
