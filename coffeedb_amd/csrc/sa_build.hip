@@ -458,14 +458,14 @@ __global__ __launch_bounds__(256) void sa_bucket_bounds_kernel(const V* __restri
     bounds[t] = lo;
 }
 
-template <typename V, typename W>
+template <typename V, typename W, typename K>
 __global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restrict__ ent,
                                                                 const BucketItem* __restrict__ items,
                                                                 const uint8_t* __restrict__ text, uint64_t n,
                                                                 const uint64_t* __restrict__ doc_start,
                                                                 const uint16_t* __restrict__ symmap, int bits, uint64_t mask,
                                                                 int nsym, uint32_t kbase, int low_bits, int npass,
-                                                                uint64_t gstart, uint32_t bucket0, uint32_t* __restrict__ k32,
+                                                                uint64_t gstart, uint32_t bucket0, K* __restrict__ k32,
                                                                 W* __restrict__ low, unsigned long long* __restrict__ hist) {
     __shared__ uint16_t s_map[256];
     __shared__ uint32_t s_hist[8][256];
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restr
         } else {
             for (int k = 1; k < nsym; ++k) key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull);
         }
-        k32[i - gstart] = (uint32_t)(key >> low_bits);
+        k32[i - gstart] = (K)(key >> low_bits);
         if constexpr (!std::is_same<W, NoVal>::value) low[i - gstart] = (W)(key & ((1ull << low_bits) - 1ull));
         for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
     }
@@ -1138,15 +1138,19 @@ void build_typed(Index& ix, bool big) {
             }
             if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
         }
-        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : -1));
+        // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
+        //  symbols, the grouped gather and no separate histogram pass)
+        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : (bbits <= 56 ? 0 : -1)));
+        const bool bwide = bbits > 48 && bbits <= 56;
         // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
         //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
         const bool brecords = ix.narrow_keys && sigma < 255 && blow >= 0 && nsym > 1;
-        st.key_layout = brecords ? (blow == 0 ? 1 : (blow == 8 ? 2 : 3)) : 0;
+        st.key_layout = brecords ? (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3))) : 0;
         if (brecords) {
             const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
             const int bpass = (int)ceil_div(bbits, 8);
             const int lowb = blow / 8;
+            const int keyb = bwide ? 8 : 4;  // bytes of the key part of a record
             // non-empty buckets and their entry ranges
             std::vector<uint64_t> bstart;  // [nb + 1]
             for (int c = 1; c <= sigma; ++c)
@@ -1181,21 +1185,22 @@ void build_typed(Index& ix, bool big) {
             size_t fre = 0, tot = 0;
             CDB_HIP(hipMemGetInfo(&fre, &tot));
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
-            const double scratch = (double)maxb * (4 + lowb + sizeof(V)) + (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1);
-            uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (4 + lowb));
+            const double scratch = (double)maxb * (keyb + lowb + 2 * sizeof(V)) + (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1);
+            uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (keyb + lowb));
             if (ix.bucket_group_limit) gcap = std::min<uint64_t>(gcap, ix.bucket_group_limit);
             gcap = std::max<uint64_t>(std::min<uint64_t>(gcap, n), maxb);
             DevBuf k32g, lowg, k32t, lowt, ET, EX, d_bh, d_items;
-            k32g.alloc(gcap * 4);
+            k32g.alloc(gcap * keyb);
             if (lowb) lowg.alloc(gcap * lowb);
-            k32t.alloc(maxb * 4);
+            k32t.alloc(maxb * keyb);
             if (lowb) lowt.alloc(maxb * lowb);
             ET.alloc(maxb * sizeof(V));
             EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
             std::vector<uint64_t> bh;
             std::vector<BucketItem> items;
-            auto run_group = [&](auto wtag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
+            auto run_group = [&](auto wtag, auto ktag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
                 using W = decltype(wtag);
+                using K = decltype(ktag);
                 constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
                 using FW = typename std::conditional<HAS_W, W, uint8_t>::type;
                 const uint64_t gstart = bstart[b0];
@@ -1214,11 +1219,11 @@ void build_typed(Index& ix, bool big) {
                     d_items.ensure(items.size() * sizeof(BucketItem));
                     CDB_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, s));
                     int t = ix.prof.begin(s);
-                    hipLaunchKernelGGL((sa_bucket_records_kernel<V, W>), dim3((unsigned)items.size()), dim3(256), 0, s,
+                    hipLaunchKernelGGL((sa_bucket_records_kernel<V, W, K>), dim3((unsigned)items.size()), dim3(256), 0, s,
                                        (const V*)E.as<V>(), (const BucketItem*)d_items.as<BucketItem>(), text, n, doc_start,
                                        (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass,
-                                       gstart, b0, k32g.as<uint32_t>(), lowg.as<W>(), d_bh.as<unsigned long long>());
-                    ix.prof.end(t, "sa_bucket_records", (bstart[b1] - gstart) * ((uint64_t)nsym + 4 + lowb + sizeof(V)), s);
+                                       gstart, b0, k32g.as<K>(), lowg.as<W>(), d_bh.as<unsigned long long>());
+                    ix.prof.end(t, "sa_bucket_records", (bstart[b1] - gstart) * ((uint64_t)nsym + keyb + lowb + sizeof(V)), s);
                 }
                 bh.resize((size_t)gb * 8 * 256);
                 CDB_HIP(hipMemcpyAsync(bh.data(), d_bh.p, bh.size() * 8, hipMemcpyDeviceToHost, s));
@@ -1226,7 +1231,7 @@ void build_typed(Index& ix, bool big) {
                 for (uint32_t b = b0; b < b1; ++b) {
                     const uint64_t start = bstart[b], cnt = bstart[b + 1] - start;
                     V* eb = E.as<V>() + start;
-                    uint32_t* kb = k32g.as<uint32_t>() + (start - gstart);
+                    K* kb = k32g.as<K>() + (start - gstart);
                     FW* lb = HAS_W ? lowg.as<FW>() + (start - gstart) : (FW*)nullptr;
                     int r = 0;
                     if (bpass > 0 && cnt > 1) {
@@ -1236,22 +1241,28 @@ void build_typed(Index& ix, bool big) {
                             r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
                                                        bbits - blow, &ss, ix.sort_variant, 8, hb, (const TextGen*)nullptr);
                         else
-                            r = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
-                                                        ix.sort_variant, 8, hb);
+                            r = radix_sort<K, V>(s, ix.rws, ix.prof, kb, k32t.as<K>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
+                                                 ix.sort_variant, 8, hb);
                         if (ix.rws.value_result == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
                     }
-                    hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
-                                       (const uint32_t*)(r ? k32t.as<uint32_t>() : kb),
-                                       HAS_W ? (const FW*)(r ? lowt.as<FW>() : lb) : (const FW*)nullptr, blow, cnt, bbase, bmagic,
-                                       flags.as<uint8_t>() + start, (start & 3) == 0);
+                    if constexpr (sizeof(K) == 8)
+                        hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                                           (const uint64_t*)(r ? k32t.as<uint64_t>() : (uint64_t*)kb), cnt, bbase, bmagic,
+                                           flags.as<uint8_t>() + start, (start & 3) == 0);
+                    else
+                        hipLaunchKernelGGL(sa_initflags32_kernel<FW>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                                           (const uint32_t*)(r ? k32t.as<uint32_t>() : (uint32_t*)kb),
+                                           HAS_W ? (const FW*)(r ? lowt.as<FW>() : lb) : (const FW*)nullptr, blow, cnt, bbase, bmagic,
+                                           flags.as<uint8_t>() + start, (start & 3) == 0);
                 }
             };
             for (uint32_t b0 = 0; b0 < nb;) {
                 uint32_t b1 = b0 + 1;
                 while (b1 < nb && bstart[b1 + 1] - bstart[b0] <= gcap) ++b1;
-                if (blow == 0) run_group(NoVal{}, b0, b1);
-                else if (blow == 8) run_group(uint8_t{}, b0, b1);
-                else run_group(uint16_t{}, b0, b1);
+                if (bwide) run_group(NoVal{}, uint64_t{}, b0, b1);
+                else if (blow == 0) run_group(NoVal{}, uint32_t{}, b0, b1);
+                else if (blow == 8) run_group(uint8_t{}, uint32_t{}, b0, b1);
+                else run_group(uint16_t{}, uint32_t{}, b0, b1);
                 st.bucket_groups++;
                 b0 = b1;
             }
