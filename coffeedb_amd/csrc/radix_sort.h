@@ -218,7 +218,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     constexpr size_t STAGE_V = HAS_V ? sizeof(VS) * TILE : 0;
     constexpr size_t STAGE_BYTES = REUSE ? (STAGE_K > STAGE_V ? STAGE_K : STAGE_V) : STAGE_K + STAGE_V;
 
+    // BLK: the generated pass of the big 32-bit-record configuration computes its keys thread-consecutively
+    // (rolling, see below); text codes, code table and document table then live in their own LDS region
+    // because the staging buffer carries the transposition
+    constexpr bool BLK = GEN && sizeof(K) == 4 && sizeof(VS) == 4 && IPT == 16 && NT == 1024;
+    constexpr uint32_t GEN_TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
+    constexpr uint32_t GEN_DOCS = 1024;
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_gen[BLK ? GEN_TEXTB + 512 + GEN_DOCS * 8 : 16];
     __shared__ WS s_aux[HAS_W ? TILE : 1];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_whist[NW][256];
@@ -251,13 +258,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         static_assert(!GEN || EARLYV, "generator pass needs early values");
         static_assert(!GEN || STAGE_BYTES >= (size_t)TILE + RS_GEN_LOOK + 2048, "staging buffer too small for the text tile");
         // stage the text of this tile (+ look-ahead) in the still unused LDS staging buffer
-        uint8_t* s_text = s_stage;
-        uint16_t* s_map = reinterpret_cast<uint16_t*>(s_stage + ((TILE + RS_GEN_LOOK + 15) / 16) * 16);
+        unsigned char* const gbuf = BLK ? s_gen : s_stage;
+        uint8_t* s_text = gbuf;
+        uint16_t* s_map = reinterpret_cast<uint16_t*>(gbuf + GEN_TEXTB);
         // document boundaries of this tile, copied to LDS when they fit (binary searches then cost
         // LDS instead of L2 latency); s_docs[i] = doc_start[dlo + i]
-        constexpr uint32_t DOC_OFF = ((TILE + RS_GEN_LOOK + 15) / 16) * 16 + 512;
-        constexpr uint32_t DOC_CAP = (uint32_t)((STAGE_BYTES - DOC_OFF) / 8);
-        uint64_t* s_docs = reinterpret_cast<uint64_t*>(s_stage + DOC_OFF);
+        constexpr uint32_t DOC_OFF = GEN_TEXTB + 512;
+        constexpr uint32_t DOC_CAP = BLK ? GEN_DOCS : (uint32_t)((STAGE_BYTES - DOC_OFF) / 8);
+        uint64_t* s_docs = reinterpret_cast<uint64_t*>(gbuf + DOC_OFF);
         const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
         const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOC_CAP;
         if (docs_in_lds)
@@ -296,6 +304,70 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         uint64_t ebase = 0;
         const int nsym = gen.nsym;
         const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
+        if constexpr (BLK) {
+            // Thread-consecutive generation: a thread owns IPT consecutive positions, so inside a document
+            //   key(q + 1) = (key(q) - code(q) * base^(nsym-1)) * base + code(q + nsym)   [0 behind the document end]
+            // and only the first position of a thread or of a document pays for a full Horner evaluation; the
+            // document state changes at most a few times per thread.  The records then cross to the
+            // lane-consecutive order of the ranking through the (XOR-swizzled, conflict-free) staging buffer.
+            uint32_t* kt = reinterpret_cast<uint32_t*>(s_stage);
+            auto swz = [](uint32_t q) -> uint32_t { return (q & ~15u) | ((q & 15u) ^ ((q >> 6) & 15u)); };
+            const uint32_t q0 = (uint32_t)tid * IPT;
+            uint64_t top = 1;  // weight of the symbol that leaves the window
+            for (int q = 1; q < nsym; ++q) top *= gen.base;
+            uint32_t ent[IPT];
+            uint64_t kk = 0;
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t q = q0 + j;
+                ent[j] = 0;
+                if (q < valid) {
+                    bool fresh = j == 0;
+                    if (j == 0 || q >= dend_l) {
+                        const uint64_t p = base + q;
+                        uint64_t ds, de;
+                        if (docs_in_lds) {
+                            d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
+                            ds = s_docs[d - dlo];
+                            de = s_docs[d - dlo + 1];
+                        } else {
+                            d = rs_doc_upper(gen.doc_start, d, dhi, p);
+                            ds = gen.doc_start[d];
+                            de = gen.doc_start[d + 1];
+                        }
+                        const uint64_t rel = de - base;
+                        dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
+                        ebase = d - (ds << gen.bits);
+                        fresh = true;
+                    }
+                    if (fresh) {
+                        kk = rs_pack_key(s_words, q, nsym, gen.base, dend_l - q);
+                    } else {
+                        const uint64_t cin = q + (uint32_t)nsym <= dend_l ? (uint64_t)s_text[q + nsym - 1] : 0ull;
+                        kk = (kk - (uint64_t)s_text[q - 1] * top) * gen.base + cin;
+                    }
+                    kt[swz(q)] = (uint32_t)(kk >> gen.low_bits);
+                    if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
+                    ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                key[j] = li < valid ? (K)kt[swz(li)] : (K)~(K)0;
+                if constexpr (HAS_W) aux[j] = li < valid ? s_aux[swz(li)] : WS(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) kt[swz(q0 + j)] = ent[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                val[j] = li < valid ? (VS)kt[swz(li)] : VS(0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
@@ -330,6 +402,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 if constexpr (sizeof(VS) == 4) val[j] = (VS)((((uint32_t)base + li) << gen.bits) + (uint32_t)ebase);
                 else val[j] = (VS)(((base + li) << gen.bits) + ebase);
             }
+        }
         }
         __syncthreads();  // the staging buffer is reused for the sorted keys below
     } else if constexpr (Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
