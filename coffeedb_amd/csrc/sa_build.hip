@@ -1065,6 +1065,9 @@ void build_typed(Index& ix, bool big) {
                 low[1].alloc(n * low_bytes);
             }
             st.alloc_ms += now_ms() - ta;
+            if (getenv("CDB_DEBUG_BUFS"))
+                std::fprintf(stderr, "[bufs] k32 %p %p vals %p %p low %p %p flags %p\n", k32[0].p, k32[1].p, vals[0].p, vals[1].p, low[0].p,
+                             low[1].p, flags.p);
             int sel;
             if (layout == SPLIT) {
                 gen.low_bits = low_bits;
