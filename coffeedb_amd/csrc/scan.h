@@ -157,19 +157,48 @@ __global__ __launch_bounds__(SC_NT) void scan_apply_kernel(In in, uint64_t n, Op
     }
 }
 
-template <typename T> struct ScanWorkspace {
-    DevBuf partials;
-    uint64_t nb = 0;
+// functors that run the scan kernels over the tile partials themselves (second level)
+template <typename T> struct PartialsIn {
+    const T* p;
+    __device__ __forceinline__ T operator()(uint64_t i) const { return p[i]; }
 };
+template <typename T> struct PartialsOut {  // exclusive prefix in place, grand total behind the last one
+    T* p;
+    uint64_t nb;
+    __device__ __forceinline__ void operator()(uint64_t i, const T& ex, const T& in) const {
+        p[i] = ex;
+        if (i + 1 == nb) p[nb] = in;
+    }
+};
+
+// exclusive scan of the nb tile partials in place (partials[nb] = grand total).  One workgroup sweeps up to
+// 2^16 partials; beyond that (n > 2^28 items) the partials are scanned like the data: reduce per 4096, scan
+// the few second-level partials, apply — three parallel launches instead of a 30 us sweep per 16 Ki partials.
+template <typename T, typename Op>
+void scan_partials_inplace(hipStream_t s, DevBuf& partials, uint64_t nb, Op op, T identity) {
+    T* d_part = partials.as<T>();
+    if (nb <= (1ull << 16)) {
+        hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part, nb, op, identity);
+        return;
+    }
+    const uint64_t nb2 = ceil_div(nb, SC_TILE);
+    T* d_part2 = d_part + nb + 1;  // second-level partials live behind the first level (space reserved by callers)
+    PartialsIn<T> pin{d_part};
+    hipLaunchKernelGGL((scan_reduce_kernel<T, PartialsIn<T>, Op>), dim3((unsigned)nb2), dim3(SC_NT), 0, s, pin, nb, op, identity, d_part2);
+    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part2, nb2, op, identity);
+    hipLaunchKernelGGL((scan_apply_kernel<T, PartialsIn<T>, PartialsOut<T>, Op>), dim3((unsigned)nb2), dim3(SC_NT), 0, s, pin, nb, op,
+                       identity, (const T*)d_part2, PartialsOut<T>{d_part, nb});
+}
+inline uint64_t scan_partials_slots(uint64_t nb) { return nb + 1 + ceil_div(nb, SC_TILE) + 1; }
 
 // Phase 1: reduce + scan of partials; returns the grand total (synchronises the stream).
 template <typename T, typename In, typename Op>
 T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity) {
     const uint64_t nb = ceil_div(n, SC_TILE);
-    partials.ensure((nb + 1) * sizeof(T));
+    partials.ensure(scan_partials_slots(nb) * sizeof(T));
     T* d_part = partials.as<T>();
     if (nb) hipLaunchKernelGGL((scan_reduce_kernel<T, In, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity, d_part);
-    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part, nb, op, identity);
+    scan_partials_inplace<T, Op>(s, partials, nb, op, identity);
     T total;
     CDB_HIP(hipMemcpyAsync(&total, d_part + nb, sizeof(T), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
@@ -180,10 +209,10 @@ T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T ident
 template <typename T, typename In, typename Op>
 void scan_totals_device(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity) {
     const uint64_t nb = ceil_div(n, SC_TILE);
-    partials.ensure((nb + 1) * sizeof(T));
+    partials.ensure(scan_partials_slots(nb) * sizeof(T));
     T* d_part = partials.as<T>();
     if (nb) hipLaunchKernelGGL((scan_reduce_kernel<T, In, Op>), dim3((unsigned)nb), dim3(SC_NT), 0, s, in, n, op, identity, d_part);
-    hipLaunchKernelGGL((scan_partials_kernel<T, Op>), dim3(1), dim3(SP_NT), 0, s, d_part, nb, op, identity);
+    scan_partials_inplace<T, Op>(s, partials, nb, op, identity);
 }
 
 // Phase 2: apply (uses the partials left by scan_totals for the same `in`, n, op).
