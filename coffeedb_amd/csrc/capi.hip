@@ -154,6 +154,7 @@ void cdb_destroy(cdb_index* h) {
         (void)hipStreamSynchronize(h->ix.stream);
         (void)hipStreamDestroy(h->ix.stream);
     }
+    if (h->ix.h_single) (void)hipHostFree(h->ix.h_single);
     delete h;
 }
 
@@ -615,6 +616,37 @@ struct PendingQuery {
 };
 
 void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
+    if (batch.size() == 1) {  // a lone keyword: one wavefront, one launch (query.hip: q_single_kernel)
+        PendingQuery* q = batch[0];
+        int64_t ids[64], counts[64];
+        size_t rows = 0;
+        bool answered = false;
+        const int rc1 = guarded(h, [&] {
+            Index& ix = h->ix;
+            std::lock_guard<std::mutex> g(ix.mu);
+            set_device(ix);
+            const double t0 = wall_ms();
+            answered = query_single_on_device(ix, q->kw, q->len, ids, counts, &rows);
+            if (answered) ix.qstats.query_ms = wall_ms() - t0;
+        });
+        if (rc1 != CDB_OK) {
+            q->rc = rc1;
+            return;
+        }
+        if (answered) {
+            q->rows = rows;
+            q->ids = (int64_t*)std::malloc(std::max<size_t>(rows, 1) * 8);
+            q->counts = (int64_t*)std::malloc(std::max<size_t>(rows, 1) * 8);
+            if (!q->ids || !q->counts) {
+                q->rc = CDB_E_DEVICE;
+                return;
+            }
+            std::memcpy(q->ids, ids, rows * 8);
+            std::memcpy(q->counts, counts, rows * 8);
+            q->rc = CDB_OK;
+            return;
+        }
+    }
     std::string blob;
     std::vector<uint64_t> offs{0};
     for (auto* q : batch) {
@@ -745,6 +777,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
+    else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
     else if (!std::strcmp(name, "bucket_group_limit")) ix.bucket_group_limit = (uint64_t)value;
     else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
         ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;

@@ -51,6 +51,9 @@ struct Index {
     bool coalesce_queries = true;
     bool keep_keys = true;        // keep d_keys when it costs <= 16 GiB (8 bytes per suffix)
     bool use_wave_rows = true;    // wavefront-per-pattern row building when every hit list has <= 64 entries
+    bool use_single_query = true; // a lone cdb_query is answered by one wavefront in one launch (query.hip)
+    void* h_single = nullptr;     // host-mapped result block of that kernel (+ its device address)
+    void* d_single = nullptr;
     bool use_fast_search = true;  // pivot-table / galloping search on sorted arrays (query.hip)
 
     // ---- host staging (cdb_add)
@@ -134,6 +137,8 @@ struct DeviceCsr {
 // grouped by result row, ascending
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
                                 bool with_offsets = false);
+// one keyword through the single-wavefront kernel; false = not applicable, use the batched path
+bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows);
 // highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
 // ix.q_keys0, inclusive span ends -> ix.q_keys1
 struct SpanResult {

@@ -9,6 +9,8 @@
 //   a11     hit gather (doc = entry & mask) + sort by document: one stable radix sort of
 //           (pattern id ∘ doc) keys for the whole batch instead of one sort per keyword;
 //   a12     run-length encoding into CSR rows (ids[doc], count), ascending document index.
+#include <cstring>
+
 #include "index_impl.h"
 #include "scan.h"
 
@@ -954,6 +956,181 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
 }
 
 }  // namespace
+
+// ---- one keyword, one wavefront, one launch ---------------------------------------------------------
+// string_index::query() is called with ONE keyword (database.cpp:392).  The batched pipeline costs ~12 launches
+// and four host round trips for it (~105 us); here a single wavefront does everything: both bounds by a
+// 64-ary search (every lane probes one position per round: log65 n = 5-6 rounds of dependent loads instead
+// of 2 log2 n = 60), the <= 64 hits are sorted and run-length encoded in registers exactly like
+// q_wave_rows_kernel, and the rows go straight into host-mapped memory.  The keyword travels in the kernel
+// arguments.  Hit lists of more than 64 entries, keywords of more than 120 bytes and not globally sorted
+// (reference-compat) arrays take the batched path.
+struct SingleKw {
+    uint32_t len;
+    uint8_t bytes[124];
+};
+struct SingleOut {
+    uint64_t nrows;  // ~0 = not answered here (more than 64 hits)
+    uint64_t hits;
+    int64_t ids[64];
+    int64_t counts[64];
+};
+
+template <typename V>
+__global__ __launch_bounds__(64) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
+                                                      const uint8_t* __restrict__ text,
+                                                      const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                      const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out) {
+    __shared__ uint8_t s_kw[128];
+    const int lane = threadIdx.x;
+    const uint64_t m = kw.len;
+    for (int i = lane; i < 128; i += 64) s_kw[i] = i < 124 ? kw.bytes[i] : (uint8_t)0;
+    __syncthreads();
+    const uint8_t* k = s_kw;
+    // three-way compare of the keyword with the suffix at slot M: <0 keyword smaller, 0 keyword is a prefix of
+    // the suffix or equal on the common part
+    auto probe = [&](int64_t M, bool& le, bool& pref) {
+        const V e = sa[M];
+        const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
+        const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
+        const int c = cmp_common(k, m, text + b, sl);
+        le = c < 0 || (c == 0 && m <= sl);
+        pref = c == 0 && sl >= m;
+    };
+    auto shfl64 = [&](int64_t v, int src) -> int64_t {
+        const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)((uint64_t)v >> 32), src);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    // ---- lower bound (index.cpp:260-274): smallest M in [0, n-1] with keyword <= suffix(M), else n-1
+    int64_t L = 0, R = (int64_t)n - 1;
+    while (R - L >= 64) {
+        const int64_t M = L + ((R - L) / 65) * (lane + 1) + (((R - L) % 65) * (lane + 1)) / 65;
+        bool le, pf;
+        probe(M, le, pf);
+        const uint64_t b = __ballot(le);
+        if (b == 0) {
+            L = shfl64(M, 63) + 1;
+        } else {
+            const int f = __ffsll((unsigned long long)b) - 1;
+            R = shfl64(M, f);
+            if (f > 0) L = shfl64(M, f - 1) + 1;
+        }
+    }
+    {
+        const int64_t M = L + lane;
+        bool le = true, pf = false;
+        if (M < R) probe(M, le, pf);  // (slot R itself is the saturated answer)
+        const uint64_t b = __ballot(le);
+        L += __ffsll((unsigned long long)b) - 1;
+    }
+    const int64_t left = L;
+    // ---- prefix upper bound (index.cpp:275-287): the hits are [left, right)
+    int64_t right = left;
+    {
+        bool le, pf = false;
+        const int64_t M = left + lane;
+        if (M < (int64_t)n) probe(M, le, pf);
+        const uint64_t np = ~__ballot(pf);  // lanes whose slot is no match (or beyond the array)
+        if (np != 0) {
+            right = left + (__ffsll((unsigned long long)np) - 1);
+        } else {  // more than 64 hits: 64-ary search for the first non-match in (left + 63, n]
+            int64_t A = left + 64, B = (int64_t)n;  // answer in [A, B], slot B counts as a non-match
+            while (B - A >= 64) {
+                const int64_t P = A + ((B - A) / 65) * (lane + 1) + (((B - A) % 65) * (lane + 1)) / 65;
+                bool l2, p2;
+                probe(P, l2, p2);
+                const uint64_t nb = __ballot(!p2);
+                if (nb == 0) {
+                    A = shfl64(P, 63) + 1;
+                } else {
+                    const int f = __ffsll((unsigned long long)nb) - 1;
+                    B = shfl64(P, f);
+                    if (f > 0) A = shfl64(P, f - 1) + 1;
+                }
+            }
+            const int64_t P = A + lane;
+            bool l2, p2 = false;
+            if (P < B) probe(P, l2, p2);
+            const uint64_t nb = ~__ballot(p2);
+            right = A + (__ffsll((unsigned long long)nb) - 1);
+        }
+    }
+    const uint64_t hits = (uint64_t)(right - left);
+    if (hits > 64) {
+        if (lane == 0) {
+            out->hits = hits;
+            out->nrows = ~0ull;
+        }
+        return;
+    }
+    // ---- rows (index.cpp:288-322): document indices sorted, run-length encoded, mapped to object ids
+    const uint32_t h = (uint32_t)hits;
+    uint32_t v = 0xFFFFFFFFu;
+    uint64_t vd = 0;
+    if ((uint32_t)lane < h) {
+        vd = (uint64_t)sa[(uint64_t)left + lane] & mask;
+        v = (uint32_t)vd;  // (document indices fit 32 bits: index.cpp:199)
+    }
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int q = kk >> 1; q > 0; q >>= 1) {
+            const uint32_t o = __shfl_xor(v, q);
+            const bool up = (lane & kk) == 0;
+            const bool lower = (lane & q) == 0;
+            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    const uint32_t prev = __shfl_up(v, 1);
+    const bool head = (uint32_t)lane < h && (lane == 0 || v != prev);
+    const uint64_t heads = __ballot(head);
+    if (head) {
+        const uint32_t r = __popcll(heads & ((1ull << lane) - 1ull));
+        const uint64_t later = heads & ~((2ull << lane) - 1ull);
+        const uint32_t next = later ? (uint32_t)(__ffsll((unsigned long long)later) - 1) : h;
+        out->ids[r] = ids[v];
+        out->counts[r] = (int64_t)(next - (uint32_t)lane);
+    }
+    if (lane == 0) {
+        out->hits = hits;
+        out->nrows = (uint64_t)__popcll(heads);
+    }
+}
+
+// true = answered (rows copied to ids_out / counts_out, up to 64); false = take the batched path
+bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows) {
+    if (!ix.use_single_query || !ix.sa_sorted || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
+        ix.ndocs >= 0xFFFFFFFFull)
+        return false;
+    hipStream_t s = ix.stream;
+    if (!ix.h_single) {
+        CDB_HIP(hipHostMalloc(&ix.h_single, sizeof(SingleOut), hipHostMallocMapped));
+        CDB_HIP(hipHostGetDevicePointer(&ix.d_single, ix.h_single, 0));
+    }
+    SingleKw k{};
+    k.len = (uint32_t)len;
+    std::memcpy(k.bytes, kw, len);
+    SingleOut* out = static_cast<SingleOut*>(ix.h_single);
+    out->nrows = ~0ull;
+    if (ix.width == 8)
+        hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(64), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
+                           ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
+    else
+        hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(64), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
+                           ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
+    CDB_HIP(hipGetLastError());
+    CDB_HIP(hipStreamSynchronize(s));
+    if (out->nrows == ~0ull) return false;
+    *nrows = (size_t)out->nrows;
+    std::memcpy(ids_out, out->ids, out->nrows * 8);
+    std::memcpy(counts_out, out->counts, out->nrows * 8);
+    ix.qstats.nhits = out->hits;
+    ix.qstats.nrows = out->nrows;
+    return true;
+}
 
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, bool with_offsets) {
     DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat, with_offsets)

@@ -564,3 +564,31 @@ def test_resident_build_equals_host_table_build(G, tmp_path):
         g.build_resident(d_text.data_ptr(), bad.data_ptr(), d_ids.data_ptr(), len(ids))
     g.build_resident(d_text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), len(ids))
     assert np.array_equal(g.sa(), o.sa())
+
+
+def test_single_keyword_wavefront_path(G):
+    # a lone cdb_query is answered by one wavefront (64-ary search + in-register rows); it must agree with the
+    # batched pipeline and the oracle for every kind of keyword, and hand over to the batch path when the
+    # hit list exceeds one wavefront or the keyword its argument block
+    blob, ds = W.ascii_corpus(4000, 300, seed=5, lo=0x61, hi=0x66)
+    ids = np.arange(4000, dtype=np.int64)[::-1].copy() * 2 + 11
+    o = _oracle(blob, ds, ids)
+    g = _gpu(G, blob, ds, ids)
+    g0 = _gpu(G, blob, ds, ids, single_query=0)
+    rng = np.random.default_rng(3)
+    kws = [bytes(blob[:1]), b"zz", b"a", bytes(blob[10:13]), bytes(blob[-5:]), bytes(blob[:300]), bytes(blob[:200]) + b"x",
+           bytes(blob[7:7 + 121]), bytes(blob[7:7 + 120]), b"\x01", b"\xff"]
+    for _ in range(400):
+        p = int(rng.integers(0, len(blob) - 40)); m = int(rng.integers(1, 30))
+        kw = bytearray(blob[p:p + m])
+        if rng.random() < 0.2:
+            kw[int(rng.integers(0, m))] = 0x7A
+        kws.append(bytes(kw))
+    for kw in kws:
+        want = o.query(kw)
+        assert g.query(kw) == want, kw
+        assert g0.query(kw) == want, kw
+    # first and last suffix, every document at once
+    srt = sorted(bytes(blob[int(ds[d]):int(ds[d + 1])]) for d in range(50))
+    for kw in (srt[0], srt[-1], srt[0][:2], srt[-1][:2]):
+        assert g.query(kw) == o.query(kw), kw
