@@ -618,7 +618,9 @@ struct PendingQuery {
 void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
     if (batch.size() == 1) {  // a lone keyword: one wavefront, one launch (query.hip: q_single_kernel)
         PendingQuery* q = batch[0];
-        int64_t ids[64], counts[64];
+        std::vector<int64_t> idbuf(4096), cntbuf(4096);  // (query.hip: SINGLE_MAX_HITS rows at most)
+        int64_t* ids = idbuf.data();
+        int64_t* counts = cntbuf.data();
         size_t rows = 0;
         bool answered = false;
         const int rc1 = guarded(h, [&] {

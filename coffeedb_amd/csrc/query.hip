@@ -963,30 +963,38 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
 // 64-ary search (every lane probes one position per round: log65 n = 5-6 rounds of dependent loads instead
 // of 2 log2 n = 60), the <= 64 hits are sorted and run-length encoded in registers exactly like
 // q_wave_rows_kernel, and the rows go straight into host-mapped memory.  The keyword travels in the kernel
-// arguments.  Hit lists of more than 64 entries, keywords of more than 120 bytes and not globally sorted
-// (reference-compat) arrays take the batched path.
+// arguments.  Hit lists of up to 4096 entries are sorted in LDS by the whole workgroup instead; longer ones,
+// keywords of more than 120 bytes and not globally sorted (reference-compat) arrays take the batched path.
 struct SingleKw {
     uint32_t len;
     uint8_t bytes[124];
 };
+constexpr uint32_t SINGLE_MAX_HITS = 4096;
 struct SingleOut {
-    uint64_t nrows;  // ~0 = not answered here (more than 64 hits)
+    uint64_t nrows;  // ~0 = not answered here (more than SINGLE_MAX_HITS hits)
     uint64_t hits;
-    int64_t ids[64];
-    int64_t counts[64];
+    int64_t ids[SINGLE_MAX_HITS];
+    int64_t counts[SINGLE_MAX_HITS];
 };
 
 template <typename V>
-__global__ __launch_bounds__(64) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
                                                       const uint8_t* __restrict__ text,
                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                       const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out) {
     __shared__ uint8_t s_kw[128];
-    const int lane = threadIdx.x;
+    __shared__ int64_t s_left;
+    __shared__ uint64_t s_hits;
+    __shared__ uint32_t s_doc[SINGLE_MAX_HITS];
+    __shared__ int64_t s_rid[SINGLE_MAX_HITS];    // rows are assembled in LDS and leave for the host-mapped block
+    __shared__ uint32_t s_rcnt[SINGLE_MAX_HITS];  // with consecutive lanes on consecutive slots
+    __shared__ uint32_t s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t m = kw.len;
-    for (int i = lane; i < 128; i += 64) s_kw[i] = i < 124 ? kw.bytes[i] : (uint8_t)0;
+    if (tid < 128) s_kw[tid] = tid < 124 ? kw.bytes[tid] : (uint8_t)0;
     __syncthreads();
     const uint8_t* k = s_kw;
+    if (wave == 0) {  // ---- the search is the first wavefront's business
     // three-way compare of the keyword with the suffix at slot M: <0 keyword smaller, 0 keyword is a prefix of
     // the suffix or equal on the common part
     auto probe = [&](int64_t M, bool& le, bool& pref) {
@@ -1055,50 +1063,115 @@ __global__ __launch_bounds__(64) void q_single_kernel(const V* __restrict__ sa, 
             right = A + (__ffsll((unsigned long long)nb) - 1);
         }
     }
-    const uint64_t hits = (uint64_t)(right - left);
-    if (hits > 64) {
-        if (lane == 0) {
+    if (lane == 0) {
+        s_left = left;
+        s_hits = (uint64_t)(right - left);
+    }
+    }  // wave 0
+    __syncthreads();
+    const int64_t left = s_left;
+    const uint64_t hits = s_hits;
+    if (hits > SINGLE_MAX_HITS) {
+        if (tid == 0) {
             out->hits = hits;
             out->nrows = ~0ull;
         }
         return;
     }
-    // ---- rows (index.cpp:288-322): document indices sorted, run-length encoded, mapped to object ids
     const uint32_t h = (uint32_t)hits;
-    uint32_t v = 0xFFFFFFFFu;
-    uint64_t vd = 0;
-    if ((uint32_t)lane < h) {
-        vd = (uint64_t)sa[(uint64_t)left + lane] & mask;
-        v = (uint32_t)vd;  // (document indices fit 32 bits: index.cpp:199)
+    if (h <= 64) {
+        // ---- rows (index.cpp:288-322) of a short hit list: sorted and run-length encoded in registers
+        if (wave != 0) return;
+        uint32_t v = 0xFFFFFFFFu;
+        if ((uint32_t)lane < h) v = (uint32_t)((uint64_t)sa[(uint64_t)left + lane] & mask);  // (doc indices fit 32 bits: index.cpp:199)
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+            for (int q = kk >> 1; q > 0; q >>= 1) {
+                const uint32_t o = __shfl_xor(v, q);
+                const bool up = (lane & kk) == 0;
+                const bool lower = (lane & q) == 0;
+                const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+                v = (lower == up) ? mn : mx;
+            }
+        }
+        const uint32_t prev = __shfl_up(v, 1);
+        const bool head = (uint32_t)lane < h && (lane == 0 || v != prev);
+        const uint64_t heads = __ballot(head);
+        if (head) {
+            const uint32_t r = __popcll(heads & ((1ull << lane) - 1ull));
+            const uint64_t later = heads & ~((2ull << lane) - 1ull);
+            const uint32_t next = later ? (uint32_t)(__ffsll((unsigned long long)later) - 1) : h;
+            out->ids[r] = ids[v];
+            out->counts[r] = (int64_t)(next - (uint32_t)lane);
+        }
+        if (lane == 0) {
+            out->hits = hits;
+            out->nrows = (uint64_t)__popcll(heads);
+        }
+        return;
     }
-#pragma unroll
-    for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-        for (int q = kk >> 1; q > 0; q >>= 1) {
-            const uint32_t o = __shfl_xor(v, q);
-            const bool up = (lane & kk) == 0;
-            const bool lower = (lane & q) == 0;
-            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
-            v = (lower == up) ? mn : mx;
+    // ---- up to SINGLE_MAX_HITS hits: bitonic sort of the document indices in LDS by the whole workgroup, heads
+    // counted per thread chunk, rows written in order
+    uint32_t cap = 128;
+    while (cap < h) cap <<= 1;
+    for (uint32_t i = tid; i < cap; i += 256) s_doc[i] = i < h ? (uint32_t)((uint64_t)sa[(uint64_t)left + i] & mask) : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= cap; kk <<= 1) {
+        for (uint32_t q = kk >> 1; q > 0; q >>= 1) {
+            for (uint32_t i = tid; i < cap; i += 256) {
+                const uint32_t partner = i ^ q;
+                if (partner > i) {
+                    const uint32_t a = s_doc[i], b = s_doc[partner];
+                    const bool up = (i & kk) == 0;
+                    if ((a > b) == up) {
+                        s_doc[i] = b;
+                        s_doc[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
-    const uint32_t prev = __shfl_up(v, 1);
-    const bool head = (uint32_t)lane < h && (lane == 0 || v != prev);
-    const uint64_t heads = __ballot(head);
-    if (head) {
-        const uint32_t r = __popcll(heads & ((1ull << lane) - 1ull));
-        const uint64_t later = heads & ~((2ull << lane) - 1ull);
-        const uint32_t next = later ? (uint32_t)(__ffsll((unsigned long long)later) - 1) : h;
-        out->ids[r] = ids[v];
-        out->counts[r] = (int64_t)(next - (uint32_t)lane);
+    // thread t owns the consecutive slots [t * per, (t + 1) * per)
+    const uint32_t per = cap / 256 ? cap / 256 : 1;
+    const uint32_t b0 = (uint32_t)tid * per;
+    uint32_t nheads = 0;
+    for (uint32_t i = b0; i < b0 + per && i < h; ++i) nheads += (i == 0 || s_doc[i] != s_doc[i - 1]) ? 1u : 0u;
+    // exclusive prefix of nheads over the 256 threads
+    uint32_t incl = nheads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off);
+        if (lane >= off) incl += x;
     }
-    if (lane == 0) {
+    if (lane == 63) s_wcnt[wave] = incl;
+    __syncthreads();
+    uint32_t base_r = incl - nheads;
+    for (int w = 0; w < wave; ++w) base_r += s_wcnt[w];
+    const uint32_t total_rows = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    for (uint32_t i = b0; i < b0 + per && i < h; ++i) {
+        if (i == 0 || s_doc[i] != s_doc[i - 1]) {
+            const uint32_t dv = s_doc[i];
+            uint32_t e = i + 1;
+            while (e < h && s_doc[e] == dv) ++e;  // run length (runs crossing into the next chunk are walked here)
+            s_rid[base_r] = ids[dv];
+            s_rcnt[base_r] = e - i;
+            ++base_r;
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < total_rows; r += 256) {
+        out->ids[r] = s_rid[r];
+        out->counts[r] = (int64_t)s_rcnt[r];
+    }
+    if (tid == 0) {
         out->hits = hits;
-        out->nrows = (uint64_t)__popcll(heads);
+        out->nrows = total_rows;
     }
 }
 
-// true = answered (rows copied to ids_out / counts_out, up to 64); false = take the batched path
+// true = answered (rows copied to ids_out / counts_out, up to SINGLE_MAX_HITS); false = take the batched path
 bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows) {
     if (!ix.use_single_query || !ix.sa_sorted || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
         ix.ndocs >= 0xFFFFFFFFull)
@@ -1114,16 +1187,19 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_
     SingleOut* out = static_cast<SingleOut*>(ix.h_single);
     out->nrows = ~0ull;
     if (ix.width == 8)
-        hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(64), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
+        hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
                            (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
     else
-        hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(64), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
+        hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
                            (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
     CDB_HIP(hipGetLastError());
     CDB_HIP(hipStreamSynchronize(s));
-    if (out->nrows == ~0ull) return false;
+    if (out->nrows == ~0ull) {
+        if (getenv("CDB_DEBUG_SINGLE")) std::fprintf(stderr, "[single] handed over: hits=%llu\n", (unsigned long long)out->hits);
+        return false;
+    }
     *nrows = (size_t)out->nrows;
     std::memcpy(ids_out, out->ids, out->nrows * 8);
     std::memcpy(counts_out, out->counts, out->nrows * 8);

@@ -578,6 +578,9 @@ def test_single_keyword_wavefront_path(G):
     rng = np.random.default_rng(3)
     kws = [bytes(blob[:1]), b"zz", b"a", bytes(blob[10:13]), bytes(blob[-5:]), bytes(blob[:300]), bytes(blob[:200]) + b"x",
            bytes(blob[7:7 + 121]), bytes(blob[7:7 + 120]), b"\x01", b"\xff"]
+    for m in (2, 3, 4, 5, 6, 7):   # hit lists from ~10^5 (batched path) through the LDS sort (<= 4096) to one wavefront (<= 64)
+        for p in (0, 777, 31337):
+            kws.append(bytes(blob[p:p + m]))
     for _ in range(400):
         p = int(rng.integers(0, len(blob) - 40)); m = int(rng.integers(1, 30))
         kw = bytearray(blob[p:p + m])
