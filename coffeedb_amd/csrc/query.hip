@@ -964,7 +964,8 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
 // of 2 log2 n = 60), the <= 64 hits are sorted and run-length encoded in registers exactly like
 // q_wave_rows_kernel, and the rows go straight into host-mapped memory.  The keyword travels in the kernel
 // arguments.  Hit lists of up to 4096 entries are sorted in LDS by the whole workgroup instead; longer ones,
-// keywords of more than 120 bytes and not globally sorted (reference-compat) arrays take the batched path.
+// keywords of more than 120 bytes take the batched path.  On not globally sorted (reference-compat) arrays one
+// lane walks the reference's own two bisections instead of the 64-ary search.
 struct SingleKw {
     uint32_t len;
     uint8_t bytes[124];
@@ -981,7 +982,8 @@ template <typename V>
 __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
                                                       const uint8_t* __restrict__ text,
                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
-                                                      const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out) {
+                                                      const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out,
+                                                      bool sorted) {
     __shared__ uint8_t s_kw[128];
     __shared__ int64_t s_left;
     __shared__ uint64_t s_hits;
@@ -1009,6 +1011,31 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
         const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)((uint64_t)v >> 32), src);
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
+    if (!sorted) {
+        // reference-compat ordering of text with bytes >= 0x80: the array is not globally sorted, so the answer
+        // is whatever the reference's two bisections visit (index.cpp:260-287) — one lane walks exactly them
+        if (lane == 0) {
+            int64_t L = 0, R = (int64_t)n - 1;
+            while (L < R) {
+                const int64_t M = L + (R - L) / 2;
+                bool le, pf;
+                probe(M, le, pf);
+                if (le) R = M; else L = M + 1;
+            }
+            const int64_t lft = L;
+            L = lft - 1;
+            R = (int64_t)n - 1;
+            while (L < R) {
+                const int64_t M = L + (R - L + 1) / 2;
+                bool le, pf;
+                probe(M, le, pf);
+                if (pf) L = M; else R = M - 1;
+            }
+            const int64_t rgt = L + 1;
+            s_left = lft;
+            s_hits = rgt > lft ? (uint64_t)(rgt - lft) : 0ull;
+        }
+    } else {
     // ---- lower bound (index.cpp:260-274): smallest M in [0, n-1] with keyword <= suffix(M), else n-1
     int64_t L = 0, R = (int64_t)n - 1;
     while (R - L >= 64) {
@@ -1067,6 +1094,7 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
         s_left = left;
         s_hits = (uint64_t)(right - left);
     }
+    }  // sorted
     }  // wave 0
     __syncthreads();
     const int64_t left = s_left;
@@ -1173,7 +1201,7 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
 
 // true = answered (rows copied to ids_out / counts_out, up to SINGLE_MAX_HITS); false = take the batched path
 bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows) {
-    if (!ix.use_single_query || !ix.sa_sorted || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
+    if (!ix.use_single_query || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
         ix.ndocs >= 0xFFFFFFFFull)
         return false;
     hipStream_t s = ix.stream;
@@ -1189,11 +1217,11 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_
     if (ix.width == 8)
         hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted);
     else
         hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single));
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted);
     CDB_HIP(hipGetLastError());
     CDB_HIP(hipStreamSynchronize(s));
     if (out->nrows == ~0ull) {

@@ -595,3 +595,15 @@ def test_single_keyword_wavefront_path(G):
     srt = sorted(bytes(blob[int(ds[d]):int(ds[d + 1])]) for d in range(50))
     for kw in (srt[0], srt[-1], srt[0][:2], srt[-1][:2]):
         assert g.query(kw) == o.query(kw), kw
+    # reference-compat ordering (bytes >= 0x80, array not globally sorted): one lane walks the reference's own
+    # bisections — same (partly wrong) answers as the reference
+    for blob2, ds2 in ((_few_symbols(400000, 5, [0x41, 0x42, 0xC3, 0xA9]), W.uniform_docs(4000, 100)),
+                       W.utf8_corpus(300, 120, seed=4)):
+        ids2 = np.arange(len(ds2) - 1, dtype=np.int64)
+        o2 = _oracle(blob2, ds2, ids2)
+        g2 = _gpu(G, blob2, ds2, ids2)
+        assert g2.stat("compat_rotations") >= 1
+        pb, po = W.sample_patterns(blob2, ds2, 300, 1, 8, seed=4, miss_frac=0.1, miss_byte=0x5A)
+        for j in range(300):
+            kw = bytes(pb[int(po[j]):int(po[j + 1])])
+            assert g2.query(kw) == o2.query(kw), kw
