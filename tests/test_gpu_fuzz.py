@@ -79,4 +79,6 @@ def test_fuzz_parity(seed):
     if len(set(ids.tolist())) == nd:
         assert g.query_or(kws) == o.filter_or(kws), (seed, opts)
     assert g.query_spans(kws) == o.highlight_spans(kws, ids), (seed, opts)
+    for kw in kws[:6]:   # a lone keyword takes the one-wavefront kernel (<= 4096 hits) or hands over to the batch path
+        assert g.query(kw) == o.query(kw), (seed, opts, kw)
     g.close()
