@@ -817,6 +817,116 @@ void apply_reference_order(Index& ix, V* sa) {
     CDB_HIP(hipStreamSynchronize(s));
 }
 
+// The same order reached in ONE out-of-place pass (when a second array fits): the rotations only move whole
+// child buckets, so every bucket of the rotated array is still a contiguous range of the plainly sorted one.
+// The bucket tree is therefore walked on the UNROTATED array — each bucket carries (its range there, where it
+// ends up) — and the leaves become copy segments.  1 read + 1 write per entry instead of 2 + 2 for every
+// level of three reversals; the kept search keys can make the same trip.
+struct CompatSeg {
+    unsigned long long src, dst;
+    uint32_t count, pad;
+};
+constexpr uint32_t CS_ITEM = 16384;
+template <typename T>
+__global__ __launch_bounds__(256) void compat_segcopy_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                             const CompatSeg* __restrict__ segs) {
+    const CompatSeg sg = segs[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < sg.count; i += 256) out[sg.dst + i] = in[sg.src + i];
+}
+
+struct CompatNode {
+    unsigned long long lo, hi, fin;  // range in the sorted array, first slot in the reference order
+};
+
+// returns false (nothing done) when the scratch array cannot be had; sa_buf is replaced by the reordered array
+template <typename V>
+bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
+    hipStream_t s = ix.stream;
+    const uint64_t n = ix.size;
+    const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
+    if (n <= chuck) return true;
+    DevBuf dst;
+    try {
+        dst.alloc(n * sizeof(V));
+    } catch (const Error&) {
+        return false;
+    }
+    const V* sa = sa_buf.as<V>();
+    std::vector<CompatNode> level{{0ull, (unsigned long long)n, 0ull}};
+    std::vector<CompatSeg> segs;
+    auto emit = [&](uint64_t src, uint64_t dstpos, uint64_t len) {
+        if (!len) return;
+        for (uint64_t o = 0; o < len; o += CS_ITEM)
+            segs.push_back(CompatSeg{(unsigned long long)(src + o), (unsigned long long)(dstpos + o),
+                                     (uint32_t)std::min<uint64_t>(CS_ITEM, len - o), 0u});
+    };
+    DevBuf d_buckets, d_bounds, d_segs;
+    uint64_t depth = 0;
+    std::vector<CompatBucket> cb;
+    while (!level.empty()) {
+        const size_t nb = level.size();
+        cb.resize(nb);
+        for (size_t b = 0; b < nb; ++b) cb[b] = CompatBucket{level[b].lo, level[b].hi};
+        d_buckets.ensure(nb * sizeof(CompatBucket));
+        d_bounds.ensure(nb * 258 * sizeof(uint64_t));
+        CDB_HIP(hipMemcpyAsync(d_buckets.p, cb.data(), nb * sizeof(CompatBucket), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL((compat_bounds_kernel<V>), dim3((unsigned)nb), dim3(320), 0, s, sa, ix.d_text,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const CompatBucket*)d_buckets.as<CompatBucket>(), depth, d_bounds.as<unsigned long long>());
+        std::vector<unsigned long long> hb(nb * 258);
+        CDB_HIP(hipMemcpyAsync(hb.data(), d_bounds.p, hb.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        std::vector<CompatNode> next;
+        for (size_t b = 0; b < nb; ++b) {
+            const unsigned long long* bd = &hb[b * 258];
+            const CompatNode nd = level[b];
+            const uint64_t a0 = bd[1], b0 = bd[129], end = bd[257];  // [a0,b0) = 0x00..0x7F, [b0,end) = 0x80..0xFF
+            const uint64_t lenEnd = a0 - nd.lo, lenA = b0 - a0, lenB = end - b0;
+            if (lenA && lenB) ix.bstats.compat_rotations++;
+            emit(nd.lo, nd.fin, lenEnd);  // suffixes that end here stay in front
+            // children in reference order: 0x80..0xFF first, then 0x00..0x7F; runs of small children are copied
+            // as one segment
+            uint64_t run_src = 0, run_dst = 0, run_len = 0;
+            auto flush = [&] {
+                emit(run_src, run_dst, run_len);
+                run_len = 0;
+            };
+            for (int k = 0; k < 256; ++k) {
+                const int v = k < 128 ? 128 + k : k - 128;
+                const uint64_t lo = bd[v + 1], len = bd[v + 2] - lo;
+                if (!len) continue;
+                const uint64_t fin = v >= 128 ? nd.fin + lenEnd + (lo - b0) : nd.fin + lenEnd + lenB + (lo - a0);
+                if (len > chuck) {
+                    flush();
+                    next.push_back(CompatNode{(unsigned long long)lo, (unsigned long long)(lo + len), (unsigned long long)fin});
+                } else if (run_len && run_src + run_len == lo && run_dst + run_len == fin) {
+                    run_len += len;
+                } else {
+                    flush();
+                    run_src = lo;
+                    run_dst = fin;
+                    run_len = len;
+                }
+            }
+            flush();
+        }
+        level.swap(next);
+        ++depth;
+    }
+    ix.bstats.compat_depth = depth;
+    if (!segs.empty()) {
+        d_segs.alloc(segs.size() * sizeof(CompatSeg));
+        CDB_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(CompatSeg), hipMemcpyHostToDevice, s));
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL((compat_segcopy_kernel<V>), dim3((unsigned)segs.size()), dim3(256), 0, s, sa, dst.as<V>(),
+                           (const CompatSeg*)d_segs.as<CompatSeg>());
+        ix.prof.end(t, "sa_compat_copy", 2 * n * sizeof(V), s);
+    }
+    CDB_HIP(hipStreamSynchronize(s));
+    sa_buf = std::move(dst);
+    return true;
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -1445,7 +1555,7 @@ void build_typed(Index& ix, bool big) {
     ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
     if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
     if (ix.reference_compat && high_bytes) {
-        apply_reference_order<V>(ix, sa);
+        if (big || !apply_reference_order_oop<V>(ix, sa_buf)) apply_reference_order<V>(ix, sa);
         ix.drop_keys();  // the rotations moved the entries away from their keys
     }
     ix.d_sa = std::move(sa_buf);
