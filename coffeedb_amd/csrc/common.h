@@ -67,7 +67,10 @@ public:
             trim();
             e = hipMalloc(&p, need);
         }
-        if (e != hipSuccess) throw Error(std::string("HIP error in hipMalloc: ") + hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();  // (callers may catch this and carry on: leave no sticky error behind)
+            throw Error(std::string("HIP error in hipMalloc: ") + hipGetErrorString(e));
+        }
         actual = need;
         return p;
     }

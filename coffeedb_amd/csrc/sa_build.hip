@@ -845,6 +845,11 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
     const uint64_t n = ix.size;
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
     if (n <= chuck) return true;
+    {   // only when the second array fits comfortably: a failed allocation would flush the block cache for nothing
+        size_t fre = 0, tot = 0;
+        CDB_HIP(hipMemGetInfo(&fre, &tot));
+        if ((double)n * sizeof(V) > 0.8 * ((double)fre + (double)DevPool::get().cached_bytes())) return false;
+    }
     DevBuf dst;
     try {
         dst.alloc(n * sizeof(V));
@@ -1555,7 +1560,7 @@ void build_typed(Index& ix, bool big) {
     ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
     if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
     if (ix.reference_compat && high_bytes) {
-        if (big || !apply_reference_order_oop<V>(ix, sa_buf)) apply_reference_order<V>(ix, sa);
+        if (!apply_reference_order_oop<V>(ix, sa_buf)) apply_reference_order<V>(ix, sa);  // (in place when no second array fits)
         ix.drop_keys();  // the rotations moved the entries away from their keys
     }
     ix.d_sa = std::move(sa_buf);
