@@ -5,12 +5,14 @@
 // multithreaded MSD radix + std::sort leaves, /root/reference/src/index.cpp:75-128) and of the
 // hit->document grouping in the query path (replaces index.cpp:294-315).
 //
-// Per pass and per element the kernel moves sizeof(K)+sizeof(V) bytes in and the same out; that is the
-// "algorithmic bytes" figure used for the HBM roofline.
+// Per pass and per element the kernel moves sizeof(K)+sizeof(V) (+ sizeof(W) for an auxiliary low-digit array)
+// bytes in and the same out; that is the "algorithmic bytes" figure used for the HBM roofline.
 //
 // Hardware mapping:
-//   * 64-wide wavefronts: per-digit ranks inside a wave come from 8 ballots (one per digit bit) —
-//     lanes with equal digits find each other without LDS atomics, which keeps the sort stable;
+//   * 64-wide wavefronts: the rank of an element among the equal digits of its wave comes from ONE returning
+//     LDS atomic on the wave's private counters (ATOMRANK; stable because same-address LDS atomics of one
+//     instruction complete in lane order on gfx950 — verified per device by rs_lane_order_probe_kernel), or
+//     from 8 ballots, one per digit bit, when that self-test fails;
 //   * LDS: keys, then values, of one tile are staged in sorted-by-digit order so that the global
 //     write-out has consecutive lanes writing consecutive addresses inside each digit run; the
 //     production tile is 1024 threads x 16 keys (150 KB of the CU's 160 KB LDS, one workgroup per CU);
