@@ -99,6 +99,8 @@ struct Index {
     // ---- scratch kept across calls
     RadixWorkspace rws;
     DevBuf scan_partials;
+    uint64_t q_spec_cap = 0;  // > 0: hits the next batch's buffers are sized for without asking (query.hip)
+    DevBuf q_spec;
     DevBuf q_pat, q_offs, q_left, q_right, q_hoff, q_keys0, q_keys1, q_flags, q_rowptr, q_ids, q_counts, q_hitptr, q_hitoff;
 
     // ---- options

@@ -297,10 +297,20 @@ __global__ __launch_bounds__(256) void q_wave_rows_kernel(const V* __restrict__ 
                                                           const uint64_t* __restrict__ hits,
                                                           const uint64_t* __restrict__ hoff, uint64_t npat,
                                                           uint32_t* __restrict__ row_doc, uint32_t* __restrict__ row_cnt,
-                                                          uint64_t* __restrict__ nrows) {
+                                                          uint64_t* __restrict__ nrows, uint64_t cap,
+                                                          unsigned long long* __restrict__ spill) {
     const int lane = threadIdx.x & 63;
     const uint64_t j = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= npat) return;
+    // (speculative launches — buffers sized from the previous batch, hit totals not yet known to the host — flag
+    //  what does not fit one wavefront or the buffers; the host then redoes the batch the ordinary way)
+    if (hits[j] > 64 || hoff[j] + hits[j] > cap) {
+        if (lane == 0) {
+            nrows[j] = 0;
+            if (spill) atomicOr(spill, 1ull);
+        }
+        return;
+    }
     const uint32_t h = (uint32_t)hits[j];
     uint32_t v = 0xFFFFFFFFu;  // sentinel behind every document index
     if ((uint32_t)lane < h) v = (uint32_t)((uint64_t)sa[(uint64_t)left[j] + lane] & mask);
@@ -693,6 +703,50 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
     launch_search<V>(ix, d_blob, d_offs, npat);
 
     HitsIn2 hin{ix.q_right.as<uint64_t>()};
+    // Speculative wavefront rows: when the previous batch of this index went down the wavefront path, buffers
+    // sized from it (x 1.5) let this batch run search -> scan -> rows -> scan -> emit without the host learning
+    // the hit totals in between; they come back together with the row count in ONE round trip.  Anything
+    // that does not fit (a hit list over 64, more hits than the buffers hold) raises a flag and the batch is
+    // redone below with the totals known.
+    if (!with_offsets && ix.use_wave_rows && ix.ndocs < 0xFFFFFFFFull && ix.q_spec_cap > 0) {
+        const uint64_t cap = ix.q_spec_cap;
+        scan_totals_device<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0});
+        const uint64_t nb1 = ceil_div(npat, SC_TILE);
+        ix.q_spec.ensure(4 * sizeof(uint64_t));  // {H, maxh, spill flag, nrows}
+        CDB_HIP(hipMemcpyAsync(ix.q_spec.p, ix.scan_partials.as<U2>() + nb1, sizeof(U2), hipMemcpyDeviceToDevice, s));
+        CDB_HIP(hipMemsetAsync(ix.q_spec.as<uint64_t>() + 2, 0, sizeof(uint64_t), s));
+        scan_apply<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0}, HitsOut2{ix.q_hoff.as<uint64_t>(), npat});
+        ix.q_keys0.ensure(cap * 4);
+        ix.q_keys1.ensure(cap * 4);
+        ix.q_flags.ensure(npat * 8);
+        ix.q_ids.ensure(std::max<uint64_t>(cap, 2) * 8);
+        ix.q_counts.ensure(std::max<uint64_t>(cap, 2) * 8);
+        t = ix.prof.begin(s);
+        hipLaunchKernelGGL((q_wave_rows_kernel<V>), dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s, sa, ix.mask,
+                           (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_right.as<uint64_t>(),
+                           (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, ix.q_keys0.as<uint32_t>(), ix.q_keys1.as<uint32_t>(),
+                           ix.q_flags.as<uint64_t>(), cap, ix.q_spec.as<unsigned long long>() + 2);
+        ix.prof.end(t, "q_wave_rows", cap * (sizeof(V) + 8), s);
+        NrowsIn nin{ix.q_flags.as<uint64_t>()};
+        scan_totals_device<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0);
+        scan_apply<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_rowptr.as<uint64_t>(), npat});
+        hipLaunchKernelGGL(q_wave_emit_kernel, dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s,
+                           (const uint32_t*)ix.q_keys0.as<uint32_t>(), (const uint32_t*)ix.q_keys1.as<uint32_t>(),
+                           (const uint64_t*)ix.q_hoff.as<uint64_t>(), (const uint64_t*)ix.q_rowptr.as<uint64_t>(), npat,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+        CDB_HIP(hipMemcpyAsync(ix.q_spec.as<uint64_t>() + 3, ix.q_rowptr.as<uint64_t>() + npat, 8, hipMemcpyDeviceToDevice, s));
+        uint64_t h4[4] = {0, 0, 1, 0};
+        CDB_HIP(hipMemcpyAsync(h4, ix.q_spec.p, sizeof(h4), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipGetLastError());
+        CDB_HIP(hipStreamSynchronize(s));
+        if (h4[2] == 0) {
+            out.nhits = h4[0];
+            out.nrows = h4[3];
+            ix.q_spec_cap = std::max<uint64_t>(h4[0] + h4[0] / 2, 4096);
+            return out;
+        }
+        ix.q_spec_cap = 0;  // this batch is not of that kind: the ordinary path below decides again
+    }
     const U2 tot = scan_totals<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0});
     scan_apply<U2>(s, ix.scan_partials, hin, npat, OpSumMax{}, U2{0, 0}, HitsOut2{ix.q_hoff.as<uint64_t>(), npat});
     const uint64_t H = tot.a, maxh = tot.b;
@@ -713,7 +767,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         hipLaunchKernelGGL((q_wave_rows_kernel<V>), dim3((unsigned)ceil_div(npat, 4)), dim3(256), 0, s, sa, ix.mask,
                            (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_right.as<uint64_t>(),
                            (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, ix.q_keys0.as<uint32_t>(), ix.q_keys1.as<uint32_t>(),
-                           ix.q_flags.as<uint64_t>());
+                           ix.q_flags.as<uint64_t>(), H, (unsigned long long*)nullptr);
         ix.prof.end(t, "q_wave_rows", H * (sizeof(V) + 8), s);
         NrowsIn nin{ix.q_flags.as<uint64_t>()};
         // rows <= hits, so the result arrays are sized by H and the number of rows is fetched together with
@@ -731,8 +785,10 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         CDB_HIP(hipGetLastError());
         CDB_HIP(hipStreamSynchronize(s));
         out.nrows = nrows;
+        ix.q_spec_cap = std::max<uint64_t>(H + H / 2, 4096);  // the next batch may run speculatively
         return out;
     }
+    ix.q_spec_cap = 0;
     const int dbits = (int)ix.bits;
     const int obits = with_offsets ? ix.off_bits : 0;  // offset field of the sort key (offset emission)
     if (with_offsets) ix.q_hitoff.ensure(H * 8);
