@@ -177,6 +177,8 @@ int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint6
         if (!ndocs) return;
         const uint64_t base = ix.host_text.size();
         ix.host_text.append(blob + doc_start[0], doc_start[ndocs] - doc_start[0]);
+        ix.ids.reserve(ix.ids.size() + ndocs);
+        ix.doc_start.reserve(ix.doc_start.size() + ndocs);
         for (uint64_t d = 0; d < ndocs; ++d) {
             ix.ids.push_back(ids[d]);
             ix.doc_start.push_back(base + doc_start[d + 1] - doc_start[0]);
