@@ -607,3 +607,43 @@ def test_single_keyword_wavefront_path(G):
         for j in range(300):
             kw = bytes(pb[int(po[j]):int(po[j + 1])])
             assert g2.query(kw) == o2.query(kw), kw
+
+
+def test_build_while_another_handle_serves_queries(G):
+    # CoffeeDB builds the next index (mutex_build, database.cpp:276) while the published one keeps answering
+    # (shared_lock, database.cpp:388): two handles, two host threads, one GPU and one block cache
+    import threading
+    blob, ds = W.ascii_corpus(20000, 200, seed=41)
+    ids = np.arange(20000, dtype=np.int64)
+    o = _oracle(blob, ds, ids)
+    live = _gpu(G, blob, ds, ids)
+    pats = W.sample_patterns(blob, ds, 2000, 3, 10, seed=8)
+    want_batch = o.query_batch(*pats)
+    kws = [bytes(blob[p:p + 6]) for p in range(0, 6000, 97)]
+    want_single = [o.query(kw) for kw in kws]
+    stop = threading.Event()
+    errors = []
+
+    def serve():
+        try:
+            while not stop.is_set():
+                got = live.query_batch(*pats)
+                assert got[3] == want_batch[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want_batch[:3]))
+                for kw, w in zip(kws, want_single):
+                    assert live.query(kw) == w
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    th = threading.Thread(target=serve)
+    th.start()
+    try:
+        blob2, ds2 = W.ascii_corpus(30000, 300, seed=42)
+        ids2 = np.arange(30000, dtype=np.int64) + 5
+        o2 = _oracle(blob2, ds2, ids2)
+        for _ in range(3):
+            nxt = _gpu(G, blob2, ds2, ids2)
+            assert np.array_equal(nxt.sa(), o2.sa())
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors[0]
