@@ -9,6 +9,8 @@ host = text[: 1 << 28].cpu().numpy()
 torch.cuda.synchronize()
 g = capi.GpuStringIndex(); g.set_option("profile", 1)
 g.build_device(text.data_ptr(), ds, ids)
+for kv in os.environ.get("CDB_OPTS", "").split(","):   # e.g. CDB_OPTS=interp_search=0
+    if kv: g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for npat, mmin, mmax in ((1000, 4, 16), (100_000, 4, 16), (1_000_000, 4, 16), (100_000, 2, 3), (100, 1, 1)):
     pb, po = W.sample_patterns(host, W.uniform_docs(1 << 18, dl), npat, mmin, mmax, seed=99)
     d_blob = torch.from_numpy(pb).cuda(); d_offs = torch.from_numpy(po.astype(np.int64)).cuda(); torch.cuda.synchronize()
