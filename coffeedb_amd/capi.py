@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
-    "cdb_query", "cdb_query_or", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify",
@@ -83,6 +83,8 @@ def load_library():
     lib.cdb_build_resident.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                               C.POINTER(C.c_size_t)]
+    lib.cdb_query_ranked.argtypes = [vp, vp, vp, u64, i64, i64, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
+                                     C.POINTER(C.c_size_t)]
     lib.cdb_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                                  C.POINTER(C.c_size_t)]
     lib.cdb_query_spans.argtypes = [vp, vp, vp, u64, C.POINTER(CdbSpans)]
@@ -196,6 +198,19 @@ class GpuStringIndex:
         ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
         self._check(self._lib.cdb_query_or(self._h, _ptr(blob) if len(blob) else None, _ptr(offs), len(keywords),
                                            C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = [(ids[i], cnt[i]) for i in range(n.value)]
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return out
+
+    def query_ranked(self, keywords, lo=1, hi=(1 << 62), limit=0):
+        """query_or, filtered to lo <= count < hi, ranked by descending count (ties: ascending id), first `limit` rows."""
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        self._check(self._lib.cdb_query_ranked(self._h, _ptr(blob) if len(blob) else None, _ptr(offs), len(keywords),
+                                               int(lo), int(hi), int(limit), C.byref(ids), C.byref(cnt), C.byref(n)))
         out = [(ids[i], cnt[i]) for i in range(n.value)]
         self._lib.cdb_free(ids)
         self._lib.cdb_free(cnt)

@@ -504,8 +504,9 @@ void cdb_hits_free(cdb_hits* x) {
     std::memset(x, 0, sizeof(*x));
 }
 
-int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
-                 size_t* nrows) {
+namespace {
+int query_or_impl(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                  size_t* nrows, bool ranked, int64_t corr_lo, int64_t corr_hi, uint64_t limit) {
     if (!h || !ids || !counts || !nrows || (nkw && !offsets)) return CDB_E_INVALID;
     *ids = nullptr;
     *counts = nullptr;
@@ -525,7 +526,8 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
         for (uint64_t j = 0; j <= nkw; ++j) rel[j] = offsets[j] - base;
         CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
         CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (nkw + 1) * 8, hipMemcpyHostToDevice, s));
-        const DeviceCsr r = query_or_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), nkw);
+        const DeviceCsr r = ranked ? query_ranked_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), nkw, corr_lo, corr_hi, limit)
+                                   : query_or_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), nkw);
         int64_t* hi = (int64_t*)host_alloc(r.nrows * 8);
         int64_t* hc = nullptr;
         try {
@@ -543,6 +545,17 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
         *counts = hc;
         *nrows = (size_t)r.nrows;
     });
+}
+}  // namespace
+
+int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                 size_t* nrows) {
+    return query_or_impl(h, blob, offsets, nkw, ids, counts, nrows, false, 0, 0, 0);
+}
+
+int cdb_query_ranked(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
+                     uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
+    return query_or_impl(h, blob, offsets, nkw, ids, counts, nrows, true, corr_lo, corr_hi, limit);
 }
 
 int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {

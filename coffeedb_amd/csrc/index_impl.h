@@ -150,5 +150,8 @@ SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_
                                  uint64_t total_pattern_bytes);
 // union over the patterns by object id with summed counts, rows ascending by id, in ix.q_ids / q_counts
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat);
+// ... filtered to lo <= count < hi and ranked: descending count, ties ascending id, at most `limit` rows (0 = all)
+DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
+                                 uint64_t limit);
 
 }  // namespace cdb

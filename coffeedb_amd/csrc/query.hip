@@ -1299,6 +1299,69 @@ DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t
     return r;
 }
 
+// ---- $correlation filter + ranking of one key's union on the device (interface.cpp:137-146) ----------
+// Rows of query_or (ascending id) whose summed count lies in [lo, hi) are compacted into (~count, id) pairs
+// and sorted by a STABLE radix sort: descending $correlation, ties ascending by object id.  (The reference
+// ranks with an unstable std::sort, so its order among equal counts is an artefact of introsort — the same
+// situation as the suffix array's equal suffixes; ascending id is the canonical form here.)
+struct CorrIn {
+    const int64_t* counts;
+    int64_t lo, hi;
+    __device__ __forceinline__ uint64_t operator()(uint64_t r) const { return counts[r] >= lo && counts[r] < hi ? 1ull : 0ull; }
+};
+struct CorrOut {
+    const int64_t* ids;
+    const int64_t* counts;
+    uint64_t* key;
+    uint64_t* val;
+    __device__ __forceinline__ void operator()(uint64_t r, uint64_t ex, uint64_t in) const {
+        if (in != ex) {
+            key[ex] = ~(uint64_t)counts[r];
+            val[ex] = (uint64_t)ids[r];
+        }
+    }
+};
+__global__ __launch_bounds__(256) void q_ranked_out_kernel(const uint64_t* __restrict__ key, const uint64_t* __restrict__ val,
+                                                           uint64_t n, int64_t* __restrict__ ids, int64_t* __restrict__ counts) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    ids[r] = (int64_t)val[r];
+    counts[r] = (int64_t)~key[r];
+}
+
+DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
+                                 uint64_t limit) {
+    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat) : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    hipStream_t s = ix.stream;
+    if (r.nrows == 0) {
+        ix.prof.resolve();
+        return r;
+    }
+    CorrIn cin{ix.q_counts.as<int64_t>(), lo, hi};
+    const uint64_t m = scan_totals<uint64_t>(s, ix.scan_partials, cin, r.nrows, OpAdd{}, (uint64_t)0);
+    DevBuf k0, k1, v0, v1;
+    k0.alloc(std::max<uint64_t>(m, 1) * 8); k1.alloc(std::max<uint64_t>(m, 1) * 8);
+    v0.alloc(std::max<uint64_t>(m, 1) * 8); v1.alloc(std::max<uint64_t>(m, 1) * 8);
+    if (m) {
+        scan_apply<uint64_t>(s, ix.scan_partials, cin, r.nrows, OpAdd{}, (uint64_t)0,
+                             CorrOut{ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>(), k0.as<uint64_t>(), v0.as<uint64_t>()});
+        const int sel = radix_sort<uint64_t, uint64_t>(s, ix.rws, ix.prof, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint64_t>(),
+                                                       v1.as<uint64_t>(), m, 0, 64, nullptr);
+        const uint64_t keep = limit ? std::min<uint64_t>(limit, m) : m;
+        hipLaunchKernelGGL(q_ranked_out_kernel, dim3((unsigned)ceil_div(keep, 256)), dim3(256), 0, s,
+                           (const uint64_t*)(sel ? k1 : k0).as<uint64_t>(), (const uint64_t*)(sel ? v1 : v0).as<uint64_t>(), keep,
+                           ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>());
+        r.nrows = keep;
+    } else {
+        r.nrows = 0;
+    }
+    CDB_HIP(hipGetLastError());
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    ix.prof.resolve();
+    return r;
+}
+
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat)
                                 : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);

@@ -129,6 +129,26 @@ index::result_type string_index::query_any(const std::vector<std::string>& keywo
     return out;
 }
 
+index::result_type string_index::query_ranked(const std::vector<std::string>& keywords, int64_t corr_lo, int64_t corr_hi,
+                                              uint64_t limit) const {
+    std::string blob;
+    std::vector<uint64_t> offs{0};
+    for (const auto& k : keywords) {
+        blob += k;
+        offs.push_back(blob.size());
+    }
+    int64_t *ids = nullptr, *counts = nullptr;
+    size_t rows = 0;
+    const int rc = cdb_query_ranked(handle, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
+    if (rc != CDB_OK) rethrow(handle, rc);
+    result_type out;
+    out.reserve(rows);
+    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+    cdb_free(ids);
+    cdb_free(counts);
+    return out;
+}
+
 std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> string_index::highlight_spans(
     const std::vector<std::string>& keywords) const {
     std::string blob;

@@ -83,6 +83,11 @@ public:
     // OR over the keywords of this key — what filter() computes per key before the AND across keys
     // (interface.cpp:78-113): union by object id, counts summed, ascending id.  One GPU call.
     result_type query_any(const std::vector<std::string>& keywords) const;
+    // The same union with the $correlation range filter and the ranking done on the GPU (interface.cpp:137-146
+    // for a query on this one key): corr_lo <= count < corr_hi, descending count, ties ascending by object id
+    // (the reference's unstable sort leaves that order open), at most `limit` rows (0 = all).
+    result_type query_ranked(const std::vector<std::string>& keywords, int64_t corr_lo, int64_t corr_hi,
+                             uint64_t limit = 0) const;
     // Highlight spans of every document that contains one of the keywords: (object id, [begin, end]
     // byte ranges, end inclusive) with the merge rule of ac_automaton::render (database.cpp:58-76).
     // Render with cdb_shim::render_spans (highlight.h).

@@ -138,6 +138,14 @@ void cdb_hits_free(cdb_hits* x);
 int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
                  size_t* nrows);
 
+/* The same union, then the $correlation range filter (interface.cpp:137-143: corr_lo <= count < corr_hi) and
+ * the final ranking (interface.cpp:144-146) on the device: rows by descending count, at most `limit` of them
+ * (0 = all).  The reference ranks with an unstable std::sort, so its order among equal counts is arbitrary;
+ * here ties ascend by object id (the shim's host-side rank_by_correlation reproduces the reference's own
+ * tie order when that is wanted bit for bit).  Release ids/counts with cdb_free. */
+int cdb_query_ranked(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
+                     uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows);
+
 /* Highlight spans — replaces the per-document re-scan of ac_automaton::render (database.cpp:58-76) that
  * select() runs for every returned object (database.cpp:394-441): for the keyword list of ONE string
  * key, every matching document's merged highlight spans [begin, end] (byte offsets, end inclusive), with

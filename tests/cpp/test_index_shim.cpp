@@ -95,6 +95,9 @@ static void gpu_string() {
     auto batch = sp->query_batch({"010", "0", "!"});
     CHECK(batch.size() == 3 && batch[0] == (R{{100, 2}, {101, 1}, {102, 2}}) && batch[1] == (R{{100, 3}, {101, 2}, {102, 4}}) && batch[2].empty());
     CHECK((sp->query_any({"010", "3"}) == R{{100, 4}, {101, 2}, {102, 2}}));
+    CHECK((sp->query_ranked({"010", "3"}, 1, 1000) == R{{100, 4}, {101, 2}, {102, 2}}));   // descending count, ties by id
+    CHECK((sp->query_ranked({"010", "3"}, 1, 3) == R{{101, 2}, {102, 2}}));
+    CHECK((sp->query_ranked({"010", "3"}, 1, 1000, 1) == R{{100, 4}}));
     {   // README.md:107-110: "010" highlighted in "3010103" gives "3<b>01010</b>3"
         auto spans = sp->highlight_spans({"010"});
         CHECK(spans.size() == 3 && spans[0].first == 100);

@@ -399,6 +399,15 @@ def test_or_merge_over_keywords_matches_reference_loop(G):
         g.query_or([b"ab", b""])
     with pytest.raises(RuntimeError, match="cannot be empty"):
         g.query_or([])
+    # interface.cpp:137-146 on the device: $correlation range filter, then descending count; the reference's
+    # unstable sort leaves the order among equal counts open — canonical here: ascending id
+    for group in (kws[:2], kws[2:7], kws[7:40], [b"a", b"b", b"ab"], [b"zzzz"]):
+        rows = o.filter_or(group)
+        for lo, hi, limit in ((1, 1 << 62, 0), (2, 5, 0), (1, 1 << 62, 10), (3, 4, 7), (1000000, 1 << 62, 0)):
+            want = sorted([r for r in rows if lo <= r[1] < hi], key=lambda r: (-r[1], r[0]))
+            if limit:
+                want = want[:limit]
+            assert g.query_ranked(group, lo, hi, limit) == want, (group, lo, hi, limit)
 
 
 def test_highlight_spans_match_aho_corasick_render(G):
