@@ -53,7 +53,7 @@ def test_fuzz_parity(seed):
         if rng.random() < 0.5: opts["bucket_group_limit"] = int(rng.integers(1, 5000))
     if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
     elif rng.random() < 0.5: opts["key_coding"] = int(rng.choice([1, 2]))
-    if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26]))
+    if rng.random() < 0.3: opts["sort_variant"] = int(rng.choice([1, 21, 26, 31, 36, 32]))
     if rng.random() < 0.2: opts["keep_keys"] = 0
     if rng.random() < 0.3: opts["narrow_keys"] = 0
     if rng.random() < 0.2: opts["fast_search"] = 0

@@ -92,7 +92,8 @@ def test_c0_full(G):
 
 
 @pytest.mark.parametrize("opts", [dict(fuse_keygen=0), dict(fuse_keygen=1, sort_variant=26), dict(fuse_keygen=1, sort_variant=1),
-                                  dict(fuse_keygen=1, sort_variant=21), dict(fuse_keygen=0, digit_bits=8)])
+                                  dict(fuse_keygen=1, sort_variant=21), dict(fuse_keygen=1, sort_variant=31),
+                                  dict(fuse_keygen=1, sort_variant=36), dict(fuse_keygen=0, digit_bits=8)])
 def test_fused_and_materialised_first_pass_agree(G, opts):
     # the first radix pass either reads keys written by sa_keygen_kernel or computes them from the text
     blob, ds = W.ragged_corpus(20000, 90, seed=15, empty_every=13)   # ragged: document-head corrections matter
