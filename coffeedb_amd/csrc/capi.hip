@@ -633,9 +633,7 @@ struct PendingQuery {
 void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
     if (batch.size() == 1) {  // a lone keyword: one wavefront, one launch (query.hip: q_single_kernel)
         PendingQuery* q = batch[0];
-        std::vector<int64_t> idbuf(4096), cntbuf(4096);  // (query.hip: SINGLE_MAX_HITS rows at most)
-        int64_t* ids = idbuf.data();
-        int64_t* counts = cntbuf.data();
+        int64_t *ids = nullptr, *counts = nullptr;
         size_t rows = 0;
         bool answered = false;
         const int rc1 = guarded(h, [&] {
@@ -643,7 +641,7 @@ void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
             std::lock_guard<std::mutex> g(ix.mu);
             set_device(ix);
             const double t0 = wall_ms();
-            answered = query_single_on_device(ix, q->kw, q->len, ids, counts, &rows);
+            answered = query_single_on_device(ix, q->kw, q->len, &ids, &counts, &rows);
             if (answered) ix.qstats.query_ms = wall_ms() - t0;
         });
         if (rc1 != CDB_OK) {
@@ -652,14 +650,8 @@ void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
         }
         if (answered) {
             q->rows = rows;
-            q->ids = (int64_t*)std::malloc(std::max<size_t>(rows, 1) * 8);
-            q->counts = (int64_t*)std::malloc(std::max<size_t>(rows, 1) * 8);
-            if (!q->ids || !q->counts) {
-                q->rc = CDB_E_DEVICE;
-                return;
-            }
-            std::memcpy(q->ids, ids, rows * 8);
-            std::memcpy(q->counts, counts, rows * 8);
+            q->ids = ids;
+            q->counts = counts;
             q->rc = CDB_OK;
             return;
         }

@@ -140,7 +140,7 @@ struct DeviceCsr {
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
                                 bool with_offsets = false);
 // one keyword through the single-wavefront kernel; false = not applicable, use the batched path
-bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows);
+bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
 // highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
 // ix.q_keys0, inclusive span ends -> ix.q_keys1
 struct SpanResult {

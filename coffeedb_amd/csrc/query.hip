@@ -1255,8 +1255,8 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
     }
 }
 
-// true = answered (rows copied to ids_out / counts_out, up to SINGLE_MAX_HITS); false = take the batched path
-bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_out, int64_t* counts_out, size_t* nrows) {
+// true = answered (rows in freshly malloc'd *ids_out / *counts_out); false = take the batched path
+bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids_out, int64_t** counts_out, size_t* nrows) {
     if (!ix.use_single_query || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
         ix.ndocs >= 0xFFFFFFFFull)
         return false;
@@ -1285,8 +1285,16 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t* ids_
         return false;
     }
     *nrows = (size_t)out->nrows;
-    std::memcpy(ids_out, out->ids, out->nrows * 8);
-    std::memcpy(counts_out, out->counts, out->nrows * 8);
+    *ids_out = (int64_t*)std::malloc(std::max<uint64_t>(out->nrows, 1) * 8);  // (released by the caller through cdb_free)
+    *counts_out = (int64_t*)std::malloc(std::max<uint64_t>(out->nrows, 1) * 8);
+    if (!*ids_out || !*counts_out) {
+        std::free(*ids_out);
+        std::free(*counts_out);
+        *ids_out = *counts_out = nullptr;
+        throw std::bad_alloc();
+    }
+    std::memcpy(*ids_out, out->ids, out->nrows * 8);
+    std::memcpy(*counts_out, out->counts, out->nrows * 8);
     ix.qstats.nhits = out->hits;
     ix.qstats.nrows = out->nrows;
     return true;
