@@ -150,12 +150,14 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
                                                             const uint32_t* __restrict__ keys32,
                                                             const void* __restrict__ keylow, int low_bits, int low_bytes,
                                                             const uint16_t* __restrict__ symmap, int nsym, uint32_t kbase,
-                                                            int64_t* __restrict__ left_out,
+                                                            bool refseq, int64_t* __restrict__ left_out,
                                                             uint64_t* __restrict__ hits_out) {
     __shared__ Pivot s_piv[PIVOT_NODES + 1];
     __shared__ uint16_t s_code[256];
     const bool keys = keys64 != nullptr || keys32 != nullptr;  // sorted initial keys available
-    for (int i = threadIdx.x; i < (1 << levels); i += 256) s_piv[i] = piv[i];
+    // (refseq: a reference-compat ordering — not globally sorted — is searched with the reference's own two
+    //  bisections, levels = 0; the kept keys, reordered with the array, still decide most probes from one load)
+    for (int i = threadIdx.x; levels > 0 && i < (1 << levels); i += 256) s_piv[i] = piv[i];
     if (keys) s_code[threadIdx.x] = symmap[threadIdx.x];
     __syncthreads();
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     while (L < R) {
         const int64_t M = L + (R - L) / 2;
         int le = 2;
-        if (id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
+        if (levels > 0 && id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
         if (le == 2 && keys) {
             const int c = key_cmp(M);
             if (c != 0) le = c > 0 ? 1 : 0;
@@ -251,7 +253,14 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
         return sl >= m && cmp_common(k, m, sp, sl) == 0;
     };
     int64_t right = left;  // first index >= left whose suffix does not start with the keyword
-    if (n > 0 && is_prefix(left)) {
+    if (refseq) {  // index.cpp:275-287 literally
+        int64_t A = left - 1, B = (int64_t)n - 1;
+        while (A < B) {
+            const int64_t M = A + (B - A + 1) / 2;
+            if (is_prefix(M)) A = M; else B = M - 1;
+        }
+        right = A + 1;
+    } else if (n > 0 && is_prefix(left)) {
         int64_t good = left, step = 1, bad = (int64_t)n;
         while (good + step < (int64_t)n) {
             if (is_prefix(good + step)) { good += step; step <<= 1; }
@@ -478,8 +487,16 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
                            ix.key_nsym && ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
                            ix.key_nsym && ix.d_keys32.p ? (const uint32_t*)ix.d_keys32.as<uint32_t>() : (const uint32_t*)nullptr,
                            ix.key_nsym && ix.d_keylow.p ? (const void*)ix.d_keylow.p : (const void*)nullptr, ix.key_low_bits,
-                           ix.key_low_bytes, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base,
+                           ix.key_low_bytes, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base, false,
                            ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
+    } else if (!ix.sa_sorted && ix.use_fast_search && ix.key_nsym) {
+        hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+                           doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)nullptr, 0,
+                           ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
+                           ix.d_keys32.p ? (const uint32_t*)ix.d_keys32.as<uint32_t>() : (const uint32_t*)nullptr,
+                           ix.d_keylow.p ? (const void*)ix.d_keylow.p : (const void*)nullptr, ix.key_low_bits, ix.key_low_bytes,
+                           (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base, true, ix.q_left.as<int64_t>(),
+                           ix.q_right.as<uint64_t>());
     } else {
         hipLaunchKernelGGL((q_search_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, ix.q_left.as<int64_t>(),

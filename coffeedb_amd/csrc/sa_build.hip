@@ -927,6 +927,26 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
                            (const CompatSeg*)d_segs.as<CompatSeg>());
         ix.prof.end(t, "sa_compat_copy", 2 * n * sizeof(V), s);
     }
+    // the kept search keys make the same trip, so that probes on the reordered array can still be decided from
+    // one load (query.hip follows the reference's probe sequence there, with the same comparisons)
+    if (!segs.empty() && ix.key_nsym) {
+        auto permute = [&](DevBuf& buf, size_t esz) {
+            if (!buf.p) return;
+            DevBuf nb;
+            nb.alloc(n * esz);
+            const dim3 grid((unsigned)segs.size());
+            const CompatSeg* sg = d_segs.as<CompatSeg>();
+            if (esz == 8) hipLaunchKernelGGL((compat_segcopy_kernel<uint64_t>), grid, dim3(256), 0, s, (const uint64_t*)buf.as<uint64_t>(), nb.as<uint64_t>(), sg);
+            else if (esz == 4) hipLaunchKernelGGL((compat_segcopy_kernel<uint32_t>), grid, dim3(256), 0, s, (const uint32_t*)buf.as<uint32_t>(), nb.as<uint32_t>(), sg);
+            else if (esz == 2) hipLaunchKernelGGL((compat_segcopy_kernel<uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)buf.as<uint16_t>(), nb.as<uint16_t>(), sg);
+            else hipLaunchKernelGGL((compat_segcopy_kernel<uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)buf.as<uint8_t>(), nb.as<uint8_t>(), sg);
+            CDB_HIP(hipStreamSynchronize(s));
+            buf = std::move(nb);
+        };
+        permute(ix.d_keys, 8);
+        permute(ix.d_keys32, 4);
+        permute(ix.d_keylow, (size_t)std::max(ix.key_low_bytes, 1));
+    }
     CDB_HIP(hipStreamSynchronize(s));
     sa_buf = std::move(dst);
     return true;
@@ -1560,8 +1580,10 @@ void build_typed(Index& ix, bool big) {
     ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
     if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
     if (ix.reference_compat && high_bytes) {
-        if (!apply_reference_order_oop<V>(ix, sa_buf)) apply_reference_order<V>(ix, sa);  // (in place when no second array fits)
-        ix.drop_keys();  // the rotations moved the entries away from their keys
+        if (!apply_reference_order_oop<V>(ix, sa_buf)) {
+            apply_reference_order<V>(ix, sa);  // in place when no second array fits
+            ix.drop_keys();                    // ... which moves the entries away from their keys
+        }
     }
     ix.d_sa = std::move(sa_buf);
 }
