@@ -1323,7 +1323,10 @@ void build_typed(Index& ix, bool big) {
             size_t fre = 0, tot = 0;
             CDB_HIP(hipMemGetInfo(&fre, &tot));
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
-            const double scratch = (double)maxb * (keyb + lowb + 2 * sizeof(V)) + (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1);
+            // (the third entry buffer is a luxury: without it an odd number of passes costs a copy back)
+            const bool third = avail > (double)maxb * (2.0 * (keyb + lowb) + 2 * sizeof(V)) * 1.15;
+            const double scratch = (double)maxb * (keyb + lowb + (third ? 2 : 1) * sizeof(V)) +
+                                   (third ? (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1) : 0.0);
             uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (keyb + lowb));
             if (ix.bucket_group_limit) gcap = std::min<uint64_t>(gcap, ix.bucket_group_limit);
             gcap = std::max<uint64_t>(std::min<uint64_t>(gcap, n), maxb);
@@ -1333,7 +1336,7 @@ void build_typed(Index& ix, bool big) {
             k32t.alloc(maxb * keyb);
             if (lowb) lowt.alloc(maxb * lowb);
             ET.alloc(maxb * sizeof(V));
-            EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
+            if (third) EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
             std::vector<uint64_t> bh;
             std::vector<BucketItem> items;
             auto run_group = [&](auto wtag, auto ktag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
@@ -1374,7 +1377,7 @@ void build_typed(Index& ix, bool big) {
                     int r = 0;
                     if (bpass > 0 && cnt > 1) {
                         const uint64_t* hb = &bh[(size_t)(b - b0) * 8 * 256];
-                        ix.rws.value_spare = EX.p;
+                        ix.rws.value_spare = EX.p;  // (null without the third buffer)
                         if constexpr (HAS_W)
                             r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
                                                        bbits - blow, &ss, ix.sort_variant, 8, hb, (const TextGen*)nullptr);
