@@ -22,57 +22,100 @@ double wall_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// queries run concurrently on one handle (database.cpp:388), so the last-error string has its own lock
+void set_error(Index& ix, const char* msg) {
+    std::lock_guard<std::mutex> g(ix.err_mu);
+    ix.err = msg;
+}
+
 template <typename F>
 int guarded(cdb_index* h, F&& f) {
     try {
         f();
         return CDB_OK;
     } catch (const Error& e) {
-        h->ix.err = e.what();
+        set_error(h->ix, e.what());
         const bool dev = std::strncmp(e.what(), "HIP error", 9) == 0;
         const bool internal = std::strstr(e.what(), "internal") != nullptr;
         return dev ? CDB_E_DEVICE : (internal ? CDB_E_INTERNAL : CDB_E_INVALID);
     } catch (const std::bad_alloc&) {
-        h->ix.err = "out of host memory";
+        set_error(h->ix, "out of host memory");
         return CDB_E_DEVICE;
     } catch (const std::exception& e) {
-        h->ix.err = e.what();
+        set_error(h->ix, e.what());
         return CDB_E_INTERNAL;
     }
 }
 
-// bits / mask / size / width exactly as string_index::build does (reference src/index.cpp:182-208)
-void compute_layout(Index& ix) {
-    const uint64_t ndocs = ix.ids.size();
-    uint64_t size = 0, mask1 = 1, mask2 = 1;
+// bits / mask / size / width exactly as string_index::build does (reference src/index.cpp:182-208).  Computed
+// into a value first: an index is only touched once everything about the new build is known to be valid.
+struct Layout {
+    uint64_t size = 0, mask = 1, bits = 1, ndocs = 0;
+    int width = 4, off_bits = 1;
+};
+Layout layout_from(uint64_t ndocs, uint64_t size, uint64_t longest) {
+    uint64_t mask1 = 1, mask2 = 1;
     while (mask1 < ndocs) mask1 = (mask1 << 1) + 1;
-    for (uint64_t d = 0; d < ndocs; ++d) {
-        const uint64_t len = ix.doc_start[d + 1] - ix.doc_start[d];
-        size += len;
-        while (mask2 < len) mask2 = (mask2 << 1) + 1;
-    }
+    while (mask2 < longest) mask2 = (mask2 << 1) + 1;
     const int bits1 = __builtin_popcountll(mask1), bits2 = __builtin_popcountll(mask2);
     if (bits1 + bits2 > 64) throw Error("The amount of data exceeds the maximum range that CoffeeDB can handle");
     if (bits1 > 32) throw Error("The number of objects exceeds the maximum range that CoffeeDB can handle");
-    ix.size = size;
-    ix.mask = mask1;
-    ix.bits = (uint64_t)bits1;
-    ix.width = bits1 + bits2 <= 32 ? 4 : 8;
-    ix.off_bits = bits2;
-    ix.ndocs = ndocs;
+    Layout L;
+    L.size = size;
+    L.mask = mask1;
+    L.bits = (uint64_t)bits1;
+    L.width = bits1 + bits2 <= 32 ? 4 : 8;
+    L.off_bits = bits2;
+    L.ndocs = ndocs;
+    return L;
+}
+Layout layout_of(const std::vector<uint64_t>& doc_start, uint64_t ndocs) {
+    uint64_t size = 0, longest = 0;
+    for (uint64_t d = 0; d < ndocs; ++d) {
+        if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+        const uint64_t len = doc_start[d + 1] - doc_start[d];
+        size += len;
+        longest = std::max(longest, len);
+    }
+    return layout_from(ndocs, size, longest);
+}
+void commit_layout(Index& ix, const Layout& L) {
+    ix.size = L.size;
+    ix.mask = L.mask;
+    ix.bits = L.bits;
+    ix.width = L.width;
+    ix.off_bits = L.off_bits;
+    ix.ndocs = L.ndocs;
 }
 
-void upload_tables(Index& ix) {
+// document tables into fresh device blocks (committed by the caller once everything else succeeded)
+void upload_tables(Index& ix, const std::vector<uint64_t>& doc_start, const std::vector<int64_t>& ids, uint64_t ndocs,
+                   DevBuf& d_start, DevBuf& d_ids) {
     hipStream_t s = ix.stream;
-    ix.d_doc_start.alloc((ix.ndocs + 1) * sizeof(uint64_t));
-    CDB_HIP(hipMemcpyAsync(ix.d_doc_start.p, ix.doc_start.data(), (ix.ndocs + 1) * sizeof(uint64_t),
-                           hipMemcpyHostToDevice, s));
-    ix.d_ids.alloc(std::max<uint64_t>(ix.ndocs, 1) * sizeof(int64_t));
-    if (ix.ndocs)
-        CDB_HIP(hipMemcpyAsync(ix.d_ids.p, ix.ids.data(), ix.ndocs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    d_start.alloc((ndocs + 1) * sizeof(uint64_t));
+    CDB_HIP(hipMemcpyAsync(d_start.p, doc_start.data(), (ndocs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    d_ids.alloc(std::max<uint64_t>(ndocs, 1) * sizeof(int64_t));
+    if (ndocs) CDB_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ndocs * sizeof(int64_t), hipMemcpyHostToDevice, s));
 }
 
-void set_device(Index& ix) { CDB_HIP(hipSetDevice(ix.device)); }
+// back to "never built" (queries answer {}): a failed build or load must not leave new parameters over an old array
+void reset_unbuilt(Index& ix) {
+    (void)hipStreamSynchronize(ix.stream);
+    ix.d_sa.release();
+    ix.drop_keys();
+    ix.d_pivots.release();
+    ix.pivot_levels = 0;
+    ix.width = 0;
+    ix.size = 0;
+    ix.q_spec_cap = 0;
+}
+
+// every entry point that touches the device: make the handle's device current and tell the block cache which
+// stream this thread issues work on (common.h: blocks released meanwhile are tagged with it)
+struct DeviceScope {
+    StreamScope ss;
+    explicit DeviceScope(Index& ix) : ss(ix.stream) { CDB_HIP(hipSetDevice(ix.device)); }
+};
 
 // resident build: longest document, order check and re-basing of the caller's device tables
 __global__ __launch_bounds__(256) void layout_kernel(const uint64_t* __restrict__ src_start,
@@ -120,6 +163,29 @@ void ensure_host_tables(Index& ix) {
     CDB_HIP(hipStreamSynchronize(s));
     ix.host_tables_valid = true;
 }
+
+// cdb_add* append to the HOST staging copy of the column.  After cdb_load / cdb_build_device / cdb_build_resident
+// (and after a cdb_build, which frees its staging copy) the documents live on the device only: fetch tables and
+// text back first, so that "load, add, rebuild" (a restart) works instead of corrupting the tables.
+void ensure_host_staging(Index& ix) {
+    if (ix.host_text_valid) return;
+    std::lock_guard<std::mutex> g(ix.mu);
+    StreamScope ss(ix.stream);
+    CDB_HIP(hipSetDevice(ix.device));
+    if (ix.width == 0 || !ix.d_text) {  // nothing on the device either: an empty column
+        ix.ids.clear();
+        ix.doc_start.assign(1, 0);
+        ix.host_text.clear();
+        ix.host_tables_valid = true;
+        ix.host_text_valid = true;
+        return;
+    }
+    ensure_host_tables(ix);
+    ix.host_text.resize(ix.size);
+    if (ix.size) CDB_HIP(hipMemcpyAsync(&ix.host_text[0], ix.d_text, ix.size, hipMemcpyDeviceToHost, ix.stream));
+    CDB_HIP(hipStreamSynchronize(ix.stream));
+    ix.host_text_valid = true;
+}
 }  // namespace cdb
 
 extern "C" {
@@ -158,15 +224,31 @@ void cdb_destroy(cdb_index* h) {
     delete h;
 }
 
-const char* cdb_last_error(const cdb_index* h) { return h ? h->ix.err.c_str() : "null handle"; }
+const char* cdb_last_error(const cdb_index* h) {
+    if (!h) return "null handle";
+    // a per-thread copy: another thread's failing call cannot pull the string away under the reader
+    static thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> g(h->ix.err_mu);
+        copy = h->ix.err;
+    }
+    return copy.c_str();
+}
 
 int cdb_add(cdb_index* h, int64_t id, const char* value, size_t len) {
     if (!h || (!value && len)) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
-        ix.ids.push_back(id);
+        ensure_host_staging(ix);
         ix.host_text.append(value, len);
-        ix.doc_start.push_back(ix.host_text.size());
+        try {
+            ix.ids.push_back(id);
+            ix.doc_start.push_back(ix.host_text.size());
+        } catch (...) {  // keep the three staging arrays consistent
+            ix.host_text.resize(ix.doc_start.back());
+            ix.ids.resize(ix.doc_start.size() - 1);
+            throw;
+        }
     });
 }
 
@@ -175,10 +257,13 @@ int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint6
     return guarded(h, [&] {
         Index& ix = h->ix;
         if (!ndocs) return;
+        for (uint64_t d = 0; d < ndocs; ++d)
+            if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+        ensure_host_staging(ix);
+        ix.ids.reserve(ix.ids.size() + ndocs);  // (allocations first: nothing below can fail half way)
+        ix.doc_start.reserve(ix.doc_start.size() + ndocs);
         const uint64_t base = ix.host_text.size();
         ix.host_text.append(blob + doc_start[0], doc_start[ndocs] - doc_start[0]);
-        ix.ids.reserve(ix.ids.size() + ndocs);
-        ix.doc_start.reserve(ix.doc_start.size() + ndocs);
         for (uint64_t d = 0; d < ndocs; ++d) {
             ix.ids.push_back(ids[d]);
             ix.doc_start.push_back(base + doc_start[d + 1] - doc_start[0]);
@@ -239,7 +324,7 @@ int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t
     size_t vl = 0;
     const int r = cdb_raw_record_find_string(record, len, key, &id, &v, &vl);
     if (r < 0) {
-        h->ix.err = "malformed raw record";
+        set_error(h->ix, "malformed raw record");
         return CDB_E_INVALID;
     }
     if (r == 0) return CDB_OK;  // the object has no string value under this key
@@ -259,7 +344,7 @@ int cdb_save(cdb_index* h, const char* path) {
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         if (ix.width == 0) throw Error("index has not been built");
         ensure_host_tables(ix);
         FILE* fp = std::fopen(path, "wb");
@@ -290,36 +375,34 @@ int cdb_load(cdb_index* h, const char* path) {
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         FILE* fp = std::fopen(path, "rb");
         if (!fp) throw Error(std::string("Cannot open file: ") + path);
         struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+        // ---- everything is read and checked into locals; the handle changes only when the file proved consistent
         SaveHeader hd{};
         if (std::fread(&hd, sizeof(hd), 1, fp) != 1 || hd.magic != SAVE_MAGIC || (hd.width != 4 && hd.width != 8))
             throw Error(std::string("Not a saved index: ") + path);
-        ix.ids.resize(hd.ndocs);
-        ix.doc_start.resize(hd.ndocs + 1);
-        bool ok = hd.ndocs == 0 || std::fread(ix.ids.data(), 8, hd.ndocs, fp) == hd.ndocs;
-        ok = ok && std::fread(ix.doc_start.data(), 8, hd.ndocs + 1, fp) == hd.ndocs + 1;
-        if (!ok || ix.doc_start[hd.ndocs] != hd.size) throw Error(std::string("Truncated index file: ") + path);
-        ix.size = hd.size; ix.ndocs = hd.ndocs; ix.bits = hd.bits; ix.mask = hd.mask; ix.width = (int)hd.width;
-        ix.reference_compat = hd.compat != 0;
-        {
-            uint64_t mask2 = 1;
-            for (uint64_t d = 0; d < hd.ndocs; ++d)
-                while (mask2 < ix.doc_start[d + 1] - ix.doc_start[d]) mask2 = (mask2 << 1) + 1;
-            ix.off_bits = __builtin_popcountll(mask2);
-        }
-        ix.sa_sorted = hd.sorted != 0;  // a reference-compat ordering keeps the reference's exact probe sequence
-        ix.pivot_levels = 0;
-        ix.drop_keys();
-        ix.host_text.clear();
-        ix.d_text_owned.alloc(ix.size + TEXT_PAD);
-        CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + ix.size, 0, TEXT_PAD, ix.stream));
-        ix.d_text = ix.d_text_owned.as<uint8_t>();
-        ix.text_padded = true;
-        ix.d_sa.alloc(std::max<uint64_t>(ix.size * hd.width, 16));
-        std::vector<char> buf(std::min<uint64_t>(std::max<uint64_t>(ix.size * hd.width, 1), 256ull << 20));
+        if (std::fseek(fp, 0, SEEK_END) != 0) throw Error(std::string("Cannot read file: ") + path);
+        const long long fsize = std::ftell(fp);
+        if (hd.ndocs >= (1ull << 33) || hd.size >= (1ull << 48) ||
+            fsize < 0 || (unsigned long long)fsize != sizeof(hd) + 8 * hd.ndocs + 8 * (hd.ndocs + 1) + hd.size + hd.size * hd.width)
+            throw Error(std::string("Truncated index file: ") + path);
+        if (std::fseek(fp, (long)sizeof(hd), SEEK_SET) != 0) throw Error(std::string("Cannot read file: ") + path);
+        std::vector<int64_t> ids(hd.ndocs);
+        std::vector<uint64_t> doc_start(hd.ndocs + 1);
+        bool ok = hd.ndocs == 0 || std::fread(ids.data(), 8, hd.ndocs, fp) == hd.ndocs;
+        ok = ok && std::fread(doc_start.data(), 8, hd.ndocs + 1, fp) == hd.ndocs + 1;
+        if (!ok) throw Error(std::string("Truncated index file: ") + path);
+        if (doc_start[0] != 0 || doc_start[hd.ndocs] != hd.size) throw Error(std::string("Corrupt index file (document table): ") + path);
+        const Layout L = layout_of(doc_start, hd.ndocs);  // (also: doc_start non-decreasing)
+        if (L.size != hd.size || L.bits != hd.bits || L.mask != hd.mask || (uint64_t)L.width != hd.width)
+            throw Error(std::string("Corrupt index file (entry layout): ") + path);
+        DevBuf text, sa, d_start, d_ids;
+        text.alloc(hd.size + TEXT_PAD);
+        CDB_HIP(hipMemsetAsync((uint8_t*)text.p + hd.size, 0, TEXT_PAD, ix.stream));
+        sa.alloc(std::max<uint64_t>(hd.size * hd.width, 16));
+        std::vector<char> buf(std::min<uint64_t>(std::max<uint64_t>(hd.size * hd.width, 1), 256ull << 20));
         auto fill = [&](void* dptr, uint64_t bytes) {
             for (uint64_t o = 0; o < bytes; o += buf.size()) {
                 const uint64_t c = std::min<uint64_t>(buf.size(), bytes - o);
@@ -328,10 +411,30 @@ int cdb_load(cdb_index* h, const char* path) {
                 CDB_HIP(hipStreamSynchronize(ix.stream));
             }
         };
-        fill(ix.d_text_owned.p, ix.size);
-        fill(ix.d_sa.p, ix.size * hd.width);
-        upload_tables(ix);
+        fill(text.p, hd.size);
+        fill(sa.p, hd.size * hd.width);
+        upload_tables(ix, doc_start, ids, hd.ndocs, d_start, d_ids);
+        // every entry must name a real (document, offset): queries decode entries without further checks
+        if (count_invalid_entries(ix.stream, sa.p, (int)hd.width, hd.size, d_start.as<uint64_t>(), hd.ndocs, (int)L.bits, L.mask) != 0)
+            throw Error(std::string("Corrupt index file (suffix array): ") + path);
         CDB_HIP(hipStreamSynchronize(ix.stream));
+        // ---- commit
+        reset_unbuilt(ix);
+        commit_layout(ix, L);
+        ix.ids.swap(ids);
+        ix.doc_start.swap(doc_start);
+        ix.host_tables_valid = true;
+        ix.host_text.clear();
+        ix.host_text.shrink_to_fit();
+        ix.host_text_valid = false;  // the text lives on the device (cdb_add* fetch it back)
+        ix.reference_compat = hd.compat != 0;
+        ix.sa_sorted = hd.sorted != 0;  // a reference-compat ordering keeps the reference's exact probe sequence
+        ix.d_text_owned = std::move(text);
+        ix.d_text = ix.d_text_owned.as<uint8_t>();
+        ix.text_padded = true;
+        ix.d_sa = std::move(sa);
+        ix.d_doc_start = std::move(d_start);
+        ix.d_ids = std::move(d_ids);
     });
 }
 
@@ -339,17 +442,35 @@ int cdb_build(cdb_index* h) {
     if (!h) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
+        ensure_host_staging(ix);  // (a rebuild after cdb_load / a device build: the staging copy is fetched back)
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
-        compute_layout(ix);
-        const uint64_t n = ix.size;
-        ix.d_text_owned.alloc(n + TEXT_PAD);
-        CDB_HIP(hipMemsetAsync((uint8_t*)ix.d_text_owned.p + n, 0, TEXT_PAD, ix.stream));
-        if (n) CDB_HIP(hipMemcpyAsync(ix.d_text_owned.p, ix.host_text.data(), n, hipMemcpyHostToDevice, ix.stream));
-        ix.d_text = ix.d_text_owned.as<uint8_t>();
-        ix.text_padded = true;
-        upload_tables(ix);
-        build_suffix_array(ix);
+        DeviceScope dscope(ix);
+        const Layout L = layout_of(ix.doc_start, ix.ids.size());  // throws the reference's capacity errors: nothing changed yet
+        const uint64_t n = L.size;
+        try {
+            DevBuf text, d_start, d_ids;
+            text.alloc(n + TEXT_PAD);
+            CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
+            if (n) CDB_HIP(hipMemcpyAsync(text.p, ix.host_text.data(), n, hipMemcpyHostToDevice, ix.stream));
+            upload_tables(ix, ix.doc_start, ix.ids, L.ndocs, d_start, d_ids);
+            reset_unbuilt(ix);  // (waits for the stream: the old arrays are idle; ix.mu keeps queries out)
+            commit_layout(ix, L);
+            ix.d_text_owned = std::move(text);
+            ix.d_text = ix.d_text_owned.as<uint8_t>();
+            ix.text_padded = true;
+            ix.d_doc_start = std::move(d_start);
+            ix.d_ids = std::move(d_ids);
+            build_suffix_array(ix);
+        } catch (...) {
+            reset_unbuilt(ix);
+            throw;
+        }
+        // the staging copy has done its job (database.cpp builds a fresh index object per build and never adds to a
+        // built one); cdb_add* fetch the column back from the device if they are called again
+        if (ix.host_text.size() >= (1u << 20)) {
+            std::string().swap(ix.host_text);
+            ix.host_text_valid = false;
+        }
     });
 }
 
@@ -358,23 +479,39 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
+        // ---- validate first
         if (((uintptr_t)d_text & 15u) != 0) throw Error("device text must be 16-byte aligned");
-        ix.ids.assign(ids, ids + ndocs);
-        ix.doc_start.resize(ndocs + 1);
-        ix.doc_start[0] = 0;
+        const uint64_t first = ndocs ? doc_start[0] : 0;
+        if (first & 15u) throw Error("first document must start 16-byte aligned");
+        std::vector<int64_t> hid(ids, ids + ndocs);
+        std::vector<uint64_t> hstart(ndocs + 1);
+        hstart[0] = 0;
         for (uint64_t d = 0; d < ndocs; ++d) {
             if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
-            ix.doc_start[d + 1] = doc_start[d + 1] - doc_start[0];
+            hstart[d + 1] = doc_start[d + 1] - first;
         }
-        ix.host_text.clear();
-        compute_layout(ix);
-        ix.d_text_owned.release();
-        ix.d_text = static_cast<const uint8_t*>(d_text) + doc_start[0];
-        if (doc_start[0] & 15u) throw Error("first document must start 16-byte aligned");
-        ix.text_padded = false;
-        upload_tables(ix);
-        build_suffix_array(ix);
+        const Layout L = layout_of(hstart, ndocs);
+        try {
+            DevBuf d_start, d_ids;
+            upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
+            reset_unbuilt(ix);
+            commit_layout(ix, L);
+            ix.ids.swap(hid);
+            ix.doc_start.swap(hstart);
+            ix.host_tables_valid = true;
+            std::string().swap(ix.host_text);
+            ix.host_text_valid = false;
+            ix.d_text_owned.release();
+            ix.d_text = static_cast<const uint8_t*>(d_text) + first;
+            ix.text_padded = false;
+            ix.d_doc_start = std::move(d_start);
+            ix.d_ids = std::move(d_ids);
+            build_suffix_array(ix);
+        } catch (...) {
+            reset_unbuilt(ix);
+            throw;
+        }
     });
 }
 
@@ -384,7 +521,7 @@ int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_s
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         if (((uintptr_t)d_text & 15u) != 0) throw Error("device text must be 16-byte aligned");
         hipStream_t s = ix.stream;
         DevBuf d_start, d_id, d_out;
@@ -402,29 +539,25 @@ int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_s
         CDB_HIP(hipStreamSynchronize(s));
         if (out[1]) throw Error("doc_start must be non-decreasing");
         if (first != 0) throw Error("d_doc_start[0] must be 0");
-        // bits / mask / size / entry width exactly as index.cpp:182-208
-        uint64_t mask1 = 1, mask2 = 1;
-        while (mask1 < ndocs) mask1 = (mask1 << 1) + 1;
-        while (mask2 < out[0]) mask2 = (mask2 << 1) + 1;
-        const int bits1 = __builtin_popcountll(mask1), bits2 = __builtin_popcountll(mask2);
-        if (bits1 + bits2 > 64) throw Error("The amount of data exceeds the maximum range that CoffeeDB can handle");
-        if (bits1 > 32) throw Error("The number of objects exceeds the maximum range that CoffeeDB can handle");
-        ix.size = total;
-        ix.mask = mask1;
-        ix.bits = (uint64_t)bits1;
-        ix.width = bits1 + bits2 <= 32 ? 4 : 8;
-        ix.off_bits = bits2;
-        ix.ndocs = ndocs;
-        ix.ids.clear();
-        ix.doc_start.assign(1, 0);
-        ix.host_text.clear();
-        ix.host_tables_valid = false;
-        ix.d_text_owned.release();
-        ix.d_text = static_cast<const uint8_t*>(d_text);
-        ix.text_padded = false;
-        ix.d_doc_start = std::move(d_start);
-        ix.d_ids = std::move(d_id);
-        build_suffix_array(ix);
+        const Layout L = layout_from(ndocs, total, out[0]);  // bits / mask / size / entry width exactly as index.cpp:182-208
+        try {
+            reset_unbuilt(ix);
+            commit_layout(ix, L);
+            ix.ids.clear();
+            ix.doc_start.assign(1, 0);
+            std::string().swap(ix.host_text);
+            ix.host_tables_valid = false;  // tables and text live on the device (fetched back on demand)
+            ix.host_text_valid = false;
+            ix.d_text_owned.release();
+            ix.d_text = static_cast<const uint8_t*>(d_text);
+            ix.text_padded = false;
+            ix.d_doc_start = std::move(d_start);
+            ix.d_ids = std::move(d_id);
+            build_suffix_array(ix);
+        } catch (...) {
+            reset_unbuilt(ix);
+            throw;
+        }
     });
 }
 
@@ -436,12 +569,12 @@ int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, ui
     if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     if (hits) std::memset(hits, 0, sizeof(*hits));
-    return guarded(h, [&] {
+    const int rc = guarded(h, [&] {
         Index& ix = h->ix;
         for (uint64_t j = 0; j < npat; ++j)
             if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         const double t0 = wall_ms();
         hipStream_t s = ix.stream;
         const uint64_t base = npat ? offsets[0] : 0;
@@ -484,6 +617,11 @@ int query_batch_impl(cdb_index* h, const char* blob, const uint64_t* offsets, ui
         ix.qstats.nhits = r.nhits;
         ix.qstats.nrows = r.nrows;
     });
+    if (rc != CDB_OK) {  // a later allocation or copy failed: nothing half-filled leaves the library
+        cdb_result_free(out);
+        if (hits) cdb_hits_free(hits);
+    }
+    return rc;
 }
 }  // namespace
 
@@ -517,7 +655,7 @@ int query_or_impl(cdb_index* h, const char* blob, const uint64_t* offsets, uint6
         for (uint64_t j = 0; j < nkw; ++j)
             if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         hipStream_t s = ix.stream;
         const uint64_t base = offsets[0], nbytes = offsets[nkw] - base;
         ix.q_pat.ensure(nbytes + 16);
@@ -536,10 +674,16 @@ int query_or_impl(cdb_index* h, const char* blob, const uint64_t* offsets, uint6
             host_free(hi);
             throw;
         }
-        if (r.nrows) {
-            CDB_HIP(hipMemcpyAsync(hi, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
-            CDB_HIP(hipMemcpyAsync(hc, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
-            CDB_HIP(hipStreamSynchronize(s));
+        try {
+            if (r.nrows) {
+                CDB_HIP(hipMemcpyAsync(hi, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipMemcpyAsync(hc, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipStreamSynchronize(s));
+            }
+        } catch (...) {
+            host_free(hi);
+            host_free(hc);
+            throw;
         }
         *ids = hi;
         *counts = hc;
@@ -561,7 +705,7 @@ int cdb_query_ranked(cdb_index* h, const char* blob, const uint64_t* offsets, ui
 int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {
     if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
-    return guarded(h, [&] {
+    const int rc = guarded(h, [&] {
         Index& ix = h->ix;
         std::vector<uint64_t> rel{0};
         std::string pat;
@@ -572,7 +716,7 @@ int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uin
         }
         const uint64_t npat = rel.size() - 1;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         hipStream_t s = ix.stream;
         SpanResult r;
         if (npat) {
@@ -596,6 +740,8 @@ int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uin
             CDB_HIP(hipStreamSynchronize(s));
         }
     });
+    if (rc != CDB_OK) cdb_spans_free(out);
+    return rc;
 }
 
 void cdb_spans_free(cdb_spans* r) {
@@ -639,7 +785,7 @@ void run_coalesced(cdb_index* h, std::vector<PendingQuery*>& batch) {
         const int rc1 = guarded(h, [&] {
             Index& ix = h->ix;
             std::lock_guard<std::mutex> g(ix.mu);
-            set_device(ix);
+            DeviceScope dscope(ix);
             const double t0 = wall_ms();
             answered = query_single_on_device(ix, q->kw, q->len, &ids, &counts, &rows);
             if (answered) ix.qstats.query_ms = wall_ms() - t0;
@@ -690,8 +836,7 @@ int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int6
     *nrows = 0;
     Index& ix = h->ix;
     if (len == 0) {  // index.cpp:239-241
-        std::lock_guard<std::mutex> g(ix.qmu);
-        ix.err = "Empty keywords are not allowed";
+        set_error(ix, "Empty keywords are not allowed");
         return CDB_E_INVALID;
     }
     PendingQuery me{keyword, len};
@@ -699,24 +844,40 @@ int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int6
         std::vector<PendingQuery*> one{&me};
         run_coalesced(h, one);
     } else {
+        // Leader / follower: whoever finds no leader takes everything queued so far (its own query included),
+        // resolves it as ONE batched GPU query and then gives the leadership up — a waiter whose query arrived
+        // meanwhile takes over.  A leader therefore never serves more than the batch holding its own query (under
+        // sustained load it would otherwise never return), and leadership cannot be stranded by an exception.
         std::unique_lock<std::mutex> lk(ix.qmu);
         ix.qpending.push_back(&me);
-        if (!ix.qleader) {
+        while (!me.done) {
+            if (ix.qleader) {
+                ix.qcv.wait(lk, [&] { return me.done || !ix.qleader; });
+                continue;
+            }
             ix.qleader = true;
-            while (!ix.qpending.empty()) {
-                std::vector<void*> taken;
-                taken.swap(ix.qpending);
-                lk.unlock();
+            std::vector<void*> taken;
+            taken.swap(ix.qpending);
+            lk.unlock();
+            try {
                 std::vector<PendingQuery*> batch;
+                batch.reserve(taken.size());
                 for (void* p : taken) batch.push_back(static_cast<PendingQuery*>(p));
                 run_coalesced(h, batch);
-                lk.lock();
-                for (auto* q : batch) q->done = true;
-                ix.qcv.notify_all();
+            } catch (...) {  // (host allocation failure while assembling the batch)
+                for (void* p : taken) {
+                    PendingQuery* q = static_cast<PendingQuery*>(p);
+                    std::free(q->ids);
+                    std::free(q->counts);
+                    q->ids = q->counts = nullptr;
+                    q->rc = CDB_E_DEVICE;
+                }
+                set_error(ix, "out of host memory");
             }
+            lk.lock();
+            for (void* p : taken) static_cast<PendingQuery*>(p)->done = true;
             ix.qleader = false;
-        } else {
-            ix.qcv.wait(lk, [&] { return me.done; });
+            ix.qcv.notify_all();
         }
     }
     if (me.rc != CDB_OK) {
@@ -738,7 +899,7 @@ int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_o
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         const double t0 = wall_ms();
         const DeviceCsr r = query_batch_on_device(ix, static_cast<const uint8_t*>(d_blob), d_offsets, npat);
         out->npat = npat;
@@ -763,7 +924,7 @@ int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes) {
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         const uint64_t need = ix.size * (uint64_t)ix.width;
         if (capacity_bytes < need) throw Error("cdb_sa_copy: buffer too small");
         if (need) {
@@ -795,7 +956,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "wave_rows")) ix.use_wave_rows = value != 0;
     else if (!std::strcmp(name, "keep_keys")) ix.keep_keys = value != 0;
     else {
-        ix.err = std::string("unknown option: ") + name;
+        set_error(ix, (std::string("unknown option: ") + name).c_str());
         return CDB_E_INVALID;
     }
     return CDB_OK;
@@ -854,7 +1015,7 @@ int cdb_debug_verify(cdb_index* h, uint64_t out[5]) {
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
-        set_device(ix);
+        DeviceScope dscope(ix);
         if (ix.width == 0) throw Error("index has not been built");
         verify_suffix_array(ix, out);
     });
@@ -869,6 +1030,7 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
         hipStream_t s;
         CDB_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         {
+            StreamScope sscope(s);
             RadixWorkspace ws;
             Profiler prof;
             prof.enabled = true;

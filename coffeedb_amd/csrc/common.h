@@ -28,11 +28,28 @@ struct Error : std::runtime_error {
 inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline int bit_width64(uint64_t x) { return x == 0 ? 0 : 64 - __builtin_clzll(x); }
 
+// The stream the calling thread is currently issuing device work on (set by every C-ABI entry point through
+// StreamScope).  DevPool uses it to make block reuse stream-aware: a block released while kernels of that stream
+// may still touch it is tagged (stream, event) and handed to ANOTHER stream only once the event has completed;
+// the same stream may take it back at once (stream order).
+inline thread_local hipStream_t tls_stream = nullptr;
+struct StreamScope {
+    hipStream_t prev;
+    explicit StreamScope(hipStream_t s) : prev(tls_stream) { tls_stream = s; }
+    ~StreamScope() { tls_stream = prev; }
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+};
+
 // Process-wide cache of device blocks.  hipMalloc of multi-GiB buffers costs ~30 ms per GiB on MI355X
 // (the driver maps and clears VRAM), i.e. ~1 s for the ~30 GiB working set of a 1 GiB build — ten times
 // the build itself.  CoffeeDB rebuilds a fresh index object on every `build` (database.cpp:170-281) while
 // the old one keeps serving, so freed blocks are kept and handed to the next build instead of going
 // back to the driver; cdb_release_cached_memory() returns them.  288 GB of HBM makes this cheap.
+// Every handle works on its own non-blocking stream and a new index is built while the old one serves
+// queries (database.cpp:276-280), so a freed block may still be in use by queued kernels of the releasing
+// stream: it carries an event recorded on that stream and is given to a different stream only after the
+// event completed (same stream: immediately).
 class DevPool {
 public:
     static DevPool& get() {
@@ -44,18 +61,36 @@ public:
         const size_t need = (bytes + gran - 1) / gran * gran;
         {
             std::lock_guard<std::mutex> g(mu_);
-            int best = -1;
+            int best = -1, best_busy = -1;
             for (int i = 0; i < (int)free_.size(); ++i) {
-                const Block& b = free_[i];
+                Block& b = free_[i];
                 if (b.device != device || b.bytes < need) continue;
                 const size_t slack = need >= (64u << 20) ? need / 4 : need + (1u << 20);
                 if (b.bytes > need + slack) continue;
-                if (best < 0 || b.bytes < free_[best].bytes) best = i;
+                bool ready = !b.ev || (b.stream == tls_stream && tls_stream != nullptr);
+                if (!ready && hipEventQuery(b.ev) == hipSuccess) {
+                    put_event(b.device, b.ev);
+                    b.ev = nullptr;
+                    ready = true;
+                } else if (!ready) {
+                    (void)hipGetLastError();  // hipErrorNotReady is not an error
+                }
+                if (ready) {
+                    if (best < 0 || b.bytes < free_[best].bytes) best = i;
+                } else if (best_busy < 0 || b.bytes < free_[best_busy].bytes) {
+                    best_busy = i;
+                }
+            }
+            if (best < 0 && best_busy >= 0) {  // waiting for the other stream beats a fresh hipMalloc
+                Block& b = free_[best_busy];
+                (void)hipEventSynchronize(b.ev);
+                best = best_busy;
             }
             if (best >= 0) {
                 Block b = free_[best];
                 free_.erase(free_.begin() + best);
                 cached_ -= b.bytes;
+                if (b.ev) put_event(b.device, b.ev);
                 actual = b.bytes;
                 return b.p;
             }
@@ -75,15 +110,33 @@ public:
         return p;
     }
     void free(void* p, size_t bytes, int device) {
+        // work queued on the releasing thread's stream may still use the block
+        hipStream_t st = tls_stream;
+        hipEvent_t ev = nullptr;
+        if (st) {
+            std::lock_guard<std::mutex> g(mu_);
+            ev = get_event(device);
+        }
+        if (st && (!ev || hipEventRecord(ev, st) != hipSuccess)) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(st);
+            if (ev) {
+                std::lock_guard<std::mutex> g(mu_);
+                put_event(device, ev);
+            }
+            ev = nullptr;
+            st = nullptr;
+        }
         {
             std::lock_guard<std::mutex> g(mu_);
             if (cached_ + bytes <= limit_) {
-                free_.push_back(Block{p, bytes, device});
+                free_.push_back(Block{p, bytes, device, st, ev});
                 cached_ += bytes;
                 return;
             }
+            if (ev) put_event(device, ev);
         }
-        // the cache is full: hand the block back to the driver
+        // the cache is full: hand the block back to the driver (hipFree waits for the device)
         int cur = 0;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
@@ -109,7 +162,11 @@ public:
         (void)hipGetDevice(&cur);
         for (auto& b : blocks) {
             (void)hipSetDevice(b.device);
-            (void)hipFree(b.p);
+            (void)hipFree(b.p);  // (waits for the device: pending work on the block has finished afterwards)
+            if (b.ev) {
+                std::lock_guard<std::mutex> g(mu_);
+                put_event(b.device, b.ev);
+            }
         }
         (void)hipSetDevice(cur);
     }
@@ -119,9 +176,26 @@ public:
     }
 
 private:
-    struct Block { void* p; size_t bytes; int device; };
+    struct Block { void* p; size_t bytes; int device; hipStream_t stream; hipEvent_t ev; };
+    // (both called with mu_ held)
+    hipEvent_t get_event(int device) {
+        auto& pool = events_[device];
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return e;
+    }
+    void put_event(int device, hipEvent_t e) { events_[device].push_back(e); }
     std::mutex mu_;
     std::vector<Block> free_;
+    std::map<int, std::vector<hipEvent_t>> events_;
     size_t cached_ = 0;
     size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
                                  // the working set of a multi-GiB build costs more than the build itself

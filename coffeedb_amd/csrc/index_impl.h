@@ -61,6 +61,8 @@ struct Index {
     std::vector<uint64_t> doc_start{0};
     std::string host_text;
     bool host_tables_valid = true;  // false after cdb_build_resident until ids / doc_start are fetched back
+    bool host_text_valid = true;    // false while the column lives on the device only (after cdb_build frees its staging
+                                    // copy, cdb_load, device builds): cdb_add* fetch it back first (capi.hip)
 
     // ---- reference-visible parameters (src/index.h:56-57)
     uint64_t bits = 1, mask = 1, size = 0;
@@ -119,17 +121,22 @@ struct Index {
     Profiler prof;
     BuildStats bstats;
     QueryStats qstats;
+    mutable std::mutex err_mu;  // guards err (concurrent failing queries)
     std::string err;
 };
 
 // capi.hip — ids / doc_start on the host (fetched from the device after a resident build)
 void ensure_host_tables(Index& ix);
+void ensure_host_staging(Index& ix);
 
 // sa_build.hip
 void build_suffix_array(Index& ix);
 
 // verify.hip — out = {inversions, tie-order violations, wrapped sum of entries, invalid entries, expected sum}
 void verify_suffix_array(Index& ix, uint64_t out[5]);
+// number of entries of a suffix array (device pointers) that do not name a real (document, offset)
+uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint64_t n, const uint64_t* d_doc_start, uint64_t ndocs,
+                               int bits, uint64_t mask);
 
 // query.hip — patterns already on the device; leaves CSR results in ix.q_rowptr / q_ids / q_counts
 struct DeviceCsr {

@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa,
     if (j >= npat) return;
     const uint8_t* k = blob + offs[j];
     const uint64_t m = offs[j + 1] - offs[j];
+    if (m == 0 || offs[j + 1] < offs[j]) {  // empty pattern (device batches are not pre-validated): no rows
+        left_out[j] = 0;
+        hits_out[j] = 0;
+        return;
+    }
     int64_t L = 0, R = (int64_t)n - 1;
     while (L < R) {
         const int64_t M = L + (R - L) / 2;
@@ -164,6 +169,11 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     if (j >= npat) return;
     const uint8_t* k = blob + offs[j];
     const uint64_t m = offs[j + 1] - offs[j];
+    if (m == 0 || offs[j + 1] < offs[j]) {  // empty pattern (device batches are not pre-validated): no rows
+        left_out[j] = 0;
+        hits_out[j] = 0;
+        return;
+    }
     uint64_t kw[2] = {0, 0};
     for (int q = 0; q < 16 && (uint64_t)q < m; ++q) kw[q >> 3] |= (uint64_t)k[q] << (56 - 8 * (q & 7));
     // keyword in the key alphabet: its first min(m, nsym) symbol codes, packed like keys[]; a byte that

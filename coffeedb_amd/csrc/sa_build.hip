@@ -1606,8 +1606,8 @@ void build_suffix_array(Index& ix) {
             else build_typed<uint64_t, uint64_t, uint64_t>(ix, true);
         }
     } catch (...) {
-        // scratch buffers go back to the shared block cache when the stack unwinds: make sure no
-        // kernel of this build is still using them
+        // (the scratch buffers went back to the block cache while the stack unwound; they carry an event of this
+        //  stream, so no other stream gets them before the kernels queued here have finished — common.h: DevPool)
         (void)hipStreamSynchronize(ix.stream);
         ix.prof.resolve();
         ix.d_sa.release();

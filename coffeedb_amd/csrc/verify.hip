@@ -57,7 +57,40 @@ __global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa
     if (threadIdx.x < 4 && s_acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_acc[threadIdx.x]);
 }
 
+template <typename V>
+__global__ __launch_bounds__(256) void sa_entry_check_kernel(const V* __restrict__ sa, uint64_t n,
+                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
+                                                             uint64_t mask, unsigned long long* __restrict__ bad) {
+    unsigned long long b = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const V e = sa[i];
+        const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
+        if (d >= ndocs || o >= doc_start[d + 1] - doc_start[d]) b += 1;
+    }
+    if (b) atomicAdd(bad, b);
+}
+
 }  // namespace
+
+uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint64_t n, const uint64_t* d_doc_start, uint64_t ndocs,
+                               int bits, uint64_t mask) {
+    if (n == 0) return 0;
+    DevBuf d_bad;
+    d_bad.alloc(sizeof(uint64_t));
+    CDB_HIP(hipMemsetAsync(d_bad.p, 0, sizeof(uint64_t), s));
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, 256), 1u << 16);
+    if (width == 4)
+        hipLaunchKernelGGL((sa_entry_check_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint32_t*>(d_sa), n,
+                           d_doc_start, ndocs, bits, mask, d_bad.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL((sa_entry_check_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint64_t*>(d_sa), n,
+                           d_doc_start, ndocs, bits, mask, d_bad.as<unsigned long long>());
+    uint64_t bad = 0;
+    CDB_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(bad), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    return bad;
+}
 
 void verify_suffix_array(Index& ix, uint64_t out[5]) {
     hipStream_t s = ix.stream;

@@ -60,7 +60,9 @@ const char* cdb_last_error(const cdb_index* h);
 /* ---- ingest ---------------------------------------------------------------------------------- */
 
 /* replaces string_index::add(int64_t id, std::string_view value) (src/index.cpp:174-177).
- * The bytes are copied into a host staging buffer (the reference keeps a non-owning view instead). */
+ * The bytes are copied into a host staging buffer (the reference keeps a non-owning view instead).  cdb_build
+ * frees that staging copy once the column is on the device; adding to an index that was built, loaded
+ * (cdb_load) or built from device memory first fetches the column back, so "load, add, rebuild" works. */
 int cdb_add(cdb_index* h, int64_t id, const char* value, size_t len);
 
 /* Bulk form of cdb_add for callers that already hold a concatenated column:
@@ -99,7 +101,8 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
 
 /* The same with the document table resident as well: d_doc_start (ndocs + 1 offsets into d_text, d_doc_start[0]
  * = 0) and d_ids are DEVICE arrays; they are validated and copied on the device, nothing but a few scalars
- * crosses PCIe.  (Host copies of the tables are fetched lazily if cdb_save / cdb_add* need them later.) */
+ * crosses PCIe.  (Host copies of the tables — and of the text, for cdb_add* followed by a rebuild — are fetched
+ * back from the device when cdb_save / cdb_add* need them later; d_text must still be valid then.) */
 int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_start, const int64_t* d_ids,
                        uint64_t ndocs);
 
@@ -165,7 +168,8 @@ void cdb_spans_free(cdb_spans* r);
 /* Batched query with patterns and results left in device memory (multi-GPU merge over RCCL, HBM-
  * resident timing).  d_blob/d_offsets are device pointers.  On return the library-owned device arrays
  * d_row_ptr (npat+1 u64), d_ids (nrows i64), d_counts (nrows i64) stay valid until the next query on
- * this handle or cdb_destroy. */
+ * this handle or cdb_destroy.  The offsets are not pre-validated on the host: an empty pattern yields zero
+ * rows here (the host entry points reject it like the reference does). */
 typedef struct cdb_device_result {
     uint64_t npat, nrows, nhits;
     const uint64_t* d_row_ptr;

@@ -657,3 +657,120 @@ def test_build_while_another_handle_serves_queries(G):
         stop.set()
         th.join()
     assert not errors, errors[0]
+
+
+def test_add_after_load_and_device_builds_rebuilds_the_whole_column(G, tmp_path):
+    # restart flow: cdb_load, then more documents, then a rebuild — the loaded column must come back from the device
+    # (cdb_add after cdb_load / cdb_build_device / cdb_build_resident used to corrupt the staging tables)
+    import torch
+    blob, ds = W.ragged_corpus(800, 90, seed=12, empty_every=13)
+    ids = np.arange(800, dtype=np.int64) * 2 + 9
+    extra = [(5001, b"abracadabra"), (5002, b""), (5003, bytes(blob[:500]))]   # (one longer than many documents)
+    blob_all = np.concatenate([blob] + [np.frombuffer(t, dtype=np.uint8) for _, t in extra])
+    ds_all = np.concatenate([ds, ds[-1] + np.cumsum([len(t) for _, t in extra]).astype(np.uint64)])
+    ids_all = np.concatenate([ids, np.array([i for i, _ in extra], dtype=np.int64)])
+    want = _oracle(blob_all, ds_all, ids_all)
+    pats = W.sample_patterns(blob_all, ds_all, 200, 1, 7, seed=5)
+
+    def check(g):
+        for i, t in extra:
+            g.add(i, t)
+        g.build()
+        assert (g.size, g.bits, g.mask, g.sa_width) == (want.size, want.bits, want.mask, want.sa_width)
+        assert np.array_equal(g.sa(), want.sa())
+        got, exp = g.query_batch(*pats), want.query_batch(*pats)
+        assert got[3] == exp[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], exp[:3]))
+
+    first = _gpu(G, blob, ds, ids)
+    path = tmp_path / "col.idx"
+    first.save(path)
+    loaded = G()
+    loaded.load(path)
+    check(loaded)                                   # load -> add -> build
+    check(_gpu(G, blob, ds, ids))                   # build (frees its staging copy when large; here kept) -> add -> build
+    pad = np.zeros(16, dtype=np.uint8)
+    d_text = torch.from_numpy(np.concatenate([blob, pad])).cuda()
+    torch.cuda.synchronize()
+    dev = G()
+    dev.build_device(d_text.data_ptr(), ds, ids)
+    check(dev)                                      # device build -> add -> build
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_ids = torch.from_numpy(ids).cuda()
+    torch.cuda.synchronize()
+    res = G()
+    res.build_resident(d_text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), len(ids))
+    check(res)                                      # resident build -> add_bulk -> build
+
+
+def test_large_build_frees_staging_and_fetches_it_back(G):
+    blob, ds = W.ascii_corpus(3000, 512, seed=8)     # 1.5 MB: above the threshold where cdb_build frees its host copy
+    ids = np.arange(3000, dtype=np.int64)
+    g = _gpu(G, blob, ds, ids)
+    g.add(77777, b"needle-in-a-haystack")
+    g.build()
+    assert g.query(b"needle-in") == [(77777, 1)]
+    kw = bytes(blob[1000:1006])
+    assert g.query(kw) == _oracle(blob, ds, ids).query(kw)
+
+
+def test_corrupt_index_files_are_refused_and_leave_the_handle_usable(G, tmp_path):
+    blob, ds = W.ascii_corpus(200, 40, seed=2, lo=0x61, hi=0x63)
+    ids = np.arange(200, dtype=np.int64)
+    g = _gpu(G, blob, ds, ids)
+    path = tmp_path / "ok.idx"
+    g.save(path)
+    raw = bytearray(path.read_bytes())
+    h = _gpu(G, blob, ds, ids)
+    kw = bytes(blob[5:8])
+    want = h.query(kw)
+
+    def refused(data, match):
+        p = tmp_path / "bad.idx"
+        p.write_bytes(bytes(data))
+        with pytest.raises(RuntimeError, match=match):
+            h.load(p)
+        assert h.query(kw) == want and h.sa_width == 4          # the old index is untouched
+
+    refused(raw[:-7], "Truncated")                               # file too short for its header
+    bad = bytearray(raw); bad[8 * 3] ^= 1                        # bits field of the header
+    refused(bad, "entry layout")
+    hdr = 8 * 8
+    bad = bytearray(raw); bad[hdr + 8 * 200 + 8 * 5: hdr + 8 * 200 + 8 * 6] = (10 ** 6).to_bytes(8, "little")
+    refused(bad, "non-decreasing|document table")                # doc_start runs backwards
+    bad = bytearray(raw); bad[-4:] = (0xFFFFFFFF).to_bytes(4, "little")
+    refused(bad, "suffix array")                                 # an entry that names no (document, offset)
+    bad = bytearray(raw); bad[16:24] = (2 ** 40).to_bytes(8, "little")
+    refused(bad, "Truncated")                                    # absurd document count
+
+
+def test_sustained_single_queries_all_return(G):
+    # leader/follower coalescing: a leader serves only the batch holding its own query, so every caller returns
+    # even while other threads keep re-enqueueing
+    import time
+    blob, ds = W.ascii_corpus(3000, 100, seed=9)
+    ids = np.arange(3000, dtype=np.int64)
+    g = _gpu(G, blob, ds, ids)
+    o = _oracle(blob, ds, ids)
+    kws = [bytes(blob[p:p + 5]) for p in range(0, 3000, 61)]
+    want = [o.query(k) for k in kws]
+    stop = time.time() + 2.0
+    done = [0] * 8
+    errs = []
+
+    def run(t):
+        try:
+            i = t
+            while time.time() < stop:
+                assert g.query(kws[i % len(kws)]) == want[i % len(kws)]
+                i += 1
+                done[t] += 1
+            with pytest.raises(RuntimeError, match="Empty keywords"):
+                g.query(b"")
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join(30) for t in th]
+    assert not errs and all(not t.is_alive() for t in th)
+    assert min(done) > 10, done                                   # nobody starved
