@@ -5,18 +5,26 @@
 One step = one pass of the hot path over one batch of synthetic input, per GPU:
     cdb_build_resident : suffix-array construction over the rank's corpus shard (text + document table resident in HBM)
     cdb_query_batch_device : the whole pattern batch against that suffix array (patterns resident in HBM)
-    (N > 1) RCCL all-gather merge of the per-shard match lists into one CSR result.
+    (N > 1) merge of the per-shard match lists into one CSR result over RCCL (cdb_shard_* of the C ABI).
 Default workload = BASELINE.json configs[1] ("c1"): 2^20 docs x 1024 B printable ASCII = 1 GiB of text
 per GPU, 100 000 patterns of length 4..16 (weak scaling: the corpus grows with N).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"     — the dominant kernel (radix-sort onesweep pass) timed live with HIP events
-  "cpu_baseline" — the CPU restatement of the reference (oracle/, kind "port") timed on this host on a
-                   bounded sample of the same workload (rank 0, N = 1 only).
+  "roofline"        — the dominant kernel of the timed region, timed live with HIP events on the library's stream
+  "query_roofline"  — SURVEY §8(d): sector-granular bytes of the batched search (A_q,sector), probes/s
+  "pcie_inclusive"  — the same build / query through the host entry points (cdb_add_bulk + cdb_build, cdb_query_batch)
+  "configs"         — the other single-GPU configurations of BASELINE.json, each with its own roofline:
+                      c2 (8 GiB Zipf-64 + 1 M patterns incl. occurrence offsets), utf8_4g (north_star target: 4 GiB
+                      UTF-8, reference-compatible order), c4shard (16 GiB UTF-8 = one GPU's share of C4, 10 M patterns,
+                      $correlation ranking); at N = 4 / 8 the per-GPU shapes of C3 / C4 run on every rank instead
+  "cpu_baseline"    — the CPU restatement of the reference (oracle/, kind "port") timed on this host: C0 in full with the
+                      thread count swept, then the largest prefix of C1 that builds in bounded time (rank 0, N = 1 only).
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -26,10 +34,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (docs per GPU, doc length, patterns, min len, max len)
-    "c0": (10_000, 256, 1_000, 4, 16),
-    "c1": (1 << 20, 1024, 100_000, 4, 16),
-    "mid": (1 << 16, 1024, 100_000, 4, 16),
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "c0": dict(kind="ascii", docs=10_000, doclen=256, npat=1_000, mmin=4, mmax=16),
+    # configs[1] — the configuration the metric is quoted on (default)
+    "c1": dict(kind="ascii", docs=1 << 20, doclen=1024, npat=100_000, mmin=4, mmax=16),
+    "mid": dict(kind="ascii", docs=1 << 16, doclen=1024, npat=100_000, mmin=4, mmax=16),
+    # configs[2]: 8 GiB, Zipf alphabet of 64 symbols, 1 M patterns with occurrence offsets.  Patterns are 6..16 bytes:
+    # on this text a sampled 2..5-byte keyword matches 10^5..10^8 suffixes, so a million of them would return more rows
+    # than any memory holds (and the reference would need hours for them) — 6 bytes is where the batch becomes answerable
+    "c2": dict(kind="zipf", docs=1 << 23, doclen=1024, npat=1_000_000, mmin=6, mmax=16, offsets=True),
+    # north_star target: SA build on 4 GiB of valid UTF-8 (reference_compat order, 8-byte entries)
+    "utf8_4g": dict(kind="utf8", bytes=4 << 30, npat=100_000, mmin=4, mmax=16),
+    # configs[3] per GPU: 8 GiB ASCII (4 of these = 32 GiB)
+    "c3shard": dict(kind="ascii", docs=1 << 23, doclen=1024, npat=100_000, mmin=4, mmax=16),
+    # configs[4] per GPU: 16 GiB UTF-8 (8 of these = 128 GiB), 10 M patterns, $correlation ranking
+    "c4shard": dict(kind="utf8", bytes=16 << 30, npat=10_000_000, mmin=4, mmax=16, ranked=True),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -39,66 +58,255 @@ class _DevArr:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def merge_on_device(torch, dist, shard, r, npat, world, device, coll_device):
-    """Wraps the library's device-resident CSR of this shard and merges it across ranks over RCCL."""
-    nrows = int(r.nrows)
-    row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
-    if nrows:
-        ids = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=device)
-        cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
-    else:
-        ids = cnt = torch.empty(0, dtype=torch.int64, device=device)
-    return shard.merge_shard_results(torch, dist, row_ptr.to(coll_device), ids.to(coll_device), cnt.to(coll_device), world)
-
-
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic_latest.json, written by tools/summarize_profile.py; FETCH_SIZE x2-corrected as
-    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself; null if absent."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def git_head():
     try:
-        k = json.load(open(path))["kernels"][kernel]
-        return round(k["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001 - the GPU box has no .git
         return None
 
 
-def cpu_baseline(W, host_text, ndocs_sample, doclen, pb, po, budget_docs):
-    """Times the CPU restatement (oracle/cpu_ref.cpp) on a bounded prefix of the same corpus."""
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic_latest.json, written by tools/summarize_profile.py; FETCH_SIZE x2-corrected as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC counters itself: the figures are tagged with the
+    profile and commit they were measured at."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
+
+
+def make_corpus(torch, W, cfg, rank, device):
+    """Synthetic shard of this rank, generated in HBM.  Returns (text, doc_start numpy u64, n)."""
+    if cfg["kind"] == "ascii":
+        n = cfg["docs"] * cfg["doclen"]
+        return W.random_bytes_torch(n, 12345, 0x20, 0x7E, stream=rank, device=device), W.uniform_docs(cfg["docs"], cfg["doclen"]), n
+    if cfg["kind"] == "zipf":
+        n = cfg["docs"] * cfg["doclen"]
+        return W.zipf_bytes_torch(n, seed=2 + rank, device=device), W.uniform_docs(cfg["docs"], cfg["doclen"]), n
+    text, ds = W.utf8_bytes_torch(cfg["bytes"], seed=4 + rank, device=device)
+    return text, ds, int(ds[-1])
+
+
+def describe(cfg, n, ndocs):
+    kind = {"ascii": "printable ASCII", "zipf": "Zipf alphabet of 64 symbols", "utf8": "valid UTF-8 (1/2/3-byte code points)"}[cfg["kind"]]
+    return (f"{ndocs} docs, {n / 2**30:.3f} GiB of {kind}; {cfg['npat']} patterns len {cfg['mmin']}-{cfg['mmax']}"
+            + (" with occurrence offsets" if cfg.get("offsets") else "") + (" + $correlation ranking" if cfg.get("ranked") else ""))
+
+
+def dominant(prof, n_elems=None):
+    """The kernel with the largest share of the HIP-event time, with its algorithmic bytes per launch."""
+    if not prof:
+        return None
+    name = max(prof, key=lambda k: prof[k]["ms"])
+    k = prof[name]
+    avg_ms = k["ms"] / max(k["launches"], 1)
+    gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] else 0.0
+    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
+            "algorithmic_bytes_per_launch": k["bytes"] // max(k["launches"], 1),
+            "share_of_kernel_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 3)}
+
+
+def build_stats(g):
+    keys = ("rounds", "ext_rounds", "dbl_rounds", "unresolved_after_initial", "sort_passes", "sort_passes_skipped",
+            "key_symbols", "symbol_bits", "alphabet", "isa_built", "bucketed", "bucket_groups", "key_layout", "hybrid")
+    out = {}
+    for k in keys:
+        try:
+            out[k] = g.stat(k)
+        except KeyError:
+            pass
+    return out
+
+
+def query_roofline(torch, r, npat, n, width, query_s, device):
+    """A_q,sector = 2 ceil(log2 n) x 128 B of probes + the hit range at 64-byte sectors + 16 B per row,
+    summed over the batch with the hit counts the query really found."""
+    levels = max(1, math.ceil(math.log2(max(n, 2))))
+    nrows = int(r.nrows)
+    hit_bytes = 0
+    if nrows:
+        rp = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
+        cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
+        cs = torch.zeros(nrows + 1, dtype=torch.int64, device=device)
+        torch.cumsum(cnt, 0, out=cs[1:])
+        hits = cs[rp[1:]] - cs[rp[:-1]]
+        hit_bytes = int((((hits * width + 63) // 64) * 64).sum().item())
+    a_q = npat * 2 * levels * 128 + hit_bytes + 16 * nrows
+    return {"patterns_per_s": round(npat / query_s, 1), "probes_per_s": round(npat * 2 * levels / query_s, 1),
+            "sector_bytes_per_batch": a_q, "achieved": round(a_q / query_s / 1e9, 2), "unit": "GB/s",
+            "levels": levels, "note": "A_q,sector of SURVEY §8(d) with measured hit and row counts; the search itself is "
+                                       "latency-bound (dependent probes), so this is reported, not priced against HBM peak"}
+
+
+def run_config(torch, capi, W, name, rank, device, local_rank, reps=2):
+    """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
+    cfg = WORKLOADS[name]
+    t_gen = time.perf_counter()
+    text, ds, n = make_corpus(torch, W, cfg, rank, device)
+    ndocs = len(ds) - 1
+    d_ds = torch.from_numpy(ds.astype(np.int64)).to(device)
+    d_ids = torch.arange(ndocs, dtype=torch.int64, device=device) + rank * ndocs
+    miss = 0xFF if cfg["kind"] == "utf8" else 0x7F
+    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, cfg["npat"], cfg["mmin"], cfg["mmax"], seed=99,
+                                                     miss_byte=miss, utf8=cfg["kind"] == "utf8")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t_gen = time.perf_counter() - t_gen
+    g = capi.GpuStringIndex(device=local_rank)
+    g.set_option("profile", 1)
+    out = {"workload": f"{name}: " + describe(cfg, n, ndocs), "generate_s": round(t_gen, 2)}
+    try:
+        bms = []
+        for i in range(reps + 1):
+            if i == 1:
+                g.profile_reset()
+            t = time.perf_counter()
+            g.build_resident(text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), ndocs)
+            bms.append((time.perf_counter() - t) * 1e3)
+        prof_build = g.profile()
+        out["sa_width"] = g.sa_width
+        out["dtype"] = "u64" if g.sa_width == 8 else "u32"
+        out["build_ms"] = [round(x, 2) for x in bms[1:]]
+        out["first_build_ms_incl_allocation"] = round(bms[0], 1)
+        out["sa_build_GiB_per_s"] = round(n / 2**30 / (min(bms[1:]) * 1e-3), 3)
+        out["build_stats"] = build_stats(g)
+        out["roofline"] = dominant(prof_build)
+        kern_ms = sum(v["ms"] for v in prof_build.values()) / reps
+        kern_bytes = sum(v["bytes"] for v in prof_build.values()) / reps
+        out["build_kernels_ms"] = round(kern_ms, 2)
+        out["build_algorithmic_bytes_per_suffix"] = round(kern_bytes / n, 1)
+        out["build_algorithmic_GBps_over_kernel_time"] = round(kern_bytes / (kern_ms * 1e-3) / 1e9, 1) if kern_ms else None
+        out["kernels_ms"] = {k: round(v["ms"] / reps, 3) for k, v in sorted(prof_build.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        qms = []
+        r = None
+        for i in range(reps + 1):
+            t = time.perf_counter()
+            if cfg.get("offsets"):
+                r, _hx = g.query_batch_offsets_device(d_blob.data_ptr(), d_offs.data_ptr(), cfg["npat"], nbytes)
+            else:
+                r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), cfg["npat"], nbytes)
+            qms.append((time.perf_counter() - t) * 1e3)
+        out["query_ms"] = [round(x, 3) for x in qms[1:]]
+        out["query_patterns_per_s"] = round(cfg["npat"] / (min(qms[1:]) * 1e-3), 1)
+        out["query_hits_per_batch"] = int(r.nhits)
+        out["query_rows_per_batch"] = int(r.nrows)
+        out["query_roofline"] = query_roofline(torch, r, cfg["npat"], n, g.sa_width, min(qms[1:]) * 1e-3, device)
+        if cfg.get("ranked"):
+            # full $correlation ranking (interface.cpp:78-146) of the union over a keyword list: OR-merge, filter, rank
+            nkw = 100_000
+            hb = d_blob[: int(d_offs[nkw].item())].cpu().numpy()
+            ho = d_offs[: nkw + 1].cpu().numpy().astype(np.uint64)
+            kws_blob, kws_offs = hb, ho
+            t = time.perf_counter()
+            rows = g.query_ranked_arrays(kws_blob, kws_offs, 1, 1 << 62, 1000)
+            out["ranked"] = {"keywords": nkw, "limit": 1000, "rows": rows, "ms": round((time.perf_counter() - t) * 1e3, 2),
+                             "note": "cdb_query_ranked: host keyword list in, top rows out (PCIe-inclusive)"}
+        v = g.verify()
+        out["verify"] = {"invalid_entries": int(v["invalid_entries"]), "inversions": int(v["inversions"]),
+                         "tie_violations": int(v["tie_violations"]), "entry_sum_ok": bool(v["entry_sum"] == v["expected_entry_sum"])}
+    finally:
+        g.close()
+        del text, d_blob, d_offs, d_ds, d_ids
+        torch.cuda.empty_cache()
+        capi.load_library().cdb_release_cached_memory()
+    return out
+
+
+def cpu_baseline(W, host_text, doclen, budget_s=25.0):
+    """CPU restatement of the reference (oracle/cpu_ref.cpp, kind "port") on this host, as BASELINE.md §3 plans:
+    C0 in full with the build's thread count swept (the reference spawns hardware_concurrency() spinning workers,
+    index.cpp:225 — oversubscription is visible in the sweep), then the largest prefix of the bench corpus that
+    builds within the budget, with the query leg on that same index."""
     from oracle import OracleIndex
     cores = os.cpu_count() or 1
-    nd = min(ndocs_sample, budget_docs)
-    while True:  # grow the sample until the build takes a few seconds (bounded: <= 2^18 docs)
+    c0 = WORKLOADS["c0"]
+    blob0, ds0 = W.ascii_corpus(c0["docs"], c0["doclen"], seed=12345)
+    ids0 = np.arange(c0["docs"], dtype=np.int64)
+    sweep = {}
+    for th in sorted({min(8, cores), min(32, cores), cores}):
+        o = OracleIndex()
+        o.add_bulk(ids0, blob0, ds0)
+        t = time.perf_counter()
+        o.build(th)
+        sweep[str(th)] = round(len(blob0) / 2**20 / (time.perf_counter() - t), 3)
+    best_th = int(max(sweep, key=lambda k: sweep[k]))
+    pb0, po0 = W.sample_patterns(blob0, ds0, c0["npat"], c0["mmin"], c0["mmax"], seed=99)
+    t = time.perf_counter()
+    o.query_batch(pb0, po0, nthreads=1, want_rows=False)
+    c0_q1 = c0["npat"] / (time.perf_counter() - t)
+    # ---- prefix of the bench corpus: x4 until the next step would leave the budget
+    out = {"unit": "GiB/s", "kind": "port", "c0_build_MiB_per_s_by_threads": sweep,
+           "c0_query_patterns_per_s_1thread": round(c0_q1, 1)}
+    if host_text is None:
+        out.update({"value": round(max(sweep.values()) / 1024, 6), "cores": best_th, "sample": "C0 in full (10k docs x 256 B)"})
+        return out
+    nd = 1 << 13
+    spent = 0.0
+    tb = None
+    while True:
         ds = W.uniform_docs(nd, doclen)
         blob = host_text[: nd * doclen]
         o = OracleIndex()
         o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
-        t = time.time()
-        o.build(0)  # hardware_concurrency threads, as index.cpp:225
-        tb = time.time() - t
-        if tb >= 4.0 or nd * 4 > min(ndocs_sample, 1 << 18):
+        t = time.perf_counter()
+        o.build(best_th)
+        tb = time.perf_counter() - t
+        spent += tb
+        if spent + 4.5 * tb > budget_s or (nd * 4) * doclen > len(host_text):
             break
         nd *= 4
-    # patterns drawn from the sample itself so that the hit structure matches the full-size run
-    spb, spo = W.sample_patterns(blob, ds, min(len(po) - 1, 100_000), 4, 16, seed=99)
-    t = time.time()
-    _, _, _, hits1 = o.query_batch(spb, spo, nthreads=1, want_rows=False)
-    tq1 = time.time() - t
-    t = time.time()
+    npat = 100_000
+    spb, spo = W.sample_patterns(blob, ds, npat, 4, 16, seed=99)
+    t = time.perf_counter()
+    o.query_batch(spb, spo, nthreads=1, want_rows=False)
+    tq1 = time.perf_counter() - t
+    t = time.perf_counter()
     o.query_batch(spb, spo, nthreads=cores, want_rows=False)
-    tqa = time.time() - t
-    npat = len(spo) - 1
-    return {
+    tqa = time.perf_counter() - t
+    out.update({
         "value": round(nd * doclen / 2**30 / tb, 6),
-        "unit": "GiB/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the same corpus, SA build with {cores} threads; "
-                  f"{npat} patterns len 4-16 sampled from that prefix",
+        "cores": best_th,
+        "host_threads_available": cores,
+        "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the bench corpus, SA build with {best_th} threads (the best of "
+                  f"the C0 sweep); {npat} patterns len 4-16 sampled from that prefix, queried on that same index",
         "build_s": round(tb, 3),
         "query_patterns_per_s_1thread": round(npat / tq1, 1),
         "query_patterns_per_s_allcores": round(npat / tqa, 1),
-    }
+    })
+    return out
+
+
+def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
+    """The same work through the host entry points: cdb_add_bulk (host staging) + cdb_build (H2D of text and tables
+    inside the timed call) and cdb_query_batch (patterns up, CSR rows down)."""
+    tb, ta = [], []
+    g = None
+    for _ in range(reps):
+        if g is not None:
+            g.close()
+        g = capi.GpuStringIndex()
+        t = time.perf_counter()
+        g.add_bulk(ids, host_text, doc_start)
+        ta.append(time.perf_counter() - t)
+        t = time.perf_counter()
+        g.build()
+        tb.append(time.perf_counter() - t)
+    tq = []
+    for _ in range(reps + 1):
+        t = time.perf_counter()
+        res = g.query_batch(pb, po)
+        tq.append(time.perf_counter() - t)
+        del res
+    out = {"build_GiB_per_s": round(n / 2**30 / min(tb), 3), "build_ms": [round(x * 1e3, 2) for x in tb],
+           "add_bulk_ms_host_memcpy": round(min(ta) * 1e3, 1),
+           "query_patterns_per_s": round(npat / min(tq[1:]), 1), "query_ms": [round(x * 1e3, 3) for x in tq[1:]],
+           "query_split_ms": {"upload": round(g.stat("query_upload_ms"), 3), "device": round(g.stat("query_device_ms"), 3),
+                              "download": round(g.stat("query_download_ms"), 3)}}
+    g.close()
+    return out
 
 
 def main():
@@ -107,10 +315,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample-docs", type=int, default=1 << 15, help="docs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--configs", default="auto",
+                    help="comma-separated extra configurations for the \"configs\" block (auto: c2,utf8_4g,c4shard at N = 1 on "
+                         "the default workload, c3shard at N = 4, c4shard at N = 8; none: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
+                    help="rendezvous backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
                          "exercise the N > 1 code path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only)")
     args = ap.parse_args()
@@ -139,20 +350,30 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    ndocs, doclen, npat, mmin, mmax = WORKLOADS[args.workload]
-    n = ndocs * doclen
-    # ---- synthetic shard of this rank (stream = rank => different text per shard), generated in HBM
-    text = W.random_bytes_torch(n, 12345, 0x20, 0x7E, stream=rank, device=device)
-    doc_start = W.uniform_docs(ndocs, doclen)
+    cfg = WORKLOADS[args.workload]
+    text, doc_start, n = make_corpus(torch, W, cfg, rank, device)
+    ndocs = len(doc_start) - 1
+    npat, mmin, mmax = cfg["npat"], cfg["mmin"], cfg["mmax"]
     ids = np.arange(ndocs, dtype=np.int64) + rank * ndocs
-    host_text = text.cpu().numpy() if rank == 0 else None
+    d_doc_start = torch.from_numpy(doc_start.astype(np.int64)).to(device)
+    d_ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(device)
+    small = n <= (2 << 30) and cfg["kind"] == "ascii"
+    host_text = text.cpu().numpy() if (rank == 0 and small) else None
 
     # ---- one pattern batch for every shard (rank 0 samples it from its own text, then broadcast)
+    pb = po = None
     if rank == 0:
-        pb, po = W.sample_patterns(host_text, doc_start, npat, mmin, mmax, seed=99)
-        meta = torch.tensor([len(pb)], dtype=torch.int64, device=device)
+        if small:
+            pb, po = W.sample_patterns(host_text, doc_start, npat, mmin, mmax, seed=99)
+            nbytes = len(pb)
+        else:
+            miss = 0xFF if cfg["kind"] == "utf8" else 0x7F
+            b_, o_, nbytes = W.sample_patterns_torch(text, d_doc_start, npat, mmin, mmax, seed=99, miss_byte=miss,
+                                                     utf8=cfg["kind"] == "utf8")
+        meta = torch.tensor([nbytes], dtype=torch.int64, device=device)
     else:
         meta = torch.zeros(1, dtype=torch.int64, device=device)
+
     def bcast(t):
         if world == 1:
             return
@@ -168,26 +389,32 @@ def main():
     d_blob = torch.zeros(nbytes + 16, dtype=torch.uint8, device=device)
     d_offs = torch.zeros(npat + 1, dtype=torch.int64, device=device)
     if rank == 0:
-        d_blob[:nbytes] = torch.from_numpy(pb).to(device)
-        d_offs.copy_(torch.from_numpy(po.astype(np.int64)).to(device))
+        if small:
+            d_blob[:nbytes] = torch.from_numpy(pb).to(device)
+            d_offs.copy_(torch.from_numpy(po.astype(np.int64)).to(device))
+        else:
+            d_blob[:nbytes] = b_[:nbytes]
+            d_offs.copy_(o_)
+            del b_, o_
     bcast(d_blob)
     bcast(d_offs)
 
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
-
-    # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
-    d_doc_start = torch.from_numpy(doc_start.astype(np.int64)).to(device)
-    d_ids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(device)
+    merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device) if world > 1 else None
 
     def step():
-        g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), len(ids))
+        # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
+        g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), ndocs)
         tb = g.stat("build_ms")
-        r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+        if cfg.get("offsets"):
+            r, _ = g.query_batch_offsets_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+        else:
+            r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
         tq = g.stat("query_ms")
-        if world > 1:
-            merge_on_device(torch, dist, shard, r, npat, world, device, coll_device)
-        return tb, tq, int(r.nhits), int(r.nrows)
+        if merger is not None:
+            merger.merge(r, npat)
+        return tb, tq, r
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
     for _ in range(args.warmup):
@@ -198,10 +425,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     build_ms = query_ms = 0.0
-    hits = rows = 0
     step_build_ms = []
+    r = None
     for _ in range(args.steps):
-        tb, tq, hits, rows = step()
+        tb, tq, r = step()
         build_ms += tb
         query_ms += tq
         step_build_ms.append(round(tb, 3))
@@ -213,16 +440,23 @@ def main():
         t = torch.tensor([elapsed, build_ms, query_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
+    hits, rows = int(r.nhits), int(r.nrows)
 
     prof = g.profile()
-    dom_name = max((k for k in prof if k.startswith("rs_onesweep_k")), key=lambda k: prof[k]["ms"])
-    dom = prof[dom_name]
-    dom_avg_ms = dom["ms"] / dom["launches"]
-    dom_gbs = dom["bytes"] / dom["launches"] / (dom_avg_ms * 1e-3) / 1e9
-
+    steps = args.steps
+    out = None
     if rank == 0:
-        steps = args.steps
         gib_total = world * n * steps / 2**30
+        roof = dominant(prof)
+        traffic = pmc_traffic()
+        if traffic and roof and roof["kernel"] in traffic.get("kernels", {}):
+            roof["traffic"] = round(traffic["kernels"][roof["kernel"]]["hbm_bytes_per_launch"])
+            roof["traffic_source"] = {k: traffic.get(k) for k in ("profile", "commit", "source")}
+        elif roof:
+            roof["traffic"] = None
+        build_kernels = {k: v for k, v in prof.items() if not k.startswith("q_")}
+        kern_ms = sum(v["ms"] for v in build_kernels.values()) / steps
+        kern_bytes = sum(v["bytes"] for v in build_kernels.values()) / steps
         out = {
             "metric": "sa_build_GiB_per_s",
             "value": round(gib_total / elapsed, 4),
@@ -234,42 +468,75 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64",  # sort keys; text is u8, suffix entries u32 (u64 for corpora the reference stores as u64)
+            "dtype": "u64" if g.sa_width == 8 else "u32",  # suffix-array entries and sort keys of this configuration (text is u8)
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: {ndocs} docs x {doclen} B printable ASCII per GPU ({n / 2**30:.3f} GiB), "
-                            f"{npat} patterns len {mmin}-{mmax}; step = SA build + batched query"
-                            + (" + RCCL all-gather merge" if world > 1 else ""),
-                "docs_per_gpu": ndocs, "doc_len": doclen, "patterns": npat,
+                "workload": f"{args.workload}: " + describe(cfg, n, ndocs) + " per GPU; step = SA build + batched query"
+                            + (" + RCCL merge of the shards' match lists" if world > 1 else ""),
+                "docs_per_gpu": ndocs, "bytes_per_gpu": n, "patterns": npat,
             },
+            "commit": git_head(),
             "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
             "query_hits_per_batch": hits,
             "query_rows_per_batch": rows,
             "build_ms_per_step": step_build_ms,
-            "build_stats": {k: g.stat(k) for k in ("rounds", "ext_rounds", "dbl_rounds", "unresolved_after_initial",
-                                                   "sort_passes", "sort_passes_skipped", "key_symbols", "symbol_bits",
-                                                   "isa_built")},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom_name,
-                "achieved": round(dom_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(dom_gbs / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(dom_name),
-                "avg_launch_ms": round(dom_avg_ms, 4),
-                "launches": dom["launches"],
-                "algorithmic_bytes_per_launch": dom["bytes"] // dom["launches"],
-            },
-            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+            "build_stats": build_stats(g),
+            "roofline": roof,
+            "build_kernels_ms_per_step": round(kern_ms, 3),
+            "build_algorithmic_bytes_per_suffix": round(kern_bytes / n, 1),
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:14]},
         }
-        if world == 1 and not args.no_cpu_baseline and args.cpu_sample_docs > 0:
-            out["cpu_baseline"] = cpu_baseline(W, host_text, ndocs, doclen, pb, po, args.cpu_sample_docs)
+        if traffic and "kernels" in traffic:
+            tot = sum(k["hbm_bytes_per_launch"] * k.get("launches", 1) for k in traffic["kernels"].values()
+                      if not str(k.get("phase", "")).startswith("q"))
+            out["build_hbm_traffic_per_suffix_profiled"] = {"bytes": round(tot / traffic.get("suffixes", n), 1),
+                                                            "profile": traffic.get("profile"), "commit": traffic.get("commit")}
+        out["query_roofline"] = query_roofline(torch, r, npat, n, g.sa_width, query_ms * 1e-3 / steps, device)
+    if merger is not None:
+        merger.close()
+
+    # ---- everything below is outside the timed region
+    extra = args.configs
+    if extra == "auto":
+        extra = ("c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
+                 "c3shard" if world == 4 else "c4shard" if world == 8 else "none")
+    if rank == 0 and world == 1 and small and not args.no_pcie:
+        try:
+            out["pcie_inclusive"] = pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat)
+        except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
+            out["pcie_inclusive"] = {"error": repr(e)[:300]}
+    g.close()
+    del text, d_blob, d_offs
+    torch.cuda.empty_cache()
+    capi.load_library().cdb_release_cached_memory()
+    if extra != "none":
+        blocks = {}
+        for name in [x for x in extra.split(",") if x]:
+            try:
+                res = run_config(torch, capi, W, name, rank, device, local_rank)
+            except Exception as e:  # noqa: BLE001
+                res = {"workload": name, "error": repr(e)[:300]}
+            if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N
+                v = torch.tensor([res.get("sa_build_GiB_per_s", 0.0), res.get("query_patterns_per_s", 0.0)],
+                                 dtype=torch.float64, device=coll_device)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                res["all_ranks"] = {"sa_build_GiB_per_s_aggregate": round(float(v[0]) * world, 3),
+                                    "query_patterns_per_s_slowest_rank": round(float(v[1]), 1), "n_gpus": world,
+                                    "note": "independent per-shard builds (no data-path collective); every shard answers "
+                                            "the whole pattern batch"}
+            blocks[name] = res
+        if rank == 0:
+            out["configs"] = blocks
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, host_text, cfg.get("doclen", 1024))
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)[:300]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    g.close()
     if world > 1:
         dist.destroy_process_group()
 

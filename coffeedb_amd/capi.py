@@ -17,10 +17,10 @@ _LIB = None
 
 EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
-    "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_size", "cdb_bits",
+    "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
-    "cdb_debug_radix_sort", "cdb_debug_verify",
+    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference",
 ]
 
 
@@ -41,6 +41,10 @@ class CdbHits(C.Structure):
 class CdbDeviceResult(C.Structure):
     _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
                 ("d_row_ptr", C.c_void_p), ("d_ids", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+class CdbDeviceHits(C.Structure):
+    _fields_ = [("d_hit_ptr", C.c_void_p), ("d_offsets", C.c_void_p)]
 
 
 def build_library(force=False):
@@ -99,6 +103,7 @@ def load_library():
     lib.cdb_result_free.argtypes = [C.POINTER(CdbResult)]
     lib.cdb_result_free.restype = None
     lib.cdb_query_batch_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(CdbDeviceResult)]
+    lib.cdb_query_batch_offsets_device.argtypes = [vp, vp, vp, u64, u64, C.POINTER(CdbDeviceResult), C.POINTER(CdbDeviceHits)]
     for f in ("cdb_size", "cdb_bits", "cdb_mask"):
         getattr(lib, f).argtypes = [vp]
         getattr(lib, f).restype = u64
@@ -117,6 +122,7 @@ def load_library():
     lib.cdb_cached_memory_bytes.argtypes = []
     lib.cdb_cached_memory_bytes.restype = u64
     lib.cdb_debug_verify.argtypes = [vp, C.POINTER(u64)]
+    lib.cdb_debug_verify_reference.argtypes = [vp, C.POINTER(u64)]
     lib.cdb_debug_radix_sort.argtypes = [C.c_int, vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_int)]
     _LIB = lib
@@ -216,6 +222,17 @@ class GpuStringIndex:
         self._lib.cdb_free(cnt)
         return out
 
+    def query_ranked_arrays(self, blob, offsets, lo=1, hi=(1 << 62), limit=0):
+        """cdb_query_ranked over an already packed keyword list (bench: 10^5 keywords); returns the number of rows."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        self._check(self._lib.cdb_query_ranked(self._h, _ptr(blob), _ptr(offsets), len(offsets) - 1, int(lo), int(hi), int(limit),
+                                               C.byref(ids), C.byref(cnt), C.byref(n)))
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return int(n.value)
+
     def query_spans(self, keywords):
         """{object id: [(begin, end_inclusive), ...]} — merged highlight spans (database.cpp:58-76)."""
         blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
@@ -287,6 +304,12 @@ class GpuStringIndex:
                                                      blob_bytes, C.byref(r)))
         return r
 
+    def query_batch_offsets_device(self, d_blob_ptr, d_offsets_ptr, npat, blob_bytes):
+        r, hx = CdbDeviceResult(), CdbDeviceHits()
+        self._check(self._lib.cdb_query_batch_offsets_device(self._h, C.c_void_p(d_blob_ptr), C.c_void_p(d_offsets_ptr), npat,
+                                                             blob_bytes, C.byref(r), C.byref(hx)))
+        return r, hx
+
     # ---- introspection / options / measurements
     size = property(lambda s: s._lib.cdb_size(s._h))
     bits = property(lambda s: s._lib.cdb_bits(s._h))
@@ -306,6 +329,12 @@ class GpuStringIndex:
         self._check(self._lib.cdb_debug_verify(self._h, out))
         return {"inversions": out[0], "tie_violations": out[1], "entry_sum": out[2], "invalid_entries": out[3],
                 "expected_entry_sum": out[4]}
+
+    def verify_reference(self):
+        """GPU-side check of the REFERENCE's order (signed child order inside radix nodes; cdb_debug_verify_reference)."""
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.cdb_debug_verify_reference(self._h, out))
+        return {"violations": out[0], "mixed_pairs": out[1], "radix_node_pairs": out[2], "tie_violations": out[3]}
 
     def set_option(self, name, value):
         self._check(self._lib.cdb_set_option(self._h, name.encode(), int(value)))

@@ -891,27 +891,46 @@ int cdb_query(cdb_index* h, const char* keyword, size_t len, int64_t** ids, int6
     return CDB_OK;
 }
 
-int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
-                           uint64_t blob_bytes, cdb_device_result* out) {
+namespace {
+int query_batch_device_impl(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat, cdb_device_result* out,
+                            cdb_device_hits* hits) {
     if (!h || !out) return CDB_E_INVALID;
-    (void)blob_bytes;
     std::memset(out, 0, sizeof(*out));
+    if (hits) std::memset(hits, 0, sizeof(*hits));
     return guarded(h, [&] {
         Index& ix = h->ix;
         std::lock_guard<std::mutex> g(ix.mu);
         DeviceScope dscope(ix);
         const double t0 = wall_ms();
-        const DeviceCsr r = query_batch_on_device(ix, static_cast<const uint8_t*>(d_blob), d_offsets, npat);
+        const DeviceCsr r = query_batch_on_device(ix, static_cast<const uint8_t*>(d_blob), d_offsets, npat, hits != nullptr);
         out->npat = npat;
         out->nrows = r.nrows;
         out->nhits = r.nhits;
         out->d_row_ptr = ix.q_rowptr.as<uint64_t>();
         out->d_ids = ix.q_ids.as<int64_t>();
         out->d_counts = ix.q_counts.as<int64_t>();
+        if (hits) {
+            hits->d_hit_ptr = ix.q_hitptr.as<uint64_t>();
+            hits->d_offsets = ix.q_hitoff.as<uint64_t>();
+        }
         ix.qstats.query_ms = wall_ms() - t0;
         ix.qstats.nhits = r.nhits;
         ix.qstats.nrows = r.nrows;
     });
+}
+}  // namespace
+
+int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
+                           uint64_t blob_bytes, cdb_device_result* out) {
+    (void)blob_bytes;
+    return query_batch_device_impl(h, d_blob, d_offsets, npat, out, nullptr);
+}
+
+int cdb_query_batch_offsets_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
+                                   uint64_t blob_bytes, cdb_device_result* out, cdb_device_hits* hits) {
+    (void)blob_bytes;
+    if (!hits) return CDB_E_INVALID;
+    return query_batch_device_impl(h, d_blob, d_offsets, npat, out, hits);
 }
 
 uint64_t cdb_size(const cdb_index* h) { return h ? h->ix.size : 0; }
@@ -1018,6 +1037,17 @@ int cdb_debug_verify(cdb_index* h, uint64_t out[5]) {
         DeviceScope dscope(ix);
         if (ix.width == 0) throw Error("index has not been built");
         verify_suffix_array(ix, out);
+    });
+}
+
+int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]) {
+    if (!h || !out) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        DeviceScope dscope(ix);
+        if (ix.width == 0) throw Error("index has not been built");
+        verify_reference_order(ix, out);
     });
 }
 

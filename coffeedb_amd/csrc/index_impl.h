@@ -134,6 +134,10 @@ void build_suffix_array(Index& ix);
 
 // verify.hip — out = {inversions, tie-order violations, wrapped sum of entries, invalid entries, expected sum}
 void verify_suffix_array(Index& ix, uint64_t out[5]);
+// the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
+// out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,
+// equal suffixes not ascending by document}
+void verify_reference_order(Index& ix, uint64_t out[4]);
 // number of entries of a suffix array (device pointers) that do not name a real (document, offset)
 uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint64_t n, const uint64_t* d_doc_start, uint64_t ndocs,
                                int bits, uint64_t mask);

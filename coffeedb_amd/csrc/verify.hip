@@ -71,7 +71,136 @@ __global__ __launch_bounds__(256) void sa_entry_check_kernel(const V* __restrict
     if (b) atomicAdd(bad, b);
 }
 
+// ---- the REFERENCE's order --------------------------------------------------------------
+// For text with bytes >= 0x80 the reference's array is not globally sorted: a radix node (bucket of more than
+// chuck_size = max(4096, n / 256) suffixes, index.cpp:96-126,218) lays its children out by
+// `(int)char - CHAR_MIN + 1` of a SIGNED char (index.h:66-73): [end of document][0x80..0xFF][0x00..0x7F]; buckets of
+// at most chuck_size suffixes are std::sort-ed by unsigned string_view order (index.cpp:86-95).  Checked here pair
+// by pair, by code that shares nothing with apply_reference_order: for adjacent entries with common prefix length l,
+//   * both end at l                      -> equal suffixes: ascending document (canonical tie order);
+//   * exactly one ends at l              -> it comes first (either order);
+//   * next bytes of the same sign class  -> ascending (signed and unsigned order agree);
+//   * one byte >= 0x80, the other < 0x80 -> the bucket of their common l-prefix decides: more than chuck_size
+//     suffixes share that prefix <=> it was a radix node <=> the byte >= 0x80 comes first; otherwise the byte < 0x80.
+// Buckets are contiguous in the reference's order (its permutation only moves whole child ranges), so the size
+// of the l-prefix bucket is found by galloping outwards from the pair until the prefix no longer matches.
+template <typename V>
+struct RefOrderCtx {
+    const V* sa;
+    uint64_t n;
+    const uint8_t* text;
+    const uint64_t* doc_start;
+    int bits;
+    uint64_t mask;
+    __device__ __forceinline__ void suffix(uint64_t i, const uint8_t*& p, uint64_t& len) const {
+        const V e = sa[i];
+        const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
+        p = text + doc_start[d] + o;
+        len = doc_start[d + 1] - doc_start[d] - o;
+    }
+    // does entry i share the first l bytes of q (a suffix known to have >= l bytes)?
+    __device__ __forceinline__ bool shares(uint64_t i, const uint8_t* q, uint64_t l) const {
+        const uint8_t* p;
+        uint64_t len;
+        suffix(i, p, len);
+        if (len < l) return false;
+        for (uint64_t k = 0; k < l; ++k)
+            if (p[k] != q[k]) return false;
+        return true;
+    }
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void sa_verify_reference_kernel(RefOrderCtx<V> c, uint64_t chuck, unsigned long long* __restrict__ out) {
+    unsigned long long bad = 0, mixed = 0, big = 0, tie = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x + 1; i < c.n; i += stride) {
+        const uint8_t *pa, *pb;
+        uint64_t la, lb;
+        c.suffix(i - 1, pa, la);
+        c.suffix(i, pb, lb);
+        const uint64_t lim = la < lb ? la : lb;
+        uint64_t l = 0;
+        while (l < lim && pa[l] == pb[l]) ++l;
+        if (l == la && l == lb) {  // equal suffixes
+            if (((uint64_t)c.sa[i - 1] & c.mask) >= ((uint64_t)c.sa[i] & c.mask)) tie += 1;
+            continue;
+        }
+        if (l == la) continue;          // the shorter one first: right in both orders
+        if (l == lb) { bad += 1; continue; }
+        const uint8_t x = pa[l], y = pb[l];
+        if ((x >= 0x80) == (y >= 0x80)) {
+            if (x > y) bad += 1;
+            continue;
+        }
+        mixed += 1;
+        // size of the bucket of the common l-prefix, counted outwards from the pair and capped at chuck + 1
+        uint64_t cnt = 2;
+        {   // backwards from i - 1
+            uint64_t good = 0, step = 1, lim_b = i - 1;  // entries i-1-good .. i-1 share the prefix
+            uint64_t badp = lim_b + 1;                   // first distance known not to share (or beyond the array)
+            while (good + step <= lim_b && good + step <= chuck) {
+                if (c.shares(i - 1 - (good + step), pa, l)) { good += step; step <<= 1; }
+                else { badp = good + step; break; }
+            }
+            if (badp > good + step && good + step > lim_b) badp = lim_b + 1;
+            if (good < chuck) {
+                uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;  // answer in [good, hi)
+                while (good + 1 < hi) {
+                    const uint64_t mid = good + (hi - good) / 2;
+                    if (mid <= lim_b && c.shares(i - 1 - mid, pa, l)) good = mid; else hi = mid;
+                }
+            }
+            cnt += good;
+        }
+        if (cnt <= chuck) {  // forwards from i
+            uint64_t good = 0, step = 1, lim_f = c.n - 1 - i;
+            uint64_t badp = lim_f + 1;
+            while (good + step <= lim_f && good + step <= chuck) {
+                if (c.shares(i + good + step, pa, l)) { good += step; step <<= 1; }
+                else { badp = good + step; break; }
+            }
+            if (good < chuck) {
+                uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;
+                while (good + 1 < hi) {
+                    const uint64_t mid = good + (hi - good) / 2;
+                    if (mid <= lim_f && c.shares(i + mid, pa, l)) good = mid; else hi = mid;
+                }
+            }
+            cnt += good;
+        }
+        const bool node = cnt > chuck;  // a radix node of the reference: signed child order
+        if (node) big += 1;
+        const bool high_first = x >= 0x80;
+        if (high_first != node) bad += 1;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (mixed) atomicAdd(&out[1], mixed);
+    if (big) atomicAdd(&out[2], big);
+    if (tie) atomicAdd(&out[3], tie);
+}
+
 }  // namespace
+
+void verify_reference_order(Index& ix, uint64_t out[4]) {
+    hipStream_t s = ix.stream;
+    DevBuf d_out;
+    d_out.alloc(4 * sizeof(uint64_t));
+    CDB_HIP(hipMemsetAsync(d_out.p, 0, 4 * sizeof(uint64_t), s));
+    const uint64_t chuck = std::max<uint64_t>(4096, ix.size / 256);  // index.cpp:218
+    if (ix.size > 1) {
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 20);
+        if (ix.width == 4) {
+            RefOrderCtx<uint32_t> c{ix.d_sa.as<uint32_t>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
+            hipLaunchKernelGGL((sa_verify_reference_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, c, chuck, d_out.as<unsigned long long>());
+        } else {
+            RefOrderCtx<uint64_t> c{ix.d_sa.as<uint64_t>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
+            hipLaunchKernelGGL((sa_verify_reference_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, c, chuck, d_out.as<unsigned long long>());
+        }
+    }
+    CDB_HIP(hipMemcpyAsync(out, d_out.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+}
 
 uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint64_t n, const uint64_t* d_doc_start, uint64_t ndocs,
                                int bits, uint64_t mask) {

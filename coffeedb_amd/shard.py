@@ -70,3 +70,44 @@ def merge_shard_results(torch, dist, row_ptr, ids, counts, world):
         out[0, dest] = allrows[:, 0, :].reshape(-1)[src]
         out[1, dest] = allrows[:, 1, :].reshape(-1)[src]
     return g_row_ptr, out[0], out[1]
+
+
+class _DevArr:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class ShardMerger:
+    """bench.py's N > 1 step: merges this rank's device-resident CSR with the other shards'.  Over RCCL the merge is the
+    library's own (cdb_comm_* of the C ABI: all-gather of the row counts, all-gatherv of the rows, HIP placement kernel);
+    `--backend gloo --share-gpu` (a one-GPU box, testing only) goes through torch.distributed instead."""
+
+    def __init__(self, capi, index, dist, rank, world, coll_device, device):
+        import torch
+        self.torch, self.dist, self.index, self.world, self.device, self.coll_device = torch, dist, index, world, device, coll_device
+        self.comm = None
+        if coll_device == device and hasattr(capi, "ShardComm"):
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                uid.copy_(torch.from_numpy(capi.ShardComm.unique_id()).to(device))
+            dist.broadcast(uid, 0)
+            self.comm = capi.ShardComm(uid.cpu().numpy(), rank, world, device.index or 0)
+
+    def merge(self, r, npat):
+        if self.comm is not None:
+            return self.comm.merge(self.index, r)
+        torch = self.torch
+        nrows = int(r.nrows)
+        row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=self.device)
+        if nrows:
+            ids = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=self.device)
+            cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=self.device)
+        else:
+            ids = cnt = torch.empty(0, dtype=torch.int64, device=self.device)
+        return merge_shard_results(torch, self.dist, row_ptr.to(self.coll_device), ids.to(self.coll_device),
+                                   cnt.to(self.coll_device), self.world)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None

@@ -157,3 +157,104 @@ def random_bytes_torch(n, seed, lo=0x20, hi=0x7E, stream=0, device="cpu", chunk_
         b = z.view(torch.uint8).to(torch.int32)
         out[s * 8:e * 8] = (lo + ((b * span) >> 8)).to(torch.uint8)
     return out[:n]
+
+
+def zipf_bytes_torch(n, seed=2, nsym=64, base=0x30, device="cuda", chunk=1 << 28):
+    """C2 text generated on the device: nsym symbols base+rank with P(rank k) ∝ 1/k (torch's own generator:
+    deterministic for a given seed and torch build, not bit-identical to zipf_corpus)."""
+    import torch
+    w = 1.0 / torch.arange(1, nsym + 1, dtype=torch.float64, device=device)
+    cdf = torch.cumsum(w / w.sum(), 0)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        u = torch.rand(e - s, dtype=torch.float64, device=device, generator=gen)
+        out[s:e] = (base + torch.searchsorted(cdf, u).clamp_(0, nsym - 1)).to(torch.uint8)
+    return out
+
+
+def utf8_bytes_torch(total_bytes, seed=4, device="cuda", doc_bytes=1024, step=1 << 27):
+    """C4-style valid UTF-8 generated on the device: 50 % 1-byte, 30 % 2-byte (U+0080-07FF), 20 % 3-byte
+    (U+0800-D7FF) code points; documents are cut at the first code-point boundary at or behind every multiple of
+    doc_bytes.  Returns (text uint8[n] with n a multiple of 16, doc_start uint64 numpy[ndocs + 1])."""
+    import torch
+    ncp = int(total_bytes / 1.7)
+    g_ = torch.Generator(device=device).manual_seed(seed)
+    cuts = []
+    total = 0
+    buf = torch.empty(int(ncp * 1.72) + (1 << 20), dtype=torch.uint8, device=device)
+    for s in range(0, ncp, step):
+        m = min(step, ncp - s)
+        cls = torch.randint(0, 10, (m,), device=device, generator=g_)
+        val = torch.randint(0, 1 << 30, (m,), device=device, generator=g_)
+        cp = torch.where(cls < 5, 0x20 + val % 0x5F, torch.where(cls < 8, 0x80 + val % 0x780, 0x800 + val % 0xD000))
+        ln = torch.where(cp < 0x80, 1, torch.where(cp < 0x800, 2, 3))
+        off = torch.cumsum(ln, 0) - ln
+        nb = int((off[-1] + ln[-1]).item())
+        out = buf[total:total + nb]
+        one, two, three = cp < 0x80, (cp >= 0x80) & (cp < 0x800), cp >= 0x800
+        out[off[one]] = cp[one].to(torch.uint8)
+        out[off[two]] = (0xC0 | (cp[two] >> 6)).to(torch.uint8)
+        out[off[two] + 1] = (0x80 | (cp[two] & 0x3F)).to(torch.uint8)
+        out[off[three]] = (0xE0 | (cp[three] >> 12)).to(torch.uint8)
+        out[off[three] + 1] = (0x80 | ((cp[three] >> 6) & 0x3F)).to(torch.uint8)
+        out[off[three] + 2] = (0x80 | (cp[three] & 0x3F)).to(torch.uint8)
+        first = (total + doc_bytes - 1) // doc_bytes * doc_bytes
+        tg = torch.arange(first, total + nb, doc_bytes, device=device) - total
+        idx = torch.searchsorted(off, tg).clamp_(max=m - 1)
+        cuts.append((off[idx] + total).cpu().numpy())
+        total += nb
+        del cls, val, cp, ln, off, one, two, three, tg, idx
+    # the corpus ends at the last document cut that keeps the length a multiple of 16 (device text must be 16-byte
+    # aligned for the next shard behind it; a cut is a code-point boundary, so the text stays valid UTF-8)
+    cuts = np.concatenate(cuts) if cuts else np.zeros(0, dtype=np.int64)
+    cuts = cuts[cuts <= total]
+    ok = cuts[cuts % 16 == 0]
+    end = int(ok[-1]) if len(ok) else 0
+    ds = np.unique(np.concatenate([[0], cuts[cuts < end], [end]])).astype(np.uint64)
+    return buf[:end], ds
+
+
+def sample_patterns_torch(text, doc_start, npat, mmin, mmax, seed=99, miss_frac=0.1, miss_byte=0x7F, utf8=False):
+    """Device-side pattern batch for corpora that have no host copy: substrings at uniform (document, offset),
+    lengths uniform in [mmin, mmax] (clipped to the document), a miss_frac share with the last byte replaced by a
+    byte the corpus never holds.  utf8=True moves both ends forward to code-point boundaries.
+    doc_start: uint64 numpy / int64 tensor [ndocs + 1].  Returns (blob uint8 tensor, offsets int64 tensor, nbytes)."""
+    import torch
+    dev = text.device
+    ds = torch.as_tensor(np.asarray(doc_start).astype(np.int64)) if not torch.is_tensor(doc_start) else doc_start
+    ds = ds.to(dev)
+    nd = ds.numel() - 1
+    g = torch.Generator(device=dev).manual_seed(seed)
+    docs = torch.randint(0, nd, (npat,), device=dev, generator=g)
+    lens = ds[docs + 1] - ds[docs]
+    m = torch.randint(mmin, mmax + 1, (npat,), device=dev, generator=g)
+    m = torch.minimum(m, lens).clamp_(min=1)
+    r = torch.randint(0, 1 << 40, (npat,), device=dev, generator=g)
+    start = ds[docs] + r % (lens - m + 1).clamp_(min=1)
+    end = start + m
+    if utf8:
+        dend = ds[docs + 1]
+        for _ in range(3):  # skip continuation bytes (10xxxxxx): at most two in a row for <= 3-byte code points
+            cont = (start < dend) & ((text[start.clamp(max=text.numel() - 1)] & 0xC0) == 0x80)
+            start = start + cont.to(start.dtype)
+        end = torch.maximum(start + 1, torch.minimum(start + m, dend))
+        for _ in range(3):
+            cont = (end < dend) & ((text[end.clamp(max=text.numel() - 1)] & 0xC0) == 0x80)
+            end = end + cont.to(end.dtype)
+        keep = start < dend
+        start = torch.where(keep, start, ds[docs])  # (a document whose tail is all continuation bytes cannot occur)
+        end = torch.where(keep, end, torch.minimum(ds[docs] + 1, dend))
+    m = (end - start).clamp_(min=1)
+    offs = torch.zeros(npat + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(m, 0, out=offs[1:])
+    nbytes = int(offs[-1].item())
+    idx = torch.repeat_interleave(start - offs[:-1], m) + torch.arange(nbytes, device=dev)
+    blob = torch.zeros(nbytes + 16, dtype=torch.uint8, device=dev)
+    blob[:nbytes] = text[idx]
+    nmiss = int(npat * miss_frac)
+    if nmiss:
+        which = torch.randint(0, npat, (nmiss,), device=dev, generator=g)
+        blob[offs[which + 1] - 1] = miss_byte
+    return blob, offs, nbytes

@@ -179,6 +179,15 @@ typedef struct cdb_device_result {
 int cdb_query_batch_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
                            uint64_t blob_bytes, cdb_device_result* out);
 
+/* The same with occurrence offsets (cdb_query_batch_offsets), everything left in device memory: d_hit_ptr
+ * (nrows + 1 u64) and d_offsets (nhits u64) are library-owned like the arrays of cdb_device_result. */
+typedef struct cdb_device_hits {
+    const uint64_t* d_hit_ptr;
+    const uint64_t* d_offsets;
+} cdb_device_hits;
+int cdb_query_batch_offsets_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
+                                   uint64_t blob_bytes, cdb_device_result* out, cdb_device_hits* hits);
+
 /* ---- introspection (parity tests; mirrors the private members src/index.h:56-60) -------------- */
 uint64_t cdb_size(const cdb_index* h);  /* number of suffixes = text bytes */
 uint64_t cdb_bits(const cdb_index* h);  /* doc-index bits of an entry */
@@ -224,6 +233,17 @@ void cdb_set_cache_limit(uint64_t bytes);
  * a valid (doc, off), out[4] = closed-form expected value of out[2].  (With reference_compat and bytes
  * >= 0x80 the reference's order is not globally sorted, so out[0] > 0 is expected there.) */
 int cdb_debug_verify(cdb_index* h, uint64_t out[5]);
+
+/* Test hook: the same kind of check against the REFERENCE's order (reference_compat = 1): inside a radix
+ * node — a bucket of more than chuck_size = max(4096, n / 256) suffixes (index.cpp:96-126,218) — children follow the
+ * signed-char symbol order of index.h:66-73 (end of document, 0x80..0xFF, 0x00..0x7F); smaller buckets are in unsigned
+ * order (std::sort leaves, index.cpp:86-95).  Adjacent pairs are classified by their common prefix and, where the two
+ * orders disagree, by the size of the bucket sharing that prefix (found by galloping over the array).
+ * out[0] = pairs out of reference order (0 for a correct array), out[1] = pairs whose next bytes lie on different
+ * sides of 0x80, out[2] = of those, pairs inside radix nodes (laid out high byte first), out[3] = equal suffixes not
+ * ascending by document.  On pure-ASCII text, or with reference_compat = 0 on text without big mixed buckets, it
+ * degenerates to the plain sortedness check. */
+int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]);
 
 /* Test hook for the radix-sort primitive (tests/test_gpu_sort.py, tools/sort_bench.py): stable sort of
  * n 64-bit keys (+ optional 4- or 8-byte values, val_bytes = 0/4/8) held in DEVICE memory by key bits

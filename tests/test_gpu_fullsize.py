@@ -10,6 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _give_memory_back():
+    """The big corpora live in torch tensors and the library's block cache: hand both back after every test."""
+    yield
+    import gc
+    import torch
+    from coffeedb_amd import capi
+    gc.collect()
+    torch.cuda.empty_cache()
+    capi.load_library().cdb_release_cached_memory()
+
+
 def _brute_counts(torch, text, pat, doclen):
     """{doc: overlapping occurrences} of `pat` by a full scan (matches must not cross documents)."""
     m = len(pat)
@@ -102,3 +114,242 @@ def test_beyond_4gib_on_one_gpu():
         assert {int(i) - 1_000_000: int(c) for i, c in zip(ri[a:b], rc[a:b])} == per_doc
     g.close()
     capi.load_library().cdb_release_cached_memory()
+
+
+def _scan_occurrences(torch, text, kw, chunk=1 << 30):
+    """All start positions of `kw` in `text` (device tensors) by a chunked scan: the first three bytes are compared
+    densely, the rest only at the surviving positions."""
+    m, n = len(kw), text.numel()
+    out = []
+    for s0 in range(0, n, chunk):
+        seg = text[s0:min(n, s0 + chunk + m - 1)]
+        L = seg.numel() - m + 1
+        if L <= 0:
+            break
+        ok = seg[:L] == kw[0]
+        for k in range(1, min(m, 3)):
+            ok &= seg[k:L + k] == kw[k]
+        pos = torch.nonzero(ok).flatten()
+        for k in range(3, m):
+            pos = pos[seg[pos + k] == kw[k]]
+        out.append(pos + s0)
+    return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=text.device)
+
+
+def test_c2_full_size_zipf_one_million_patterns_with_offsets():
+    """BASELINE.json configs[2] at FULL size: 2^23 docs x 1024 B of Zipf(64) text = 8 GiB (8-byte entries, bucket-wise
+    initial sort, text-extension rounds), one batch of 10^6 patterns with occurrence offsets.  Checked through
+    size-independent properties and brute-force scans of sampled patterns incl. their offsets."""
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    nd, dl, npat = 1 << 23, 1024, 1_000_000
+    n = nd * dl
+    text = W.zipf_bytes_torch(n, seed=2, device="cuda")
+    ds = W.uniform_docs(nd, dl)
+    ids = np.arange(nd, dtype=np.int64) * 2 + 1
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, npat, 6, 16, seed=99, miss_byte=0x7F)
+    pb = d_blob[:nbytes].cpu().numpy()
+    po = d_offs.cpu().numpy().astype(np.uint64)
+    del d_blob, d_offs
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), ds, ids)
+    assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1       # 24 + 11 bits -> u64 entries
+    v = g.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+    assert v["entry_sum"] == v["expected_entry_sum"]
+
+    rp, ri, rc, hp, off = g.query_batch_offsets(pb, po)
+    hits = int(hp[-1])
+    assert len(rp) == npat + 1 and rp[0] == 0 and rp[-1] == len(ri) == len(rc) == len(hp) - 1
+    assert int(rc.sum()) == hits == len(off) and (rc > 0).all()
+    assert np.array_equal(np.diff(hp.astype(np.int64)), rc)                              # a row owns `count` offsets
+    rows = np.diff(rp.astype(np.int64))
+    assert (rows > 0).mean() > 0.88
+    # offsets ascend inside a row and every occurrence fits its document
+    inner = np.ones(len(off), dtype=bool)
+    inner[hp[:-1].astype(np.int64)] = False
+    assert (np.diff(off.astype(np.int64))[inner[1:]] > 0).all() and int(off.max()) < dl
+    rng = np.random.default_rng(11)
+    lens = np.diff(po.astype(np.int64))
+    picks = rng.choice(npat, 10, replace=False).tolist() + [int(np.argmax(rows)), int(np.argmin(lens))]
+    for j in picks:
+        kw = pb[int(po[j]):int(po[j + 1])]
+        pos = _scan_occurrences(torch, text, torch.from_numpy(kw.copy()).cuda())
+        pos = pos[(pos % dl) + len(kw) <= dl]                                            # matches never cross documents
+        want_docs, want_cnt = torch.unique(pos // dl, return_counts=True)
+        a, b = int(rp[j]), int(rp[j + 1])
+        assert np.array_equal((ri[a:b] - 1) // 2, want_docs.cpu().numpy()), (j, bytes(kw))
+        assert np.array_equal(rc[a:b], want_cnt.cpu().numpy()), (j, bytes(kw))
+        got_off = off[int(hp[a]):int(hp[b])]
+        assert np.array_equal(got_off, (pos % dl).cpu().numpy().astype(np.uint64)), (j, bytes(kw))   # (doc, offset) ascending
+    g.close()
+    capi.load_library().cdb_release_cached_memory()
+
+
+def test_utf8_4gib_reference_order_and_true_order():
+    """north_star target shape: 4 GiB of valid UTF-8 on one GPU.  reference_compat = 1 must give the REFERENCE's order
+    (signed child order inside radix nodes, index.h:66-73 / index.cpp:96-126; checked by cdb_debug_verify_reference),
+    reference_compat = 0 the plain unsigned order with true counts (brute-force scans)."""
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    text, ds = W.utf8_bytes_torch(4 << 30, seed=4, device="cuda")
+    nd, n = len(ds) - 1, int(ds[-1])
+    assert n > (4 << 30) - (64 << 20) and n % 16 == 0
+    text[: 1 << 20].cpu().numpy().tobytes()[: int(ds[64])].decode("utf-8")             # valid UTF-8, cut at code points
+    ids = np.arange(nd, dtype=np.int64)
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, 100_000, 4, 16, seed=99, miss_byte=0xFF, utf8=True)
+    pb = d_blob[:nbytes].cpu().numpy()
+    po = d_offs.cpu().numpy().astype(np.uint64)
+    del d_blob, d_offs
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), ds, ids)                                              # reference_compat = 1 (default)
+    assert g.size == n and g.sa_width == 8 and g.stat("compat_rotations") >= 1
+    v = g.verify()
+    assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
+    assert v["inversions"] == g.stat("compat_rotations")        # not globally sorted: one inversion per rotated node
+    r = g.verify_reference()
+    assert r["violations"] == 0 and r["tie_violations"] == 0, r
+    assert r["radix_node_pairs"] == g.stat("compat_rotations") and r["mixed_pairs"] > r["radix_node_pairs"], r
+    # the lone-keyword kernel walks the reference's own bisections on this array; the batch must agree with it
+    rp, ri, rc, hits = g.query_batch(pb[: int(po[2000])], po[:2001])
+    for j in range(0, 2000, 97):
+        a, b = int(rp[j]), int(rp[j + 1])
+        assert g.query(bytes(pb[int(po[j]):int(po[j + 1])])) == list(zip(ri[a:b].tolist(), rc[a:b].tolist())), j
+    g.close()
+
+    g = capi.GpuStringIndex()
+    g.set_option("reference_compat", 0)
+    g.build_device(text.data_ptr(), ds, ids)
+    v = g.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+    assert v["entry_sum"] == v["expected_entry_sum"]
+    rp, ri, rc, hits = g.query_batch(pb, po)
+    assert int(rc.sum()) == hits and (np.diff(rp.astype(np.int64)) > 0).mean() > 0.88
+    for j in np.random.default_rng(3).choice(100_000, 8, replace=False).tolist():
+        kw = pb[int(po[j]):int(po[j + 1])]
+        pos = _scan_occurrences(torch, text, torch.from_numpy(kw.copy()).cuda())
+        doc = torch.searchsorted(d_ds, pos, right=True) - 1
+        pos = pos[pos + len(kw) <= d_ds[doc + 1]]
+        doc = torch.searchsorted(d_ds, pos, right=True) - 1
+        wd, wc = torch.unique(doc, return_counts=True)
+        a, b = int(rp[j]), int(rp[j + 1])
+        assert np.array_equal(ri[a:b], wd.cpu().numpy()) and np.array_equal(rc[a:b], wc.cpu().numpy()), (j, bytes(kw))
+    g.close()
+    capi.load_library().cdb_release_cached_memory()
+
+
+def test_c4_shard_16gib_utf8_ten_million_patterns():
+    """One GPU's share of BASELINE.json configs[4]: 16 GiB of valid UTF-8 (8-byte entries, reference order), a batch
+    of 10^7 patterns, $correlation ranking of a keyword list."""
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    free, _ = torch.cuda.mem_get_info()
+    if free < (250 << 30):
+        pytest.skip("needs a whole 288 GB MI355X")
+    text, ds = W.utf8_bytes_torch(16 << 30, seed=5, device="cuda")
+    nd, n = len(ds) - 1, int(ds[-1])
+    ids = np.arange(nd, dtype=np.int64) + 10
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    npat = 10_000_000
+    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, npat, 4, 16, seed=7, miss_byte=0xFF, utf8=True)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), ds, ids)
+    assert g.size == n and g.sa_width == 8 and g.stat("bucketed") == 1
+    v = g.verify()
+    assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
+    r = g.verify_reference()
+    assert r["violations"] == 0 and r["radix_node_pairs"] >= 1, r
+    res = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+    assert int(res.npat) == npat and int(res.nrows) > 0.85 * npat and int(res.nhits) >= int(res.nrows)
+    # the first 20 000 patterns again through the host API with the plain reference-sequence search: same rows
+    hb = d_blob[: int(d_offs[20_000].item())].cpu().numpy()
+    ho = d_offs[:20_001].cpu().numpy().astype(np.uint64)
+    fast = g.query_batch(hb, ho)
+    g.set_option("fast_search", 0)
+    g.set_option("wave_rows", 0)
+    slow = g.query_batch(hb, ho)
+    assert fast[3] == slow[3] and all(np.array_equal(a, b) for a, b in zip(fast[:3], slow[:3]))
+    # device rows of those patterns equal the host API's
+    rp_d = torch.as_tensor(_Dev(res.d_row_ptr, npat + 1), device="cuda")[:20_001].cpu().numpy()
+    assert np.array_equal(rp_d.astype(np.uint64), fast[0])
+    # $correlation ranking of the union over 1000 keywords: descending counts, filter respected, top rows consistent
+    kws = [bytes(hb[int(ho[j]):int(ho[j + 1])]) for j in range(1000)]
+    g.set_option("fast_search", 1)
+    ranked = g.query_ranked(kws, lo=1, limit=50)
+    union = dict(g.query_or(kws))
+    assert len(ranked) == min(50, len(union)) and all(union[i] == c for i, c in ranked)
+    assert [c for _, c in ranked] == sorted(union.values(), reverse=True)[: len(ranked)]
+    g.close()
+    capi.load_library().cdb_release_cached_memory()
+
+
+class _Dev:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def test_reference_test_string_at_its_real_size():
+    """test/test-string.py:25-56 as the reference runs it: 5000 docs x 5000 random a-z characters, 100 random 3-character
+    keywords, and for EVERY document $correlation == overlapping brute-force count (absent when 0)."""
+    from coffeedb_amd import capi, workloads as W
+    nd, dl = 5000, 5000
+    blob, ds = W.ascii_corpus(nd, dl, seed=2024, lo=0x61, hi=0x7A)
+    ids = np.arange(nd, dtype=np.int64)
+    g = capi.GpuStringIndex()
+    g.add_bulk(ids, blob, ds)
+    g.build()
+    mat = blob.reshape(nd, dl)
+    for i in range(100):
+        kw = W.random_bytes(3, 9000 + i, 0x61, 0x7A)
+        ok = (mat[:, :-2] == kw[0]) & (mat[:, 1:-1] == kw[1]) & (mat[:, 2:] == kw[2])    # count(): overlapping occurrences
+        want = ok.sum(axis=1)
+        got = dict(g.query(bytes(kw)))
+        assert got == {int(d): int(want[d]) for d in np.nonzero(want)[0]}, bytes(kw)
+    g.close()
+
+
+def test_reference_test_highlight_sequential_replace():
+    """test/test-highlight.py:31-60 restated: 5 keywords of 4 characters over disjoint letters of a shuffled alphabet; the
+    result set must be the documents `str.replace` changes, and every rendered document must equal the sequential
+    replace(k, "<b>" + k + "</b>") — here from cdb_query_spans + the shim's span rendering."""
+    from coffeedb_amd import capi, workloads as W
+    nd, dl = 5000, 5000
+    blob, ds = W.ascii_corpus(nd, dl, seed=77, lo=0x61, hi=0x7A)
+    letters = [chr(c) for c in range(0x61, 0x7B)]
+    np.random.default_rng(5).shuffle(letters)
+    kws = ["".join(letters[4 * i:4 * i + 4]).encode() for i in range(5)]
+    # plant some occurrences (random text holds ~55 of each; make runs and document edges certain)
+    planted = blob.copy()
+    planted[0:4] = np.frombuffer(kws[0], dtype=np.uint8)
+    planted[dl - 4:dl] = np.frombuffer(kws[1], dtype=np.uint8)
+    planted[3 * dl + 10:3 * dl + 14] = np.frombuffer(kws[2], dtype=np.uint8)
+    planted[3 * dl + 14:3 * dl + 18] = np.frombuffer(kws[3], dtype=np.uint8)              # adjacent occurrences: two spans
+    ids = np.arange(nd, dtype=np.int64) + 1000
+    g = capi.GpuStringIndex()
+    g.add_bulk(ids, planted, ds)
+    g.build()
+    spans = dict(g.query_spans(kws))
+    docs = [planted[i * dl:(i + 1) * dl].tobytes() for i in range(nd)]
+    changed = set()
+    for i, text in enumerate(docs):
+        want = text
+        for k in kws:
+            want = want.replace(k, b"<b>" + k + b"</b>")
+        if want != text:
+            changed.add(1000 + i)
+            out, last = [], 0
+            for b, e in spans[1000 + i]:                                                  # shim/highlight.h render_spans
+                out += [text[last:b], b"<b>", text[b:e + 1], b"</b>"]
+                last = e + 1
+            out.append(text[last:])
+            assert b"".join(out) == want, i
+    assert set(spans) == changed and len(changed) > 200
+    g.close()

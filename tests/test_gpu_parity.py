@@ -774,3 +774,25 @@ def test_sustained_single_queries_all_return(G):
     [t.join(30) for t in th]
     assert not errs and all(not t.is_alive() for t in th)
     assert min(done) > 10, done                                   # nobody starved
+
+
+def test_reference_order_verifier_agrees_with_oracle_parity(G):
+    # cdb_debug_verify_reference checks the reference's order pair by pair (signed child order inside radix nodes,
+    # unsigned leaves).  Where SA parity with the oracle holds it must find nothing; on the plainly sorted array of the
+    # same text (reference_compat = 0) it must object exactly where radix nodes hold bytes on both sides of 0x80.
+    cases = [(_few_symbols(400000, 5, [0x41, 0x42, 0xC3, 0xA9]), W.uniform_docs(4000, 100)),
+             W.ascii_corpus(600, 64, seed=21, lo=0x00, hi=0xFF), W.utf8_corpus(300, 120, seed=4),
+             W.ascii_corpus(3000, 100, seed=3)]
+    for k, (blob, ds) in enumerate(cases):
+        ids = np.arange(len(ds) - 1, dtype=np.int64)
+        g, o = _check_parity(G, blob, ds, ids=ids)
+        v = g.verify_reference()
+        assert v["violations"] == 0 and v["tie_violations"] == 0, (k, v)
+        if k < 3:
+            assert v["radix_node_pairs"] >= 1 and v["mixed_pairs"] >= v["radix_node_pairs"], (k, v)
+            plain = _gpu(G, blob, ds, ids, reference_compat=0)
+            pv = plain.verify_reference()
+            assert pv["violations"] == v["radix_node_pairs"], (k, pv, v)   # one misplaced boundary per mixed radix node
+            assert plain.verify()["inversions"] == 0
+        else:
+            assert v["mixed_pairs"] == 0
