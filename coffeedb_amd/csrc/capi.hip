@@ -205,6 +205,7 @@ int cdb_create(cdb_index** out, int device) {
     cdb_index* h = new (std::nothrow) cdb_index();
     if (!h) return CDB_E_DEVICE;
     h->ix.device = device;
+    if (const char* e = std::getenv("CDB_HYBRID")) h->ix.hybrid = std::atoi(e);  // test hook: default of the "hybrid" option
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return CDB_E_DEVICE;
@@ -965,6 +966,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
+    else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
     else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
     else if (!std::strcmp(name, "bucket_group_limit")) ix.bucket_group_limit = (uint64_t)value;
@@ -989,7 +991,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"hybrid", (double)b.hybrid}, {"hybrid_largest_bucket", (double)b.hybrid_largest_bucket},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "bucket_sort.h"
 #include "index_impl.h"
 #include "scan.h"
 
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                                                          const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                          uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
                                                          int nsym, int npass, bool padded,
-                                                         unsigned long long* __restrict__ hist) {
+                                                         unsigned long long* __restrict__ hist, uint64_t hyb_w,
+                                                         uint64_t hyb_magic) {
     __shared__ __attribute__((aligned(16))) uint8_t s_code[KH_TILE + KG_LOOK];
     __shared__ uint16_t s_map[256];
     __shared__ uint64_t s_drange[2];
@@ -282,7 +284,12 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                     const uint64_t cin = p + (uint64_t)nsym <= dend ? (uint64_t)s_code[li + nsym - 1] : 0ull;
                     key = (key - (uint64_t)s_code[li - 1] * top) * kbase + cin;
                 }
-                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+                uint64_t dk = key;
+                if (hyb_w) {  // hybrid sort: the passes run over the digits of the bucket number b = key / w
+                    dk = __umul64hi(key, hyb_magic);
+                    if (key - dk * hyb_w >= hyb_w) dk += 1;
+                }
+                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(dk >> (8 * q)) & 0xFFu], 1u);
             }
         }
     }
@@ -760,11 +767,14 @@ __global__ __launch_bounds__(320) void compat_bounds_kernel(const V* __restrict_
 // a round trip through a scratch copy, but without the scratch (up to n entries at the root bucket)
 template <typename V>
 __global__ __launch_bounds__(256) void compat_reverse_kernel(V* __restrict__ x, uint64_t len) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len / 2) return;
-    const V a = x[i], b = x[len - 1 - i];
-    x[i] = b;
-    x[len - 1 - i] = a;
+    // grid-stride: the root bucket of a 16 GiB shard has more than 2^32 pairs, which one launch cannot address
+    // with a thread each (found by tests/test_gpu_fullsize.py: the last of the three reversals silently did not run)
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < len / 2; i += stride) {
+        const V a = x[i], b = x[len - 1 - i];
+        x[i] = b;
+        x[len - 1 - i] = a;
+    }
 }
 
 template <typename V>
@@ -778,7 +788,8 @@ void apply_reference_order(Index& ix, V* sa) {
     uint64_t depth = 0;
     auto reverse = [&](uint64_t at, uint64_t len) {
         if (len > 1)
-            hipLaunchKernelGGL((compat_reverse_kernel<V>), dim3((unsigned)ceil_div(len / 2, 256)), dim3(256), 0, s, sa + at, len);
+            hipLaunchKernelGGL((compat_reverse_kernel<V>), dim3((unsigned)std::min<uint64_t>(ceil_div(len / 2, 256), 1u << 20)), dim3(256),
+                               0, s, sa + at, len);
     };
     while (!level.empty()) {
         const size_t nb = level.size();
@@ -1084,6 +1095,14 @@ void build_typed(Index& ix, bool big) {
     int key_bits = nsym * symbits;
     uint32_t kbase = 1u << symbits;
     bool dense = false;
+    // The hybrid sort (bucket_sort.h: a few global passes by bucket = key / w, the rest of the key sorted in LDS)
+    // needs no whole-symbol digits at all, so it always takes the dense coding.  hybrid: 0 = off, 1 = corpora of
+    // 2^27 suffixes and more (where the passes dominate), 2 = whenever the key layout allows (tests).
+    const bool want_hybrid = ix.hybrid != 0 && !big && sizeof(V) == 4 && ix.narrow_keys && ix.fuse_keygen && ix.digit_bits == 0 &&
+                             ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255 && nsym <= HC_MAXSYM &&
+                             (n >= (1ull << 27) || ix.hybrid == 2) &&
+                             (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1 ||
+                              ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32);
     if (!big && ix.digit_bits == 0 && ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255) {
         const unsigned __int128 B = (unsigned)sigma + 1u;
         auto bits_of = [&](int k) {  // bits of B^k - 1; 999 when beyond 56 bits
@@ -1096,7 +1115,7 @@ void build_typed(Index& ix, bool big) {
         };
         const int bd = bits_of(nsym);
         const int passes_dense = (int)ceil_div(bd, 8), passes_aligned = (int)ceil_div(key_bits, dbits);
-        if (bd <= 56 && (passes_dense < passes_aligned || ix.key_coding == 2)) {
+        if (bd <= 56 && (passes_dense < passes_aligned || ix.key_coding == 2 || want_hybrid)) {
             dense = true;
             while (nsym < HC_MAXSYM && bits_of(nsym + 1) <= 8 * passes_dense) ++nsym;  // symbols that ride along for free
             key_bits = bits_of(nsym);
@@ -1119,8 +1138,8 @@ void build_typed(Index& ix, bool big) {
                                 ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32));
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
-    if (fused && dense) {
-        const int npass = (int)ceil_div(key_bits, 8);
+    // digit histograms of the keys (hyb_w = 0) or of the hybrid sort's bucket numbers, counted in one sweep over the text
+    auto key_histograms = [&](int npass, uint64_t hyb_w, uint64_t hyb_magic) {
         DevBuf d_kh;
         d_kh.alloc((size_t)npass * 256 * sizeof(uint64_t));
         CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
@@ -1128,11 +1147,45 @@ void build_typed(Index& ix, bool big) {
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
                            (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
-                           d_kh.as<unsigned long long>());
+                           d_kh.as<unsigned long long>(), hyb_w, hyb_magic);
         ix.prof.end(t, "sa_keyhist", n, s);
         h_hist.assign((size_t)npass * 256, 0);
         CDB_HIP(hipMemcpyAsync(h_hist.data(), d_kh.p, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         CDB_HIP(hipStreamSynchronize(s));
+    };
+    // Hybrid plan: G global passes over the digits of b = K / w, then every bucket is finished in LDS.  G is the
+    // smallest number of passes that makes the expected bucket (n / buckets; the keys of real text are close enough
+    // to uniform in key space for that, and a bucket that does not fit sends the build down the plain path) fit a
+    // workgroup; the record must still fit (u32 key, entry, u8 / u16).
+    HybridPlan plan;
+    if (want_hybrid && fused && dense && key_bits <= 56) {
+        unsigned __int128 space = 1;
+        for (int i = 0; i < nsym; ++i) space *= kbase;
+        const int cap = n >= (1ull << 22) ? BS_CAP_BIG32 : BS_CAP_SMALL;
+        for (int G = 1; G <= 3 && !plan.ok; ++G) {
+            const unsigned __int128 nbmax = (unsigned __int128)1 << (8 * G);
+            const uint64_t w = (uint64_t)std::max<unsigned __int128>((space + nbmax - 1) / nbmax, 1);
+            const uint64_t nb = (uint64_t)((space + w - 1) / w);
+            const int rbits = bit_width64(w - 1);
+            if ((double)n / (double)nb > 0.92 * cap) continue;
+            int lead = 0;
+            if (rbits + 8 * (G - 1) <= 32) lead = 1;
+            else if (G >= 2 && rbits + 8 * (G - 2) <= 32) lead = 2;
+            if (!lead) continue;
+            plan.ok = true;
+            plan.G = G;
+            plan.lead = lead;
+            plan.rbits = rbits;
+            plan.w = w;
+            plan.magic = w > 1 ? ~0ull / w : 0;  // floor(2^64 / w) for w that is no power of two, one less otherwise: both fine
+            plan.nb = nb;
+            plan.cap = cap;
+        }
+        if (plan.ok && plan.w == 1) plan.ok = false;  // (nothing left to sort inside a bucket: the plain path is as good)
+    }
+    if (fused && dense) {
+        if (plan.ok) key_histograms(plan.G, plan.w, plan.magic);
+        else key_histograms((int)ceil_div(key_bits, 8), 0, 0);
     } else if (fused) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
@@ -1188,6 +1241,8 @@ void build_typed(Index& ix, bool big) {
     DevBuf sorted_k32, sorted_low;
     const int low_bits = layout == SPLIT ? dbits : (layout == SPLIT2 ? 2 * dbits : 0);
     const int low_bytes = layout == SPLIT ? 1 : (layout == SPLIT2 ? 2 : 0);
+    int hyb_low_bits = low_bits;  // low digits of the KEPT keys (the hybrid sort always keeps them split)
+    bool flags_done = false;  // the hybrid sort writes the group flags itself
     if (!big && layout != WIDE) {
         if constexpr (sizeof(V) == 4) {
             DevBuf k32[2], vals[2], low[2];
@@ -1195,16 +1250,67 @@ void build_typed(Index& ix, bool big) {
             k32[1].alloc(n * sizeof(uint32_t));
             vals[0].alloc(n * sizeof(V));
             vals[1].alloc(n * sizeof(V));
-            if (low_bytes) {
-                low[0].alloc(n * low_bytes);
-                low[1].alloc(n * low_bytes);
+            const int low_alloc = std::max(low_bytes, plan.ok ? plan.lead : 0);
+            if (low_alloc) {
+                low[0].alloc(n * low_alloc);
+                low[1].alloc(n * low_alloc);
             }
             st.alloc_ms += now_ms() - ta;
             if (getenv("CDB_DEBUG_BUFS"))
                 std::fprintf(stderr, "[bufs] k32 %p %p vals %p %p low %p %p flags %p\n", k32[0].p, k32[1].p, vals[0].p, vals[1].p, low[0].p,
                              low[1].p, flags.p);
-            int sel;
-            if (layout == SPLIT) {
+            int sel = 0;
+            if (plan.ok) {
+                // ---- hybrid: G global passes by bucket, buckets finished in LDS (bucket_sort.h)
+                DevBuf bstart;
+                bstart.alloc((plan.nb + 1) * sizeof(uint32_t));
+                CDB_HIP(hipMemsetAsync(bstart.p, 0xFF, (plan.nb + 1) * sizeof(uint32_t), s));
+                BStartArgs bsa;
+                bsa.table = bstart.p;
+                bsa.wide = 0;
+                bsa.rbits = plan.rbits;
+                bsa.lead_bits = 8 * plan.lead;
+                TextGen hgen = gen;
+                hgen.low_bits = 8 * plan.lead;
+                hgen.hyb_w = plan.w;
+                hgen.hyb_magic = plan.magic;
+                hgen.hyb_rbits = plan.rbits;
+                const int hi_bits = plan.rbits + 8 * (plan.G - plan.lead);
+                uint64_t largest = 0;
+                bool ok;
+                if (plan.lead == 1) {
+                    sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
+                                                       vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n, hi_bits, &ss,
+                                                       ix.sort_variant, 8, h_hist.data(), &hgen, plan.rbits, &bsa);
+                    ok = bucket_sort_finish<V, uint8_t, uint32_t, uint8_t>(
+                        s, ix.prof, ix.scan_partials, k32[sel].as<uint32_t>(), vals[sel].as<V>(), low[sel].as<uint8_t>(),
+                        bstart.as<uint32_t>(), plan, n, kbase, kmagic, 8, flags.as<uint8_t>(),
+                        ix.keep_keys ? low[sel].as<uint8_t>() : (uint8_t*)nullptr, &largest);
+                } else {
+                    sel = radix_sort_split<V, uint16_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
+                                                        vals[1].as<V>(), low[0].as<uint16_t>(), low[1].as<uint16_t>(), n, hi_bits, &ss,
+                                                        ix.sort_variant, 8, h_hist.data(), &hgen, plan.rbits, &bsa);
+                    ok = bucket_sort_finish<V, uint16_t, uint32_t, uint16_t>(
+                        s, ix.prof, ix.scan_partials, k32[sel].as<uint32_t>(), vals[sel].as<V>(), low[sel].as<uint16_t>(),
+                        bstart.as<uint32_t>(), plan, n, kbase, kmagic, 16, flags.as<uint8_t>(),
+                        ix.keep_keys ? low[sel].as<uint16_t>() : (uint16_t*)nullptr, &largest);
+                }
+                st.hybrid = ok ? plan.G : -1;
+                st.hybrid_largest_bucket = largest;
+                if (ok) {
+                    flags_done = true;
+                    layout = plan.lead == 1 ? SPLIT : SPLIT2;  // (the layout of the kept keys)
+                    st.key_layout = (int)layout;
+                } else {
+                    // a bucket larger than a workgroup's capacity (skewed key distribution): the plain LSD sort redoes it
+                    plan.ok = false;
+                    key_histograms((int)ceil_div(key_bits, 8), 0, 0);
+                }
+            }
+            const int low_bits_h = flags_done ? 8 * plan.lead : low_bits;
+            if (flags_done) {
+                sorted_low = std::move(low[sel]);
+            } else if (layout == SPLIT) {
                 gen.low_bits = low_bits;
                 sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
                                                    vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n,
@@ -1220,6 +1326,7 @@ void build_typed(Index& ix, bool big) {
                 sel = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
                                               vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
             }
+            hyb_low_bits = low_bits_h;
             CDB_HIP(hipStreamSynchronize(s));
             sorted_k32 = std::move(k32[sel]);
             sa_buf = std::move(vals[sel]);
@@ -1439,7 +1546,7 @@ void build_typed(Index& ix, bool big) {
         st.bucketed = 1;
         sa_buf = std::move(E);
     }
-    if (!big) {  // (the bucket-wise sort writes the flags bucket by bucket)
+    if (!big && !flags_done) {  // (the bucket-wise and the hybrid sort write the flags themselves)
         int t = ix.prof.begin(s);
         if (layout == WIDE)
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
@@ -1464,8 +1571,8 @@ void build_typed(Index& ix, bool big) {
         ix.d_keys = std::move(sorted_keys);
         ix.d_keys32 = std::move(sorted_k32);
         ix.d_keylow = std::move(sorted_low);
-        ix.key_low_bits = low_bits;
-        ix.key_low_bytes = low_bytes;
+        ix.key_low_bits = flags_done ? hyb_low_bits : low_bits;
+        ix.key_low_bytes = flags_done ? hyb_low_bits / 8 : low_bytes;
         ix.key_nsym = nsym;
         ix.key_base = kbase;
     } else {
@@ -1497,6 +1604,8 @@ void build_typed(Index& ix, bool big) {
         if (st.rounds == 0) st.unresolved_initial = m;
         st.unresolved_max = std::max(st.unresolved_max, m);
         if (m == 0) break;
+        // (the per-entry kernels of a round address one thread per unresolved entry: a launch holds < 2^32 of them)
+        if (m >= (1ull << 32) - 4096) throw Error("too many unresolved suffixes for one refinement round (internal limit: 2^32)");
         const int gbits = bit_width64(G - 1);
         int nsym2 = std::min((64 - gbits) / symbits, KG_LOOK);
         if (!isa) {
