@@ -23,6 +23,17 @@
 
 namespace cdb {
 
+// Fully unrolled per-slot loops let the scheduler hoist every load of a phase to its front, which multiplies the
+// registers in flight by the slots per thread; a scheduling fence after every four slots keeps a phase at "four slots
+// in flight" (enough to cover LDS latency, a quarter of the registers).
+#define BS_FENCE(j)                                         \
+    do {                                                    \
+        if (((j) & 3) == 3) __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+constexpr int BS_IPT_BIG = 20;                     // 1024 x 20 = 20 Ki records per round: 80 KB of staging
+constexpr int BS_CAP_BIG = 1024 * BS_IPT_BIG, BS_CAP_SMALL = 256 * 16;
+
 struct HybridPlan {
     bool ok = false;
     int G = 0;          // global passes (digits of b)
@@ -78,84 +89,111 @@ __device__ __forceinline__ uint64_t bs_lower_bound(const P* __restrict__ bstart,
 }
 
 // V = entry type, W = auxiliary digit type (u8 / u16), P = position type of the bucket table, KW = type of the kept
-// low digits (u8 / u16).  NT x IPT = capacity.
+// low digits (u8 / u16).  NT x IPT = capacity (< 2^16 records).
+//
+// A record is held as TWO registers — the local key and (position << 16 | index of the record in the round's input) —
+// and the entries themselves never pass through registers: they are read once, coalesced, into the staging buffer
+// after the keys are done, and leave through an LDS gather by the sorted indices.  That is what lets a workgroup
+// finish 32 Ki records (128 KB of staging + 16 KB of counters) without spilling.
 template <typename V, typename W, typename P, typename KW, int NT, int IPT>
 __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict__ k32, V* __restrict__ ent, W* __restrict__ aux,
                                                            const P* __restrict__ bstart, BucketSortParams pr,
                                                            uint8_t* __restrict__ flags, KW* __restrict__ keylow_out,
                                                            unsigned long long* __restrict__ oversize /*[0] count, [1] largest*/) {
     constexpr int CAP = NT * IPT;
+    static_assert(CAP <= 65536, "positions and indices are 16-bit");
     constexpr int NW = NT / 64;
     constexpr int WCHUNK = 64 * IPT;
-    constexpr size_t STAGE = (sizeof(V) > 4 ? sizeof(V) : 4) * (size_t)CAP;
-    __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE];
+    constexpr int VCAP = sizeof(V) > 4 ? CAP / 2 : CAP;  // entries staged per sweep of the final gather
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[CAP];  // keys, then 16-bit indices, then entries
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint32_t s_tstart[256];
     __shared__ uint32_t s_wsum[4];
-    uint32_t* s_keys = reinterpret_cast<uint32_t*>(s_stage);
-    V* s_vals = reinterpret_cast<V*>(s_stage);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t wbase = wave * WCHUNK + lane;
+    __shared__ unsigned long long s_round[3];  // {first bucket, one past the last bucket, records} of the round
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_keys);
+    V* s_vals = reinterpret_cast<V*>(s_keys);
+    const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
+    const uint32_t wbase0 = wave * WCHUNK + lane;
     const uint32_t rmask = pr.rbits >= 32 ? 0xFFFFFFFFu : ((1u << pr.rbits) - 1u);
     const uint32_t lmask = (1u << pr.lead_bits) - 1u;
     const uint64_t max_rel = pr.rbits >= 32 ? 1ull : (1ull << (32 - pr.rbits));  // buckets one round can tell apart
 
     const uint64_t win_lo = (uint64_t)blockIdx.x * pr.step;
     const uint64_t win_hi = win_lo + pr.step < pr.n ? win_lo + pr.step : pr.n;
-    uint64_t b = bs_lower_bound(bstart, pr.nb, win_lo);
-    const uint64_t b_end = bs_lower_bound(bstart, pr.nb, win_hi);  // buckets [b, b_end) start in this window
+    uint64_t b = 0, b_end = 0;
+    uint32_t tid = tid0, wbase = wbase0;
+    if (tid == 0) {
+        s_round[0] = bs_lower_bound(bstart, pr.nb, win_lo);
+        s_round[1] = bs_lower_bound(bstart, pr.nb, win_hi);  // buckets [b, b_end) start in this window
+    }
+    __syncthreads();
+    b = s_round[0];
+    b_end = s_round[1];
     while (b < b_end) {
-        // ---- one round: buckets [b, b1) with at most CAP records and at most max_rel buckets
-        const uint64_t lo = (uint64_t)bstart[b];
-        uint64_t b1;
-        {
-            // largest b1 in (b, b_end] with bstart[b1] - lo <= CAP (bisect), capped by max_rel
-            uint64_t l = b, h = b_end;  // invariant: bstart[l] - lo <= CAP
+        // ---- one round: buckets [b, b1) with at most CAP records and at most max_rel buckets (found by one thread)
+        // (opaque copies: otherwise the compiler hoists the 2 x IPT per-slot index and address computations out of
+        //  the round loop and keeps them alive — in scratch memory — across it)
+        tid = tid0;
+        wbase = wbase0;
+        asm volatile("" : "+v"(tid), "+v"(wbase));
+        __syncthreads();
+        if (tid == 0) {
+            const uint64_t lo0 = (uint64_t)bstart[b];
+            uint64_t l = b, h = b_end;  // invariant: bstart[l] - lo0 <= CAP
             if (h - b > max_rel) h = b + max_rel;
             while (l < h) {
                 const uint64_t mid = l + (h - l + 1) / 2;
-                if ((uint64_t)bstart[mid] - lo <= (uint64_t)CAP) l = mid; else h = mid - 1;
+                if ((uint64_t)bstart[mid] - lo0 <= (uint64_t)CAP) l = mid; else h = mid - 1;
             }
-            b1 = l;
-        }
-        if (b1 == b) {  // bucket b alone exceeds the capacity: report it (the host falls back to the plain sort)
-            if (tid == 0) {
+            s_round[1] = l;
+            s_round[2] = (uint64_t)bstart[l] - lo0;
+            if (l == b) {  // bucket b alone exceeds the capacity: report it (the host falls back to the plain sort)
                 atomicAdd(&oversize[0], 1ull);
-                atomicMax(&oversize[1], (unsigned long long)((uint64_t)bstart[b + 1] - lo));
+                atomicMax(&oversize[1], (unsigned long long)((uint64_t)bstart[b + 1] - lo0));
             }
+        }
+        __syncthreads();
+        const uint64_t b1 = s_round[1];
+        const uint32_t m = (uint32_t)s_round[2];
+        if (b1 == b) {
             b += 1;
             continue;
         }
-        const uint32_t m = (uint32_t)((uint64_t)bstart[b1] - lo);
-        const uint32_t nrel = (uint32_t)(b1 - b);
         if (m == 0) {  // (only empty buckets)
             b = b1;
             continue;
         }
+        const uint64_t lo = (uint64_t)bstart[b];
+        const uint32_t nrel = (uint32_t)(b1 - b);
         int lbits = pr.rbits;
         if (nrel > 1) lbits += 32 - __clz(nrel - 1);
         const int npass = lbits > 8 ? (lbits + 7) / 8 : 1;
         // ---- load (wave-striped: every wave owns a contiguous chunk, which keeps the local sort stable)
-        uint32_t lk[IPT];
-        V val[IPT];
+        uint32_t lk[IPT], pi[IPT];  // local key; (position << 16) | index of the record in the round's input
+        {
+            const uint32_t* kp = k32 + lo;
+            const W* ap = aux + lo;
+            const uint32_t b32 = (uint32_t)b;
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const uint32_t li = wbase + j * 64;
-            lk[j] = 0xFFFFFFFFu;
-            val[j] = V(0);
-            if (li < m) {
-                const uint32_t k = k32[lo + li];
-                // bucket of the record relative to the round's first one (bucket numbers fit 32 bits: nb <= 2^24)
-                const uint32_t brel = (((pr.rbits >= 32 ? 0u : (k >> pr.rbits)) << pr.lead_bits) | ((uint32_t)aux[lo + li] & lmask)) - (uint32_t)b;
-                lk[j] = (pr.rbits >= 32 ? 0u : (brel << pr.rbits)) | (k & rmask);
-                val[j] = ent[lo + li];
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                lk[j] = 0xFFFFFFFFu;
+                if (li < m) {
+                    const uint32_t k = kp[li];
+                    // bucket of the record relative to the round's first one (bucket numbers fit 32 bits: nb <= 2^24)
+                    const uint32_t brel = (((pr.rbits >= 32 ? 0u : (k >> pr.rbits)) << pr.lead_bits) | ((uint32_t)ap[li] & lmask)) - b32;
+                    lk[j] = (pr.rbits >= 32 ? 0u : (brel << pr.rbits)) | (k & rmask);
+                }
+                BS_FENCE(j);
             }
+            // (the input indices are derived from an opaque copy of the lane's base: as the same values as the load
+            //  addresses above they would be kept zero-extended to 64 bits, two registers per slot, across the passes)
+            uint32_t wb2 = wbase;
+            asm volatile("" : "+v"(wb2));
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) pi[j] = wb2 + j * 64;
         }
-        // ---- LSD passes in LDS (positions < CAP < 2^16: two per register)
-        static_assert(IPT % 2 == 0 && NT * IPT < 65536, "packed positions");
-        uint32_t pp[IPT / 2];
-        auto get_pos = [&](int j) -> uint32_t { return (j & 1) ? (pp[j >> 1] >> 16) : (pp[j >> 1] & 0xFFFFu); };
-        auto set_pos = [&](int j, uint32_t v) { pp[j >> 1] = (j & 1) ? ((pp[j >> 1] & 0xFFFFu) | (v << 16)) : ((pp[j >> 1] & 0xFFFF0000u) | v); };
+        // ---- LSD passes in LDS
         for (int p = 0; p < npass; ++p) {
             for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
             __syncthreads();  // (also: the staging buffer of the previous pass has been read back)
@@ -165,7 +203,9 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
                 // slots behind the round's records hold all-ones keys, i.e. digit 255 in every pass, and the largest
                 // indices of their wave's chunk: they stay behind every real record
                 const uint32_t d = (lk[j] >> sh) & 255u;
-                set_pos(j, atomicAdd(&s_whist[wave][d], 1u));  // rank inside the wave (lane order: radix_sort.h ATOMRANK)
+                // rank inside the wave (same-address LDS atomics of one instruction complete in lane order: radix_sort.h)
+                pi[j] = (pi[j] & 0xFFFFu) | (atomicAdd(&s_whist[wave][d], 1u) << 16);
+                BS_FENCE(j);
             }
             __syncthreads();
             uint32_t cnt = 0, incl = 0;
@@ -196,24 +236,34 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const uint32_t d = (lk[j] >> sh) & 255u;
-                const uint32_t at = s_tstart[d] + s_whist[wave][d] + get_pos(j);
-                set_pos(j, at);
+                const uint32_t at = s_tstart[d] + s_whist[wave][d] + (pi[j] >> 16);
+                pi[j] = (pi[j] & 0xFFFFu) | (at << 16);
                 s_keys[at] = lk[j];
+                BS_FENCE(j);
             }
             __syncthreads();
             if (p + 1 < npass) {
 #pragma unroll
-                for (int j = 0; j < IPT; ++j) lk[j] = s_keys[wbase + j * 64];
+                for (int j = 0; j < IPT; ++j) {
+                    lk[j] = s_keys[wbase + j * 64];
+                    BS_FENCE(j);
+                }
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < IPT; ++j) s_vals[get_pos(j)] = val[j];
+                for (int j = 0; j < IPT; ++j) {
+                    s_idx[pi[j] >> 16] = (uint16_t)pi[j];
+                    BS_FENCE(j);
+                }
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < IPT; ++j) val[j] = s_vals[wbase + j * 64];
+                for (int j = 0; j < IPT; ++j) {
+                    pi[j] = s_idx[wbase + j * 64];
+                    BS_FENCE(j);
+                }
                 // (the next pass starts with a barrier before the staging buffer is written again)
             }
         }
-        // ---- the round's records are sorted (keys in LDS): flags and kept keys, then the entries
+        // ---- the round's records are sorted (keys in LDS): flags and kept keys
         // (after pass 0 the padding slots sit at positions >= m and their keys are all ones)
 #pragma unroll 2
         for (int j = 0; j < IPT; ++j) {
@@ -232,15 +282,45 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
             }
         }
         __syncthreads();
+        // ---- the entries: sorted position -> input index, then the input window is staged (coalesced) and gathered
+        // in LDS.  8-byte entries are staged in two halves of the window.
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) s_vals[get_pos(j)] = val[j];
+        for (int j = 0; j < IPT; ++j) {
+                    lk[j] = pi[j] & 0xFFFFu;
+                    BS_FENCE(j);
+                }  // (keys are done: their registers carry the indices)
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+                    s_idx[pi[j] >> 16] = (uint16_t)lk[j];
+                    BS_FENCE(j);
+                }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint32_t i = j * NT + tid;
-            if (i < m) ent[lo + i] = s_vals[i];
+                    lk[j] = s_idx[j * NT + tid];
+                    BS_FENCE(j);
+                }  // input index of the record at sorted position j * NT + tid
+        __syncthreads();
+        V outv[IPT];
+        for (uint32_t half = 0; half < (uint32_t)(CAP / VCAP); ++half) {
+            const uint32_t h0 = half * VCAP;
+            if (h0 >= m) break;
+            for (uint32_t i = tid; i < (uint32_t)VCAP && h0 + i < m; i += NT) s_vals[i] = ent[lo + h0 + i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t src = lk[j] - h0;
+                if ((uint32_t)(j * NT + tid) < m && src < (uint32_t)VCAP) outv[j] = s_vals[src];
+                BS_FENCE(j);
+            }
+            __syncthreads();
         }
-        __syncthreads();  // the next round reuses the staging buffer
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = j * NT + tid;
+            if (i < m) ent[lo + i] = outv[j];
+            BS_FENCE(j);
+        }
         b = b1;
     }
 }
@@ -264,7 +344,7 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     int t = prof.begin(s);
     const bool big = plan.cap > 4096;
     if (big) {
-        constexpr int IPT = sizeof(V) == 8 ? 12 : 18;
+        constexpr int IPT = BS_IPT_BIG;
         pr.step = (uint64_t)1024 * 16;
         hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 1024, IPT>), dim3((unsigned)ceil_div(n, pr.step)), dim3(1024), 0, s, k32, ent,
                            aux, (const P*)bstart, pr, flags, keylow_out, d_over.as<unsigned long long>());
@@ -282,6 +362,5 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     return over[0] == 0;
 }
 
-constexpr int BS_CAP_BIG32 = 1024 * 18, BS_CAP_BIG64 = 1024 * 12, BS_CAP_SMALL = 256 * 16;
 
 }  // namespace cdb

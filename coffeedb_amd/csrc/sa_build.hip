@@ -1161,7 +1161,7 @@ void build_typed(Index& ix, bool big) {
     if (want_hybrid && fused && dense && key_bits <= 56) {
         unsigned __int128 space = 1;
         for (int i = 0; i < nsym; ++i) space *= kbase;
-        const int cap = n >= (1ull << 22) ? BS_CAP_BIG32 : BS_CAP_SMALL;
+        const int cap = n >= (1ull << 22) ? BS_CAP_BIG : BS_CAP_SMALL;
         for (int G = 1; G <= 3 && !plan.ok; ++G) {
             const unsigned __int128 nbmax = (unsigned __int128)1 << (8 * G);
             const uint64_t w = (uint64_t)std::max<unsigned __int128>((space + nbmax - 1) / nbmax, 1);
