@@ -31,7 +31,7 @@ namespace cdb {
         if (((j) & 3) == 3) __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
-constexpr int BS_IPT_BIG = 20;                     // 1024 x 20 = 20 Ki records per round: 80 KB of staging
+constexpr int BS_IPT_BIG = 26;                     // 1024 x 26 = 26 Ki records per round: 104 KB of staging
 constexpr int BS_CAP_BIG = 1024 * BS_IPT_BIG, BS_CAP_SMALL = 256 * 16;
 
 struct HybridPlan {
@@ -235,7 +235,11 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
-                const uint32_t d = (lk[j] >> sh) & 255u;
+                // (the digit and the counter address are recomputed from an opaque copy of the key: shared with the
+                //  ranking loop above they would stay in registers across the barriers, two more per slot)
+                uint32_t kx = lk[j];
+                asm volatile("" : "+v"(kx));
+                const uint32_t d = (kx >> sh) & 255u;
                 const uint32_t at = s_tstart[d] + s_whist[wave][d] + (pi[j] >> 16);
                 pi[j] = (pi[j] & 0xFFFFu) | (at << 16);
                 s_keys[at] = lk[j];

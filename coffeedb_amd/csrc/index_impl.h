@@ -30,6 +30,8 @@ struct BuildStats {
     int hybrid = 0;              // hybrid initial sort: global passes before the LDS bucket sort (0 = plain LSD sort,
                                  // -1 = tried, a bucket did not fit, redone by the plain sort)
     uint64_t hybrid_largest_bucket = 0;
+    uint64_t hybrid_estimate = 0;  // fullest bucket predicted from the key sample
+    int hybrid_retries = 0;        // plans that failed on a bucket larger than a workgroup's capacity
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved

@@ -150,6 +150,21 @@ __global__ __launch_bounds__(256) void sa_sample_count_kernel(const uint64_t* __
     if (threadIdx.x >= 1 && threadIdx.x < 32 && s_eq[threadIdx.x]) atomicAdd(&eq[threadIdx.x], (unsigned long long)s_eq[threadIdx.x]);
 }
 
+// Hybrid sort: how evenly would the buckets b = K / w be filled?  The sorted sample is binned into groups of
+// 2^gshift neighbouring buckets (single buckets hold too few sample keys for a count to mean anything).
+__global__ __launch_bounds__(256) void sa_sample_buckets_kernel(const uint64_t* __restrict__ keys, uint64_t S, int symbits, int kmax,
+                                                                int nsym, uint32_t kbase, uint64_t w, uint64_t magic, int gshift,
+                                                                unsigned int* __restrict__ groups) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const uint64_t x = keys[i];
+    uint64_t K = 0;
+    for (int k = 0; k < nsym; ++k) K = K * kbase + ((x >> ((kmax - 1 - k) * symbits)) & ((1ull << symbits) - 1ull));
+    uint64_t b = __umul64hi(K, magic);
+    if (K - b * w >= w) b += 1;
+    atomicAdd(&groups[b >> gshift], 1u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2. key generation
 // ---------------------------------------------------------------------------------------------
@@ -1033,12 +1048,17 @@ void build_typed(Index& ix, bool big) {
     // too optimistic for correlated text such as multi-byte UTF-8.)  Small corpora use the order-0 model.
     int nsym;
     const int kmax = std::min(64 / symbits, 16);
+    DevBuf sample_sorted;  // the sorted key sample (kept for the hybrid sort's bucket-size estimate)
+    uint64_t sample_n = 0;
+    int sample_kmax = 0;
     if (ix.initial_passes > 0) {
         const int passes = std::min(ix.initial_passes, 8);
         nsym = std::min((8 * passes) / symbits, 64 / symbits);
     } else if (n >= (1ull << 24)) {
         const uint64_t S = n >= (1ull << 32) ? 1ull << 22 : 1ull << 21;  // S^2 / 2 sample pairs must resolve 1 / (64 n)
         DevBuf sk0, sk1, d_eq;
+        sample_n = S;
+        sample_kmax = kmax;
         sk0.alloc(S * 8);
         sk1.alloc(S * 8);
         d_eq.alloc(32 * 8);
@@ -1052,6 +1072,7 @@ void build_typed(Index& ix, bool big) {
         uint64_t h_eq[32];
         CDB_HIP(hipMemcpyAsync(h_eq, d_eq.p, sizeof(h_eq), hipMemcpyDeviceToHost, s));
         CDB_HIP(hipStreamSynchronize(s));
+        sample_sorted = std::move(ssel ? sk1 : sk0);
         const double pairs = (double)S * (double)S / 2.0;
         if (getenv("CDB_DEBUG_SAMPLE")) {
             for (int k = 1; k <= kmax; ++k) std::fprintf(stderr, "[sample] k=%d adjacent-equal=%llu\n", k, (unsigned long long)h_eq[k]);
@@ -1157,32 +1178,59 @@ void build_typed(Index& ix, bool big) {
     // smallest number of passes that makes the expected bucket (n / buckets; the keys of real text are close enough
     // to uniform in key space for that, and a bucket that does not fit sends the build down the plain path) fit a
     // workgroup; the record must still fit (u32 key, entry, u8 / u16).
-    HybridPlan plan;
+    // Candidates: G = 1, 2, 3 global passes, tried in that order (fewest passes first).  A plan is viable when the
+    // record still fits (u32 key, entry, u8 / u16) and the AVERAGE bucket leaves room for skew (0.7 of a workgroup's
+    // capacity: the keys of even "uniform" text are not uniform in key space — C1's fullest bucket holds 1.33 x the
+    // average).  Gross skew shows in the key sample already and rules a plan out up front; what the sample cannot
+    // see is caught by the bucket sort itself (a bucket that does not fit), and the next plan — more, smaller
+    // buckets — or finally the plain LSD sort takes over.
+    std::vector<HybridPlan> plans;
     if (want_hybrid && fused && dense && key_bits <= 56) {
         unsigned __int128 space = 1;
         for (int i = 0; i < nsym; ++i) space *= kbase;
         const int cap = n >= (1ull << 22) ? BS_CAP_BIG : BS_CAP_SMALL;
-        for (int G = 1; G <= 3 && !plan.ok; ++G) {
+        for (int G = 1; G <= 3; ++G) {
             const unsigned __int128 nbmax = (unsigned __int128)1 << (8 * G);
             const uint64_t w = (uint64_t)std::max<unsigned __int128>((space + nbmax - 1) / nbmax, 1);
             const uint64_t nb = (uint64_t)((space + w - 1) / w);
             const int rbits = bit_width64(w - 1);
-            if ((double)n / (double)nb > 0.92 * cap) continue;
+            if (w == 1) break;  // (nothing left to sort inside a bucket: the plain sort is as good)
+            if ((double)n / (double)nb > 0.7 * cap) continue;
             int lead = 0;
             if (rbits + 8 * (G - 1) <= 32) lead = 1;
             else if (G >= 2 && rbits + 8 * (G - 2) <= 32) lead = 2;
             if (!lead) continue;
-            plan.ok = true;
-            plan.G = G;
-            plan.lead = lead;
-            plan.rbits = rbits;
-            plan.w = w;
-            plan.magic = w > 1 ? ~0ull / w : 0;  // floor(2^64 / w) for w that is no power of two, one less otherwise: both fine
-            plan.nb = nb;
-            plan.cap = cap;
+            HybridPlan p;
+            p.ok = true;
+            p.G = G;
+            p.lead = lead;
+            p.rbits = rbits;
+            p.w = w;
+            p.magic = ~0ull / w;  // floor(2^64 / w), or one less for a power of two: the quotient is corrected either way
+            p.nb = nb;
+            p.cap = cap;
+            if (sample_sorted.p && G < 3) {  // fullest group of buckets in the sample, with 20 % for what happens inside a group
+                const int gshift = std::max(0, bit_width64(nb - 1) - 10);
+                const uint64_t ngroups = (nb >> gshift) + 1;
+                DevBuf d_groups;
+                d_groups.alloc(ngroups * sizeof(uint32_t));
+                CDB_HIP(hipMemsetAsync(d_groups.p, 0, ngroups * sizeof(uint32_t), s));
+                hipLaunchKernelGGL(sa_sample_buckets_kernel, dim3((unsigned)ceil_div(sample_n, 256)), dim3(256), 0, s,
+                                   (const uint64_t*)sample_sorted.as<uint64_t>(), sample_n, symbits, sample_kmax, nsym, kbase, w, p.magic,
+                                   gshift, d_groups.as<unsigned int>());
+                std::vector<uint32_t> hg(ngroups);
+                CDB_HIP(hipMemcpyAsync(hg.data(), d_groups.p, ngroups * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipStreamSynchronize(s));
+                const double est = (double)*std::max_element(hg.begin(), hg.end()) / (double)(1ull << gshift) * ((double)n / (double)sample_n) * 1.2;
+                st.hybrid_estimate = (uint64_t)est;
+                if (est > 0.95 * cap) continue;
+            }
+            plans.push_back(p);
+            if (plans.size() == 2) break;
         }
-        if (plan.ok && plan.w == 1) plan.ok = false;  // (nothing left to sort inside a bucket: the plain path is as good)
     }
+    sample_sorted.release();
+    HybridPlan plan = plans.empty() ? HybridPlan() : plans[0];
     if (fused && dense) {
         if (plan.ok) key_histograms(plan.G, plan.w, plan.magic);
         else key_histograms((int)ceil_div(key_bits, 8), 0, 0);
@@ -1250,7 +1298,8 @@ void build_typed(Index& ix, bool big) {
             k32[1].alloc(n * sizeof(uint32_t));
             vals[0].alloc(n * sizeof(V));
             vals[1].alloc(n * sizeof(V));
-            const int low_alloc = std::max(low_bytes, plan.ok ? plan.lead : 0);
+            int low_alloc = low_bytes;
+            for (const HybridPlan& hp : plans) low_alloc = std::max(low_alloc, hp.lead);
             if (low_alloc) {
                 low[0].alloc(n * low_alloc);
                 low[1].alloc(n * low_alloc);
@@ -1260,8 +1309,10 @@ void build_typed(Index& ix, bool big) {
                 std::fprintf(stderr, "[bufs] k32 %p %p vals %p %p low %p %p flags %p\n", k32[0].p, k32[1].p, vals[0].p, vals[1].p, low[0].p,
                              low[1].p, flags.p);
             int sel = 0;
-            if (plan.ok) {
+            for (size_t attempt = 0; attempt < plans.size() && !flags_done; ++attempt) {
                 // ---- hybrid: G global passes by bucket, buckets finished in LDS (bucket_sort.h)
+                plan = plans[attempt];
+                if (attempt > 0) key_histograms(plan.G, plan.w, plan.magic);
                 DevBuf bstart;
                 bstart.alloc((plan.nb + 1) * sizeof(uint32_t));
                 CDB_HIP(hipMemsetAsync(bstart.p, 0xFF, (plan.nb + 1) * sizeof(uint32_t), s));
@@ -1302,11 +1353,13 @@ void build_typed(Index& ix, bool big) {
                     layout = plan.lead == 1 ? SPLIT : SPLIT2;  // (the layout of the kept keys)
                     st.key_layout = (int)layout;
                 } else {
-                    // a bucket larger than a workgroup's capacity (skewed key distribution): the plain LSD sort redoes it
+                    // a bucket larger than a workgroup's capacity (skewed key distribution): the next plan (more, smaller
+                    // buckets) or, after the last one, the plain LSD sort redoes the work
                     plan.ok = false;
-                    key_histograms((int)ceil_div(key_bits, 8), 0, 0);
+                    st.hybrid_retries++;
                 }
             }
+            if (!plans.empty() && !flags_done) key_histograms((int)ceil_div(key_bits, 8), 0, 0);
             const int low_bits_h = flags_done ? 8 * plan.lead : low_bits;
             if (flags_done) {
                 sorted_low = std::move(low[sel]);
