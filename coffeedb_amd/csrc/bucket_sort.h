@@ -88,70 +88,146 @@ __device__ __forceinline__ uint64_t bs_lower_bound(const P* __restrict__ bstart,
     return lo;
 }
 
-// V = entry type, W = auxiliary digit type (u8 / u16), P = position type of the bucket table, KW = type of the kept
-// low digits (u8 / u16).  NT x IPT = capacity (< 2^16 records).
-//
-// A record is held as TWO registers — the local key and (position << 16 | index of the record in the round's input) —
-// and the entries themselves never pass through registers: they are read once, coalesced, into the staging buffer
-// after the keys are done, and leave through an LDS gather by the sorted indices.  That is what lets a workgroup
-// finish 32 Ki records (128 KB of staging + 16 KB of counters) without spilling.
-template <typename V, typename W, typename P, typename KW, int NT, int IPT>
-__global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict__ k32, V* __restrict__ ent, W* __restrict__ aux,
-                                                           const P* __restrict__ bstart, BucketSortParams pr,
-                                                           uint8_t* __restrict__ flags, KW* __restrict__ keylow_out,
-                                                           unsigned long long* __restrict__ oversize /*[0] count, [1] largest*/) {
-    constexpr int CAP = NT * IPT;
-    static_assert(CAP <= 65536, "positions and indices are 16-bit");
-    constexpr int NW = NT / 64;
-    constexpr int WCHUNK = 64 * IPT;
-    constexpr int VCAP = sizeof(V) > 4 ? CAP / 2 : CAP;  // entries staged per sweep of the final gather
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[CAP];  // keys, then 16-bit indices, then entries
-    __shared__ uint32_t s_whist[NW][256];
-    __shared__ uint32_t s_tstart[256];
-    __shared__ uint32_t s_wsum[4];
-    __shared__ unsigned long long s_round[3];  // {first bucket, one past the last bucket, records} of the round
-    uint16_t* s_idx = reinterpret_cast<uint16_t*>(s_keys);
-    V* s_vals = reinterpret_cast<V*>(s_keys);
-    const int tid0 = threadIdx.x, lane = tid0 & 63, wave = tid0 >> 6;
-    const uint32_t wbase0 = wave * WCHUNK + lane;
-    const uint32_t rmask = pr.rbits >= 32 ? 0xFFFFFFFFu : ((1u << pr.rbits) - 1u);
-    const uint32_t lmask = (1u << pr.lead_bits) - 1u;
-    const uint64_t max_rel = pr.rbits >= 32 ? 1ull : (1ull << (32 - pr.rbits));  // buckets one round can tell apart
-
-    const uint64_t win_lo = (uint64_t)blockIdx.x * pr.step;
-    const uint64_t win_hi = win_lo + pr.step < pr.n ? win_lo + pr.step : pr.n;
-    uint64_t b = 0, b_end = 0;
-    uint32_t tid = tid0, wbase = wbase0;
-    if (tid == 0) {
-        s_round[0] = bs_lower_bound(bstart, pr.nb, win_lo);
-        s_round[1] = bs_lower_bound(bstart, pr.nb, win_hi);  // buckets [b, b_end) start in this window
-    }
-    __syncthreads();
-    b = s_round[0];
-    b_end = s_round[1];
-    while (b < b_end) {
-        // ---- one round: buckets [b, b1) with at most CAP records and at most max_rel buckets (found by one thread)
-        // (opaque copies: otherwise the compiler hoists the 2 x IPT per-slot index and address computations out of
-        //  the round loop and keeps them alive — in scratch memory — across it)
-        tid = tid0;
-        wbase = wbase0;
-        asm volatile("" : "+v"(tid), "+v"(wbase));
-        __syncthreads();
-        if (tid == 0) {
-            const uint64_t lo0 = (uint64_t)bstart[b];
-            uint64_t l = b, h = b_end;  // invariant: bstart[l] - lo0 <= CAP
-            if (h - b > max_rel) h = b + max_rel;
-            while (l < h) {
-                const uint64_t mid = l + (h - l + 1) / 2;
-                if ((uint64_t)bstart[mid] - lo0 <= (uint64_t)CAP) l = mid; else h = mid - 1;
-            }
-            s_round[1] = l;
-            s_round[2] = (uint64_t)bstart[l] - lo0;
-            if (l == b) {  // bucket b alone exceeds the capacity: report it (the host falls back to the plain sort)
-                atomicAdd(&oversize[0], 1ull);
-                atomicMax(&oversize[1], (unsigned long long)((uint64_t)bstart[b + 1] - lo0));
+// ---- sorting inside a wavefront: a bitonic network over 64 * R values held R per lane (element r * 64 + lane) ------
+// Exchanges between lanes are shuffles, exchanges across 64-element blocks are register pairs: no LDS traffic, no
+// barriers.  Ascending order; callers pad with all-ones.
+template <int R>
+__device__ __forceinline__ void bs_wave_sort(uint32_t (&v)[R], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int q = k >> 1; q > 0; q >>= 1) {
+            if (q >= 64) {
+                const int rq = q >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if ((r & rq) == 0) {
+                        const int r2 = r | rq;
+                        const bool up = ((r * 64) & k) == 0;  // (k >= 128 here: bit k of the element index is a bit of r)
+                        const uint32_t a = v[r], c = v[r2];
+                        const uint32_t mn = a < c ? a : c, mx = a < c ? c : a;
+                        v[r] = up ? mn : mx;
+                        v[r2] = up ? mx : mn;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t o = __shfl_xor(v[r], q);
+                    const bool up = (((r * 64) | lane) & k) == 0;
+                    const bool lower = (lane & q) == 0;
+                    const uint32_t mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
+                    v[r] = (lower == up) ? mn : mx;
+                }
             }
         }
+    }
+}
+
+// one wavefront sorts x[0, len) in LDS for any len (rare path: sub-buckets of more than 256 records): bitonic merge
+// sort in its "flip" form, every comparator ascending, partners beyond len skipped (= padding with +infinity)
+__device__ __forceinline__ void bs_wave_sort_lds(uint32_t* x, uint32_t len, int lane) {
+    uint32_t np2 = 2;
+    while (np2 < len) np2 <<= 1;
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t t = lane; t < np2 / 2; t += 64) {  // flip: i = block start + u, partner = block end - u
+            const uint32_t blk = t / (k / 2), u = t % (k / 2);
+            const uint32_t i = blk * k + u, p2 = blk * k + (k - 1 - u);
+            if (p2 < len) {
+                const uint32_t a = x[i], c = x[p2];
+                if (a > c) { x[i] = c; x[p2] = a; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = k >> 2; q > 0; q >>= 1) {
+            for (uint32_t t = lane; t < np2 / 2; t += 64) {
+                const uint32_t i = ((t / q) * 2 * q) + (t % q), p2 = i + q;
+                if (p2 < len) {
+                    const uint32_t a = x[i], c = x[p2];
+                    if (a > c) { x[i] = c; x[p2] = a; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// for every nominal window of `step` records: the first bucket that starts inside it (one parallel search per
+// window instead of a chain of dependent loads at the head of every workgroup)
+template <typename P>
+__global__ __launch_bounds__(256) void bs_windows_kernel(const P* __restrict__ bstart, uint64_t nb, uint64_t n, uint64_t step,
+                                                         uint64_t nwin, uint32_t* __restrict__ wfirst /*[nwin + 1]*/) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t > nwin) return;
+    const uint64_t pos = t * step < n ? t * step : n;
+    wfirst[t] = (uint32_t)bs_lower_bound(bstart, nb, pos);
+}
+
+// V = entry type, W = auxiliary digit type (u8 / u16), P = position type of the bucket table, KW = type of the kept
+// low digits (u8 / u16).  NT x IPT = capacity (<= 2^15 records: input indices are 15-bit).
+//
+// One round = consecutive buckets [b, b1) of together m <= capacity records whose local key
+//     lk = (bucket - b) << rbits | r            (lbits <= 25 bits)
+// is sorted in two steps:
+//   A. counting sort in LDS on the top hb = min(8, lbits) bits of lk — ONE pass, and it need not be stable, because
+//      what it stores per record is the word  (low bits of lk) << 15 | (index of the record in the round's input):
+//   B. every sub-bucket (one value of the top bits: ~ m / 256 records) is sorted by ONE wavefront in registers
+//      (bs_wave_sort), as plain integers — low key bits first, input index as tie-break, i.e. stably.  The wavefront
+//      then knows the final neighbours of its records and writes their group flags and kept keys itself.
+// The entries never pass through registers before they are final: the input window is read once, coalesced, into
+// the staging buffer after the keys are done, and leaves through an LDS gather by the sorted indices.
+template <typename V, typename W, typename P, typename KW, int NT, int IPT>
+__global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict__ k32, V* __restrict__ ent, W* __restrict__ aux,
+                                                           const P* __restrict__ bstart, const uint32_t* __restrict__ wfirst,
+                                                           BucketSortParams pr, uint8_t* __restrict__ flags,
+                                                           KW* __restrict__ keylow_out,
+                                                           unsigned long long* __restrict__ oversize /*[0] count, [1] largest*/) {
+    constexpr int CAP = NT * IPT;
+    static_assert(CAP <= 32768, "input indices are 15-bit");
+    constexpr int NW = NT / 64;
+    constexpr int VCAP = sizeof(V) > 4 ? CAP / 2 : CAP;  // entries staged per sweep of the final gather
+    constexpr int LBITS_MAX = 25;                        // 8 bits of counting sort + 17 bits beside the 15-bit index
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[CAP];  // packed records, then entries
+    __shared__ uint32_t s_cnt[256], s_start[257];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ unsigned long long s_round[3];  // {unused, one past the last bucket, records} of the round
+    V* s_vals = reinterpret_cast<V*>(s_keys);
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t rmask = (1u << pr.rbits) - 1u;  // (rbits <= 24: bucket_sort_plan)
+    const uint32_t lmask = (1u << pr.lead_bits) - 1u;
+    const uint64_t max_rel = 1ull << (LBITS_MAX - pr.rbits);  // buckets one round can tell apart
+
+    uint64_t b = wfirst[blockIdx.x];
+    const uint64_t b_end = wfirst[blockIdx.x + 1];  // buckets [b, b_end) start in this workgroup's window
+    while (b < b_end) {
+        // ---- the round: as many buckets from b on as fit (64-ary search by the first wavefront)
+        __syncthreads();
+        if (wave == 0) {
+            const uint64_t lo0 = (uint64_t)bstart[b];
+            uint64_t l = b, h = b_end;  // invariant: bstart[l] - lo0 <= CAP; answer = largest such index in [l, h]
+            if (h - b > max_rel) h = b + max_rel;
+            while (l < h) {
+                const uint64_t span = h - l;
+                const uint64_t c = l + (span * (uint64_t)(lane + 1) + 63) / 64;  // l < c <= h, ascending with the lane
+                const bool ok = (uint64_t)bstart[c] - lo0 <= (uint64_t)CAP;
+                const uint64_t okm = __ballot(ok);
+                const int nok = __popcll(okm);  // (monotone: the first nok lanes)
+                const uint64_t lnew = nok ? __shfl(c, nok - 1) : l;
+                const uint64_t hnew = nok < 64 ? __shfl(c, nok) - 1 : h;
+                l = lnew;
+                h = hnew;
+            }
+            if (lane == 0) {
+                s_round[1] = l;
+                s_round[2] = (uint64_t)bstart[l] - lo0;
+                if (l == b) {  // bucket b alone exceeds the capacity: report it (the host falls back)
+                    atomicAdd(&oversize[0], 1ull);
+                    atomicMax(&oversize[1], (unsigned long long)((uint64_t)bstart[b + 1] - lo0));
+                }
+            }
+        }
+        if (tid < 256) s_cnt[tid] = 0;
         __syncthreads();
         const uint64_t b1 = s_round[1];
         const uint32_t m = (uint32_t)s_round[2];
@@ -167,55 +243,35 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
         const uint32_t nrel = (uint32_t)(b1 - b);
         int lbits = pr.rbits;
         if (nrel > 1) lbits += 32 - __clz(nrel - 1);
-        const int npass = lbits > 8 ? (lbits + 7) / 8 : 1;
-        // ---- load (wave-striped: every wave owns a contiguous chunk, which keeps the local sort stable)
-        uint32_t lk[IPT], pi[IPT];  // local key; (position << 16) | index of the record in the round's input
+        const int hb = lbits < 8 ? lbits : 8;
+        const int lowbits = lbits - hb;
+        const uint32_t lowmask = (1u << lowbits) - 1u;
+        // ---- A. load + count the top digit
+        uint32_t lk[IPT];
         {
             const uint32_t* kp = k32 + lo;
             const W* ap = aux + lo;
             const uint32_t b32 = (uint32_t)b;
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
-                const uint32_t li = wbase + j * 64;
-                lk[j] = 0xFFFFFFFFu;
+                const uint32_t li = j * NT + tid;
+                lk[j] = 0;
                 if (li < m) {
                     const uint32_t k = kp[li];
                     // bucket of the record relative to the round's first one (bucket numbers fit 32 bits: nb <= 2^24)
-                    const uint32_t brel = (((pr.rbits >= 32 ? 0u : (k >> pr.rbits)) << pr.lead_bits) | ((uint32_t)ap[li] & lmask)) - b32;
-                    lk[j] = (pr.rbits >= 32 ? 0u : (brel << pr.rbits)) | (k & rmask);
+                    const uint32_t brel = (((k >> pr.rbits) << pr.lead_bits) | ((uint32_t)ap[li] & lmask)) - b32;
+                    lk[j] = (brel << pr.rbits) | (k & rmask);
+                    atomicAdd(&s_cnt[lk[j] >> lowbits], 1u);
                 }
                 BS_FENCE(j);
             }
-            // (the input indices are derived from an opaque copy of the lane's base: as the same values as the load
-            //  addresses above they would be kept zero-extended to 64 bits, two registers per slot, across the passes)
-            uint32_t wb2 = wbase;
-            asm volatile("" : "+v"(wb2));
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) pi[j] = wb2 + j * 64;
         }
-        // ---- LSD passes in LDS
-        for (int p = 0; p < npass; ++p) {
-            for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
-            __syncthreads();  // (also: the staging buffer of the previous pass has been read back)
-            const int sh = 8 * p;
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                // slots behind the round's records hold all-ones keys, i.e. digit 255 in every pass, and the largest
-                // indices of their wave's chunk: they stay behind every real record
-                const uint32_t d = (lk[j] >> sh) & 255u;
-                // rank inside the wave (same-address LDS atomics of one instruction complete in lane order: radix_sort.h)
-                pi[j] = (pi[j] & 0xFFFFu) | (atomicAdd(&s_whist[wave][d], 1u) << 16);
-                BS_FENCE(j);
-            }
-            __syncthreads();
+        __syncthreads();
+        // exclusive scan of the 256 counts
+        {
             uint32_t cnt = 0, incl = 0;
             if (tid < 256) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const uint32_t t = s_whist[w][tid];
-                    s_whist[w][tid] = cnt;
-                    cnt += t;
-                }
+                cnt = s_cnt[tid];
                 incl = cnt;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -230,59 +286,82 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
                     if (w < wave) wpre += s_wsum[w];
-                s_tstart[tid] = wpre + incl - cnt;
+                s_start[tid] = wpre + incl - cnt;
+                s_cnt[tid] = wpre + incl - cnt;  // running fill position
+                if (tid == 255) s_start[256] = wpre + incl;
             }
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                // (the digit and the counter address are recomputed from an opaque copy of the key: shared with the
-                //  ranking loop above they would stay in registers across the barriers, two more per slot)
-                uint32_t kx = lk[j];
-                asm volatile("" : "+v"(kx));
-                const uint32_t d = (kx >> sh) & 255u;
-                const uint32_t at = s_tstart[d] + s_whist[wave][d] + (pi[j] >> 16);
-                pi[j] = (pi[j] & 0xFFFFu) | (at << 16);
-                s_keys[at] = lk[j];
-                BS_FENCE(j);
-            }
-            __syncthreads();
-            if (p + 1 < npass) {
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) {
-                    lk[j] = s_keys[wbase + j * 64];
-                    BS_FENCE(j);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) {
-                    s_idx[pi[j] >> 16] = (uint16_t)pi[j];
-                    BS_FENCE(j);
-                }
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) {
-                    pi[j] = s_idx[wbase + j * 64];
-                    BS_FENCE(j);
-                }
-                // (the next pass starts with a barrier before the staging buffer is written again)
-            }
         }
-        // ---- the round's records are sorted (keys in LDS): flags and kept keys
-        // (after pass 0 the padding slots sit at positions >= m and their keys are all ones)
-#pragma unroll 2
+#pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint32_t i = j * NT + tid;
-            if (i < m) {
-                const uint32_t x = s_keys[i];
-                const bool head = i == 0 || s_keys[i - 1] != x;
-                const bool tail = i + 1 == m || s_keys[i + 1] != x;
-                const uint64_t K = (b + (uint64_t)(pr.rbits >= 32 ? 0u : (x >> pr.rbits))) * pr.w + (uint64_t)(x & rmask);
+            const uint32_t li = j * NT + tid;
+            if (li < m) {
+                uint32_t kx = lk[j];
+                asm volatile("" : "+v"(kx));  // (no sharing of the digit with the counting loop across the barriers)
+                const uint32_t at = atomicAdd(&s_cnt[kx >> lowbits], 1u);
+                s_keys[at] = ((kx & lowmask) << 15) | li;
+            }
+            BS_FENCE(j);
+        }
+        __syncthreads();
+        // ---- B. every sub-bucket sorted by one wavefront; flags and kept keys of its records
+        for (uint32_t d = wave; d < (1u << hb); d += NW) {
+            const uint32_t st = s_start[d], len = s_start[d + 1] - st;
+            if (len == 0) continue;
+            uint32_t* x = s_keys + st;
+            // emits the records of sorted slots [st + base, st + base + 64): v = packed word of this lane's slot,
+            // pv / nv = the packed words before / behind it (all-ones = none inside the sub-bucket)
+            auto emit = [&](uint32_t i, uint32_t v, uint32_t pv, uint32_t nv) {
+                if (i >= len) return;
+                const uint32_t low = v >> 15;
+                const bool head = i == 0 || (pv >> 15) != low;          // (another sub-bucket = another key)
+                const bool tail = i + 1 == len || (nv >> 15) != low;
+                const uint32_t lkx = (d << lowbits) | low;
+                const uint64_t K = (b + (uint64_t)(lkx >> pr.rbits)) * pr.w + (uint64_t)(lkx & rmask);
                 const bool exhausted = pr.kmagic ? (K - __umul64hi(K, pr.kmagic) * pr.kbase) == 0 : (K & (uint64_t)(pr.kbase - 1u)) == 0;
-                flags[lo + i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+                const uint64_t g = lo + st + i;
+                flags[g] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
                 if (keylow_out) {  // kept search keys in the layout of the plain split sort
-                    k32[lo + i] = (uint32_t)(K >> pr.out_low_bits);
-                    keylow_out[lo + i] = (KW)(K & ((1ull << pr.out_low_bits) - 1ull));
+                    k32[g] = (uint32_t)(K >> pr.out_low_bits);
+                    keylow_out[g] = (KW)(K & ((1ull << pr.out_low_bits) - 1ull));
                 }
+            };
+            if (len <= 64) {
+                uint32_t v[1] = {(uint32_t)lane < len ? x[lane] : 0xFFFFFFFFu};
+                bs_wave_sort<1>(v, lane);
+                if ((uint32_t)lane < len) x[lane] = v[0];
+                const uint32_t pv = __shfl_up(v[0], 1), nv = __shfl_down(v[0], 1);
+                emit(lane, v[0], pv, nv);
+            } else if (len <= 128) {
+                uint32_t v[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) v[r] = r * 64 + lane < len ? x[r * 64 + lane] : 0xFFFFFFFFu;
+                bs_wave_sort<2>(v, lane);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r * 64 + lane < len) x[r * 64 + lane] = v[r];
+                    uint32_t pv = __shfl_up(v[r], 1), nv = __shfl_down(v[r], 1);
+                    if (r > 0) { const uint32_t e = __shfl(v[r - 1], 63); if (lane == 0) pv = e; }
+                    if (r < 1) { const uint32_t e = __shfl(v[r + 1], 0); if (lane == 63) nv = e; }
+                    emit(r * 64 + lane, v[r], pv, nv);
+                }
+            } else if (len <= 256) {
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = r * 64 + lane < len ? x[r * 64 + lane] : 0xFFFFFFFFu;
+                bs_wave_sort<4>(v, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r * 64 + lane < len) x[r * 64 + lane] = v[r];
+                    uint32_t pv = __shfl_up(v[r], 1), nv = __shfl_down(v[r], 1);
+                    if (r > 0) { const uint32_t e = __shfl(v[r - 1], 63); if (lane == 0) pv = e; }
+                    if (r < 3) { const uint32_t e = __shfl(v[r + 1], 0); if (lane == 63) nv = e; }
+                    emit(r * 64 + lane, v[r], pv, nv);
+                }
+            } else {
+                bs_wave_sort_lds(x, len, lane);
+                for (uint32_t i = lane; i < len; i += 64)
+                    emit(i, x[i], i ? x[i - 1] : 0xFFFFFFFFu, i + 1 < len ? x[i + 1] : 0xFFFFFFFFu);
             }
         }
         __syncthreads();
@@ -290,20 +369,10 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
         // in LDS.  8-byte entries are staged in two halves of the window.
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-                    lk[j] = pi[j] & 0xFFFFu;
-                    BS_FENCE(j);
-                }  // (keys are done: their registers carry the indices)
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-                    s_idx[pi[j] >> 16] = (uint16_t)lk[j];
-                    BS_FENCE(j);
-                }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-                    lk[j] = s_idx[j * NT + tid];
-                    BS_FENCE(j);
-                }  // input index of the record at sorted position j * NT + tid
+            const uint32_t i = j * NT + tid;
+            lk[j] = i < m ? (s_keys[i] & 0x7FFFu) : 0u;  // (the keys are done: their registers carry the indices)
+            BS_FENCE(j);
+        }
         __syncthreads();
         V outv[IPT];
         for (uint32_t half = 0; half < (uint32_t)(CAP / VCAP); ++half) {
@@ -345,17 +414,23 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     d_over.alloc(2 * sizeof(uint64_t));
     CDB_HIP(hipMemsetAsync(d_over.p, 0, 2 * sizeof(uint64_t), s));
     BucketSortParams pr{n, plan.nb, plan.w, plan.rbits, 8 * plan.lead, kbase, kmagic, out_low_bits, 0};
-    int t = prof.begin(s);
     const bool big = plan.cap > 4096;
+    pr.step = big ? (uint64_t)1024 * 16 : 2048;
+    const uint64_t nwin = ceil_div(n, pr.step);
+    DevBuf d_win;
+    d_win.alloc((nwin + 1) * sizeof(uint32_t));
+    hipLaunchKernelGGL((bs_windows_kernel<P>), dim3((unsigned)ceil_div(nwin + 1, 256)), dim3(256), 0, s, (const P*)bstart, plan.nb, n,
+                       pr.step, nwin, d_win.as<uint32_t>());
+    int t = prof.begin(s);
     if (big) {
         constexpr int IPT = BS_IPT_BIG;
-        pr.step = (uint64_t)1024 * 16;
-        hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 1024, IPT>), dim3((unsigned)ceil_div(n, pr.step)), dim3(1024), 0, s, k32, ent,
-                           aux, (const P*)bstart, pr, flags, keylow_out, d_over.as<unsigned long long>());
+        hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 1024, IPT>), dim3((unsigned)nwin), dim3(1024), 0, s, k32, ent, aux,
+                           (const P*)bstart, (const uint32_t*)d_win.as<uint32_t>(), pr, flags, keylow_out,
+                           d_over.as<unsigned long long>());
     } else {
-        pr.step = 2048;
-        hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 256, 16>), dim3((unsigned)ceil_div(n, pr.step)), dim3(256), 0, s, k32, ent, aux,
-                           (const P*)bstart, pr, flags, keylow_out, d_over.as<unsigned long long>());
+        hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 256, 16>), dim3((unsigned)nwin), dim3(256), 0, s, k32, ent, aux,
+                           (const P*)bstart, (const uint32_t*)d_win.as<uint32_t>(), pr, flags, keylow_out,
+                           d_over.as<unsigned long long>());
     }
     prof.end(t, "sa_bucket_sort", n * (2 * (4 + sizeof(V)) + sizeof(W) + 1 + (keylow_out ? sizeof(KW) : 0)), s);
     uint64_t over[2] = {0, 0};

@@ -1196,6 +1196,7 @@ void build_typed(Index& ix, bool big) {
             const int rbits = bit_width64(w - 1);
             if (w == 1) break;  // (nothing left to sort inside a bucket: the plain sort is as good)
             if ((double)n / (double)nb > 0.7 * cap) continue;
+            if (rbits > 24) continue;  // (the bucket sort packs a round's key into 25 bits beside a 15-bit index)
             int lead = 0;
             if (rbits + 8 * (G - 1) <= 32) lead = 1;
             else if (G >= 2 && rbits + 8 * (G - 2) <= 32) lead = 2;
