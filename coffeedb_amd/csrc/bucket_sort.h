@@ -54,6 +54,8 @@ struct BucketSortParams {
     uint64_t kmagic;    // floor(2^64 / kbase) + 1, 0 for a power of two
     int out_low_bits;   // kept keys: k32 = K >> out_low_bits, low = K & (2^out_low_bits - 1)
     uint64_t step;      // nominal window
+    int ablate;         // timing experiments only (CDB_BS_ABLATE; WRONG results): 1 = no wave sorts, 2 = no flags / kept keys,
+                        // 4 = no entry gather, 8 = no counting / scatter
 };
 
 struct OpMinU64 {
@@ -243,7 +245,12 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
         const uint32_t nrel = (uint32_t)(b1 - b);
         int lbits = pr.rbits;
         if (nrel > 1) lbits += 32 - __clz(nrel - 1);
-        const int hb = lbits < 8 ? lbits : 8;
+        // top digit: as many bits as give sub-buckets of ~48 records (one wavefront sorts up to 64 in a single
+        // register), at least lbits - 17 (the rest must fit beside the index), at most 8
+        int hb = 32 - __clz((m + 47) / 48);
+        if (hb < lbits - 17) hb = lbits - 17;
+        if (hb > 8) hb = 8;
+        if (hb > lbits) hb = lbits;
         const int lowbits = lbits - hb;
         const uint32_t lowmask = (1u << lowbits) - 1u;
         // ---- A. load + count the top digit
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
                     // bucket of the record relative to the round's first one (bucket numbers fit 32 bits: nb <= 2^24)
                     const uint32_t brel = (((k >> pr.rbits) << pr.lead_bits) | ((uint32_t)ap[li] & lmask)) - b32;
                     lk[j] = (brel << pr.rbits) | (k & rmask);
-                    atomicAdd(&s_cnt[lk[j] >> lowbits], 1u);
+                    if (!(pr.ablate & 8)) atomicAdd(&s_cnt[lk[j] >> lowbits], 1u);
                 }
                 BS_FENCE(j);
             }
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
             if (li < m) {
                 uint32_t kx = lk[j];
                 asm volatile("" : "+v"(kx));  // (no sharing of the digit with the counting loop across the barriers)
-                const uint32_t at = atomicAdd(&s_cnt[kx >> lowbits], 1u);
+                const uint32_t at = (pr.ablate & 8) ? li : atomicAdd(&s_cnt[kx >> lowbits], 1u);
                 s_keys[at] = ((kx & lowmask) << 15) | li;
             }
             BS_FENCE(j);
@@ -307,12 +314,12 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
         // ---- B. every sub-bucket sorted by one wavefront; flags and kept keys of its records
         for (uint32_t d = wave; d < (1u << hb); d += NW) {
             const uint32_t st = s_start[d], len = s_start[d + 1] - st;
-            if (len == 0) continue;
+            if (len == 0 || (pr.ablate & 8)) continue;
             uint32_t* x = s_keys + st;
             // emits the records of sorted slots [st + base, st + base + 64): v = packed word of this lane's slot,
             // pv / nv = the packed words before / behind it (all-ones = none inside the sub-bucket)
             auto emit = [&](uint32_t i, uint32_t v, uint32_t pv, uint32_t nv) {
-                if (i >= len) return;
+                if (i >= len || (pr.ablate & 2)) return;
                 const uint32_t low = v >> 15;
                 const bool head = i == 0 || (pv >> 15) != low;          // (another sub-bucket = another key)
                 const bool tail = i + 1 == len || (nv >> 15) != low;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
             };
             if (len <= 64) {
                 uint32_t v[1] = {(uint32_t)lane < len ? x[lane] : 0xFFFFFFFFu};
-                bs_wave_sort<1>(v, lane);
+                if (!(pr.ablate & 1)) bs_wave_sort<1>(v, lane);
                 if ((uint32_t)lane < len) x[lane] = v[0];
                 const uint32_t pv = __shfl_up(v[0], 1), nv = __shfl_down(v[0], 1);
                 emit(lane, v[0], pv, nv);
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
                 uint32_t v[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) v[r] = r * 64 + lane < len ? x[r * 64 + lane] : 0xFFFFFFFFu;
-                bs_wave_sort<2>(v, lane);
+                if (!(pr.ablate & 1)) bs_wave_sort<2>(v, lane);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     if (r * 64 + lane < len) x[r * 64 + lane] = v[r];
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
                 uint32_t v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = r * 64 + lane < len ? x[r * 64 + lane] : 0xFFFFFFFFu;
-                bs_wave_sort<4>(v, lane);
+                if (!(pr.ablate & 1)) bs_wave_sort<4>(v, lane);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (r * 64 + lane < len) x[r * 64 + lane] = v[r];
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
         V outv[IPT];
         for (uint32_t half = 0; half < (uint32_t)(CAP / VCAP); ++half) {
             const uint32_t h0 = half * VCAP;
-            if (h0 >= m) break;
+            if (h0 >= m || (pr.ablate & 4)) break;
             for (uint32_t i = tid; i < (uint32_t)VCAP && h0 + i < m; i += NT) s_vals[i] = ent[lo + h0 + i];
             __syncthreads();
 #pragma unroll
@@ -413,7 +420,8 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     DevBuf d_over;
     d_over.alloc(2 * sizeof(uint64_t));
     CDB_HIP(hipMemsetAsync(d_over.p, 0, 2 * sizeof(uint64_t), s));
-    BucketSortParams pr{n, plan.nb, plan.w, plan.rbits, 8 * plan.lead, kbase, kmagic, out_low_bits, 0};
+    BucketSortParams pr{n, plan.nb, plan.w, plan.rbits, 8 * plan.lead, kbase, kmagic, out_low_bits, 0, 0};
+    if (const char* e = std::getenv("CDB_BS_ABLATE")) pr.ablate = std::atoi(e);
     const bool big = plan.cap > 4096;
     pr.step = big ? (uint64_t)1024 * 16 : 2048;
     const uint64_t nwin = ceil_div(n, pr.step);

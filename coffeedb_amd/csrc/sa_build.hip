@@ -1121,7 +1121,7 @@ void build_typed(Index& ix, bool big) {
     // 2^27 suffixes and more (where the passes dominate), 2 = whenever the key layout allows (tests).
     const bool want_hybrid = ix.hybrid != 0 && !big && sizeof(V) == 4 && ix.narrow_keys && ix.fuse_keygen && ix.digit_bits == 0 &&
                              ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255 && nsym <= HC_MAXSYM &&
-                             (n >= (1ull << 27) || ix.hybrid == 2) &&
+                             (n >= (1ull << 27) || ix.hybrid >= 2) &&
                              (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1 ||
                               ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32);
     if (!big && ix.digit_bits == 0 && ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255) {
