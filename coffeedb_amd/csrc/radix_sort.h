@@ -836,7 +836,7 @@ template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                    int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
                    const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr, int lead_in = 0,
-                   const BStartArgs* bstart = nullptr) {
+                   const BStartArgs* bstart = nullptr, const unsigned long long* d_hist_in = nullptr) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
@@ -849,7 +849,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     int lead = 0;
     if constexpr (GEN && HAS_W) lead = gen->low_bits / dbits;
     else if constexpr (HAS_W) lead = lead_in;
-    if (HAS_W && !GEN && !h_hist_in) throw Error("radix_sort: split records need caller-supplied histograms (internal)");
+    if (HAS_W && !GEN && !h_hist_in && !d_hist_in) throw Error("radix_sort: split records need caller-supplied histograms (internal)");
     const int LEAD = lead;
     if (n == 0 || end_bit < begin_bit || (!LEAD && end_bit == begin_bit)) return 0;
     const int nbits = end_bit - begin_bit;
@@ -863,7 +863,12 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     unsigned long long* d_hist = ws.hist.as<unsigned long long>();
     unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
     std::vector<uint64_t> h_hist((size_t)npass * 256);
-    if (h_hist_in) {
+    if (d_hist_in) {
+        // histograms already on the device ([npass][256], lowest digit first): no host round trip at all — the
+        // bucket-wise build queues hundreds of sorts back to back (no pass is skipped: the host never sees the counts)
+        CDB_HIP(hipMemcpyAsync(d_hist, d_hist_in, (size_t)npass * 256 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
+    } else if (h_hist_in) {
         std::copy(h_hist_in, h_hist_in + h_hist.size(), h_hist.begin());
         CDB_HIP(hipMemcpyAsync(d_hist, h_hist.data(), h_hist.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(rs_digit_start_kernel, dim3(npass), dim3(256), 0, s, d_hist, d_start);
@@ -960,7 +965,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
 template <typename K, typename V>
 int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                int begin_bit, int end_bit, SortStats* stats = nullptr, int variant = 0, int dbits = 8,
-               const uint64_t* h_hist_in = nullptr, const TextGen* gen = nullptr) {
+               const uint64_t* h_hist_in = nullptr, const TextGen* gen = nullptr, const unsigned long long* d_hist_in = nullptr) {
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     const bool atomrank = rs_atomic_rank_ok(s);
     if constexpr (!HAS_V) {
@@ -980,7 +985,10 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
                                : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
         if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
-#define CDB_RS(...) return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in)
+#define CDB_RS(...)                                                                                                      \
+    return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in, \
+                                                    (const NoGen*)nullptr, (NoVal*)nullptr, (NoVal*)nullptr, 0,           \
+                                                    (const BStartArgs*)nullptr, d_hist_in)
 #define CDB_RS_GEN(...)                                                                                               \
     if (gen)                                                                                                          \
         return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
@@ -1031,7 +1039,8 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
 template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
                      W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
-                     const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const BStartArgs* bstart = nullptr) {
+                     const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const BStartArgs* bstart = nullptr,
+                     const unsigned long long* d_hist = nullptr) {
     const bool atomrank = rs_atomic_rank_ok(s);
     // 8-byte values: a 12 Ki-key tile keeps staging + auxiliary bytes inside the 160 KB of LDS
     constexpr int IPT_BIG = sizeof(V) == 8 ? 12 : 16;
@@ -1046,7 +1055,7 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
                                                                            0, bstart);                                  \
     return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin, hi_bits, \
                                                                      stats, dbits, h_hist, (const NoGen*)nullptr, w0, w1, \
-                                                                     (int)sizeof(W), bstart)
+                                                                     (int)sizeof(W), bstart, d_hist)
     switch (variant) {
         default:
         case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);

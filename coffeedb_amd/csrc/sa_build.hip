@@ -1527,9 +1527,9 @@ void build_typed(Index& ix, bool big) {
                                        gstart, b0, k32g.as<K>(), lowg.as<W>(), d_bh.as<unsigned long long>());
                     ix.prof.end(t, "sa_bucket_records", (bstart[b1] - gstart) * ((uint64_t)nsym + keyb + lowb + sizeof(V)), s);
                 }
-                bh.resize((size_t)gb * 8 * 256);
-                CDB_HIP(hipMemcpyAsync(bh.data(), d_bh.p, bh.size() * 8, hipMemcpyDeviceToHost, s));
-                CDB_HIP(hipStreamSynchronize(s));  // (also: `items` may be rebuilt for the next group)
+                // (the per-bucket digit histograms stay on the device: the sorts below are queued without a single host
+                //  round trip; this one synchronisation per GROUP only protects `items`, rebuilt for the next group)
+                CDB_HIP(hipStreamSynchronize(s));
                 for (uint32_t b = b0; b < b1; ++b) {
                     const uint64_t start = bstart[b], cnt = bstart[b + 1] - start;
                     V* eb = E.as<V>() + start;
@@ -1537,14 +1537,15 @@ void build_typed(Index& ix, bool big) {
                     FW* lb = HAS_W ? lowg.as<FW>() + (start - gstart) : (FW*)nullptr;
                     int r = 0;
                     if (bpass > 0 && cnt > 1) {
-                        const uint64_t* hb = &bh[(size_t)(b - b0) * 8 * 256];
+                        const unsigned long long* hb = d_bh.as<unsigned long long>() + (size_t)(b - b0) * 8 * 256;
                         ix.rws.value_spare = EX.p;  // (null without the third buffer)
                         if constexpr (HAS_W)
                             r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
-                                                       bbits - blow, &ss, ix.sort_variant, 8, hb, (const TextGen*)nullptr);
+                                                       bbits - blow, &ss, ix.sort_variant, 8, (const uint64_t*)nullptr,
+                                                       (const TextGen*)nullptr, 0, (const BStartArgs*)nullptr, hb);
                         else
                             r = radix_sort<K, V>(s, ix.rws, ix.prof, kb, k32t.as<K>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
-                                                 ix.sort_variant, 8, hb);
+                                                 ix.sort_variant, 8, (const uint64_t*)nullptr, (const TextGen*)nullptr, hb);
                         if (ix.rws.value_result == 1) CDB_HIP(hipMemcpyAsync(eb, ET.p, cnt * sizeof(V), hipMemcpyDeviceToDevice, s));
                     }
                     if constexpr (sizeof(K) == 8)
