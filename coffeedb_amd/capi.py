@@ -21,6 +21,9 @@ EXPORTS = [
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference",
+    "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
+    "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
+    "cdb_shards_transport", "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge",
 ]
 
 
@@ -125,6 +128,31 @@ def load_library():
     lib.cdb_debug_verify_reference.argtypes = [vp, C.POINTER(u64)]
     lib.cdb_debug_radix_sort.argtypes = [C.c_int, vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_int)]
+    lib.cdb_shards_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    lib.cdb_shards_destroy.argtypes = [vp]
+    lib.cdb_shards_destroy.restype = None
+    lib.cdb_shards_last_error.argtypes = [vp]
+    lib.cdb_shards_last_error.restype = cp
+    lib.cdb_shards_add.argtypes = [vp, i64, cp, C.c_size_t]
+    lib.cdb_shards_add_bulk.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_shards_set_option.argtypes = [vp, cp, i64]
+    lib.cdb_shards_build.argtypes = [vp]
+    lib.cdb_shards_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
+    lib.cdb_shards_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
+    lib.cdb_shards_count.argtypes = [vp]
+    lib.cdb_shards_get.argtypes = [vp, C.c_int]
+    lib.cdb_shards_get.restype = vp
+    lib.cdb_shards_first_doc.argtypes = [vp, C.c_int]
+    lib.cdb_shards_first_doc.restype = u64
+    lib.cdb_shards_transport.argtypes = [vp]
+    lib.cdb_shards_transport.restype = cp
+    lib.cdb_comm_unique_id.argtypes = [vp]
+    lib.cdb_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int]
+    lib.cdb_comm_destroy.argtypes = [vp]
+    lib.cdb_comm_destroy.restype = None
+    lib.cdb_comm_last_error.argtypes = [vp]
+    lib.cdb_comm_last_error.restype = cp
+    lib.cdb_comm_merge.argtypes = [vp, C.POINTER(CdbDeviceResult), C.POINTER(CdbDeviceResult)]
     _LIB = lib
     return lib
 
@@ -356,6 +384,113 @@ class GpuStringIndex:
 
     def profile_reset(self):
         self._lib.cdb_profile_reset(self._h)
+
+
+class GpuShards:
+    """cdb_shards: the string index spread over several GPUs of one process (devices may repeat on a one-GPU box)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self._lib.cdb_shards_create(C.byref(h), arr, len(devices))
+        if rc != 0:
+            raise RuntimeError(f"cdb_shards_create failed (code {rc}): no usable gfx950 device — there is no CPU fallback")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cdb_shards_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.cdb_shards_last_error(self._h).decode(errors="replace"))
+
+    def add(self, id_, value: bytes):
+        self._check(self._lib.cdb_shards_add(self._h, int(id_), value, len(value)))
+
+    def add_bulk(self, ids, blob, doc_start):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+        self._check(self._lib.cdb_shards_add_bulk(self._h, _ptr(ids), _ptr(blob), _ptr(doc_start), len(ids)))
+
+    def set_option(self, name, value):
+        self._check(self._lib.cdb_shards_set_option(self._h, name.encode(), int(value)))
+
+    def build(self):
+        self._check(self._lib.cdb_shards_build(self._h))
+
+    count = property(lambda s: s._lib.cdb_shards_count(s._h))
+    transport = property(lambda s: s._lib.cdb_shards_transport(s._h).decode())
+
+    def first_doc(self, i):
+        return int(self._lib.cdb_shards_first_doc(self._h, i))
+
+    def shard(self, i):
+        """Borrowed GpuStringIndex view of shard i (do not close it)."""
+        g = GpuStringIndex.__new__(GpuStringIndex)
+        g._lib = self._lib
+        g._h = C.c_void_p(self._lib.cdb_shards_get(self._h, i))
+        g.close = lambda: None
+        return g
+
+    def query(self, kw: bytes):
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        self._check(self._lib.cdb_shards_query(self._h, kw, len(kw), C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = [(ids[i], cnt[i]) for i in range(n.value)]
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return out
+
+    def query_batch(self, blob, offsets):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        npat = len(offsets) - 1
+        r = CdbResult()
+        self._check(self._lib.cdb_shards_query_batch(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r)))
+        own = GpuStringIndex._Owner(self._lib, ("cdb_result_free", r))
+        nrows = int(r.nrows)
+        ad = GpuStringIndex._adopt
+        return (ad(r.row_ptr, npat + 1, np.uint64, own), ad(r.ids, nrows, np.int64, own), ad(r.counts, nrows, np.int64, own),
+                int(r.nhits))
+
+
+class ShardComm:
+    """cdb_comm: one rank of a one-process-per-GPU group; merge() is collective."""
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = np.zeros(128, dtype=np.uint8)
+        if lib.cdb_comm_unique_id(_ptr(buf)) != 0:
+            raise RuntimeError("cdb_comm_unique_id failed: RCCL is not available")
+        return buf
+
+    def __init__(self, uid, rank, world, device):
+        self._lib = load_library()
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        h = C.c_void_p()
+        rc = self._lib.cdb_comm_create(C.byref(h), _ptr(uid), rank, world, device)
+        if rc != 0:
+            raise RuntimeError(f"cdb_comm_create failed (code {rc})")
+        self._h = h
+
+    def merge(self, local: "CdbDeviceResult"):
+        out = CdbDeviceResult()
+        if self._lib.cdb_comm_merge(self._h, C.byref(local), C.byref(out)) != 0:
+            raise RuntimeError(self._lib.cdb_comm_last_error(self._h).decode(errors="replace"))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cdb_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def debug_radix_sort(d_keys_ptr, d_vals_ptr, n, val_bytes, key_bits, variant=0, device=-1):

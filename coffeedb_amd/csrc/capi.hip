@@ -11,10 +11,6 @@
 
 using namespace cdb;
 
-struct cdb_index {
-    Index ix;
-};
-
 namespace {
 
 double wall_ms() {

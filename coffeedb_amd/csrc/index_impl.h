@@ -173,3 +173,8 @@ DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_
                                  uint64_t limit);
 
 }  // namespace cdb
+
+// the object behind the C ABI's opaque handle (capi.hip, shards.hip)
+struct cdb_index {
+    cdb::Index ix;
+};

@@ -1,0 +1,725 @@
+// shards.hip — the string index across several GPUs, behind the C ABI.
+//
+// Suffixes never cross document boundaries (reference src/index.h:61-65) and a result row belongs to exactly one
+// document (src/index.cpp:317-321), so a column splits into document-aligned byte ranges with one independent
+// suffix array per GPU.  Every shard answers the whole pattern batch for its documents; concatenating the rows of
+// a pattern in shard order is already ascending in document index, so the merge is an all-gatherv plus a
+// placement — no reduction:
+//     1. all-gather of the per-pattern row counts (u32 x patterns),
+//     2. one exclusive scan over the (shard, pattern) counts = where every shard's rows of every pattern sit in the
+//        gathered stream, and the merged row_ptr,
+//     3. all-gatherv of the (id, count) rows — grouped ncclBroadcast, one root per shard (xGMI is point to point
+//        and every peer is one hop away: a direct exchange, not a ring),
+//     4. a placement kernel moves the rows from shard-major to pattern-major order.
+// Two ways in: cdb_shards_* — ONE process owning G devices (what the CoffeeDB shim uses: database.cpp is a single
+// process), one host thread per shard; cdb_comm_* — one process per GPU (bench.py under torchrun), each rank
+// merging its own shard.  Both run the same merge over RCCL (loaded at run time: single-GPU users need no RCCL);
+// shards that share a device (tests on a one-GPU box) exchange through device-to-device copies instead, because
+// RCCL refuses two ranks on one GPU.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "../../include/coffeedb_gpu.h"
+#include "index_impl.h"
+#include "scan.h"
+
+using namespace cdb;
+
+namespace {
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+    static RcclApi& get() {
+        static RcclApi api;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            // (a process that already loaded an RCCL — PyTorch bundles one — gets that one back by soname)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (api.lib) break;
+            }
+            if (!api.lib) return;
+            auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+            api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+            api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.Broadcast ||
+                !api.GroupStart || !api.GroupEnd) {
+                dlclose(api.lib);
+                api.lib = nullptr;
+            }
+        });
+        return api;
+    }
+    bool ok() const { return lib != nullptr; }
+};
+
+#define CDB_NCCL(expr)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) {                                                                          \
+            const RcclApi& a_ = RcclApi::get();                                                           \
+            throw ::cdb::Error(std::string("HIP error in " #expr " (RCCL): ") +                           \
+                               (a_.GetErrorString ? a_.GetErrorString(r_) : "unknown"));                  \
+        }                                                                                                 \
+    } while (0)
+
+// ---- exchange between the shards of one merge ---------------------------------------------------------------------
+struct Transport {
+    virtual ~Transport() = default;
+    // recv[q * bytes .. ) = rank q's `bytes` bytes of send, for every q
+    virtual void all_gather(int rank, const void* send, void* recv, size_t bytes, hipStream_t s) = 0;
+    // recv[off[q] * 8 .. ) = rank q's cnt[q] 8-byte elements of send (send holds cnt[rank] elements)
+    virtual void all_gather_v(int rank, const void* send, void* recv, const uint64_t* cnt, const uint64_t* off, hipStream_t s) = 0;
+    virtual const char* name() const = 0;
+};
+
+// one RCCL communicator per rank (ranks may live in one process — cdb_shards — or in one process each — cdb_comm)
+struct RcclTransport : Transport {
+    int world;
+    std::vector<ncclComm_t> comms;  // indexed by LOCAL rank slot
+    std::vector<int> local_rank;    // global rank of every local slot
+    explicit RcclTransport(int w) : world(w) {}
+    ~RcclTransport() override {
+        for (ncclComm_t c : comms)
+            if (c) (void)RcclApi::get().CommDestroy(c);
+    }
+    ncclComm_t comm_of(int rank) const {
+        for (size_t i = 0; i < local_rank.size(); ++i)
+            if (local_rank[i] == rank) return comms[i];
+        throw Error("internal: rank is not local to this communicator");
+    }
+    void all_gather(int rank, const void* send, void* recv, size_t bytes, hipStream_t s) override {
+        CDB_NCCL(RcclApi::get().AllGather(send, recv, bytes, ncclUint8, comm_of(rank), s));
+    }
+    void all_gather_v(int rank, const void* send, void* recv, const uint64_t* cnt, const uint64_t* off, hipStream_t s) override {
+        // all-gatherv = one broadcast per root inside a group (every rank knows every count, so empty roots are
+        // skipped consistently)
+        const RcclApi& a = RcclApi::get();
+        ncclComm_t c = comm_of(rank);
+        CDB_NCCL(a.GroupStart());
+        for (int q = 0; q < world; ++q) {
+            if (!cnt[q]) continue;
+            char* dst = static_cast<char*>(recv) + off[q] * 8;
+            ncclResult_t r = a.Broadcast(q == rank ? send : (const void*)dst, dst, cnt[q], ncclUint64, q, c, s);
+            if (r != ncclSuccess) {
+                (void)a.GroupEnd();
+                CDB_NCCL(r);
+            }
+        }
+        CDB_NCCL(a.GroupEnd());
+    }
+    const char* name() const override { return "rccl"; }
+};
+
+// shards of ONE process that share devices: a board of published buffers, device-to-device copies
+struct LocalTransport : Transport {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    std::vector<const void*> send;
+    explicit LocalTransport(int w) : world(w), send(w, nullptr) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+    void exchange(int rank, const void* snd, void* recv, const uint64_t* bytes, const uint64_t* off_bytes, hipStream_t s) {
+        CDB_HIP(hipStreamSynchronize(s));  // this rank's buffer is complete
+        {
+            std::lock_guard<std::mutex> g(mu);
+            send[rank] = snd;
+        }
+        barrier();  // every buffer is published and complete
+        for (int q = 0; q < world; ++q)
+            if (bytes[q])
+                CDB_HIP(hipMemcpyAsync(static_cast<char*>(recv) + off_bytes[q], send[q], bytes[q], hipMemcpyDeviceToDevice, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        barrier();  // every rank has read every buffer: they may be reused
+    }
+    void all_gather(int rank, const void* snd, void* recv, size_t bytes, hipStream_t s) override {
+        std::vector<uint64_t> b(world, bytes), o(world);
+        for (int q = 0; q < world; ++q) o[q] = (uint64_t)q * bytes;
+        exchange(rank, snd, recv, b.data(), o.data(), s);
+    }
+    void all_gather_v(int rank, const void* snd, void* recv, const uint64_t* cnt, const uint64_t* off, hipStream_t s) override {
+        std::vector<uint64_t> b(world), o(world);
+        for (int q = 0; q < world; ++q) {
+            b[q] = cnt[q] * 8;
+            o[q] = off[q] * 8;
+        }
+        exchange(rank, snd, recv, b.data(), o.data(), s);
+    }
+    const char* name() const override { return "device copies"; }
+};
+
+// ---- merge kernels ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sh_counts_kernel(const uint64_t* __restrict__ row_ptr, uint64_t npat, uint32_t* __restrict__ cnt) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < npat) cnt[j] = (uint32_t)(row_ptr[j + 1] - row_ptr[j]);
+}
+struct FlatCntIn {  // (shard, pattern) counts in shard-major order = the order of the gathered row stream
+    const uint32_t* c;
+    __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return c[i]; }
+};
+struct FlatPtrOut {
+    uint64_t* p;
+    uint64_t n;
+    __device__ __forceinline__ void operator()(uint64_t i, uint64_t ex, uint64_t in) const {
+        p[i] = ex;
+        if (i + 1 == n) p[n] = in;
+    }
+};
+struct ColSumIn {  // rows of pattern j over all shards
+    const uint32_t* c;
+    uint64_t npat;
+    int world;
+    __device__ __forceinline__ uint64_t operator()(uint64_t j) const {
+        uint64_t t = 0;
+        for (int q = 0; q < world; ++q) t += c[(uint64_t)q * npat + j];
+        return t;
+    }
+};
+__global__ __launch_bounds__(64) void sh_rank_offsets_kernel(const uint64_t* __restrict__ flat_ptr, uint64_t npat, int world,
+                                                             uint64_t* __restrict__ out /*[world + 1]*/) {
+    const int q = threadIdx.x;
+    if (q <= world) out[q] = flat_ptr[(uint64_t)q * npat];
+}
+// merged row i: its pattern (search in the merged row_ptr), then the shard whose rows of that pattern cover it
+__global__ __launch_bounds__(256) void sh_place_kernel(const uint64_t* __restrict__ g_row_ptr, const uint32_t* __restrict__ all_cnt,
+                                                       const uint64_t* __restrict__ flat_ptr, uint64_t npat, int world, uint64_t total,
+                                                       const int64_t* __restrict__ in_ids, const int64_t* __restrict__ in_cnt,
+                                                       int64_t* __restrict__ out_ids, int64_t* __restrict__ out_cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        uint64_t lo = 0, hi = npat - 1;  // largest j with g_row_ptr[j] <= i
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (g_row_ptr[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t j = lo;
+        uint64_t k = i - g_row_ptr[j];
+        int q = 0;
+        for (; q < world - 1; ++q) {
+            const uint64_t c = all_cnt[(uint64_t)q * npat + j];
+            if (k < c) break;
+            k -= c;
+        }
+        const uint64_t src = flat_ptr[(uint64_t)q * npat + j] + k;
+        out_ids[i] = in_ids[src];
+        out_cnt[i] = in_cnt[src];
+    }
+}
+
+// ---- one rank of a merge ------------------------------------------------------------------------------------------
+struct MergeRank {
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::shared_ptr<Transport> tr;
+    DevBuf cnt, all_cnt, flat_ptr, g_row_ptr, offs, st_ids, st_cnt, out_ids, out_cnt, partials;
+    std::mutex err_mu;
+    std::string err;
+    ~MergeRank() {
+        if (own_stream && stream) {
+            (void)hipSetDevice(device);
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+    }
+};
+
+// collective over all ranks of mr.tr; local = this shard's device CSR; merged arrays live in mr
+void merge_core(MergeRank& mr, const cdb_device_result& local, cdb_device_result& merged) {
+    CDB_HIP(hipSetDevice(mr.device));
+    StreamScope ss(mr.stream);
+    hipStream_t s = mr.stream;
+    const uint64_t npat = local.npat;
+    const int G = mr.world;
+    std::memset(&merged, 0, sizeof(merged));
+    merged.npat = npat;
+    mr.g_row_ptr.ensure((npat + 1) * 8);
+    if (npat == 0) {
+        CDB_HIP(hipMemsetAsync(mr.g_row_ptr.p, 0, 8, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        merged.d_row_ptr = mr.g_row_ptr.as<uint64_t>();
+        return;
+    }
+    mr.cnt.ensure(npat * 4);
+    mr.all_cnt.ensure((size_t)G * npat * 4);
+    mr.flat_ptr.ensure(((size_t)G * npat + 1) * 8);
+    mr.offs.ensure((G + 2) * 8);
+    hipLaunchKernelGGL(sh_counts_kernel, dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, local.d_row_ptr, npat, mr.cnt.as<uint32_t>());
+    mr.tr->all_gather(mr.rank, mr.cnt.p, mr.all_cnt.p, npat * 4, s);
+    // where every (shard, pattern) group starts in the gathered stream, and the merged row_ptr
+    FlatCntIn fin{mr.all_cnt.as<uint32_t>()};
+    scan_totals_device<uint64_t>(s, mr.partials, fin, (uint64_t)G * npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, mr.partials, fin, (uint64_t)G * npat, OpAdd{}, (uint64_t)0, FlatPtrOut{mr.flat_ptr.as<uint64_t>(), (uint64_t)G * npat});
+    ColSumIn cin{mr.all_cnt.as<uint32_t>(), npat, G};
+    scan_totals_device<uint64_t>(s, mr.partials, cin, npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, mr.partials, cin, npat, OpAdd{}, (uint64_t)0, FlatPtrOut{mr.g_row_ptr.as<uint64_t>(), npat});
+    hipLaunchKernelGGL(sh_rank_offsets_kernel, dim3(1), dim3(64), 0, s, (const uint64_t*)mr.flat_ptr.as<uint64_t>(), npat, G,
+                       mr.offs.as<uint64_t>());
+    std::vector<uint64_t> off(G + 1), cntv(G);
+    CDB_HIP(hipMemcpyAsync(off.data(), mr.offs.p, (G + 1) * 8, hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipGetLastError());
+    CDB_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < G; ++q) cntv[q] = off[q + 1] - off[q];
+    const uint64_t total = off[G];
+    if (cntv[mr.rank] != local.nrows) throw Error("internal: shard row count does not match its row_ptr");
+    merged.nrows = total;
+    merged.d_row_ptr = mr.g_row_ptr.as<uint64_t>();
+    if (total == 0) return;
+    mr.st_ids.ensure(total * 8);
+    mr.st_cnt.ensure(total * 8);
+    mr.out_ids.ensure(total * 8);
+    mr.out_cnt.ensure(total * 8);
+    mr.tr->all_gather_v(mr.rank, local.d_ids, mr.st_ids.p, cntv.data(), off.data(), s);
+    mr.tr->all_gather_v(mr.rank, local.d_counts, mr.st_cnt.p, cntv.data(), off.data(), s);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(total, 256), 1u << 20);
+    hipLaunchKernelGGL(sh_place_kernel, dim3(grid), dim3(256), 0, s, (const uint64_t*)mr.g_row_ptr.as<uint64_t>(),
+                       (const uint32_t*)mr.all_cnt.as<uint32_t>(), (const uint64_t*)mr.flat_ptr.as<uint64_t>(), npat, G, total,
+                       (const int64_t*)mr.st_ids.as<int64_t>(), (const int64_t*)mr.st_cnt.as<int64_t>(), mr.out_ids.as<int64_t>(),
+                       mr.out_cnt.as<int64_t>());
+    CDB_HIP(hipGetLastError());
+    CDB_HIP(hipStreamSynchronize(s));
+    merged.d_ids = mr.out_ids.as<int64_t>();
+    merged.d_counts = mr.out_cnt.as<int64_t>();
+}
+
+template <typename T, typename F>
+int guarded_on(T* obj, F&& f) {
+    try {
+        f();
+        return CDB_OK;
+    } catch (const Error& e) {
+        std::lock_guard<std::mutex> g(obj->err_mu);
+        obj->err = e.what();
+        const bool dev = std::strncmp(e.what(), "HIP error", 9) == 0;
+        return dev ? CDB_E_DEVICE : (std::strstr(e.what(), "internal") ? CDB_E_INTERNAL : CDB_E_INVALID);
+    } catch (const std::bad_alloc&) {
+        std::lock_guard<std::mutex> g(obj->err_mu);
+        obj->err = "out of host memory";
+        return CDB_E_DEVICE;
+    } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> g(obj->err_mu);
+        obj->err = e.what();
+        return CDB_E_INTERNAL;
+    }
+}
+
+// doc-aligned split into `parts` contiguous ranges balanced by bytes: docs [b[r], b[r+1])
+std::vector<uint64_t> shard_bounds(const std::vector<uint64_t>& doc_start, int parts) {
+    const uint64_t nd = doc_start.size() - 1, total = doc_start[nd];
+    std::vector<uint64_t> b{0};
+    for (int r = 1; r < parts; ++r) {
+        const unsigned __int128 target128 = (unsigned __int128)total * r / parts;
+        const uint64_t target = (uint64_t)target128;
+        uint64_t d = std::lower_bound(doc_start.begin(), doc_start.end(), target) - doc_start.begin();
+        d = std::min<uint64_t>(std::max<uint64_t>(d, b.back()), nd);
+        b.push_back(d);
+    }
+    b.push_back(nd);
+    return b;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// one process per GPU
+// =====================================================================================================================
+struct cdb_comm {
+    MergeRank mr;
+};
+
+extern "C" {
+
+int cdb_comm_unique_id(void* id128) {
+    if (!id128) return CDB_E_INVALID;
+    const RcclApi& a = RcclApi::get();
+    if (!a.ok()) return CDB_E_DEVICE;
+    ncclUniqueId id;
+    if (a.GetUniqueId(&id) != ncclSuccess) return CDB_E_DEVICE;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return CDB_OK;
+}
+
+int cdb_comm_create(cdb_comm** out, const void* id128, int rank, int world, int device) {
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return CDB_E_INVALID;
+    *out = nullptr;
+    const RcclApi& a = RcclApi::get();
+    if (!a.ok()) return CDB_E_DEVICE;
+    cdb_comm* c = new (std::nothrow) cdb_comm();
+    if (!c) return CDB_E_DEVICE;
+    try {
+        if (device < 0) CDB_HIP(hipGetDevice(&device));
+        CDB_HIP(hipSetDevice(device));
+        c->mr.rank = rank;
+        c->mr.world = world;
+        c->mr.device = device;
+        CDB_HIP(hipStreamCreateWithFlags(&c->mr.stream, hipStreamNonBlocking));
+        c->mr.own_stream = true;
+        auto tr = std::make_shared<RcclTransport>(world);
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        ncclComm_t comm = nullptr;
+        CDB_NCCL(a.CommInitRank(&comm, world, id, rank));
+        tr->comms.push_back(comm);
+        tr->local_rank.push_back(rank);
+        c->mr.tr = tr;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "cdb_comm_create: %s\n", e.what());
+        delete c;
+        return CDB_E_DEVICE;
+    }
+    *out = c;
+    return CDB_OK;
+}
+
+void cdb_comm_destroy(cdb_comm* c) { delete c; }
+
+const char* cdb_comm_last_error(const cdb_comm* c) {
+    if (!c) return "null handle";
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(const_cast<cdb_comm*>(c)->mr.err_mu);
+    copy = c->mr.err;
+    return copy.c_str();
+}
+
+int cdb_comm_merge(cdb_comm* c, const cdb_device_result* local, cdb_device_result* merged) {
+    if (!c || !local || !merged) return CDB_E_INVALID;
+    return guarded_on(&c->mr, [&] { merge_core(c->mr, *local, *merged); });
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// one process, G devices
+// =====================================================================================================================
+struct cdb_shards {
+    std::vector<int> devices;
+    std::vector<cdb_index*> shard;                  // one handle per device slot
+    std::vector<std::unique_ptr<MergeRank>> ranks;  // merge state of the shards in use
+    std::shared_ptr<Transport> tr;
+    int used = 0;                                   // shards holding documents after the last build
+    std::vector<uint64_t> bounds;                   // docs [bounds[i], bounds[i+1]) live on shard i
+    // host staging of the whole column (cdb_shards_add*)
+    std::vector<int64_t> ids;
+    std::vector<uint64_t> doc_start{0};
+    std::string text;
+    uint64_t max_shard_bytes = 12ull << 30;  // a shard beyond this is split although fewer devices would do
+    bool use_all = false;                    // always spread over every device (bench / tests)
+    std::vector<std::pair<std::string, int64_t>> options;
+    std::mutex mu;
+    std::mutex err_mu;
+    std::string err;
+};
+
+namespace {
+
+// runs f(i) for i in [0, n) on n host threads (each shard has its own device, stream and locks); rethrows the first error
+template <typename F>
+void parallel_shards(int n, F&& f) {
+    std::vector<std::thread> th;
+    std::mutex emu;
+    std::string first;
+    bool failed = false;
+    for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+            try {
+                f(i);
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(emu);
+                if (!failed) first = e.what();
+                failed = true;
+            }
+        });
+    for (auto& t : th) t.join();
+    if (failed) throw Error(first);
+}
+
+void check_shard(cdb_shards* h, int i, int rc) {
+    if (rc != CDB_OK) throw Error(cdb_last_error(h->shard[i]));
+}
+
+// (re)creates the merge ranks and their transport for the first `used` shards
+void setup_merge(cdb_shards* h) {
+    h->ranks.clear();
+    h->tr.reset();
+    const int G = h->used;
+    if (G <= 1) return;
+    bool distinct = true;
+    for (int i = 0; i < G; ++i)
+        for (int j = 0; j < i; ++j)
+            if (h->devices[i] == h->devices[j]) distinct = false;
+    const char* force = std::getenv("CDB_SHARD_TRANSPORT");
+    const bool want_rccl = distinct && RcclApi::get().ok() && !(force && std::string(force) == "copy");
+    if (want_rccl) {
+        auto tr = std::make_shared<RcclTransport>(G);
+        tr->comms.assign(G, nullptr);
+        CDB_NCCL(RcclApi::get().CommInitAll(tr->comms.data(), G, h->devices.data()));
+        for (int i = 0; i < G; ++i) tr->local_rank.push_back(i);
+        h->tr = tr;
+    } else {
+        h->tr = std::make_shared<LocalTransport>(G);
+    }
+    for (int i = 0; i < G; ++i) {
+        auto mr = std::make_unique<MergeRank>();
+        mr->rank = i;
+        mr->world = G;
+        mr->device = h->devices[i];
+        mr->stream = h->shard[i]->ix.stream;  // the shard's own stream: its query results are complete in stream order
+        mr->tr = h->tr;
+        h->ranks.push_back(std::move(mr));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdb_shards_create(cdb_shards** out, const int* devices, int ndev) {
+    if (!out || ndev < 1 || !devices) return CDB_E_INVALID;
+    *out = nullptr;
+    cdb_shards* h = new (std::nothrow) cdb_shards();
+    if (!h) return CDB_E_DEVICE;
+    for (int i = 0; i < ndev; ++i) {
+        cdb_index* ix = nullptr;
+        const int rc = cdb_create(&ix, devices[i]);
+        if (rc != CDB_OK) {
+            for (cdb_index* p : h->shard) cdb_destroy(p);
+            delete h;
+            return rc;
+        }
+        h->shard.push_back(ix);
+        h->devices.push_back(ix->ix.device);
+    }
+    *out = h;
+    return CDB_OK;
+}
+
+void cdb_shards_destroy(cdb_shards* h) {
+    if (!h) return;
+    h->ranks.clear();
+    h->tr.reset();
+    for (cdb_index* p : h->shard) cdb_destroy(p);
+    delete h;
+}
+
+const char* cdb_shards_last_error(const cdb_shards* h) {
+    if (!h) return "null handle";
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(const_cast<cdb_shards*>(h)->err_mu);
+    copy = h->err;
+    return copy.c_str();
+}
+
+int cdb_shards_add(cdb_shards* h, int64_t id, const char* value, size_t len) {
+    if (!h || (!value && len)) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        h->text.append(value, len);
+        h->ids.push_back(id);
+        h->doc_start.push_back(h->text.size());
+    });
+}
+
+int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs) {
+    if (!h || (ndocs && (!ids || !doc_start))) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        if (!ndocs) return;
+        for (uint64_t d = 0; d < ndocs; ++d)
+            if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+        h->ids.reserve(h->ids.size() + ndocs);
+        h->doc_start.reserve(h->doc_start.size() + ndocs);
+        const uint64_t base = h->text.size();
+        h->text.append(blob + doc_start[0], doc_start[ndocs] - doc_start[0]);
+        for (uint64_t d = 0; d < ndocs; ++d) {
+            h->ids.push_back(ids[d]);
+            h->doc_start.push_back(base + doc_start[d + 1] - doc_start[0]);
+        }
+    });
+}
+
+int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value) {
+    if (!h || !name) return CDB_E_INVALID;
+    if (!std::strcmp(name, "max_shard_bytes")) {
+        h->max_shard_bytes = value > 0 ? (uint64_t)value : 1;
+        return CDB_OK;
+    }
+    if (!std::strcmp(name, "use_all_devices")) {
+        h->use_all = value != 0;
+        return CDB_OK;
+    }
+    for (cdb_index* p : h->shard) {
+        const int rc = cdb_set_option(p, name, value);
+        if (rc != CDB_OK) {
+            std::lock_guard<std::mutex> g(h->err_mu);
+            h->err = cdb_last_error(p);
+            return rc;
+        }
+    }
+    h->options.emplace_back(name, value);  // (replayed on the fresh handles of every rebuild)
+    return CDB_OK;
+}
+
+int cdb_shards_build(cdb_shards* h) {
+    if (!h) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        std::lock_guard<std::mutex> g(h->mu);
+        const int G = (int)h->shard.size();
+        const uint64_t nd = h->ids.size(), total = h->doc_start[nd];
+        // shard only when the column exceeds what one GPU should hold (north star), unless told to spread anyway
+        int used = h->use_all ? G : (int)std::min<uint64_t>((uint64_t)G, std::max<uint64_t>(1, ceil_div(total, h->max_shard_bytes)));
+        used = std::max(1, std::min<int>(used, (int)std::max<uint64_t>(nd, 1)));
+        const std::vector<uint64_t> b = shard_bounds(h->doc_start, used);
+        // fresh handles for the shards (a rebuild replaces the whole column, as database.cpp does with new objects)
+        for (int i = 0; i < G; ++i) {
+            cdb_index* fresh = nullptr;
+            if (cdb_create(&fresh, h->devices[i]) != CDB_OK) throw Error("HIP error: cannot create a shard handle");
+            for (auto& kv : h->options) (void)cdb_set_option(fresh, kv.first.c_str(), kv.second);
+            cdb_destroy(h->shard[i]);
+            h->shard[i] = fresh;
+        }
+        parallel_shards(used, [&](int i) {
+            const uint64_t d0 = b[i], d1 = b[i + 1];
+            check_shard(h, i, cdb_add_bulk(h->shard[i], h->ids.data() + d0, h->text.data(), h->doc_start.data() + d0, d1 - d0));
+            check_shard(h, i, cdb_build(h->shard[i]));
+        });
+        h->used = used;
+        h->bounds = b;
+        setup_merge(h);
+    });
+}
+
+int cdb_shards_count(const cdb_shards* h) { return h ? h->used : 0; }
+cdb_index* cdb_shards_get(cdb_shards* h, int i) { return (h && i >= 0 && i < (int)h->shard.size()) ? h->shard[i] : nullptr; }
+uint64_t cdb_shards_first_doc(const cdb_shards* h, int i) {
+    return (h && i >= 0 && i < (int)h->bounds.size()) ? h->bounds[i] : 0;
+}
+const char* cdb_shards_transport(const cdb_shards* h) { return (h && h->tr) ? h->tr->name() : "none"; }
+
+int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows) {
+    if (!h || !ids || !counts || !nrows) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    return guarded_on(h, [&] {
+        // shards in order = ascending document index; one keyword: the lone-keyword kernel of every shard, concatenated
+        std::vector<int64_t> ri, rc;
+        for (int i = 0; i < std::max(h->used, 1); ++i) {
+            int64_t *pi = nullptr, *pc = nullptr;
+            size_t n = 0;
+            check_shard(h, i, cdb_query(h->shard[i], keyword, len, &pi, &pc, &n));
+            ri.insert(ri.end(), pi, pi + n);
+            rc.insert(rc.end(), pc, pc + n);
+            cdb_free(pi);
+            cdb_free(pc);
+        }
+        int64_t* oi = (int64_t*)std::malloc(std::max<size_t>(ri.size(), 1) * 8);
+        int64_t* oc = (int64_t*)std::malloc(std::max<size_t>(ri.size(), 1) * 8);
+        if (!oi || !oc) {
+            std::free(oi);
+            std::free(oc);
+            throw std::bad_alloc();
+        }
+        std::memcpy(oi, ri.data(), ri.size() * 8);
+        std::memcpy(oc, rc.data(), rc.size() * 8);
+        *ids = oi;
+        *counts = oc;
+        *nrows = ri.size();
+    });
+}
+
+int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+    if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    const int rc = guarded_on(h, [&] {
+        for (uint64_t j = 0; j < npat; ++j)
+            if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
+        std::lock_guard<std::mutex> g(h->mu);
+        const int G = std::max(h->used, 1);
+        if (G == 1) {
+            check_shard(h, 0, cdb_query_batch(h->shard[0], blob, offsets, npat, out));
+            return;
+        }
+        const uint64_t base = npat ? offsets[0] : 0, nbytes = npat ? offsets[npat] - base : 0;
+        std::vector<uint64_t> rel(npat + 1);
+        for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
+        std::vector<cdb_device_result> local(G), merged(G);
+        uint64_t hits = 0;
+        // every shard: patterns up (the host broadcasts over each GPU's own PCIe link) and the batched query ...
+        parallel_shards(G, [&](int i) {
+            Index& ix = h->shard[i]->ix;
+            std::lock_guard<std::mutex> lk(ix.mu);
+            CDB_HIP(hipSetDevice(ix.device));
+            StreamScope ss(ix.stream);
+            hipStream_t s = ix.stream;
+            ix.q_pat.ensure(nbytes + 16);
+            ix.q_offs.ensure((npat + 1) * 8);
+            if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
+            CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
+            const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+            local[i] = cdb_device_result{npat, r.nrows, r.nhits, ix.q_rowptr.as<uint64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>()};
+        });
+        for (int i = 0; i < G; ++i) hits += local[i].nhits;
+        // ... then the collective merge (a phase of its own: a shard that failed above never leaves the others waiting)
+        parallel_shards(G, [&](int i) {
+            std::lock_guard<std::mutex> lk(h->shard[i]->ix.mu);
+            merge_core(*h->ranks[i], local[i], merged[i]);
+        });
+        // the merged CSR is identical on every shard's device: rank 0 hands it to the host
+        Index& ix0 = h->shard[0]->ix;
+        CDB_HIP(hipSetDevice(ix0.device));
+        hipStream_t s = ix0.stream;
+        const cdb_device_result& m = merged[0];
+        out->npat = npat;
+        out->nrows = m.nrows;
+        out->nhits = hits;
+        out->row_ptr = (uint64_t*)host_alloc((npat + 1) * 8);
+        out->ids = (int64_t*)host_alloc(m.nrows * 8);
+        out->counts = (int64_t*)host_alloc(m.nrows * 8);
+        CDB_HIP(hipMemcpyAsync(out->row_ptr, m.d_row_ptr, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (m.nrows) {
+            CDB_HIP(hipMemcpyAsync(out->ids, m.d_ids, m.nrows * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipMemcpyAsync(out->counts, m.d_counts, m.nrows * 8, hipMemcpyDeviceToHost, s));
+        }
+        CDB_HIP(hipStreamSynchronize(s));
+    });
+    if (rc != CDB_OK) cdb_result_free(out);
+    return rc;
+}
+
+}  // extern "C"

@@ -95,7 +95,7 @@ class ShardMerger:
 
     def merge(self, r, npat):
         if self.comm is not None:
-            return self.comm.merge(self.index, r)
+            return self.comm.merge(r)
         torch = self.torch
         nrows = int(r.nrows)
         row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=self.device)

@@ -188,6 +188,45 @@ typedef struct cdb_device_hits {
 int cdb_query_batch_offsets_device(cdb_index* h, const void* d_blob, const uint64_t* d_offsets, uint64_t npat,
                                    uint64_t blob_bytes, cdb_device_result* out, cdb_device_hits* hits);
 
+/* ---- several GPUs: document-aligned shards (no reference counterpart: the reference is one process on one host) ----
+ * Suffixes never cross documents (src/index.h:61-65) and a result row belongs to one document (src/index.cpp:317-321),
+ * so a column splits into document-aligned byte ranges, one independent suffix array per GPU.  Every shard answers
+ * the whole pattern batch; the per-shard match lists are merged on the devices: all-gather of the row counts, one scan,
+ * all-gatherv of the rows over RCCL / xGMI (grouped broadcasts, every peer one hop away), a placement kernel — rows of a
+ * pattern stay ascending in document order because shards are document ranges.
+ *
+ * cdb_shards: ONE process owning several GPUs — what replaces string_index when the column exceeds one GPU (the shim
+ * switches to it).  Same surface as cdb_index: add / build / query / query_batch.  build() spreads the
+ * column over as many devices as max_shard_bytes requires (option "max_shard_bytes", default 12 GiB per GPU;
+ * "use_all_devices" = 1 spreads over all of them regardless); other options are forwarded to every shard. */
+typedef struct cdb_shards cdb_shards;
+int cdb_shards_create(cdb_shards** out, const int* devices, int ndev); /* devices may repeat (tests on a one-GPU box) */
+void cdb_shards_destroy(cdb_shards* h);
+const char* cdb_shards_last_error(const cdb_shards* h);
+int cdb_shards_add(cdb_shards* h, int64_t id, const char* value, size_t len);                 /* index.cpp:174-177 */
+int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
+int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value);
+int cdb_shards_build(cdb_shards* h);                                                           /* index.cpp:178-236 */
+int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows);
+int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
+/* introspection: shards in use after build, the handle of shard i (per-shard parity: its suffix array is that of its
+ * documents alone), its first document, and how the shards exchange ("rccl" / "device copies" / "none") */
+int cdb_shards_count(const cdb_shards* h);
+cdb_index* cdb_shards_get(cdb_shards* h, int i);
+uint64_t cdb_shards_first_doc(const cdb_shards* h, int i);
+const char* cdb_shards_transport(const cdb_shards* h);
+
+/* cdb_comm: one process per GPU (bench.py under torchrun; MPI-style services).  Rank 0 draws a 128-byte id
+ * (ncclGetUniqueId) and distributes it by whatever means the processes share; every rank then creates its communicator
+ * (ncclCommInitRank) and merges its shard's device-resident result with the others' — a collective call.  On return
+ * `merged` (identical on every rank) points to device arrays owned by the communicator, valid until its next merge. */
+typedef struct cdb_comm cdb_comm;
+int cdb_comm_unique_id(void* id128);
+int cdb_comm_create(cdb_comm** out, const void* id128, int rank, int world, int device);
+void cdb_comm_destroy(cdb_comm* c);
+const char* cdb_comm_last_error(const cdb_comm* c);
+int cdb_comm_merge(cdb_comm* c, const cdb_device_result* local, cdb_device_result* merged);
+
 /* ---- introspection (parity tests; mirrors the private members src/index.h:56-60) -------------- */
 uint64_t cdb_size(const cdb_index* h);  /* number of suffixes = text bytes */
 uint64_t cdb_bits(const cdb_index* h);  /* doc-index bits of an entry */
