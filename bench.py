@@ -141,7 +141,7 @@ def query_roofline(torch, r, npat, n, width, query_s, device):
                                        "latency-bound (dependent probes), so this is reported, not priced against HBM peak"}
 
 
-def run_config(torch, capi, W, name, rank, device, local_rank, reps=2):
+def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
     t_gen = time.perf_counter()
@@ -189,6 +189,16 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2):
             else:
                 r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), cfg["npat"], nbytes)
             qms.append((time.perf_counter() - t) * 1e3)
+        if make_merger is not None:  # N > 1: the shards' match lists merged over RCCL (cdb_comm_merge), every rank collective
+            merger = make_merger(g)
+            mms = []
+            for i in range(reps + 1):
+                t = time.perf_counter()
+                mres = merger.merge(r, cfg["npat"])
+                mms.append((time.perf_counter() - t) * 1e3)
+            out["merge_ms"] = [round(x, 3) for x in mms[1:]]
+            out["merged_rows"] = int(getattr(mres, "nrows", 0)) if not isinstance(mres, tuple) else int(mres[1].numel())
+            merger.close()
         out["query_ms"] = [round(x, 3) for x in qms[1:]]
         out["query_patterns_per_s"] = round(cfg["npat"] / (min(qms[1:]) * 1e-3), 1)
         out["query_hits_per_batch"] = int(r.nhits)
@@ -514,7 +524,8 @@ def main():
         blocks = {}
         for name in [x for x in extra.split(",") if x]:
             try:
-                res = run_config(torch, capi, W, name, rank, device, local_rank)
+                mk = (lambda gi: shard.ShardMerger(capi, gi, dist, rank, world, coll_device, device)) if world > 1 else None
+                res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk)
             except Exception as e:  # noqa: BLE001
                 res = {"workload": name, "error": repr(e)[:300]}
             if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N

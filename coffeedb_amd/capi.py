@@ -386,6 +386,15 @@ class GpuStringIndex:
         self._lib.cdb_profile_reset(self._h)
 
 
+class _BorrowedIndex(GpuStringIndex):
+    """A shard handle owned by its cdb_shards object: never destroyed from here."""
+
+    def close(self):
+        self._h = None
+
+    __del__ = close
+
+
 class GpuShards:
     """cdb_shards: the string index spread over several GPUs of one process (devices may repeat on a one-GPU box)."""
 
@@ -432,10 +441,9 @@ class GpuShards:
 
     def shard(self, i):
         """Borrowed GpuStringIndex view of shard i (do not close it)."""
-        g = GpuStringIndex.__new__(GpuStringIndex)
+        g = _BorrowedIndex.__new__(_BorrowedIndex)
         g._lib = self._lib
         g._h = C.c_void_p(self._lib.cdb_shards_get(self._h, i))
-        g.close = lambda: None
         return g
 
     def query(self, kw: bytes):

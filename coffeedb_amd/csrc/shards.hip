@@ -684,6 +684,7 @@ int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offs
         parallel_shards(G, [&](int i) {
             Index& ix = h->shard[i]->ix;
             std::lock_guard<std::mutex> lk(ix.mu);
+            if (std::getenv("CDB_DEBUG_SHARDS")) std::fprintf(stderr, "[shards] query: shard %d of %d handle %p device %d\n", i, G, (void*)h->shard[i], ix.device);
             CDB_HIP(hipSetDevice(ix.device));
             StreamScope ss(ix.stream);
             hipStream_t s = ix.stream;
