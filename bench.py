@@ -141,7 +141,7 @@ def query_roofline(torch, r, npat, n, width, query_s, device):
                                        "latency-bound (dependent probes), so this is reported, not priced against HBM peak"}
 
 
-def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None):
+def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
     t_gen = time.perf_counter()
@@ -189,8 +189,9 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
             else:
                 r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), cfg["npat"], nbytes)
             qms.append((time.perf_counter() - t) * 1e3)
-        if make_merger is not None:  # N > 1: the shards' match lists merged over RCCL (cdb_comm_merge), every rank collective
-            merger = make_merger(g)
+        if make_merger is not None and agree(True):  # N > 1: the shards' match lists merged over RCCL (cdb_comm_merge);
+            merger = make_merger(g)                  # collective — entered only when every rank got this far
+            out["merge_ms"] = None
             mms = []
             for i in range(reps + 1):
                 t = time.perf_counter()
@@ -217,6 +218,10 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         v = g.verify()
         out["verify"] = {"invalid_entries": int(v["invalid_entries"]), "inversions": int(v["inversions"]),
                          "tie_violations": int(v["tie_violations"]), "entry_sum_ok": bool(v["entry_sum"] == v["expected_entry_sum"])}
+    except Exception:
+        if agree is not None and "merge_ms" not in out and "query_ms" not in out:
+            agree(False)  # (the other ranks must not wait for this one in the merge)
+        raise
     finally:
         g.close()
         del text, d_blob, d_offs, d_ds, d_ids
@@ -525,7 +530,13 @@ def main():
         for name in [x for x in extra.split(",") if x]:
             try:
                 mk = (lambda gi: shard.ShardMerger(capi, gi, dist, rank, world, coll_device, device)) if world > 1 else None
-                res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk)
+
+                def agree(ok):
+                    t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
+                    dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+                    return bool(t_.item())
+
+                res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk, agree=agree if world > 1 else None)
             except Exception as e:  # noqa: BLE001
                 res = {"workload": name, "error": repr(e)[:300]}
             if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N
