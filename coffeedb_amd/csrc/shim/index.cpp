@@ -4,6 +4,7 @@
 #include "index.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../../include/coffeedb_gpu.h"
 #ifdef CDB_USE_REFERENCE_UTILITY
@@ -54,26 +55,82 @@ index::result_type bool_index::query(const std::string& range) const {
 
 // ---- string index: forwards to the GPU library
 namespace {
-[[noreturn]] void rethrow(const cdb_index* h, int rc) {
+[[noreturn]] void rethrow_msg(const std::string& msg, int rc) {
     // the library reports the reference's own wording for conditions the reference throws on
-    const std::string msg = cdb_last_error(h);
     if (rc == CDB_E_INVALID) throw std::runtime_error(msg);
     throw std::runtime_error("GPU index: " + msg);
+}
+[[noreturn]] void rethrow(const cdb_index* h, int rc) { rethrow_msg(cdb_last_error(h), rc); }
+[[noreturn]] void rethrow(const cdb_shards* h, int rc) { rethrow_msg(cdb_shards_last_error(h), rc); }
+
+// COFFEEDB_GPUS = "4" (devices 0..3) or "0,2,5": string columns may spread over these GPUs.  The library shards a
+// column only once it exceeds what one GPU should hold (cdb_shards: max_shard_bytes), so small columns keep living
+// on the first device.  Unset or one device: plain single-GPU handles.
+std::vector<int> shard_devices() {
+    std::vector<int> dev;
+    const char* e = std::getenv("COFFEEDB_GPUS");
+    if (!e || !*e) return dev;
+    const std::string v(e);
+    if (v.find(',') == std::string::npos) {
+        const int n = std::atoi(v.c_str());
+        for (int i = 0; i < n; ++i) dev.push_back(i);
+    } else {
+        size_t p = 0;
+        while (p < v.size()) {
+            const size_t q = v.find(',', p);
+            dev.push_back(std::atoi(v.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+            if (q == std::string::npos) break;
+            p = q + 1;
+        }
+    }
+    if (dev.size() < 2) dev.clear();
+    return dev;
+}
+
+std::pair<std::string, std::vector<uint64_t>> pack(const std::vector<std::string>& keywords) {
+    std::pair<std::string, std::vector<uint64_t>> out;
+    out.second.push_back(0);
+    for (const auto& k : keywords) {
+        out.first += k;
+        out.second.push_back(out.first.size());
+    }
+    return out;
 }
 }  // namespace
 
 string_index::string_index() {
+    const std::vector<int> dev = shard_devices();
+    if (!dev.empty()) {
+        if (cdb_shards_create(&shards, dev.data(), (int)dev.size()) != CDB_OK || !shards)
+            throw std::runtime_error("GPU index: no usable MI355X (gfx950) devices for COFFEEDB_GPUS");
+        if (const char* all = std::getenv("COFFEEDB_SHARD_ALL"); all && *all == '1')  // spread even small columns (tests)
+            (void)cdb_shards_set_option(shards, "use_all_devices", 1);
+        return;
+    }
     if (cdb_create(&handle, -1) != CDB_OK || !handle)
         throw std::runtime_error("GPU index: no usable MI355X (gfx950) device");
 }
-string_index::~string_index() { cdb_destroy(handle); }
+string_index::~string_index() {
+    cdb_destroy(handle);
+    cdb_shards_destroy(shards);
+}
 
 void string_index::add(int64_t id, std::string_view value) {
+    if (shards) {
+        const int rc = cdb_shards_add(shards, id, value.data(), value.size());
+        if (rc != CDB_OK) rethrow(shards, rc);
+        return;
+    }
     const int rc = cdb_add(handle, id, value.data(), value.size());
     if (rc != CDB_OK) rethrow(handle, rc);
 }
 
 void string_index::build() {
+    if (shards) {
+        const int rc = cdb_shards_build(shards);
+        if (rc != CDB_OK) rethrow(shards, rc);
+        return;
+    }
     const int rc = cdb_build(handle);
     if (rc != CDB_OK) rethrow(handle, rc);
 }
@@ -81,8 +138,13 @@ void string_index::build() {
 index::result_type string_index::query(const std::string& keyword) const {
     int64_t *ids = nullptr, *counts = nullptr;
     size_t rows = 0;
-    const int rc = cdb_query(handle, keyword.data(), keyword.size(), &ids, &counts, &rows);
-    if (rc != CDB_OK) rethrow(handle, rc);
+    if (shards) {
+        const int rc = cdb_shards_query(shards, keyword.data(), keyword.size(), &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(shards, rc);
+    } else {
+        const int rc = cdb_query(handle, keyword.data(), keyword.size(), &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(handle, rc);
+    }
     result_type out;
     out.reserve(rows);
     for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
@@ -92,15 +154,15 @@ index::result_type string_index::query(const std::string& keyword) const {
 }
 
 std::vector<index::result_type> string_index::query_batch(const std::vector<std::string>& keywords) const {
-    std::string blob;
-    std::vector<uint64_t> offs{0};
-    for (const auto& k : keywords) {
-        blob += k;
-        offs.push_back(blob.size());
-    }
+    const auto [blob, offs] = pack(keywords);
     cdb_result res;
-    const int rc = cdb_query_batch(handle, blob.data(), offs.data(), keywords.size(), &res);
-    if (rc != CDB_OK) rethrow(handle, rc);
+    if (shards) {
+        const int rc = cdb_shards_query_batch(shards, blob.data(), offs.data(), keywords.size(), &res);
+        if (rc != CDB_OK) rethrow(shards, rc);
+    } else {
+        const int rc = cdb_query_batch(handle, blob.data(), offs.data(), keywords.size(), &res);
+        if (rc != CDB_OK) rethrow(handle, rc);
+    }
     std::vector<result_type> out(keywords.size());
     for (size_t j = 0; j < keywords.size(); ++j) {
         out[j].reserve((size_t)(res.row_ptr[j + 1] - res.row_ptr[j]));
@@ -110,61 +172,68 @@ std::vector<index::result_type> string_index::query_batch(const std::vector<std:
     return out;
 }
 
+// The per-key operations below work shard by shard when the column is sharded: documents — hence object ids — are
+// disjoint across shards, so the union over shards is a concatenation (then ordered as the single-GPU call orders it).
 index::result_type string_index::query_any(const std::vector<std::string>& keywords) const {
-    std::string blob;
-    std::vector<uint64_t> offs{0};
-    for (const auto& k : keywords) {
-        blob += k;
-        offs.push_back(blob.size());
-    }
-    int64_t *ids = nullptr, *counts = nullptr;
-    size_t rows = 0;
-    const int rc = cdb_query_or(handle, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
-    if (rc != CDB_OK) rethrow(handle, rc);
+    const auto [blob, offs] = pack(keywords);
     result_type out;
-    out.reserve(rows);
-    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
-    cdb_free(ids);
-    cdb_free(counts);
+    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
+    for (int i = 0; i < parts; ++i) {
+        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
+        int64_t *ids = nullptr, *counts = nullptr;
+        size_t rows = 0;
+        const int rc = cdb_query_or(h, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(h, rc);
+        out.reserve(out.size() + rows);
+        for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+        cdb_free(ids);
+        cdb_free(counts);
+    }
+    if (parts > 1) std::sort(out.begin(), out.end());  // ascending object id, as cdb_query_or returns it
     return out;
 }
 
 index::result_type string_index::query_ranked(const std::vector<std::string>& keywords, int64_t corr_lo, int64_t corr_hi,
                                               uint64_t limit) const {
-    std::string blob;
-    std::vector<uint64_t> offs{0};
-    for (const auto& k : keywords) {
-        blob += k;
-        offs.push_back(blob.size());
-    }
-    int64_t *ids = nullptr, *counts = nullptr;
-    size_t rows = 0;
-    const int rc = cdb_query_ranked(handle, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
-    if (rc != CDB_OK) rethrow(handle, rc);
+    const auto [blob, offs] = pack(keywords);
     result_type out;
-    out.reserve(rows);
-    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
-    cdb_free(ids);
-    cdb_free(counts);
+    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
+    for (int i = 0; i < parts; ++i) {
+        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
+        int64_t *ids = nullptr, *counts = nullptr;
+        size_t rows = 0;
+        // every shard's own top `limit` rows contain its share of the global top `limit`
+        const int rc = cdb_query_ranked(h, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(h, rc);
+        out.reserve(out.size() + rows);
+        for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+        cdb_free(ids);
+        cdb_free(counts);
+    }
+    if (parts > 1) {  // descending count, ties ascending id (the order cdb_query_ranked defines)
+        std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
+        if (limit && out.size() > limit) out.resize(limit);
+    }
     return out;
 }
 
 std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> string_index::highlight_spans(
     const std::vector<std::string>& keywords) const {
-    std::string blob;
-    std::vector<uint64_t> offs{0};
-    for (const auto& k : keywords) {
-        blob += k;
-        offs.push_back(blob.size());
+    const auto [blob, offs] = pack(keywords);
+    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> out;
+    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
+    for (int i = 0; i < parts; ++i) {  // shard order = ascending document index
+        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
+        cdb_spans sp;
+        const int rc = cdb_query_spans(h, blob.data(), offs.data(), keywords.size(), &sp);
+        if (rc != CDB_OK) rethrow(h, rc);
+        const size_t base = out.size();
+        out.resize(base + sp.ndocs);
+        for (uint64_t d = 0; d < sp.ndocs; ++d) {
+            out[base + d].first = sp.ids[d];
+            for (uint64_t k = sp.span_ptr[d]; k < sp.span_ptr[d + 1]; ++k) out[base + d].second.emplace_back(sp.begin[k], sp.end[k]);
+        }
+        cdb_spans_free(&sp);
     }
-    cdb_spans sp;
-    const int rc = cdb_query_spans(handle, blob.data(), offs.data(), keywords.size(), &sp);
-    if (rc != CDB_OK) rethrow(handle, rc);
-    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> out(sp.ndocs);
-    for (uint64_t d = 0; d < sp.ndocs; ++d) {
-        out[d].first = sp.ids[d];
-        for (uint64_t k = sp.span_ptr[d]; k < sp.span_ptr[d + 1]; ++k) out[d].second.emplace_back(sp.begin[k], sp.end[k]);
-    }
-    cdb_spans_free(&sp);
     return out;
 }

@@ -18,7 +18,8 @@
 #include <utility>
 #include <vector>
 
-struct cdb_index;  // opaque GPU index (include/coffeedb_gpu.h)
+struct cdb_index;   // opaque GPU index (include/coffeedb_gpu.h)
+struct cdb_shards;  // ... spread over several GPUs (COFFEEDB_GPUS)
 
 class index {
 public:
@@ -95,6 +96,8 @@ public:
         const std::vector<std::string>& keywords) const;
 
 private:
-    cdb_index* handle = nullptr;
+    cdb_index* handle = nullptr;   // one GPU
+    cdb_shards* shards = nullptr;  // several GPUs (environment COFFEEDB_GPUS; the library shards a column only when it
+                                   // exceeds one GPU's share)
 };
 #endif

@@ -29,3 +29,15 @@ def test_shim_string_index_on_gpu():
         exe = _build()
     out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_string_index_spread_over_shards():
+    # the same database.cpp-style walk with every string column split over two shards (COFFEEDB_GPUS; both on device
+    # 0 here): add / build / query / query_batch through cdb_shards_*, OR / ranking / highlight shard by shard
+    exe = os.path.join(CPP, "test_index_shim")
+    if not os.path.exists(exe):
+        exe = _build()
+    env = dict(os.environ, COFFEEDB_GPUS="0,0", COFFEEDB_SHARD_ALL="1")
+    out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
