@@ -512,6 +512,23 @@ def main():
         merger.close()
 
     # ---- everything below is outside the timed region
+    if rank == 0 and world == 1 and small:
+        # the call database.cpp:392 makes: ONE keyword through cdb_query (one wavefront, host-mapped result)
+        try:
+            kws = [bytes(host_text[p:p + 8]) for p in range(1000, 1000 + 97 * 64, 97)]
+            for kw in kws[:8]:
+                g.query(kw)
+            lat = []
+            for kw in kws:
+                t = time.perf_counter()
+                g.query(kw)
+                lat.append((time.perf_counter() - t) * 1e6)
+            lat.sort()
+            out["single_query_us"] = {"median": round(lat[len(lat) // 2], 2), "p10": round(lat[len(lat) // 10], 2),
+                                      "p90": round(lat[(len(lat) * 9) // 10], 2), "keywords": len(kws),
+                                      "note": "cdb_query through the Python ctypes binding (adds ~2 us), 8-byte keywords, one caller"}
+        except Exception as e:  # noqa: BLE001
+            out["single_query_us"] = {"error": repr(e)[:200]}
     extra = args.configs
     if extra == "auto":
         extra = ("c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
