@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
 _LIB = None
 
 EXPORTS = [
-    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_save", "cdb_load",
-    "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
+    "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference",
@@ -44,6 +44,11 @@ class CdbHits(C.Structure):
 class CdbDeviceResult(C.Structure):
     _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
                 ("d_row_ptr", C.c_void_p), ("d_ids", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+class CdbKeyQuery(C.Structure):
+    _fields_ = [("index", C.c_void_p), ("blob", C.c_void_p), ("offsets", C.c_void_p), ("nkw", C.c_uint64),
+                ("ids", C.c_void_p), ("counts", C.c_void_p), ("nrows", C.c_size_t)]
 
 
 class CdbDeviceHits(C.Structure):
@@ -83,6 +88,7 @@ def load_library():
     lib.cdb_add_bulk.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_raw_record_find_string.argtypes = [vp, C.c_size_t, cp, C.POINTER(i64), C.POINTER(cp), C.POINTER(C.c_size_t)]
     lib.cdb_add_raw_record.argtypes = [vp, cp, vp, C.c_size_t]
+    lib.cdb_add_raw_dir.argtypes = [vp, cp, cp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdb_save.argtypes = [vp, cp]
     lib.cdb_load.argtypes = [vp, cp]
     lib.cdb_build.argtypes = [vp]
@@ -94,6 +100,8 @@ def load_library():
                                      C.POINTER(C.c_size_t)]
     lib.cdb_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
                                  C.POINTER(C.c_size_t)]
+    lib.cdb_query_and.argtypes = [C.POINTER(CdbKeyQuery), C.c_int, C.c_int, i64, i64, u64, C.POINTER(C.POINTER(i64)),
+                                  C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
     lib.cdb_query_spans.argtypes = [vp, vp, vp, u64, C.POINTER(CdbSpans)]
     lib.cdb_spans_free.argtypes = [C.POINTER(CdbSpans)]
     lib.cdb_spans_free.restype = None
@@ -199,6 +207,12 @@ class GpuStringIndex:
 
     def add_raw_record(self, key: bytes, record: bytes):
         self._check(self._lib.cdb_add_raw_record(self._h, key, record, len(record)))
+
+    def add_raw_dir(self, directory, key: bytes):
+        """Every record file of `directory` (ascending name order); returns (records parsed, documents added)."""
+        nrec, nadd = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.cdb_add_raw_dir(self._h, os.fsencode(directory), key, C.byref(nrec), C.byref(nadd)))
+        return nrec.value, nadd.value
 
     def save(self, path):
         self._check(self._lib.cdb_save(self._h, os.fsencode(path)))
@@ -499,6 +513,41 @@ class ShardComm:
             self._h = None
 
     __del__ = close
+
+
+def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):
+    """AND across keys on the device (cdb_query_and).  keys: (GpuStringIndex, [keywords]) for a string column or
+    (None, [(id, count), ...]) for rows resolved elsewhere (ascending id).  Returns [(id, summed count), ...]."""
+    lib = load_library()
+    arr = (CdbKeyQuery * len(keys))()
+    keep = []
+    lead = None
+    for k, (ix, data) in enumerate(keys):
+        if ix is not None:
+            lead = lead or ix
+            blob = np.frombuffer(b"".join(data), dtype=np.uint8)
+            offs = np.zeros(len(data) + 1, dtype=np.uint64)
+            np.cumsum([len(x) for x in data], out=offs[1:])
+            keep += [blob, offs]
+            arr[k].index = ix._h
+            arr[k].blob = blob.ctypes.data if len(blob) else None
+            arr[k].offsets = offs.ctypes.data
+            arr[k].nkw = len(data)
+        else:
+            ri = np.ascontiguousarray([r[0] for r in data], dtype=np.int64)
+            rc = np.ascontiguousarray([r[1] for r in data], dtype=np.int64)
+            keep += [ri, rc]
+            arr[k].ids = ri.ctypes.data if len(ri) else None
+            arr[k].counts = rc.ctypes.data if len(rc) else None
+            arr[k].nrows = len(ri)
+    ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+    rc_ = lib.cdb_query_and(arr, len(keys), 1 if ranked else 0, int(lo), int(hi), int(limit), C.byref(ids), C.byref(cnt), C.byref(n))
+    if rc_ != 0:
+        raise RuntimeError(lib.cdb_last_error(lead._h).decode(errors="replace") if lead is not None else "cdb_query_and: no string key")
+    out = [(ids[i], cnt[i]) for i in range(n.value)]
+    lib.cdb_free(ids)
+    lib.cdb_free(cnt)
+    return out
 
 
 def debug_radix_sort(d_keys_ptr, d_vals_ptr, n, val_bytes, key_bits, variant=0, device=-1):

@@ -1,6 +1,9 @@
 // capi.hip — the C ABI of libcoffeedb_gpu.so (include/coffeedb_gpu.h).  Host logic only: staging of
 // cdb_add, the reference's width rule, uploads/downloads and error translation.  All device work is in
 // sa_build.hip / query.hip / radix_sort.h.
+#include <dirent.h>
+
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -326,6 +329,64 @@ int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t
     }
     if (r == 0) return CDB_OK;  // the object has no string value under this key
     return cdb_add(h, id, v, vl);
+}
+
+// Bulk form of the raw-file ingest (database.cpp:170-275 walks storage_location/raw/ with a directory_iterator, parses
+// every record into a map and hands string_index::add a view of each value): here every record file of `dir` is read
+// once and the string stored under `key` goes straight into the concatenated staging column (text, doc_start, ids) —
+// no per-object map, no per-value std::string.  Files are taken in ascending NAME order (the reference's
+// directory order is unspecified; document order only shows in the entry encoding, never in a result).
+int cdb_add_raw_dir(cdb_index* h, const char* dir, const char* key, uint64_t* records, uint64_t* added) {
+    if (!h || !dir || !key) return CDB_E_INVALID;
+    if (records) *records = 0;
+    if (added) *added = 0;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        DIR* d = opendir(dir);
+        if (!d) throw Error(std::string("Cannot open directory: ") + dir);
+        std::vector<std::string> names;
+        while (const dirent* e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            names.emplace_back(e->d_name);
+        }
+        closedir(d);
+        std::sort(names.begin(), names.end());
+        ensure_host_staging(ix);
+        const size_t mark_ids = ix.ids.size(), mark_text = ix.host_text.size();
+        std::vector<char> buf;
+        uint64_t nrec = 0, nadd = 0;
+        try {
+            for (const std::string& name : names) {
+                const std::string path = std::string(dir) + "/" + name;
+                FILE* fp = std::fopen(path.c_str(), "rb");
+                if (!fp) throw Error("Cannot open file: " + path);
+                struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+                if (std::fseek(fp, 0, SEEK_END) != 0) throw Error("Cannot read file: " + path);
+                const long len = std::ftell(fp);
+                if (len < 0 || std::fseek(fp, 0, SEEK_SET) != 0) throw Error("Cannot read file: " + path);
+                buf.resize((size_t)len);
+                if (len && std::fread(buf.data(), 1, (size_t)len, fp) != (size_t)len) throw Error("Cannot read file: " + path);
+                int64_t id = 0;
+                const char* v = nullptr;
+                size_t vl = 0;
+                const int r = cdb_raw_record_find_string(buf.data(), buf.size(), key, &id, &v, &vl);
+                if (r < 0) throw Error("malformed raw record: " + path);
+                ++nrec;
+                if (r == 0) continue;  // the object has no string value under this key
+                ix.host_text.append(v, vl);
+                ix.ids.push_back(id);
+                ix.doc_start.push_back(ix.host_text.size());
+                ++nadd;
+            }
+        } catch (...) {  // all or nothing: a half-read directory must not leave a partial column behind
+            ix.ids.resize(mark_ids);
+            ix.doc_start.resize(mark_ids + 1);
+            ix.host_text.resize(mark_text);
+            throw;
+        }
+        if (records) *records = nrec;
+        if (added) *added = nadd;
+    });
 }
 
 // ---- f4: persistence of a built index (the reference rebuilds every index at start, server.cpp:44) ----
@@ -697,6 +758,99 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
 int cdb_query_ranked(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
                      uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
     return query_or_impl(h, blob, offsets, nkw, ids, counts, nrows, true, corr_lo, corr_hi, limit);
+}
+
+int cdb_query_and(const cdb_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi, uint64_t limit, int64_t** ids,
+                  int64_t** counts, size_t* nrows) {
+    if (!keys || nkeys < 1 || !ids || !counts || !nrows) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    cdb_index* lead = nullptr;  // the first string key: its stream runs the merge, its handle carries the error
+    for (int k = 0; k < nkeys; ++k)
+        if (keys[k].index && !lead) lead = keys[k].index;
+    if (!lead) return CDB_E_INVALID;
+    return guarded(lead, [&] {
+        Index& ix = lead->ix;
+        for (int k = 0; k < nkeys; ++k) {
+            const cdb_key_query& q = keys[k];
+            if (q.index) {
+                if (q.index->ix.device != ix.device) throw Error("cdb_query_and: all string keys must live on one GPU");
+                if (q.nkw == 0) throw Error("The constraint list cannot be empty");  // interface.cpp:75-77
+                if (!q.offsets) throw Error("cdb_query_and: keyword offsets missing");
+                for (uint64_t j = 0; j < q.nkw; ++j)
+                    if (q.offsets[j + 1] <= q.offsets[j]) throw Error("Empty keywords are not allowed");
+            } else if (q.nrows && (!q.ids || !q.counts)) {
+                throw Error("cdb_query_and: row list missing");
+            }
+        }
+        // every handle involved stays locked until the merge has read its rows (address order: no lock inversion)
+        std::vector<cdb_index*> hs;
+        for (int k = 0; k < nkeys; ++k)
+            if (keys[k].index) hs.push_back(keys[k].index);
+        std::sort(hs.begin(), hs.end());
+        hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+        std::vector<std::unique_lock<std::mutex>> locks;
+        for (cdb_index* p : hs) locks.emplace_back(p->ix.mu);
+        DeviceScope dscope(ix);
+        hipStream_t s = ix.stream;
+        std::vector<DeviceRows> lists;
+        std::vector<DevBuf> held;  // copies of rows that would be overwritten by a later query on the same handle
+        for (int k = 0; k < nkeys; ++k) {
+            const cdb_key_query& q = keys[k];
+            DevBuf di, dc;
+            uint64_t n = 0;
+            if (q.index) {
+                Index& kx = q.index->ix;
+                StreamScope kss(kx.stream);
+                const uint64_t base = q.offsets[0], nbytes = q.offsets[q.nkw] - base;
+                kx.q_pat.ensure(nbytes + 16);
+                kx.q_offs.ensure((q.nkw + 1) * 8);
+                std::vector<uint64_t> rel(q.nkw + 1);
+                for (uint64_t j = 0; j <= q.nkw; ++j) rel[j] = q.offsets[j] - base;
+                CDB_HIP(hipMemcpyAsync(kx.q_pat.p, q.blob + base, nbytes, hipMemcpyHostToDevice, kx.stream));
+                CDB_HIP(hipMemcpyAsync(kx.q_offs.p, rel.data(), (q.nkw + 1) * 8, hipMemcpyHostToDevice, kx.stream));
+                const DeviceCsr r = query_or_on_device(kx, kx.q_pat.as<uint8_t>(), kx.q_offs.as<uint64_t>(), q.nkw);  // (synchronises)
+                n = r.nrows;
+                di.alloc(std::max<uint64_t>(n, 1) * 8);
+                dc.alloc(std::max<uint64_t>(n, 1) * 8);
+                if (n) {
+                    CDB_HIP(hipMemcpyAsync(di.p, kx.q_ids.p, n * 8, hipMemcpyDeviceToDevice, s));
+                    CDB_HIP(hipMemcpyAsync(dc.p, kx.q_counts.p, n * 8, hipMemcpyDeviceToDevice, s));
+                }
+            } else {  // rows resolved elsewhere (numeric / bool keys: index.cpp:63-74,129-173 return (id, 0) rows)
+                n = q.nrows;
+                di.alloc(std::max<uint64_t>(n, 1) * 8);
+                dc.alloc(std::max<uint64_t>(n, 1) * 8);
+                if (n) {
+                    CDB_HIP(hipMemcpyAsync(di.p, q.ids, n * 8, hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipMemcpyAsync(dc.p, q.counts, n * 8, hipMemcpyHostToDevice, s));
+                }
+            }
+            lists.push_back(DeviceRows{di.as<int64_t>(), dc.as<int64_t>(), n});
+            held.push_back(std::move(di));
+            held.push_back(std::move(dc));
+        }
+        CDB_HIP(hipStreamSynchronize(s));  // (host rows are pageable)
+        const DeviceCsr r = and_merge_on_device(ix, lists, ranked != 0, corr_lo, corr_hi, limit);
+        int64_t* hi = (int64_t*)host_alloc(r.nrows * 8);
+        int64_t* hc = nullptr;
+        try {
+            hc = (int64_t*)host_alloc(r.nrows * 8);
+            if (r.nrows) {
+                CDB_HIP(hipMemcpyAsync(hi, ix.q_ids.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipMemcpyAsync(hc, ix.q_counts.p, r.nrows * 8, hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipStreamSynchronize(s));
+            }
+        } catch (...) {
+            host_free(hi);
+            host_free(hc);
+            throw;
+        }
+        *ids = hi;
+        *counts = hc;
+        *nrows = (size_t)r.nrows;
+    });
 }
 
 int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {

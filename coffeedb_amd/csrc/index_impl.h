@@ -172,6 +172,16 @@ DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d
 DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
                                  uint64_t limit);
 
+// AND across keys (interface.cpp:114-134): intersection of row lists (each ascending by id, ids unique within a list)
+// by object id with summed counts, on ix's stream; rows land in ix.q_ids / q_counts — ascending id, or filtered to
+// lo <= count < hi and ranked (descending count, ties ascending id, at most `limit` rows) when `ranked`
+struct DeviceRows {
+    const int64_t* d_ids;
+    const int64_t* d_counts;
+    uint64_t n;
+};
+DeviceCsr and_merge_on_device(Index& ix, const std::vector<DeviceRows>& lists, bool ranked, int64_t lo, int64_t hi, uint64_t limit);
+
 }  // namespace cdb
 
 // the object behind the C ABI's opaque handle (capi.hip, shards.hip)

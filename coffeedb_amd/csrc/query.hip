@@ -1382,9 +1382,8 @@ __global__ __launch_bounds__(256) void q_ranked_out_kernel(const uint64_t* __res
     counts[r] = (int64_t)~key[r];
 }
 
-DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
-                                 uint64_t limit) {
-    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat) : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+// rows (ids ascending) in ix.q_ids / q_counts -> filtered to lo <= count < hi and ranked, in place
+static DeviceCsr rank_rows_on_device(Index& ix, DeviceCsr r, int64_t lo, int64_t hi, uint64_t limit) {
     hipStream_t s = ix.stream;
     if (r.nrows == 0) {
         ix.prof.resolve();
@@ -1413,6 +1412,82 @@ DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_
     CDB_HIP(hipStreamSynchronize(s));
     ix.prof.resolve();
     return r;
+}
+
+DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
+                                 uint64_t limit) {
+    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat) : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    return rank_rows_on_device(ix, r, lo, hi, limit);
+}
+
+// ---- AND across keys (interface.cpp:114-134) ---------------------------------------------------------------------
+// filter() intersects the per-key row lists by object id and adds the counts up.  Every list holds an id at most once
+// and ascends by id, so after ONE stable sort of the concatenated lists an id survives iff it heads a run of exactly
+// `nlists` equal keys; the run's counts are summed on the way out (compaction by scan).  The $correlation filter and
+// the ranking (interface.cpp:137-146) follow on the device as for a single key.
+__global__ __launch_bounds__(256) void q_and_flip_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ counts, uint64_t n,
+                                                         uint64_t* __restrict__ key, uint64_t* __restrict__ val) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    key[r] = (uint64_t)ids[r] ^ (1ull << 63);  // unsigned order == signed order
+    val[r] = (uint64_t)counts[r];
+}
+struct AndIn {  // 1 where slot i closes a run of nl equal ids
+    const uint64_t* key;
+    uint64_t nl;
+    __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return i + 1 >= nl && key[i + 1 - nl] == key[i] ? 1ull : 0ull; }
+};
+struct AndOut {
+    const uint64_t* key;
+    const uint64_t* val;
+    uint64_t nl;
+    int64_t* ids;
+    int64_t* counts;
+    __device__ __forceinline__ void operator()(uint64_t i, uint64_t ex, uint64_t in) const {
+        if (in == ex) return;
+        uint64_t sum = 0;
+        for (uint64_t q = 0; q < nl; ++q) sum += val[i - q];
+        ids[ex] = (int64_t)(key[i] ^ (1ull << 63));
+        counts[ex] = (int64_t)sum;
+    }
+};
+
+DeviceCsr and_merge_on_device(Index& ix, const std::vector<DeviceRows>& lists, bool ranked, int64_t lo, int64_t hi, uint64_t limit) {
+    hipStream_t s = ix.stream;
+    DeviceCsr out;
+    ix.q_ids.ensure(16);
+    ix.q_counts.ensure(16);
+    uint64_t total = 0;
+    for (const DeviceRows& l : lists) {
+        if (l.n == 0) return out;  // an empty list empties the intersection
+        total += l.n;
+    }
+    if (lists.empty()) return out;
+    DevBuf k0, k1, v0, v1;
+    k0.alloc(total * 8); k1.alloc(total * 8); v0.alloc(total * 8); v1.alloc(total * 8);
+    uint64_t at = 0;
+    for (const DeviceRows& l : lists) {
+        hipLaunchKernelGGL(q_and_flip_kernel, dim3((unsigned)ceil_div(l.n, 256)), dim3(256), 0, s, l.d_ids, l.d_counts, l.n,
+                           k0.as<uint64_t>() + at, v0.as<uint64_t>() + at);
+        at += l.n;
+    }
+    const int sel = radix_sort<uint64_t, uint64_t>(s, ix.rws, ix.prof, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint64_t>(), v1.as<uint64_t>(),
+                                                   total, 0, 64, nullptr);
+    const uint64_t* key = (sel ? k1 : k0).as<uint64_t>();
+    const uint64_t* val = (sel ? v1 : v0).as<uint64_t>();
+    AndIn ain{key, (uint64_t)lists.size()};
+    const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, ain, total, OpAdd{}, (uint64_t)0);
+    ix.q_ids.ensure(std::max<uint64_t>(nrows, 2) * 8);
+    ix.q_counts.ensure(std::max<uint64_t>(nrows, 2) * 8);
+    scan_apply<uint64_t>(s, ix.scan_partials, ain, total, OpAdd{}, (uint64_t)0,
+                         AndOut{key, val, (uint64_t)lists.size(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>()});
+    out.nrows = nrows;
+    CDB_HIP(hipGetLastError());
+    radix_check_error(s, ix.rws);
+    CDB_HIP(hipStreamSynchronize(s));
+    if (ranked) return rank_rows_on_device(ix, out, lo, hi, limit);
+    ix.prof.resolve();
+    return out;
 }
 
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {

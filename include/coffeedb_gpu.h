@@ -79,6 +79,11 @@ int cdb_add_bulk(cdb_index* h, const int64_t* ids, const char* blob, const uint6
 int cdb_raw_record_find_string(const void* record, size_t len, const char* key, int64_t* id, const char** value,
                                size_t* value_len);
 int cdb_add_raw_record(cdb_index* h, const char* key, const void* record, size_t len);
+/* Bulk form: every record file of directory `dir` (CoffeeDB's storage_location/raw/, one file per object) in ascending
+ * file-name order; the string under `key` of each record goes straight into the staged column.  *records = files
+ * parsed, *added = documents added.  All or nothing: a malformed or unreadable file fails the call and leaves the
+ * staged column as it was. */
+int cdb_add_raw_dir(cdb_index* h, const char* dir, const char* key, uint64_t* records, uint64_t* added);
 
 /* Persistence of a built index (the reference has none and rebuilds every index at start,
  * server.cpp:44): header + ids + doc_start + text + suffix array.  cdb_load restores a queryable index
@@ -148,6 +153,26 @@ int cdb_query_or(cdb_index* h, const char* blob, const uint64_t* offsets, uint64
  * tie order when that is wanted bit for bit).  Release ids/counts with cdb_free. */
 int cdb_query_ranked(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
                      uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows);
+
+/* AND across keys — replaces the second half of filter() (interface.cpp:114-146): the per-key row lists are intersected
+ * by object id with the counts added up, then optionally filtered by the $correlation range and ranked, all on the
+ * device.  A key is either a string column (index + its keyword list: resolved here with the OR of cdb_query_or) or a
+ * row list resolved elsewhere (index = NULL: numeric and bool keys return (id, 0) rows, ascending by id, each id once).
+ * ranked = 0: rows ascending by object id (the list filter() holds after line 134; corr_* and limit ignored);
+ * ranked = 1: corr_lo <= count < corr_hi, descending count, ties ascending id, at most `limit` rows (0 = all).
+ * All string keys must live on one GPU; errors are reported on the first string key's handle.  Release ids / counts
+ * with cdb_free. */
+typedef struct cdb_key_query {
+    cdb_index* index;        /* string key, or NULL */
+    const char* blob;        /* its keywords: blob[offsets[j] .. offsets[j+1]) */
+    const uint64_t* offsets;
+    uint64_t nkw;
+    const int64_t* ids;      /* index == NULL: host rows */
+    const int64_t* counts;
+    size_t nrows;
+} cdb_key_query;
+int cdb_query_and(const cdb_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi, uint64_t limit, int64_t** ids,
+                  int64_t** counts, size_t* nrows);
 
 /* Highlight spans — replaces the per-document re-scan of ac_automaton::render (database.cpp:58-76) that
  * select() runs for every returned object (database.cpp:394-441): for the keyword list of ONE string

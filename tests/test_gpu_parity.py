@@ -811,3 +811,77 @@ def test_hybrid_sort_option_matches_oracle(G):
         g, _ = _check_parity(G, blob, ds, patterns=pats, hybrid=2)
         took += g.stat("hybrid") > 0
     assert took >= 2
+
+
+def test_bulk_raw_directory_ingest(G, tmp_path):
+    # f3: a raw/ directory in the reference's on-disk layout (database.cpp:334-378: one file per object, named by its
+    # id) loaded in one call; same index as adding the values one by one; malformed files fail the call atomically
+    from tests.test_capi_cpu import _raw_record
+    blob, ds = W.ragged_corpus(300, 60, seed=14, lo=0x61, hi=0x64, empty_every=9)
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    ids = [1700000000000 + 37 * d for d in range(300)]
+    for d in range(300):
+        text = bytes(blob[int(ds[d]):int(ds[d + 1])])
+        fields = [(b"number", d), (b"flag", d % 2 == 0)]
+        if d % 10 != 3:                                            # some objects have no such key
+            fields.insert(1, (b"body", text))
+        fields.append((b"title", b"t%d" % d))
+        (raw / str(ids[d])).write_bytes(_raw_record(ids[d], fields))
+    g = G()
+    assert g.add_raw_dir(raw, b"body") == (300, 270)
+    g.build()
+    keep = [d for d in range(300) if d % 10 != 3]
+    order = sorted(keep, key=lambda d: str(ids[d]))                # ascending file name
+    h = G()
+    for d in order:
+        h.add(ids[d], bytes(blob[int(ds[d]):int(ds[d + 1])]))
+    h.build()
+    assert np.array_equal(g.sa(), h.sa()) and (g.size, g.bits) == (h.size, h.bits)
+    for kw in (b"ab", b"dcb", b"a"):
+        assert g.query(kw) == h.query(kw)
+    (raw / "zzz-broken").write_bytes(b"\\x01\\x02\\x03")
+    t = G()
+    t.add(5, b"keep me")
+    with pytest.raises(RuntimeError, match="malformed raw record"):
+        t.add_raw_dir(raw, b"body")
+    t.build()
+    assert t.size == 7 and t.query(b"keep") == [(5, 1)]
+    with pytest.raises(RuntimeError, match="Cannot open directory"):
+        t.add_raw_dir(tmp_path / "nope", b"body")
+
+
+def test_and_merge_across_keys_matches_reference_loop(G):
+    # interface.cpp:114-146: per-key lists intersected by object id with summed counts, $correlation filter, ranking —
+    # on the device (cdb_query_and) against the restated merge loop over oracle results
+    from coffeedb_amd import capi
+    nd = 3000
+    ids = np.arange(nd, dtype=np.int64) * 3 - 1500                      # (negative ids too)
+    cols = [W.ascii_corpus(nd, 60, seed=s_, lo=0x61, hi=0x64) for s_ in (1, 2)]
+    gs = [_gpu(G, b, d, ids) for b, d in cols]
+    os_ = [_oracle(b, d, ids) for b, d in cols]
+    numeric = [(int(i), 0) for i in ids[::2]]                              # an integer key's rows: (id, 0), ascending id
+
+    def ref_or(o, kws):
+        acc = {}
+        for kw in kws:
+            for i, c in o.query(kw):
+                acc[i] = acc.get(i, 0) + c
+        return acc
+
+    for kws_a, kws_b, with_num in (([b"ab", b"cd"], [b"ba"], False), ([b"abc"], [b"d", b"aa"], True), ([b"zz"], [b"a"], False),
+                                   ([b"a"], [b"b"], True)):
+        a, b = ref_or(os_[0], kws_a), ref_or(os_[1], kws_b)
+        want = {i: a[i] + b[i] for i in a if i in b}
+        keys = [(gs[0], kws_a), (gs[1], kws_b)]
+        if with_num:
+            want = {i: c for i, c in want.items() if (i + 1500) % 6 == 0}
+            keys.insert(1, (None, numeric))
+        got = capi.query_and(keys)
+        assert got == sorted(want.items()), (kws_a, kws_b)
+        ranked = capi.query_and(keys, ranked=True, lo=2, hi=6, limit=40)
+        exp = sorted(((i, c) for i, c in want.items() if 2 <= c < 6), key=lambda r: (-r[1], r[0]))[:40]
+        assert ranked == exp, (kws_a, kws_b)
+    assert capi.query_and([(gs[0], [b"ab"])]) == sorted(ref_or(os_[0], [b"ab"]).items())   # one key: its own OR list
+    with pytest.raises(RuntimeError, match="Empty keywords"):
+        capi.query_and([(gs[0], [b"ab"]), (gs[1], [b""])])
