@@ -1115,6 +1115,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
+    else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
     else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;

@@ -116,6 +116,7 @@ struct Index {
     int initial_passes = 0;
     int sort_variant = 0;
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
+    bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;

@@ -1104,10 +1104,9 @@ void build_typed(Index& ix, bool big) {
     }
     if (ix.digit_bits > 0) dbits = ix.digit_bits;
     if (big) {
-        // the bucket-wise sort partitions on whole symbols and generates its keys from the text
-        if (symbits > 8 || nsym > HC_MAXSYM)
-            throw Error("corpora of 4 GiB and more need an alphabet of at most 255 byte values");
-        dbits = symbits;
+        // the bucket-wise sort partitions by the FIRST symbol and gathers the keys behind it bucket by bucket
+        if (nsym > HC_MAXSYM) throw Error("internal: key of more than 16 symbols on the bucket-wise path");
+        dbits = std::min(symbits, 8);
     }
     // Key coding.  Bit-aligned symbols (base 2^symbits) waste log2(2^symbits / (alphabet + 1)) bits per
     // symbol; the dense base-(alphabet + 1) number is used when it saves a whole radix pass (95-symbol
@@ -1235,7 +1234,7 @@ void build_typed(Index& ix, bool big) {
     if (fused && dense) {
         if (plan.ok) key_histograms(plan.G, plan.w, plan.magic);
         else key_histograms((int)ceil_div(key_bits, 8), 0, 0);
-    } else if (fused) {
+    } else if (fused && !big) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
         const size_t corr_words = (size_t)HC_MAXSYM * 257 + HC_MAXSYM;
@@ -1418,10 +1417,28 @@ void build_typed(Index& ix, bool big) {
         E.alloc(n * sizeof(V));
         st.alloc_ms += now_ms() - ta;
         const int top_shift = (nsym - 1) * symbits;
-        const uint64_t* h_first = &h_hist[(size_t)(nsym - 1) * 256];
+        // Every position starts a suffix, and a suffix is never empty: the first symbol is never "end of document", so
+        // the partition digit is code - 1 (0 .. alphabet - 1: 8 bits even for all 256 byte values, where the codes
+        // 1 .. 256 themselves need 9) and its histogram is simply the byte histogram.
+        std::vector<uint64_t> first_by_code(258, 0), first_digit(256, 0);
+        uint16_t h_map_first[256];
+        for (int b = 0; b < 256; ++b) {
+            h_map_first[b] = h_map[b] ? (uint16_t)(h_map[b] - 1) : (uint16_t)0;
+            if (h_map[b]) {
+                first_by_code[h_map[b]] = h_counts[b];
+                first_digit[h_map[b] - 1] = h_counts[b];
+            }
+        }
+        const uint64_t* h_first = first_by_code.data();  // (indexed by symbol code 1 .. alphabet)
+        DevBuf d_symmap_first;
+        d_symmap_first.alloc(256 * sizeof(uint16_t));
+        CDB_HIP(hipMemcpyAsync(d_symmap_first.p, h_map_first, sizeof(h_map_first), hipMemcpyHostToDevice, s));
+        CDB_HIP(hipStreamSynchronize(s));  // (h_map_first is a stack array)
         gen.first_only = true;
-        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n,
-                                      top_shift, key_bits, &ss, ix.sort_variant, dbits, h_first, &gen);
+        gen.symmap = d_symmap_first.as<uint16_t>();
+        const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
+        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
+                                      &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
         uint64_t maxb = 0;
         for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
         // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
@@ -1443,7 +1460,7 @@ void build_typed(Index& ix, bool big) {
         const bool bwide = bbits > 48 && bbits <= 56;
         // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
         //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
-        const bool brecords = ix.narrow_keys && sigma < 255 && blow >= 0 && nsym > 1;
+        const bool brecords = ix.narrow_keys && blow >= 0 && nsym > 1;  // (codes up to 256 are u16 in the record kernel)
         st.key_layout = brecords ? (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3))) : 0;
         if (brecords) {
             const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
@@ -1738,6 +1755,7 @@ void build_typed(Index& ix, bool big) {
         st.rounds++;
         if (st.rounds > 80) throw Error("suffix-array refinement did not converge (internal error)");
     }
+    if (ix.debug_fail_build) throw Error("debug: build failure requested (test hook)");
     st.final_depth = h;
     st.sort_passes = ss.passes_run;
     st.sort_passes_skipped = ss.passes_skipped;

@@ -514,20 +514,34 @@ def test_concurrent_queries_same_handle(G):
 
 
 def test_failed_build_leaves_index_unbuilt(G):
-    # a build that cannot complete (here: >= 4 GiB path forced on a full 256-value alphabet) must leave a
-    # queryable "never built" index behind, not a half-built one
+    # a build that cannot complete (test hook: it throws after its sorts) must leave a queryable "never built" index
+    # behind, not a half-built one
     blob, ds = W.ascii_corpus(300, 64, seed=3, lo=0x00, hi=0xFF)
     g = G()
     g.add_bulk(np.arange(300, dtype=np.int64), blob, ds)
     g.build()
     assert g.query(bytes(blob[:2]))
-    g.set_option("force_big_path", 1)
-    with pytest.raises(RuntimeError, match="alphabet"):
+    g.set_option("debug_fail_build", 1)
+    with pytest.raises(RuntimeError, match="build failure requested"):
         g.build()
     assert g.sa_width == 0 and g.query(bytes(blob[:2])) == []
-    g.set_option("force_big_path", 0)
+    g.set_option("debug_fail_build", 0)
     g.build()
     assert g.query(bytes(blob[:2]))
+
+
+def test_bucket_wise_path_with_all_256_byte_values(G):
+    # corpora of 4 GiB and more (here: the same code path forced at small size) with every byte value present: the
+    # first-symbol partition runs on code - 1 (8 bits), the keys behind it carry 9-bit codes (reference: 257 buckets,
+    # index.cpp:96-126, no alphabet limit)
+    for seed, shape in ((3, (600, 64)), (5, (3000, 100))):
+        blob, ds = W.ascii_corpus(*shape, seed=seed, lo=0x00, hi=0xFF)
+        assert len(np.unique(blob)) == 256
+        pats = W.sample_patterns(blob, ds, 200, 1, 3, seed=2, miss_frac=0)
+        for group_limit in (0, 5000):
+            g, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, bucket_group_limit=group_limit)
+            assert g.stat("bucketed") == 1
+        _check_parity(G, blob, ds, patterns=pats, force_big_path=1, reference_compat=0, narrow_keys=0)
 
 
 def test_rebuild_after_more_adds(G):
