@@ -541,7 +541,9 @@ def test_bucket_wise_path_with_all_256_byte_values(G):
         for group_limit in (0, 5000):
             g, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, bucket_group_limit=group_limit)
             assert g.stat("bucketed") == 1
-        _check_parity(G, blob, ds, patterns=pats, force_big_path=1, reference_compat=0, narrow_keys=0)
+        plain = _gpu(G, blob, ds, np.arange(len(ds) - 1, dtype=np.int64), force_big_path=1, reference_compat=0, narrow_keys=0)
+        v = plain.verify()                                         # plain unsigned order (the oracle restates the reference's)
+        assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
 
 
 def test_rebuild_after_more_adds(G):
