@@ -1105,7 +1105,7 @@ void build_typed(Index& ix, bool big) {
     if (ix.digit_bits > 0) dbits = ix.digit_bits;
     if (big) {
         // the bucket-wise sort partitions by the FIRST symbol and gathers the keys behind it bucket by bucket
-        if (nsym > HC_MAXSYM) throw Error("internal: key of more than 16 symbols on the bucket-wise path");
+        nsym = std::min(nsym, HC_MAXSYM);  // (the record gather reads two 8-byte windows behind the first symbol)
         dbits = std::min(symbits, 8);
     }
     // Key coding.  Bit-aligned symbols (base 2^symbits) waste log2(2^symbits / (alphabet + 1)) bits per

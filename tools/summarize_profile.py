@@ -5,7 +5,7 @@ coalesced reads by 2x (MI355X_MICROARCH.md §HBM: requests tallied at 64 B inste
 corrected read traffic is 2 x FETCH_SIZE; WRITE_SIZE is taken as is.  Kernel instantiations are mapped
 to the names the library's own HIP-event profiler uses (rs_onesweep_k64_v32_t<tile>, ...), so that
 bench.py can quote `roofline.traffic` for exactly the kernel it times.
-usage: summarize_profile.py <gpurun_out/prof_dir> [traffic.json]
+usage: summarize_profile.py <gpurun_out/prof_dir> [traffic.json [tag commit suffixes]]
 """
 import csv
 import glob
@@ -26,15 +26,15 @@ def find(sub, pat):
 def family(name):
     """rocprof kernel name -> the library profiler's name for the same instantiation."""
     m = re.search(r"rs_onesweep_kernel<(unsigned int|unsigned long), (unsigned int|unsigned long|cdb::NoVal), "
-                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|cdb::NoVal)>", name)
+                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|unsigned short|cdb::NoVal)>", name)
     if m:
         k = {"unsigned int": "k32", "unsigned long": "k64"}[m.group(1)]
         v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(2)]
         tile = int(m.group(3)) * int(m.group(4))
-        split = m.group(6) == "unsigned char"
+        aux = {"unsigned char": "_w8", "unsigned short": "_w16", "cdb::NoVal": ""}[m.group(6)]
         if m.group(5) == "TextGen":
-            return f"rs_onesweep_textgen{'_split' if split else ''}_t{tile}"
-        return f"rs_onesweep_{k}{v}{'_w8' if split else ''}_t{tile}"
+            return f"rs_onesweep_textgen{'_split' if aux else ''}_t{tile}"
+        return f"rs_onesweep_{k}{v}{aux}_t{tile}"
     m = re.search(r"(?:cdb::(?:\(anonymous namespace\)::)?)(\w+?)(?:_kernel)?[<(]", name)
     return m.group(1) if m and "cdb::" in name else name.split("(")[0][:48]
 
@@ -76,6 +76,10 @@ if fetch or write:
         print(f"{k:34s} launches={nf:4d} FETCH={fb/1e9:8.3f} GB (x2 -> {2*fb/1e9:8.3f}) WRITE={wb/1e9:8.3f} GB "
               f"traffic={(2*fb+wb)/1e9:8.3f} GB/launch")
 if len(sys.argv) > 2 and traffic:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 "
+    meta = {}
+    if len(sys.argv) > 3:   # tag commit suffixes_per_step
+        meta = {"profile": sys.argv[3], "commit": sys.argv[4] if len(sys.argv) > 4 else None,
+                "suffixes": int(sys.argv[5]) if len(sys.argv) > 5 else None}
+    json.dump({**meta, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 "
                          "--warmup 0 --no-cpu-baseline`; read side x2 (gfx950 FETCH_SIZE correction)",
                "kernels": traffic}, open(sys.argv[2], "w"), indent=1)
