@@ -339,6 +339,8 @@ def main():
                     help="rendezvous backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
                          "exercise the N > 1 code path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only)")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="run the RCCL merge of the N > 1 step with a one-rank communicator (testing the plumbing on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -416,7 +418,7 @@ def main():
 
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
-    merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device) if world > 1 else None
+    merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device) if (world > 1 or args.force_merge) else None
 
     def step():
         # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step

@@ -90,7 +90,8 @@ class ShardMerger:
             uid = torch.zeros(128, dtype=torch.uint8, device=device)
             if rank == 0:
                 uid.copy_(torch.from_numpy(capi.ShardComm.unique_id()).to(device))
-            dist.broadcast(uid, 0)
+            if world > 1:
+                dist.broadcast(uid, 0)
             self.comm = capi.ShardComm(uid.cpu().numpy(), rank, world, device.index or 0)
 
     def merge(self, r, npat):

@@ -78,3 +78,19 @@ def test_raw_record_parser(lib):
     for cut in (3, 11, 20, len(rec) - 1):
         with pytest.raises(ValueError):
             capi.raw_record_find_string(rec[:cut], b"secret")
+
+
+def test_sharded_and_bulk_entry_points_refuse_cleanly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    dev = (C.c_int * 2)(0, 0)
+    assert lib.cdb_shards_create(C.byref(h), dev, 2) == 2 and not h.value      # CDB_E_DEVICE, nothing half-created
+    assert lib.cdb_shards_create(C.byref(h), dev, 0) == 1                      # CDB_E_INVALID
+    assert lib.cdb_add_raw_dir(None, b"/tmp", b"k", None, None) == 1
+    ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+    assert lib.cdb_query_and(None, 0, 0, 0, 0, 0, C.byref(ids), C.byref(cnt), C.byref(n)) == 1
+    assert lib.cdb_comm_merge(None, None, None) == 1
+    lib.cdb_shards_destroy(None)
+    lib.cdb_comm_destroy(None)
