@@ -87,6 +87,7 @@ struct Index {
     DevBuf d_keys;                    // optional: the sorted initial keys (first key_nsym symbol codes of every
                                       // suffix, packed) kept for the search: one load decides most probes
     DevBuf d_symmap_q;                // byte -> symbol code (u16[256]) matching d_keys
+    uint16_t h_symmap_q[256] = {};    // ... and its host copy (the lone-keyword path codes its keyword on the host)
     DevBuf d_keys32, d_keylow;        // ... or, after a narrow / split sort, key >> key_low_bits as u32 and (split) the
     int key_low_bits = 0;             // low digit(s) in one or two bytes per suffix: 5-6 instead of 8 bytes per suffix
     int key_low_bytes = 0;

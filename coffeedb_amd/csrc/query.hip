@@ -1053,6 +1053,16 @@ struct SingleKw {
     uint32_t len;
     uint8_t bytes[124];
 };
+// kept sort keys for the lone-keyword kernel: suffixes starting with the keyword's first min(m, nsym) symbols are
+// exactly those with key in [klo, khi] (coded on the host); decisive = the keyword has at most nsym symbols
+struct SingleKeys {
+    const uint64_t* keys64 = nullptr;
+    const uint32_t* keys32 = nullptr;
+    const void* keylow = nullptr;
+    int low_bits = 0, low_bytes = 0, nsym = 0;
+    bool decisive = false;
+    uint64_t klo = 0, khi = 0;
+};
 constexpr uint32_t SINGLE_MAX_HITS = 4096;
 struct SingleOut {
     uint64_t nrows;  // written LAST by the kernel; ~0 = still pending, ~0 - 1 = not answered here (more than SINGLE_MAX_HITS hits)
@@ -1066,7 +1076,7 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
                                                       const uint8_t* __restrict__ text,
                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                       const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out,
-                                                      bool sorted) {
+                                                      bool sorted, SingleKeys sk) {
     __shared__ uint8_t s_kw[128];
     __shared__ int64_t s_left;
     __shared__ uint64_t s_hits;
@@ -1083,6 +1093,36 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
     // three-way compare of the keyword with the suffix at slot M: <0 keyword smaller, 0 keyword is a prefix of
     // the suffix or equal on the common part
     auto probe = [&](int64_t M, bool& le, bool& pref) {
+        if (sk.nsym) {  // the kept sort key of slot M decides most probes with ONE load (see q_search_fast_kernel)
+            uint64_t key;
+            bool known = true;
+            if (sk.keys64) {
+                key = sk.keys64[M];
+            } else {
+                const uint64_t hpart = sk.keys32[M];
+                if (sk.keylow) {
+                    const uint64_t a = sk.klo >> sk.low_bits, b2 = sk.khi >> sk.low_bits;
+                    if (hpart < a || hpart > b2 || (hpart > a && hpart < b2)) {
+                        key = hpart < a ? 0 : (hpart > b2 ? ~0ull : sk.klo);  // below / above / inside the range
+                        known = false;
+                        if (hpart < a) { le = false; pref = false; return; }
+                        if (hpart > b2) { le = true; pref = false; return; }
+                        if (sk.decisive) { le = true; pref = true; return; }
+                    } else {
+                        key = (hpart << sk.low_bits) | (sk.low_bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(sk.keylow)[M]
+                                                                          : (uint64_t)static_cast<const uint16_t*>(sk.keylow)[M]);
+                    }
+                } else {
+                    key = hpart;
+                }
+            }
+            if (known) {
+                if (key < sk.klo) { le = false; pref = false; return; }
+                if (key > sk.khi) { le = true; pref = false; return; }
+                if (sk.decisive) { le = true; pref = true; return; }
+            }
+            // the suffix starts with the keyword's first symbols and the keyword is longer than the key: the text decides
+        }
         const V e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
@@ -1299,15 +1339,49 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids
     k.len = (uint32_t)len;
     std::memcpy(k.bytes, kw, len);
     SingleOut* out = static_cast<SingleOut*>(ix.h_single);
+    SingleKeys sk;
+    if (ix.sa_sorted && ix.use_fast_search && ix.key_nsym && (ix.d_keys.p || ix.d_keys32.p)) {
+        const int kc = (int)std::min<size_t>(len, (size_t)ix.key_nsym);
+        uint64_t kwc = 0, kpw = 1;
+        bool absent = false;
+        for (size_t q = 0; q < len; ++q) {
+            const uint64_t c = ix.h_symmap_q[(uint8_t)kw[q]];
+            absent |= c == 0;
+            if ((int)q < kc) kwc = kwc * ix.key_base + c;
+        }
+        if (absent) {  // a byte the text never holds: the keyword occurs nowhere
+            *nrows = 0;
+            *ids_out = (int64_t*)std::malloc(8);
+            *counts_out = (int64_t*)std::malloc(8);
+            if (!*ids_out || !*counts_out) {
+                std::free(*ids_out);
+                std::free(*counts_out);
+                *ids_out = *counts_out = nullptr;
+                throw std::bad_alloc();
+            }
+            ix.qstats.nhits = ix.qstats.nrows = 0;
+            return true;
+        }
+        for (int q = kc; q < ix.key_nsym; ++q) kpw *= ix.key_base;
+        sk.keys64 = ix.d_keys.p ? ix.d_keys.as<uint64_t>() : nullptr;
+        sk.keys32 = ix.d_keys32.p ? ix.d_keys32.as<uint32_t>() : nullptr;
+        sk.keylow = ix.d_keylow.p;
+        sk.low_bits = ix.key_low_bits;
+        sk.low_bytes = ix.key_low_bytes;
+        sk.nsym = ix.key_nsym;
+        sk.decisive = len <= (size_t)ix.key_nsym;
+        sk.klo = kwc * kpw;
+        sk.khi = sk.klo + (kpw - 1);
+    }
     out->nrows = ~0ull;
     if (ix.width == 8)
         hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted);
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
     else
         hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted);
+                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
     CDB_HIP(hipGetLastError());
     // The kernel publishes its row count last (system-scope release) into host-mapped memory: the host polls that word
     // instead of paying for hipStreamSynchronize's wake-up (~10 us of the ~20 us a call used to cost).  The stream

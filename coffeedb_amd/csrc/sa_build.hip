@@ -33,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "bucket_sort.h"
 #include "index_impl.h"
@@ -1763,7 +1764,10 @@ void build_typed(Index& ix, bool big) {
     CDB_HIP(hipStreamSynchronize(s));
     ix.sa_sorted = !(ix.reference_compat && high_bytes);
     ix.pivot_levels = 0;  // the pivot table belongs to the previous suffix array
-    if (ix.key_nsym) ix.d_symmap_q = std::move(d_symmap);  // the code table the kept keys were built with
+    if (ix.key_nsym) {  // the code table the kept keys were built with
+        ix.d_symmap_q = std::move(d_symmap);
+        std::memcpy(ix.h_symmap_q, h_map, sizeof(h_map));
+    }
     if (ix.reference_compat && high_bytes) {
         if (!apply_reference_order_oop<V>(ix, sa_buf)) {
             apply_reference_order<V>(ix, sa);  // in place when no second array fits
