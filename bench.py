@@ -309,6 +309,8 @@ def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
         t = time.perf_counter()
         g.build()
         tb.append(time.perf_counter() - t)
+    v = g.verify()  # (the column went through the chunked pinned staging path: the index must be the same sorted permutation)
+    verify_ok = bool(v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"])
     tq = []
     for _ in range(reps + 1):
         t = time.perf_counter()
@@ -316,7 +318,7 @@ def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
         tq.append(time.perf_counter() - t)
         del res
     out = {"build_GiB_per_s": round(n / 2**30 / min(tb), 3), "build_ms": [round(x * 1e3, 2) for x in tb],
-           "add_bulk_ms_host_memcpy": round(min(ta) * 1e3, 1),
+           "add_bulk_ms_host_memcpy": round(min(ta) * 1e3, 1), "build_device_part_ms": round(g.stat("build_ms"), 2), "verify_ok": verify_ok,
            "query_patterns_per_s": round(npat / min(tq[1:]), 1), "query_ms": [round(x * 1e3, 3) for x in tq[1:]],
            "query_split_ms": {"upload": round(g.stat("query_upload_ms"), 3), "device": round(g.stat("query_device_ms"), 3),
                               "download": round(g.stat("query_download_ms"), 3)}}

@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "../../include/coffeedb_gpu.h"
 #include "index_impl.h"
@@ -95,6 +96,56 @@ void upload_tables(Index& ix, const std::vector<uint64_t>& doc_start, const std:
     CDB_HIP(hipMemcpyAsync(d_start.p, doc_start.data(), (ndocs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     d_ids.alloc(std::max<uint64_t>(ndocs, 1) * sizeof(int64_t));
     if (ndocs) CDB_HIP(hipMemcpyAsync(d_ids.p, ids.data(), ndocs * sizeof(int64_t), hipMemcpyHostToDevice, s));
+}
+
+// Host-to-device copy of a large PAGEABLE buffer (the staged column).  The runtime moves pageable memory through its own
+// staging at ~11 GB/s (95 ms per GiB on MI355X); here four host threads copy 16 MiB chunks into pinned blocks of the
+// host cache and queue the DMA behind each, so the page-touching memcpy of one chunk overlaps the DMA of the others.
+void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, int device) {
+    constexpr size_t CHUNK = 16u << 20;
+    constexpr int T = 4;
+    if (bytes < 4 * CHUNK) {
+        if (bytes) CDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+    std::string failure;
+    std::mutex fmu;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            void* pin[2] = {nullptr, nullptr};
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            try {
+                CDB_HIP(hipSetDevice(device));
+                for (int k = 0; k < 2; ++k) {
+                    pin[k] = HostPool::get().alloc(CHUNK);
+                    if (!pin[k]) throw Error("HIP error: no pinned staging memory");
+                    CDB_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+                }
+                int k = 0;
+                bool used[2] = {false, false};
+                for (size_t c = t; c < nchunks; c += T, k ^= 1) {
+                    const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
+                    if (used[k]) CDB_HIP(hipEventSynchronize(ev[k]));  // the DMA out of this block has finished
+                    std::memcpy(pin[k], src + off, len);
+                    CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipEventRecord(ev[k], s));
+                    used[k] = true;
+                }
+                for (int q = 0; q < 2; ++q)
+                    if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> g(fmu);
+                if (failure.empty()) failure = e.what();
+            }
+            for (int q = 0; q < 2; ++q) {
+                if (ev[q]) (void)hipEventDestroy(ev[q]);
+                if (pin[q]) (void)HostPool::get().release(pin[q]);
+            }
+        });
+    for (auto& x : th) x.join();
+    if (!failure.empty()) throw Error(failure);
 }
 
 // back to "never built" (queries answer {}): a failed build or load must not leave new parameters over an old array
@@ -509,7 +560,7 @@ int cdb_build(cdb_index* h) {
             DevBuf text, d_start, d_ids;
             text.alloc(n + TEXT_PAD);
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
-            if (n) CDB_HIP(hipMemcpyAsync(text.p, ix.host_text.data(), n, hipMemcpyHostToDevice, ix.stream));
+            upload_pageable(text.p, ix.host_text.data(), n, ix.stream, ix.device);
             upload_tables(ix, ix.doc_start, ix.ids, L.ndocs, d_start, d_ids);
             reset_unbuilt(ix);  // (waits for the stream: the old arrays are idle; ix.mu keeps queries out)
             commit_layout(ix, L);
