@@ -318,7 +318,7 @@ def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
         tq.append(time.perf_counter() - t)
         del res
     out = {"build_GiB_per_s": round(n / 2**30 / min(tb), 3), "build_ms": [round(x * 1e3, 2) for x in tb],
-           "add_bulk_ms_host_memcpy": round(min(ta) * 1e3, 1), "build_device_part_ms": round(g.stat("build_ms"), 2), "verify_ok": verify_ok,
+           "add_bulk_ms_host_memcpy": round(min(ta) * 1e3, 1), "build_device_part_ms": round(g.stat("build_ms"), 2), "build_upload_ms": round(g.stat("host_upload_ms"), 2), "build_free_staging_ms": round(g.stat("host_free_ms"), 2), "verify_ok": verify_ok,
            "query_patterns_per_s": round(npat / min(tq[1:]), 1), "query_ms": [round(x * 1e3, 3) for x in tq[1:]],
            "query_split_ms": {"upload": round(g.stat("query_upload_ms"), 3), "device": round(g.stat("query_device_ms"), 3),
                               "download": round(g.stat("query_download_ms"), 3)}}

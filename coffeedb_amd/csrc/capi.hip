@@ -560,9 +560,11 @@ int cdb_build(cdb_index* h) {
             DevBuf text, d_start, d_ids;
             text.alloc(n + TEXT_PAD);
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
+            const double tu = wall_ms();
             upload_pageable(text.p, ix.host_text.data(), n, ix.stream, ix.device);
             upload_tables(ix, ix.doc_start, ix.ids, L.ndocs, d_start, d_ids);
             reset_unbuilt(ix);  // (waits for the stream: the old arrays are idle; ix.mu keeps queries out)
+            ix.host_upload_ms = wall_ms() - tu;
             commit_layout(ix, L);
             ix.d_text_owned = std::move(text);
             ix.d_text = ix.d_text_owned.as<uint8_t>();
@@ -577,8 +579,16 @@ int cdb_build(cdb_index* h) {
         // the staging copy has done its job (database.cpp builds a fresh index object per build and never adds to a
         // built one); cdb_add* fetch the column back from the device if they are called again
         if (ix.host_text.size() >= (1u << 20)) {
-            std::string().swap(ix.host_text);
+            // (returning a GiB of pages to the kernel takes ~65 ms: not the caller's time — a helper thread lets go of it)
+            const double tf = wall_ms();
+            std::string gone;
+            gone.swap(ix.host_text);
             ix.host_text_valid = false;
+            try {
+                std::thread([g2 = std::move(gone)]() mutable { std::string().swap(g2); }).detach();
+            } catch (...) {  // no thread to be had: release it here (the moved-from lambda state already did, or `gone` does)
+            }
+            ix.host_free_ms = wall_ms() - tf;
         }
     });
 }
@@ -1197,6 +1207,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
+        {"host_upload_ms", h->ix.host_upload_ms}, {"host_free_ms", h->ix.host_free_ms},
         {"query_ms", q.query_ms}, {"query_upload_ms", q.upload_ms}, {"query_device_ms", q.device_ms}, {"query_download_ms", q.download_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
     };
     for (auto& e : tab)

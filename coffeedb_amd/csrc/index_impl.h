@@ -127,6 +127,7 @@ struct Index {
     int key_coding = 0;           // initial sort keys: 0 = dense when that saves a pass, 1 = bit-aligned symbols, 2 = dense
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 
+    double host_upload_ms = 0, host_free_ms = 0;  // cdb_build: staged column to the device / staging copy released
     Profiler prof;
     BuildStats bstats;
     QueryStats qstats;
