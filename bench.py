@@ -468,7 +468,7 @@ def main():
         gib_total = world * n * steps / 2**30
         roof = dominant(prof)
         traffic = pmc_traffic()
-        if traffic and roof and roof["kernel"] in traffic.get("kernels", {}):
+        if traffic and roof and roof["kernel"] in traffic.get("kernels", {}) and traffic.get("suffixes") in (None, n):
             roof["traffic"] = round(traffic["kernels"][roof["kernel"]]["hbm_bytes_per_launch"])
             roof["traffic_source"] = {k: traffic.get(k) for k in ("profile", "commit", "source")}
         elif roof:
@@ -506,7 +506,7 @@ def main():
             "build_algorithmic_bytes_per_suffix": round(kern_bytes / n, 1),
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:14]},
         }
-        if traffic and "kernels" in traffic:
+        if traffic and "kernels" in traffic and traffic.get("suffixes") in (None, n):
             tot = sum(k["hbm_bytes_per_launch"] * k.get("launches", 1) for k in traffic["kernels"].values()
                       if not str(k.get("phase", "")).startswith("q"))
             out["build_hbm_traffic_per_suffix_profiled"] = {"bytes": round(tot / traffic.get("suffixes", n), 1),

@@ -353,3 +353,38 @@ def test_reference_test_highlight_sequential_replace():
             assert b"".join(out) == want, i
     assert set(spans) == changed and len(changed) > 200
     g.close()
+
+
+def test_c3_shard_8gib_ascii():
+    """One GPU's share of BASELINE.json configs[3] (32 GiB over 4 GPUs): 2^23 docs x 1024 B of printable ASCII = 8 GiB,
+    8-byte entries, bucket-wise build; sorted permutation + brute-force scans of sampled patterns."""
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    nd, dl = 1 << 23, 1024
+    n = nd * dl
+    text = W.random_bytes_torch(n, 12345, 0x20, 0x7E, stream=3, device="cuda")
+    ds = W.uniform_docs(nd, dl)
+    ids = np.arange(nd, dtype=np.int64)
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, 100_000, 4, 16, seed=99, miss_byte=0x7F)
+    pb = d_blob[:nbytes].cpu().numpy()
+    po = d_offs.cpu().numpy().astype(np.uint64)
+    del d_blob, d_offs
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), ds, ids)
+    assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1
+    v = g.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+    assert v["entry_sum"] == v["expected_entry_sum"]
+    rp, ri, rc, hits = g.query_batch(pb, po)
+    assert int(rc.sum()) == hits and (np.diff(rp.astype(np.int64)) > 0).mean() > 0.88
+    for j in np.random.default_rng(2).choice(100_000, 6, replace=False).tolist():
+        kw = pb[int(po[j]):int(po[j + 1])]
+        pos = _scan_occurrences(torch, text, torch.from_numpy(kw.copy()).cuda())
+        pos = pos[(pos % dl) + len(kw) <= dl]
+        wd, wc = torch.unique(pos // dl, return_counts=True)
+        a, b = int(rp[j]), int(rp[j + 1])
+        assert np.array_equal(ri[a:b], wd.cpu().numpy()) and np.array_equal(rc[a:b], wc.cpu().numpy()), (j, bytes(kw))
+    g.close()
