@@ -54,6 +54,7 @@ struct BucketSortParams {
     uint64_t kmagic;    // floor(2^64 / kbase) + 1, 0 for a power of two
     int out_low_bits;   // kept keys: k32 = K >> out_low_bits, low = K & (2^out_low_bits - 1)
     uint64_t step;      // nominal window
+    int list_mode;      // workgroup kernel: wfirst holds (first, one past last) bucket pairs instead of window starts
     int ablate;         // timing experiments only (CDB_BS_ABLATE; WRONG results): 1 = no wave sorts, 2 = no flags / kept keys,
                         // 4 = no entry gather, 8 = no counting / scatter
 };
@@ -200,8 +201,9 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
     const uint32_t lmask = (1u << pr.lead_bits) - 1u;
     const uint64_t max_rel = 1ull << (LBITS_MAX - pr.rbits);  // buckets one round can tell apart
 
-    uint64_t b = wfirst[blockIdx.x];
-    const uint64_t b_end = wfirst[blockIdx.x + 1];  // buckets [b, b_end) start in this workgroup's window
+    // buckets [b, b_end): those that start in this workgroup's window, or (list mode) one listed range
+    uint64_t b = pr.list_mode ? wfirst[2 * blockIdx.x] : wfirst[blockIdx.x];
+    const uint64_t b_end = pr.list_mode ? wfirst[2 * blockIdx.x + 1] : wfirst[blockIdx.x + 1];
     while (b < b_end) {
         // ---- the round: as many buckets from b on as fit (64-ary search by the first wavefront)
         __syncthreads();
@@ -405,6 +407,115 @@ __global__ __launch_bounds__(NT) void bs_local_sort_kernel(uint32_t* __restrict_
     }
 }
 
+// ---- small buckets: one WAVEFRONT per round, straight from global memory --------------------------------------------
+// After three global passes a bucket holds a few dozen records (C1: 64 on average).  A wavefront takes consecutive
+// buckets of together <= 256 records, loads them into registers (4 per lane), sorts the packed words
+//     ((bucket - first bucket) << rbits | r) << 8 | index in the round
+// with the register network above — low key bits first, input index as tie-break, i.e. stably —, pulls the entries
+// to their sorted places with lane shuffles, and writes entries, group flags and kept keys.  No LDS, no barriers,
+// many wavefronts per SIMD to hide the loads: the kernel streams.  Buckets of more than 256 records are listed for
+// the workgroup kernel above.
+template <typename V>
+__device__ __forceinline__ V bs_shfl_any(V v, int src) {
+    if constexpr (sizeof(V) == 4) {
+        return (V)__shfl((uint32_t)v, src);
+    } else {
+        const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)((uint64_t)v >> 32), src);
+        return (V)(((uint64_t)hi << 32) | lo);
+    }
+}
+
+template <int R, typename V, typename W, typename KW>
+__device__ __forceinline__ void bs_wave_round(uint32_t* __restrict__ k32, V* __restrict__ ent, W* __restrict__ aux, uint64_t lo, uint32_t m,
+                                              uint32_t b32, const BucketSortParams& pr, uint8_t* __restrict__ flags,
+                                              KW* __restrict__ keylow_out, int lane) {
+    const uint32_t rmask = (1u << pr.rbits) - 1u;
+    const uint32_t lmask = (1u << pr.lead_bits) - 1u;
+    uint32_t v[R];
+    V e[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t li = r * 64 + lane;
+        v[r] = 0xFFFFFFFFu;
+        e[r] = V(0);
+        if (li < m) {
+            const uint32_t k = k32[lo + li];
+            const uint32_t brel = (((k >> pr.rbits) << pr.lead_bits) | ((uint32_t)aux[lo + li] & lmask)) - b32;
+            v[r] = (((brel << pr.rbits) | (k & rmask)) << 8) | li;
+            e[r] = ent[lo + li];
+        }
+    }
+    bs_wave_sort<R>(v, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = r * 64 + lane;
+        // the entry of the record that sorted to slot i sits in register (idx >> 6) of lane (idx & 63)
+        const uint32_t idx = v[r] & 255u;
+        V o = bs_shfl_any<V>(e[0], (int)(idx & 63u));
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+            const V t = bs_shfl_any<V>(e[q], (int)(idx & 63u));
+            o = (idx >> 6) == (uint32_t)q ? t : o;
+        }
+        uint32_t pv = __shfl_up(v[r], 1), nv = __shfl_down(v[r], 1);
+        if (r > 0) { const uint32_t x = __shfl(v[r - 1], 63); if (lane == 0) pv = x; }
+        if (r + 1 < R) { const uint32_t x = __shfl(v[r + 1], 0); if (lane == 63) nv = x; }
+        if (i < m) {
+            const uint32_t lkx = v[r] >> 8;
+            const bool head = i == 0 || (pv >> 8) != lkx;
+            const bool tail = i + 1 == m || (nv >> 8) != lkx;
+            const uint64_t K = ((uint64_t)b32 + (uint64_t)(lkx >> pr.rbits)) * pr.w + (uint64_t)(lkx & rmask);
+            const bool exhausted = pr.kmagic ? (K - __umul64hi(K, pr.kmagic) * pr.kbase) == 0 : (K & (uint64_t)(pr.kbase - 1u)) == 0;
+            const uint64_t g = lo + i;
+            ent[g] = o;
+            flags[g] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+            if (keylow_out) {
+                k32[g] = (uint32_t)(K >> pr.out_low_bits);
+                keylow_out[g] = (KW)(K & ((1ull << pr.out_low_bits) - 1ull));
+            }
+        }
+    }
+}
+
+template <typename V, typename W, typename P, typename KW>
+__global__ __launch_bounds__(256) void bs_wave_sort_kernel(uint32_t* __restrict__ k32, V* __restrict__ ent, W* __restrict__ aux,
+                                                          const P* __restrict__ bstart, BucketSortParams pr, uint32_t per_wave,
+                                                          uint8_t* __restrict__ flags, KW* __restrict__ keylow_out,
+                                                          uint32_t* __restrict__ big_list, uint32_t big_cap,
+                                                          unsigned long long* __restrict__ big_count) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint64_t b = wv * per_wave;
+    if (b >= pr.nb) return;
+    const uint64_t b_end = b + per_wave < pr.nb ? b + per_wave : pr.nb;  // this wavefront's buckets
+    // buckets one round can tell apart: the packed word holds (bucket - first) << rbits | r above the 8-bit index
+    const uint64_t max_rel = 1ull << (24 - pr.rbits);
+    while (b < b_end) {
+        const uint64_t lo = (uint64_t)bstart[b];
+        const uint64_t b_lim = b_end - b > max_rel ? b + max_rel : b_end;
+        const uint64_t c = b + 1 + (uint64_t)lane;
+        const uint64_t endc = c <= b_lim ? (uint64_t)bstart[c] : ~0ull;
+        const bool ok = c <= b_lim && endc - lo <= 256;
+        const int nok = __popcll(__ballot(ok));  // (bucket starts ascend: the lanes that fit are the first nok)
+        if (nok == 0) {  // bucket b alone has more than 256 records: the workgroup kernel takes it
+            if (lane == 0) {
+                const unsigned long long at = atomicAdd(big_count, 1ull);
+                if (at < big_cap) {
+                    big_list[2 * at] = (uint32_t)b;
+                    big_list[2 * at + 1] = (uint32_t)b + 1;
+                }
+            }
+            b += 1;
+            continue;
+        }
+        const uint32_t m = (uint32_t)(bs_shfl_any<uint64_t>(endc, nok - 1) - lo);
+        if (m > 128) bs_wave_round<4, V, W, KW>(k32, ent, aux, lo, m, (uint32_t)b, pr, flags, keylow_out, lane);
+        else if (m > 64) bs_wave_round<2, V, W, KW>(k32, ent, aux, lo, m, (uint32_t)b, pr, flags, keylow_out, lane);
+        else if (m > 0) bs_wave_round<1, V, W, KW>(k32, ent, aux, lo, m, (uint32_t)b, pr, flags, keylow_out, lane);
+        b += (uint64_t)nok;
+    }
+}
+
 // Finishes a hybrid sort in place: k32 / ent / aux hold the records sorted by bucket, bstart the (raw) table of the
 // last global pass.  Afterwards ent = suffix-array entries in key order, flags = group flags; with keep_keys k32 /
 // keylow = the sorted keys in split layout (keylow may alias aux when the types agree).  Returns false when a
@@ -420,9 +531,54 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     DevBuf d_over;
     d_over.alloc(2 * sizeof(uint64_t));
     CDB_HIP(hipMemsetAsync(d_over.p, 0, 2 * sizeof(uint64_t), s));
-    BucketSortParams pr{n, plan.nb, plan.w, plan.rbits, 8 * plan.lead, kbase, kmagic, out_low_bits, 0, 0};
+    BucketSortParams pr{n, plan.nb, plan.w, plan.rbits, 8 * plan.lead, kbase, kmagic, out_low_bits, 0, 0, 0};
     if (const char* e = std::getenv("CDB_BS_ABLATE")) pr.ablate = std::atoi(e);
     const bool big = plan.cap > 4096;
+    if (plan.rbits <= 22 && (double)n / (double)plan.nb <= 160.0) {
+        // small buckets: one wavefront per round of <= 256 records (bs_wave_sort_kernel); what does not fit goes to
+        // the workgroup kernel through a list
+        uint32_t per_wave = 1;
+        while (per_wave < 256 && (double)n / (double)plan.nb * (2.0 * per_wave) <= 384.0) per_wave *= 2;
+        const uint64_t waves = ceil_div(plan.nb, (uint64_t)per_wave);
+        constexpr uint32_t BIG_CAP = 1u << 20;
+        DevBuf d_list;
+        d_list.alloc((size_t)BIG_CAP * 2 * sizeof(uint32_t));
+        int t = prof.begin(s);
+        hipLaunchKernelGGL((bs_wave_sort_kernel<V, W, P, KW>), dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, s, k32, ent, aux,
+                           (const P*)bstart, pr, per_wave, flags, keylow_out, d_list.as<uint32_t>(), BIG_CAP,
+                           d_over.as<unsigned long long>());
+        prof.end(t, "sa_bucket_wave_sort", n * (2 * (4 + sizeof(V)) + sizeof(W) + 1 + (keylow_out ? sizeof(KW) : 0)), s);
+        uint64_t nbig = 0;
+        CDB_HIP(hipMemcpyAsync(&nbig, d_over.p, sizeof(nbig), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipGetLastError());
+        CDB_HIP(hipStreamSynchronize(s));
+        if (nbig > BIG_CAP) {
+            if (largest_bucket) *largest_bucket = 0;
+            return false;  // (too many large buckets for the list: a skewed corpus — the caller falls back)
+        }
+        if (nbig == 0) {
+            if (largest_bucket) *largest_bucket = 0;
+            return true;
+        }
+        CDB_HIP(hipMemsetAsync(d_over.p, 0, 2 * sizeof(uint64_t), s));
+        pr.list_mode = 1;
+        int t2 = prof.begin(s);
+        if (big)
+            hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 1024, BS_IPT_BIG>), dim3((unsigned)nbig), dim3(1024), 0, s, k32, ent, aux,
+                               (const P*)bstart, (const uint32_t*)d_list.as<uint32_t>(), pr, flags, keylow_out,
+                               d_over.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL((bs_local_sort_kernel<V, W, P, KW, 256, 16>), dim3((unsigned)nbig), dim3(256), 0, s, k32, ent, aux,
+                               (const P*)bstart, (const uint32_t*)d_list.as<uint32_t>(), pr, flags, keylow_out,
+                               d_over.as<unsigned long long>());
+        prof.end(t2, "sa_bucket_sort", 0, s);
+        uint64_t over2[2] = {0, 0};
+        CDB_HIP(hipMemcpyAsync(over2, d_over.p, sizeof(over2), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipGetLastError());
+        CDB_HIP(hipStreamSynchronize(s));
+        if (largest_bucket) *largest_bucket = over2[1];
+        return over2[0] == 0;
+    }
     pr.step = big ? (uint64_t)1024 * 16 : 2048;
     const uint64_t nwin = ceil_div(n, pr.step);
     DevBuf d_win;

@@ -255,7 +255,8 @@ int cdb_create(cdb_index** out, int device) {
     cdb_index* h = new (std::nothrow) cdb_index();
     if (!h) return CDB_E_DEVICE;
     h->ix.device = device;
-    if (const char* e = std::getenv("CDB_HYBRID")) h->ix.hybrid = std::atoi(e);  // test hook: default of the "hybrid" option
+    if (const char* e = std::getenv("CDB_HYBRID")) h->ix.hybrid = std::atoi(e);
+    if (const char* e = std::getenv("CDB_HYBRID_PASSES")) h->ix.hybrid_passes = std::atoi(e);  // test hook: default of the "hybrid" option
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return CDB_E_DEVICE;
@@ -1179,6 +1180,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
     else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
+    else if (!std::strcmp(name, "hybrid_passes")) ix.hybrid_passes = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
     else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
     else if (!std::strcmp(name, "bucket_group_limit")) ix.bucket_group_limit = (uint64_t)value;

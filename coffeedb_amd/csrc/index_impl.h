@@ -124,6 +124,7 @@ struct Index {
     bool narrow_keys = true;      // 32-bit sort keys (+ a byte for the dropped low digit) when the key width allows
     int hybrid = 0;               // hybrid initial sort (bucket_sort.h; experimental, measured slower than the plain LSD
                                   // sort — DESIGN.md §4.5): 0 = off, 1 = from 2^27 suffixes, 2 = whenever the key layout allows
+    int hybrid_passes = 0;        // hybrid sort: 0 = fewest global passes that fit, 1..3 = exactly that many
     int key_coding = 0;           // initial sort keys: 0 = dense when that saves a pass, 1 = bit-aligned symbols, 2 = dense
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 

@@ -1190,6 +1190,7 @@ void build_typed(Index& ix, bool big) {
         for (int i = 0; i < nsym; ++i) space *= kbase;
         const int cap = n >= (1ull << 22) ? BS_CAP_BIG : BS_CAP_SMALL;
         for (int G = 1; G <= 3; ++G) {
+            if (ix.hybrid_passes && G != ix.hybrid_passes) continue;  // (option: only this many global passes)
             const unsigned __int128 nbmax = (unsigned __int128)1 << (8 * G);
             const uint64_t w = (uint64_t)std::max<unsigned __int128>((space + nbmax - 1) / nbmax, 1);
             const uint64_t nb = (uint64_t)((space + w - 1) / w);
