@@ -445,7 +445,7 @@ __device__ __forceinline__ void bs_wave_round(uint32_t* __restrict__ k32, V* __r
             e[r] = ent[lo + li];
         }
     }
-    bs_wave_sort<R>(v, lane);
+    if (!(pr.ablate & 1)) bs_wave_sort<R>(v, lane);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = r * 64 + lane;
@@ -537,8 +537,11 @@ bool bucket_sort_finish(hipStream_t s, Profiler& prof, DevBuf& scan_partials, ui
     if (plan.rbits <= 22 && (double)n / (double)plan.nb <= 160.0) {
         // small buckets: one wavefront per round of <= 256 records (bs_wave_sort_kernel); what does not fit goes to
         // the workgroup kernel through a list
+        // buckets per wavefront: ~16 rounds of <= 256 records each (short-lived wavefronts start and finish in step
+        // with each other and leave the memory pipes idle while they all sort; CDB_BS_PER_WAVE overrides)
         uint32_t per_wave = 1;
-        while (per_wave < 256 && (double)n / (double)plan.nb * (2.0 * per_wave) <= 384.0) per_wave *= 2;
+        while (per_wave < 4096 && (double)n / (double)plan.nb * (2.0 * per_wave) <= 16.0 * 256.0) per_wave *= 2;
+        if (const char* e = std::getenv("CDB_BS_PER_WAVE")) per_wave = (uint32_t)std::max(1, std::atoi(e));
         const uint64_t waves = ceil_div(plan.nb, (uint64_t)per_wave);
         constexpr uint32_t BIG_CAP = 1u << 20;
         DevBuf d_list;
