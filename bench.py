@@ -144,6 +144,10 @@ def query_roofline(torch, r, npat, n, width, query_s, device):
 def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
+    if make_merger is not None and cfg["npat"] > 1_000_000:
+        # N > 1: every rank ends up holding the merged rows of ALL shards; 10^7 patterns x N shards would be ~10^9 rows
+        # per rank — the batch is cut to 10^6 patterns for the sharded run (the single-GPU block runs the full 10^7)
+        cfg = dict(cfg, npat=1_000_000)
     t_gen = time.perf_counter()
     text, ds, n = make_corpus(torch, W, cfg, rank, device)
     ndocs = len(ds) - 1
