@@ -499,6 +499,7 @@ def main():
                 "docs_per_gpu": ndocs, "bytes_per_gpu": n, "patterns": npat,
             },
             "commit": git_head(),
+            "merge": merger.note if merger is not None else None,
             "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
             "query_hits_per_batch": hits,
@@ -583,6 +584,14 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)[:300]}
         else:
             out["cpu_baseline"] = None
+        # (RCCL announces its version through C stdio, which is flushed at exit: push that out first, so that the JSON line
+        #  is the last thing on stdout)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -86,13 +86,28 @@ class ShardMerger:
         import torch
         self.torch, self.dist, self.index, self.world, self.device, self.coll_device = torch, dist, index, world, device, coll_device
         self.comm = None
+        self.note = "torch.distributed all-gathers (gloo test mode)"
         if coll_device == device and hasattr(capi, "ShardComm"):
             uid = torch.zeros(128, dtype=torch.uint8, device=device)
             if rank == 0:
                 uid.copy_(torch.from_numpy(capi.ShardComm.unique_id()).to(device))
             if world > 1:
                 dist.broadcast(uid, 0)
-            self.comm = capi.ShardComm(uid.cpu().numpy(), rank, world, device.index or 0)
+            try:
+                self.comm = capi.ShardComm(uid.cpu().numpy(), rank, world, device.index or 0)
+                ok = 1
+            except RuntimeError as e:   # reported in the bench line, never silent
+                self.note = f"torch.distributed all-gathers (cdb_comm_create failed on rank {rank}: {e})"
+                ok = 0
+            if world > 1:   # all ranks use the same path
+                t = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                if int(t.item()) == 0 and self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+                    self.note = "torch.distributed all-gathers (cdb_comm_create failed on another rank)"
+            if self.comm is not None:
+                self.note = "cdb_comm_merge (RCCL all-gather + grouped broadcasts + placement kernel)"
 
     def merge(self, r, npat):
         if self.comm is not None:
