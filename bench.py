@@ -576,6 +576,16 @@ def main():
             blocks[name] = res
         if rank == 0:
             out["configs"] = blocks
+    # (RCCL announces its version through C stdio, flushed at exit: every rank pushes that out now, so that rank 0's JSON
+    #  line is the last thing on the job's stdout)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -584,14 +594,6 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)[:300]}
         else:
             out["cpu_baseline"] = None
-        # (RCCL announces its version through C stdio, which is flushed at exit: push that out first, so that the JSON line
-        #  is the last thing on stdout)
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
-        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
