@@ -22,7 +22,7 @@ EXPORTS = [
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
-    "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
+    "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge",
 ]
 
@@ -147,6 +147,10 @@ def load_library():
     lib.cdb_shards_build.argtypes = [vp]
     lib.cdb_shards_query.argtypes = [vp, cp, C.c_size_t, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
     lib.cdb_shards_query_batch.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult)]
+    lib.cdb_shards_query_or.argtypes = [vp, vp, vp, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
+    lib.cdb_shards_query_ranked.argtypes = [vp, vp, vp, u64, i64, i64, u64, C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(i64)),
+                                            C.POINTER(C.c_size_t)]
+    lib.cdb_shards_query_spans.argtypes = [vp, vp, vp, u64, C.POINTER(CdbSpans)]
     lib.cdb_shards_count.argtypes = [vp]
     lib.cdb_shards_get.argtypes = [vp, C.c_int]
     lib.cdb_shards_get.restype = vp
@@ -467,6 +471,36 @@ class GpuShards:
         self._lib.cdb_free(ids)
         self._lib.cdb_free(cnt)
         return out
+
+    @staticmethod
+    def _pack(keywords):
+        blob = np.frombuffer(b"".join(keywords), dtype=np.uint8)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        np.cumsum([len(k) for k in keywords], out=offs[1:])
+        return blob, offs
+
+    def query_or(self, keywords, ranked=False, lo=1, hi=(1 << 62), limit=0):
+        blob, offs = self._pack(keywords)
+        ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
+        bp = _ptr(blob) if len(blob) else None
+        if ranked:
+            self._check(self._lib.cdb_shards_query_ranked(self._h, bp, _ptr(offs), len(keywords), int(lo), int(hi), int(limit),
+                                                          C.byref(ids), C.byref(cnt), C.byref(n)))
+        else:
+            self._check(self._lib.cdb_shards_query_or(self._h, bp, _ptr(offs), len(keywords), C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = [(ids[i], cnt[i]) for i in range(n.value)]
+        self._lib.cdb_free(ids)
+        self._lib.cdb_free(cnt)
+        return out
+
+    def query_spans(self, keywords):
+        blob, offs = self._pack(keywords)
+        r = CdbSpans()
+        self._check(self._lib.cdb_shards_query_spans(self._h, _ptr(blob) if len(blob) else None, _ptr(offs), len(keywords), C.byref(r)))
+        try:
+            return [(r.ids[d], [(r.begin[k], r.end[k]) for k in range(r.span_ptr[d], r.span_ptr[d + 1])]) for d in range(r.ndocs)]
+        finally:
+            self._lib.cdb_spans_free(C.byref(r))
 
     def query_batch(self, blob, offsets):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)

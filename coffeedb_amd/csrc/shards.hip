@@ -663,6 +663,104 @@ int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** i
     });
 }
 
+// The per-key operations work shard by shard: documents — hence object ids — are disjoint across shards, so the union over
+// shards is a concatenation, ordered afterwards the way the single-GPU call orders it.
+namespace {
+int shards_or_impl(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, bool ranked, int64_t lo, int64_t hi,
+                   uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
+    if (!h || !ids || !counts || !nrows || (nkw && !offsets)) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    return guarded_on(h, [&] {
+        std::vector<std::pair<int64_t, int64_t>> rows;
+        for (int i = 0; i < std::max(h->used, 1); ++i) {
+            int64_t *pi = nullptr, *pc = nullptr;
+            size_t n = 0;
+            // (every shard's own top `limit` rows contain its share of the global top `limit`)
+            check_shard(h, i, ranked ? cdb_query_ranked(h->shard[i], blob, offsets, nkw, lo, hi, limit, &pi, &pc, &n)
+                                     : cdb_query_or(h->shard[i], blob, offsets, nkw, &pi, &pc, &n));
+            for (size_t r = 0; r < n; ++r) rows.emplace_back(pi[r], pc[r]);
+            cdb_free(pi);
+            cdb_free(pc);
+        }
+        if (h->used > 1) {
+            if (ranked) {
+                std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
+                if (limit && rows.size() > limit) rows.resize(limit);
+            } else {
+                std::sort(rows.begin(), rows.end());
+            }
+        }
+        int64_t* oi = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
+        int64_t* oc = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
+        if (!oi || !oc) {
+            std::free(oi);
+            std::free(oc);
+            throw std::bad_alloc();
+        }
+        for (size_t r = 0; r < rows.size(); ++r) {
+            oi[r] = rows[r].first;
+            oc[r] = rows[r].second;
+        }
+        *ids = oi;
+        *counts = oc;
+        *nrows = rows.size();
+    });
+}
+}  // namespace
+
+int cdb_shards_query_or(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                        size_t* nrows) {
+    return shards_or_impl(h, blob, offsets, nkw, false, 0, 0, 0, ids, counts, nrows);
+}
+
+int cdb_shards_query_ranked(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
+                            uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
+    return shards_or_impl(h, blob, offsets, nkw, true, corr_lo, corr_hi, limit, ids, counts, nrows);
+}
+
+int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {
+    if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    const int rc = guarded_on(h, [&] {
+        std::vector<cdb_spans> parts(std::max(h->used, 1));
+        struct Cleanup {
+            std::vector<cdb_spans>& p;
+            ~Cleanup() { for (auto& x : p) cdb_spans_free(&x); }
+        } cleanup{parts};
+        uint64_t nd = 0, ns = 0;
+        for (size_t i = 0; i < parts.size(); ++i) {  // shard order = ascending document index
+            std::memset(&parts[i], 0, sizeof(cdb_spans));
+            check_shard(h, (int)i, cdb_query_spans(h->shard[i], blob, offsets, nkw, &parts[i]));
+            nd += parts[i].ndocs;
+            ns += parts[i].nspans;
+        }
+        out->ndocs = nd;
+        out->nspans = ns;
+        out->ids = (int64_t*)host_alloc(nd * 8);
+        out->span_ptr = (uint64_t*)host_alloc((nd + 1) * 8, true);
+        out->begin = (uint64_t*)host_alloc(ns * 8);
+        out->end = (uint64_t*)host_alloc(ns * 8);
+        uint64_t d0 = 0, s0 = 0;
+        for (const cdb_spans& p : parts) {
+            for (uint64_t d = 0; d < p.ndocs; ++d) {
+                out->ids[d0 + d] = p.ids[d];
+                out->span_ptr[d0 + d] = s0 + p.span_ptr[d];
+            }
+            if (p.nspans) {
+                std::memcpy(out->begin + s0, p.begin, p.nspans * 8);
+                std::memcpy(out->end + s0, p.end, p.nspans * 8);
+            }
+            d0 += p.ndocs;
+            s0 += p.nspans;
+        }
+        out->span_ptr[nd] = ns;
+    });
+    if (rc != CDB_OK) cdb_spans_free(out);
+    return rc;
+}
+
 int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
     if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));

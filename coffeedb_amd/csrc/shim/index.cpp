@@ -172,68 +172,63 @@ std::vector<index::result_type> string_index::query_batch(const std::vector<std:
     return out;
 }
 
-// The per-key operations below work shard by shard when the column is sharded: documents — hence object ids — are
-// disjoint across shards, so the union over shards is a concatenation (then ordered as the single-GPU call orders it).
+// The per-key operations: one call either way (cdb_shards_* concatenate the shards' answers — documents, hence object
+// ids, are disjoint across shards — and order them as the single-GPU calls do).
 index::result_type string_index::query_any(const std::vector<std::string>& keywords) const {
     const auto [blob, offs] = pack(keywords);
-    result_type out;
-    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
-    for (int i = 0; i < parts; ++i) {
-        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
-        int64_t *ids = nullptr, *counts = nullptr;
-        size_t rows = 0;
-        const int rc = cdb_query_or(h, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
-        if (rc != CDB_OK) rethrow(h, rc);
-        out.reserve(out.size() + rows);
-        for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
-        cdb_free(ids);
-        cdb_free(counts);
+    int64_t *ids = nullptr, *counts = nullptr;
+    size_t rows = 0;
+    if (shards) {
+        const int rc = cdb_shards_query_or(shards, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(shards, rc);
+    } else {
+        const int rc = cdb_query_or(handle, blob.data(), offs.data(), keywords.size(), &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(handle, rc);
     }
-    if (parts > 1) std::sort(out.begin(), out.end());  // ascending object id, as cdb_query_or returns it
+    result_type out;
+    out.reserve(rows);
+    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+    cdb_free(ids);
+    cdb_free(counts);
     return out;
 }
 
 index::result_type string_index::query_ranked(const std::vector<std::string>& keywords, int64_t corr_lo, int64_t corr_hi,
                                               uint64_t limit) const {
     const auto [blob, offs] = pack(keywords);
+    int64_t *ids = nullptr, *counts = nullptr;
+    size_t rows = 0;
+    if (shards) {
+        const int rc = cdb_shards_query_ranked(shards, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(shards, rc);
+    } else {
+        const int rc = cdb_query_ranked(handle, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
+        if (rc != CDB_OK) rethrow(handle, rc);
+    }
     result_type out;
-    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
-    for (int i = 0; i < parts; ++i) {
-        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
-        int64_t *ids = nullptr, *counts = nullptr;
-        size_t rows = 0;
-        // every shard's own top `limit` rows contain its share of the global top `limit`
-        const int rc = cdb_query_ranked(h, blob.data(), offs.data(), keywords.size(), corr_lo, corr_hi, limit, &ids, &counts, &rows);
-        if (rc != CDB_OK) rethrow(h, rc);
-        out.reserve(out.size() + rows);
-        for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
-        cdb_free(ids);
-        cdb_free(counts);
-    }
-    if (parts > 1) {  // descending count, ties ascending id (the order cdb_query_ranked defines)
-        std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
-        if (limit && out.size() > limit) out.resize(limit);
-    }
+    out.reserve(rows);
+    for (size_t r = 0; r < rows; ++r) out.emplace_back(ids[r], counts[r]);
+    cdb_free(ids);
+    cdb_free(counts);
     return out;
 }
 
 std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> string_index::highlight_spans(
     const std::vector<std::string>& keywords) const {
     const auto [blob, offs] = pack(keywords);
-    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> out;
-    const int parts = shards ? std::max(cdb_shards_count(shards), 1) : 1;
-    for (int i = 0; i < parts; ++i) {  // shard order = ascending document index
-        cdb_index* h = shards ? cdb_shards_get(shards, i) : handle;
-        cdb_spans sp;
-        const int rc = cdb_query_spans(h, blob.data(), offs.data(), keywords.size(), &sp);
-        if (rc != CDB_OK) rethrow(h, rc);
-        const size_t base = out.size();
-        out.resize(base + sp.ndocs);
-        for (uint64_t d = 0; d < sp.ndocs; ++d) {
-            out[base + d].first = sp.ids[d];
-            for (uint64_t k = sp.span_ptr[d]; k < sp.span_ptr[d + 1]; ++k) out[base + d].second.emplace_back(sp.begin[k], sp.end[k]);
-        }
-        cdb_spans_free(&sp);
+    cdb_spans sp;
+    if (shards) {
+        const int rc = cdb_shards_query_spans(shards, blob.data(), offs.data(), keywords.size(), &sp);
+        if (rc != CDB_OK) rethrow(shards, rc);
+    } else {
+        const int rc = cdb_query_spans(handle, blob.data(), offs.data(), keywords.size(), &sp);
+        if (rc != CDB_OK) rethrow(handle, rc);
     }
+    std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> out(sp.ndocs);
+    for (uint64_t d = 0; d < sp.ndocs; ++d) {
+        out[d].first = sp.ids[d];
+        for (uint64_t k = sp.span_ptr[d]; k < sp.span_ptr[d + 1]; ++k) out[d].second.emplace_back(sp.begin[k], sp.end[k]);
+    }
+    cdb_spans_free(&sp);
     return out;
 }

@@ -234,6 +234,13 @@ int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value);
 int cdb_shards_build(cdb_shards* h);                                                           /* index.cpp:178-236 */
 int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows);
 int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
+/* cdb_query_or / cdb_query_ranked / cdb_query_spans over all shards (object ids are disjoint across shards: the shard
+ * answers are concatenated and ordered the way the single-GPU calls order them) */
+int cdb_shards_query_or(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t** ids, int64_t** counts,
+                        size_t* nrows);
+int cdb_shards_query_ranked(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
+                            uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows);
+int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out);
 /* introspection: shards in use after build, the handle of shard i (per-shard parity: its suffix array is that of its
  * documents alone), its first document, and how the shards exchange ("rccl" / "device copies" / "none") */
 int cdb_shards_count(const cdb_shards* h);

@@ -54,6 +54,15 @@ def test_sharded_index_matches_single_index(nshards):
         assert sh.query(kw) == full.query(kw)
     with pytest.raises(RuntimeError, match="Empty keywords"):
         sh.query(b"")
+    # OR over a key's keywords, ranking and highlight spans across the shards = the single-index answers
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(12)]
+    one = capi.GpuStringIndex()
+    one.add_bulk(ids, blob, ds)
+    one.build()
+    assert sh.query_or(kws) == one.query_or(kws) == full.filter_or(kws)
+    assert sh.query_or(kws, ranked=True, lo=2, limit=25) == one.query_ranked(kws, lo=2, limit=25)
+    assert sh.query_spans(kws) == one.query_spans(kws) == full.highlight_spans(kws, ids)
+    one.close()
     # a rebuild after more documents replaces every shard
     sh.add(99999, b"abcabcabc")
     sh.build()
