@@ -268,12 +268,15 @@ int cdb_create(cdb_index** out, int device) {
 void cdb_destroy(cdb_index* h) {
     if (!h) return;
     (void)hipSetDevice(h->ix.device);
-    if (h->ix.stream) {
-        (void)hipStreamSynchronize(h->ix.stream);
-        (void)hipStreamDestroy(h->ix.stream);
-    }
+    hipStream_t s = h->ix.stream;
+    if (s) (void)hipStreamSynchronize(s);
     if (h->ix.h_single) (void)hipHostFree(h->ix.h_single);
-    delete h;
+    h->ix.stream = nullptr;
+    delete h;  // (device blocks go back to the cache untagged: the stream is idle)
+    if (s) {
+        DevPool::get().retire_stream(s);  // blocks released earlier under this stream: their events die with it
+        (void)hipStreamDestroy(s);
+    }
 }
 
 const char* cdb_last_error(const cdb_index* h) {
@@ -1309,6 +1312,7 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
             if (onesweep_ms) *onesweep_ms = ms;
             if (passes) *passes = st.passes_run;
         }
+        DevPool::get().retire_stream(s);
         (void)hipStreamDestroy(s);
         return CDB_OK;
     } catch (const std::exception& e) {

@@ -83,7 +83,7 @@ public:
             }
             if (best < 0 && best_busy >= 0) {  // waiting for the other stream beats a fresh hipMalloc
                 Block& b = free_[best_busy];
-                (void)hipEventSynchronize(b.ev);
+                if (hipEventSynchronize(b.ev) != hipSuccess) (void)hipGetLastError();
                 best = best_busy;
             }
             if (best >= 0) {
@@ -143,6 +143,24 @@ public:
         (void)hipFree(p);
         if (cur != device) (void)hipSetDevice(cur);
     }
+    // A stream is about to be destroyed (its owner has synchronised it): blocks it released are plainly free now, and
+    // their events must not be queried any more — an event keeps a pointer to the stream it was recorded on, and
+    // hipEventQuery on one whose stream is gone reads freed memory (seen as a spurious "stream is capturing" error after
+    // a few hundred handle create / destroy cycles).
+    void retire_stream(hipStream_t s) {
+        if (!s) return;
+        std::vector<hipEvent_t> dead;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (Block& b : free_)
+                if (b.stream == s) {
+                    if (b.ev) dead.push_back(b.ev);
+                    b.ev = nullptr;
+                    b.stream = nullptr;
+                }
+        }
+        for (hipEvent_t e : dead) (void)hipEventDestroy(e);
+    }
     void set_limit(size_t bytes) {
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -177,14 +195,9 @@ public:
 
 private:
     struct Block { void* p; size_t bytes; int device; hipStream_t stream; hipEvent_t ev; };
-    // (both called with mu_ held)
-    hipEvent_t get_event(int device) {
-        auto& pool = events_[device];
-        if (!pool.empty()) {
-            hipEvent_t e = pool.back();
-            pool.pop_back();
-            return e;
-        }
+    // (both called with mu_ held.  Events are not recycled: one that was recorded on a stream which has been destroyed
+    //  since still points at it)
+    hipEvent_t get_event(int) {
         hipEvent_t e = nullptr;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
@@ -192,10 +205,9 @@ private:
         }
         return e;
     }
-    void put_event(int device, hipEvent_t e) { events_[device].push_back(e); }
+    void put_event(int, hipEvent_t e) { (void)hipEventDestroy(e); }
     std::mutex mu_;
     std::vector<Block> free_;
-    std::map<int, std::vector<hipEvent_t>> events_;
     size_t cached_ = 0;
     size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
                                  // the working set of a multi-GiB build costs more than the build itself

@@ -256,6 +256,8 @@ struct MergeRank {
         if (own_stream && stream) {
             (void)hipSetDevice(device);
             (void)hipStreamSynchronize(stream);
+            for (DevBuf* b : {&cnt, &all_cnt, &flat_ptr, &g_row_ptr, &offs, &st_ids, &st_cnt, &out_ids, &out_cnt, &partials}) b->release();
+            DevPool::get().retire_stream(stream);
             (void)hipStreamDestroy(stream);
         }
     }
