@@ -30,6 +30,12 @@ namespace cdb {
 constexpr int RS_MAX_PASSES = 16;
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+// XCD-aware tile order of the big-tile configurations: groups of RS_GROUP consecutive tiles go to one XCD (RsCfg::GROUP).
+// Tiles are reserved for workgroups that have not started yet, so up to 7 * RS_GROUP resident workgroups can wait for
+// one that is still to be dispatched: the pass needs more than that many resident at a time (it has 256 when it runs
+// alone; concurrent kernels can take some away) — a pass that starves raises the look-back error flag (bounded
+// spins), and the callers redo the sort in plain ticket order (variant 33), which needs one.
+constexpr int RS_GROUP = 8;
 
 struct NoVal {};
 
@@ -96,8 +102,17 @@ __device__ __forceinline__ void rs_st_status(uint64_t* p, uint64_t v) {
 // LDS staging buffer (two write-out phases, smaller footprint -> more workgroups per CU); EARLYV =
 // values are fetched together with the keys instead of after the look-back.
 template <int IPT_, bool REUSE_, bool EARLYV_, int NT_ = 256, bool NONTEMP_ = false, int MINW_ = 1, int ABL_ = 0,
-          int LB_ = 1, bool DMA_ = false, bool ATOMRANK_ = false>
+          int LB_ = 1, bool DMA_ = false, bool ATOMRANK_ = false, bool TICKET_ = true, int LOAD_ = 0, int GROUP_ = 0>
 struct RsCfg {
+    static constexpr int GROUP = GROUP_;      // > 0: XCD-aware tile order — workgroup b draws from the ticket counter of
+                                              // class b % 8 (the XCD it runs on, as observed) and class x owns the tile
+                                              // groups x, x + 8, ... of GROUP consecutive tiles each, so neighbouring
+                                              // tiles (whose digit runs touch) are written through the same L2
+    static constexpr int LOAD = LOAD_;        // plain load path: 0 = predicated loads, keys -> values -> auxiliary digits;
+                                              // 1 = unpredicated, keys -> digits -> values (values in flight under the
+                                              // ranking); 2 = unpredicated, keys -> values -> digits
+    static constexpr bool TICKET = TICKET_;   // tile id from an atomic ticket (false: blockIdx.x — relies on in-order
+                                              // dispatch of workgroups; every spin is bounded either way)
     static constexpr bool ATOMRANK = ATOMRANK_;  // rank inside the wave with one returning LDS atomic per element
                                               // instead of 8 ballots (relies on same-address LDS atomics of one
                                               // instruction completing in lane order — checked by a self-test)
@@ -265,11 +280,22 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     VS* s_vals = reinterpret_cast<VS*>(s_stage + (REUSE ? 0 : STAGE_K));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    if constexpr (Cfg::GROUP > 0) {
+        if (tid == 0) {
+            const uint32_t x = blockIdx.x & 7u;
+            const uint32_t slot = atomicAdd(ticket + x, 1u);
+            s_tile = ((slot / Cfg::GROUP) * 8u + x) * Cfg::GROUP + slot % Cfg::GROUP;
+        }
+    } else if constexpr (Cfg::TICKET) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    }
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t tile = s_tile;
+    const uint64_t tile = (Cfg::TICKET || Cfg::GROUP > 0) ? (uint64_t)s_tile : (uint64_t)blockIdx.x;
     const uint64_t base = tile * TILE;
+    if constexpr (Cfg::GROUP > 0) {
+        if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
+    }
     const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
 
     // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             e = e < last_vec ? e : last_vec;
             __builtin_amdgcn_global_load_lds((gptr_t)(vin + e), (lptr_t)(wdst + i * 1024), 16, 0, 0);
         }
-    } else {
+    } else if constexpr (Cfg::LOAD == 0) {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
@@ -487,6 +513,40 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 aux[j] = li < valid ? rs_load<NTM>(win + base + li) : WS(0);
             }
         }
+    } else {
+        // Unpredicated loads (slots behind the end of the input re-read its last element and are masked afterwards):
+        // straight-line code lets the compiler count outstanding loads exactly, so the ranking starts as soon as what
+        // it needs has landed (loads return in issue order).
+        const uint32_t lastv = valid - 1;  // (valid >= 1: the grid has ceil(n / TILE) tiles)
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t li = wbase + j * 64;
+            key[j] = rs_load<NTM>(kin + base + (li < valid ? li : lastv));
+        }
+        if constexpr (HAS_W && Cfg::LOAD == 1) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+            }
+        }
+        if constexpr (EARLYV) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                val[j] = rs_load<NTM>(vin + base + (li < valid ? li : lastv));
+            }
+        }
+        if constexpr (HAS_W && Cfg::LOAD != 1) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+            if (wbase + j * 64 >= valid) key[j] = (K)~(K)0;
     }
 
     // ---- rank inside the wave: lanes with the same digit find each other with 8 ballots, or (ATOMRANK) one
@@ -773,7 +833,7 @@ inline bool rs_atomic_rank_ok(hipStream_t s) {
 struct RadixWorkspace {
     DevBuf hist;     // [2][RS_MAX_PASSES][256] u64 : counts, then digit starts
     DevBuf status;   // [tiles][256] u64
-    DevBuf tickets;  // [256] u32 tickets (indexed by epoch) + [1] u32 error flag
+    DevBuf tickets;  // [256] u32 tickets (indexed by epoch) + [4] u32 error flag / counters + [256][8] per-class tickets
     DevBuf tile_doc; // [tiles + 1] u64, generated first pass only
     // optional third value buffer for the NEXT sort (cleared by it): with it an odd number of passes still ends
     // with the values in buffer 0 (v0 -> spare -> v1 -> spare ... -> v0) instead of needing a copy back;
@@ -782,12 +842,16 @@ struct RadixWorkspace {
     int value_result = 0;
     uint32_t epoch = 0;
     uint64_t min_tile = 0;
+    // XCD-aware tile order (RS_GROUP) is used only where the caller can redo the sort after a starved pass: the
+    // suffix-array build sets allow_group for its own sorts and falls back to plain_order after a look-back timeout
+    bool allow_group = false;
+    bool plain_order = false;
 
     void prepare(uint64_t n, int tile, hipStream_t s) {
         const uint64_t tiles = ceil_div(n, (uint64_t)tile);
         if (!hist.p) hist.alloc(2 * RS_MAX_PASSES * 256 * sizeof(uint64_t));
         if (!tickets.p) {
-            tickets.alloc(260 * sizeof(uint32_t));
+            tickets.alloc((260 + 256 * 8) * sizeof(uint32_t));
             CDB_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes, s));
         }
         const size_t need = (size_t)tiles * 256 * sizeof(uint64_t);
@@ -795,6 +859,7 @@ struct RadixWorkspace {
             status.alloc(need + need / 4);
             CDB_HIP(hipMemsetAsync(status.p, 0, status.bytes, s));
             CDB_HIP(hipMemsetAsync(tickets.p, 0, 256 * sizeof(uint32_t), s));
+            CDB_HIP(hipMemsetAsync(tickets.as<uint32_t>() + 260, 0, 256 * 8 * sizeof(uint32_t), s));
             epoch = 0;
         }
     }
@@ -802,11 +867,13 @@ struct RadixWorkspace {
         if (epoch == 255) {  // tags wrap: forget every published word
             CDB_HIP(hipMemsetAsync(status.p, 0, status.bytes, s));
             CDB_HIP(hipMemsetAsync(tickets.p, 0, 256 * sizeof(uint32_t), s));
+            CDB_HIP(hipMemsetAsync(tickets.as<uint32_t>() + 260, 0, 256 * 8 * sizeof(uint32_t), s));
             epoch = 0;
         }
         return ++epoch;
     }
     uint32_t* ticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + (e & 255u); }
+    uint32_t* xticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + 260 + (e & 255u) * 8; }
     uint32_t* err_ptr() { return tickets.as<uint32_t>() + 256; }
     void release() { hist.release(); status.release(); tickets.release(); tile_doc.release(); epoch = 0; }
 };
@@ -822,6 +889,12 @@ template <> inline const char* rs_kernel_name<uint32_t, NoVal>() { return "rs_on
 struct SortStats {
     int passes_run = 0, passes_skipped = 0;
 };
+
+// kernel configurations (radix_sort's `variant`) that have a generated first pass
+inline bool rs_variant_has_gen(int v) {
+    return v == 0 || v == 21 || v == 26 || v == 1 || v == 31 || v == 33 || v == 36 || v == 32 || (v >= 51 && v <= 59);
+}
+inline bool rs_variant_experimental(int v) { return v >= 51 && v <= 59; }
 
 struct SortPlan {
     int npass, begin_bit;
@@ -891,6 +964,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     int cur = 0;
     bool materialised = !GEN;  // with a generator the input exists only after the first executed pass
     const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
+    const uint32_t grid_tiles = Cfg::GROUP > 0 ? (uint32_t)(ceil_div(tiles, 8u * Cfg::GROUP) * 8u * Cfg::GROUP) : tiles;
     const size_t pair_bytes = sizeof(K) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0);
     // which passes run (a constant digit is skipped; the leading pass of a generated sort always runs: it
     // produces the records) and through which value buffers
@@ -936,18 +1010,19 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                 hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles + 1, 256)), dim3(256), 0, s,
                                    g2.doc_start, g2.ndocs, n, (uint64_t)TILE, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
                 g2.tile_doc = ws.tile_doc.as<uint64_t>();
-                hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
+                hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(grid_tiles), dim3(Cfg::NT), 0, s,
                                    (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vout_p, n, shift, dmask,
                                    (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
-                                   ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift, bsa);
+                                   Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift, bsa);
             }
             prof.end(t, (std::string("rs_onesweep_textgen") + (HAS_W ? "_split" : "") + "_t" + std::to_string(TILE)).c_str(),
                      n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0)), s);
             materialised = true;
         } else {
-            hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(tiles), dim3(Cfg::NT), 0, s,
+            hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(grid_tiles), dim3(Cfg::NT), 0, s,
                                (const K*)kb[cur], kb[cur ^ 1], (const V*)vin_p, vout_p, n, shift, dmask,
-                               (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(), ws.ticket_ptr(e), e,
+                               (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
+                               Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e,
                                ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift, bsa);
             prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : "_w16") : "") + "_t" + std::to_string(TILE)).c_str(),
                      2 * n * pair_bytes, s);
@@ -970,6 +1045,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
     const bool atomrank = rs_atomic_rank_ok(s);
     if constexpr (!HAS_V) {
         if (n >= (1ull << 23)) {  // key-only: same 16 Ki-key tile as the pair sort
+            if (atomrank && variant != 21 && variant != 33 && ws.allow_group && !ws.plain_order)
+                return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
             if (atomrank && variant != 21)
                 return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4, false, true>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
             return radix_sort_cfg<K, V, RsCfg<16, false, false, 1024, false, 1, 0, 4>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in);
@@ -984,6 +1061,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
         if (variant == 0)
             variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
                                : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
+        if (variant == 31 && (!ws.allow_group || ws.plain_order)) variant = 33;
+        if (!atomrank && variant == 33) variant = 21;
         if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
 #define CDB_RS(...)                                                                                                      \
     return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in, \
@@ -994,8 +1073,25 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
         return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
                                                                  stats, dbits, h_hist_in, gen);                       \
     CDB_RS(__VA_ARGS__)
-        if (gen && variant != 21 && variant != 26 && variant != 1 && variant != 31 && variant != 36 && variant != 32)
+        if (rs_variant_experimental(variant) && (!atomrank || sizeof(V) != 4 || sizeof(K) != 4)) variant = atomrank ? 31 : 21;
+        if (variant >= 61 && variant <= 63 && !atomrank) variant = 21;
+        if (gen && !rs_variant_has_gen(variant))
             throw Error("radix_sort: this kernel configuration has no generated first pass (internal)");
+        if constexpr (sizeof(K) == 4 && sizeof(V) == 4) {
+            switch (variant) {
+                // experiments (A/B through the `sort_variant` option; one-atomic ranking, 4-byte keys and values only)
+                case 51: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 8, false, true);          // look-back window 8
+                case 52: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 16, false, true);         // look-back window 16
+                case 53: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true, false);   // tile id = blockIdx.x
+                case 54: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 8, false, true, false);
+                case 55: CDB_RS_GEN(24, true, true, 512, false, 4, 0, 4, false, true);           // 12 Ki-key tile, 2 WG/CU
+                case 56: CDB_RS_GEN(20, true, true, 512, false, 4, 0, 4, false, true);           // 10 Ki-key tile, 2 WG/CU
+                case 57: CDB_RS_GEN(24, true, true, 512, false, 4, 0, 8, false, true, false);
+                case 58: CDB_RS_GEN(16, true, true, 1024, false, 1, 8, 4, false, true);          // look-back depth counters
+                case 59: CDB_RS_GEN(16, true, true, 1024, false, 1, 8, 16, false, true);
+                default: break;
+            }
+        }
         switch (variant) {
             // production configurations: IPT, REUSE, EARLYV, NT, NONTEMP, MINW, ABL, LB
             default:
@@ -1003,7 +1099,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 26: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4);    // 4.5 Ki-key tile, 3 WG/CU
             case 1: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1);     // 3.75 Ki-key tile, 4 WG/CU
             // the same three with LDS-atomic ranking
-            case 31: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true);
+            case 31: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP);  // + XCD-aware tile order
+            case 33: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true);                     // (plain ticket order)
             case 36: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4, false, true);
             case 32: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1, false, true);
             // kept for A/B measurements (tools/sort_bench.py): the first version and the LDS-DMA load path; the other
@@ -1011,6 +1108,10 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             // ablations) are recorded in DESIGN.md §4.1
             case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);        // round-1 first version
             case 41: CDB_RS(16, true, true, 1024, false, 1, 0, 4, true);  // 16 Ki tile, LDS-DMA loads, ballot ranking
+            // timing-only ablations of the production tile (WRONG results; tools/sort_bench.py)
+            case 61: CDB_RS(16, true, true, 1024, false, 1, 1, 4, false, true);  // no look-back
+            case 62: CDB_RS(16, true, true, 1024, false, 1, 2, 4, false, true);  // linear write-out
+            case 63: CDB_RS(16, true, true, 1024, false, 1, 3, 4, false, true);  // both
         }
 #undef CDB_RS
 #undef CDB_RS_GEN
@@ -1023,7 +1124,10 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
     uint32_t e = 0;
     CDB_HIP(hipMemcpyAsync(&e, ws.err_ptr(), sizeof(e), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
-    if (e) throw Error("radix sort look-back timed out (internal error)");
+    if (e) {
+        CDB_HIP(hipMemsetAsync(ws.err_ptr(), 0, sizeof(uint32_t), s));
+        throw Error("radix sort look-back timed out (internal error)");
+    }
     if (getenv("CDB_LOOKBACK_STATS")) {
         uint32_t c[3] = {0, 0, 0};
         CDB_HIP(hipMemcpy(c, ws.err_ptr(), sizeof(c), hipMemcpyDeviceToHost));
@@ -1047,7 +1151,10 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
     if (variant == 0)
         variant = atomrank ? (n >= (1ull << 23) ? 31 : (n >= (1ull << 19) ? 36 : 32))
                            : (n >= (1ull << 23) ? 21 : (n >= (1ull << 19) ? 26 : 1));
+    if (variant == 31 && (!ws.allow_group || ws.plain_order)) variant = 33;
+    if (!atomrank && variant == 33) variant = 21;
     if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
+    if (rs_variant_experimental(variant) && (!atomrank || sizeof(V) != 4)) variant = atomrank ? 31 : 21;
 #define CDB_RS_SPLIT(...)                                                                                              \
     if (gen)                                                                                                           \
         return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin,   \
@@ -1056,12 +1163,27 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
     return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin, hi_bits, \
                                                                      stats, dbits, h_hist, (const NoGen*)nullptr, w0, w1, \
                                                                      (int)sizeof(W), bstart, d_hist)
+    if constexpr (sizeof(V) == 4) {
+        switch (variant) {
+            case 51: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 8, false, true);
+            case 52: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 16, false, true);
+            case 53: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true, false);
+            case 54: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 8, false, true, false);
+            case 55: CDB_RS_SPLIT(24, true, true, 512, false, 4, 0, 4, false, true);
+            case 56: CDB_RS_SPLIT(20, true, true, 512, false, 4, 0, 4, false, true);
+            case 57: CDB_RS_SPLIT(24, true, true, 512, false, 4, 0, 8, false, true, false);
+            case 58: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 8, 4, false, true);
+            case 59: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 8, 16, false, true);
+            default: break;
+        }
+    }
     switch (variant) {
         default:
         case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);
         case 26: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4);
         case 1: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1);
-        case 31: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true);
+        case 31: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP);
+        case 33: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true);
         case 36: CDB_RS_SPLIT(18, true, true, 256, false, 1, 0, 4, false, true);
         case 32: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1, false, true);
     }

@@ -1122,8 +1122,7 @@ void build_typed(Index& ix, bool big) {
     const bool want_hybrid = ix.hybrid != 0 && !big && sizeof(V) == 4 && ix.narrow_keys && ix.fuse_keygen && ix.digit_bits == 0 &&
                              ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255 && nsym <= HC_MAXSYM &&
                              (n >= (1ull << 27) || ix.hybrid >= 2) &&
-                             (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1 ||
-                              ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32);
+                             rs_variant_has_gen(ix.sort_variant);
     if (!big && ix.digit_bits == 0 && ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255) {
         const unsigned __int128 B = (unsigned)sigma + 1u;
         auto bits_of = [&](int k) {  // bits of B^k - 1; 999 when beyond 56 bits
@@ -1155,8 +1154,7 @@ void build_typed(Index& ix, bool big) {
     DevBuf sorted_keys, sa_buf, flags;
     SortStats ss;
     const bool fused = big || (ix.fuse_keygen && (dense || dbits == symbits) && nsym <= HC_MAXSYM &&
-                               (ix.sort_variant == 0 || ix.sort_variant == 21 || ix.sort_variant == 26 || ix.sort_variant == 1 ||
-                                ix.sort_variant == 31 || ix.sort_variant == 36 || ix.sort_variant == 32));
+                               rs_variant_has_gen(ix.sort_variant));
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
     // digit histograms of the keys (hyb_w = 0) or of the hybrid sort's bucket numbers, counted in one sweep over the text
@@ -1782,7 +1780,12 @@ void build_typed(Index& ix, bool big) {
 
 void build_suffix_array(Index& ix) {
     const double t0 = now_ms();
-    try {
+    struct GroupScope {  // the build's sorts may use the XCD-aware tile order: a starved pass is redone below
+        RadixWorkspace& ws;
+        explicit GroupScope(RadixWorkspace& w) : ws(w) { ws.allow_group = true; }
+        ~GroupScope() { ws.allow_group = false; }
+    } gscope(ix.rws);
+    auto run = [&]() {
         const bool wide = ix.size + ix.ndocs + 2 >= (1ull << 32) || ix.force_big_path;
         if (wide && ix.width != 8 && !ix.force_big_path) throw Error("internal: a corpus >= 2^32 bytes must have 8-byte entries");
         if (!wide) {
@@ -1791,6 +1794,23 @@ void build_suffix_array(Index& ix) {
         } else {
             if (ix.width == 4) build_typed<uint32_t, uint64_t, uint64_t>(ix, true);  // only reachable through force_big_path
             else build_typed<uint64_t, uint64_t, uint64_t>(ix, true);
+        }
+    };
+    try {
+        try {
+            run();
+        } catch (const Error& e) {
+            // A pass in XCD-aware tile order needs a few dozen workgroups resident at once (radix_sort.h: RS_GROUP);
+            // other kernels on the device can starve it, which ends in the (bounded) look-back timeout.  The plain
+            // ticket order needs one resident workgroup: rebuild with it, and keep it for this handle.
+            if (ix.rws.plain_order || std::strstr(e.what(), "look-back timed out") == nullptr) throw;
+            (void)hipStreamSynchronize(ix.stream);
+            ix.prof.resolve();
+            ix.d_sa.release();
+            ix.drop_keys();
+            ix.rws.plain_order = true;
+            ix.group_fallbacks += 1;
+            run();
         }
     } catch (...) {
         // (the scratch buffers went back to the block cache while the stack unwound; they carry an event of this
