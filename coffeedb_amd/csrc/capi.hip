@@ -1177,10 +1177,13 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "force_doubling")) ix.force_doubling = value != 0;
     else if (!std::strcmp(name, "initial_passes")) ix.initial_passes = (int)value;
     else if (!std::strcmp(name, "sort_variant")) ix.sort_variant = (int)value;
+    else if (!std::strcmp(name, "keyhist3")) ix.keyhist3 = value != 0;
     else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
+    else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = value != 0;
+    else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
     else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
     else if (!std::strcmp(name, "hybrid_passes")) ix.hybrid_passes = (int)value;

@@ -116,8 +116,10 @@ struct Index {
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;
+    bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
+    bool debug_starve_group = false;  // test hook: a build in XCD-aware tile order reports a look-back timeout once
     bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)

@@ -314,6 +314,122 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
         if (s_hist[p][tid]) atomicAdd(&hist[p * 256 + tid], (unsigned long long)s_hist[p][tid]);
 }
 
+// The same histograms for keys of 3 P symbols (P = 2..5; what the key-width choice produces for byte alphabets:
+// 6 symbols for printable ASCII and UTF-8 text, 9 for the 64-symbol Zipf alphabet), with most of the arithmetic in
+// 24 bits: a key is the number (G(p) W + G(p + 3)) W + ... with W = base^3 <= 2^24 and G(p) = the three codes at p
+// as a base-`base` number — two full-rate v_mad_u32_u24 per position and ONE 64-bit multiply-add per further part
+// instead of a rolling 64-bit key (64-bit multiplies run at quarter rate).  G(p) is evaluated afresh for every
+// position, so a document end only spoils the nsym - 1 keys whose window crosses it: a thread whose 32 positions
+// (+ look-ahead) meet at most one document end runs straight-line code and re-does those few keys with the masked
+// Horner evaluation; threads that see more ends (tiny documents, empty documents) and the ragged last tile walk
+// position by position like sa_keyhist_kernel.
+constexpr int KH3_PER = 32;
+static_assert(KH_TILE == 256 * KH3_PER, "sa_keyhist3_kernel: one thread walks KH3_PER positions");
+template <int P>
+__global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restrict__ text,
+                                                          const uint64_t* __restrict__ doc_start, uint64_t ndocs,
+                                                          uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
+                                                          int npass, bool padded, unsigned long long* __restrict__ hist) {
+    constexpr int NSYM = 3 * P;
+    constexpr int NG = KH3_PER + 3 * (P - 1);  // G values a thread needs
+    static_assert(NG + 2 <= 48, "window of three 16-byte reads");
+    __shared__ __attribute__((aligned(16))) uint8_t s_code[KH_TILE + KG_LOOK];
+    __shared__ uint16_t s_map[256];
+    __shared__ uint64_t s_drange[2];
+    __shared__ uint32_t s_hist[8][256];
+    const int tid = threadIdx.x;
+    s_map[tid] = symmap[tid];
+    for (int p = 0; p < npass; ++p) s_hist[p][tid] = 0;
+    const uint32_t W = kbase * kbase * kbase;
+    const uint64_t tiles = (n + KH_TILE - 1) / KH_TILE;
+    auto count = [&](uint64_t key) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < npass) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+    };
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * KH_TILE;
+        const uint32_t cnt = (uint32_t)((n - p0) < (uint64_t)KH_TILE ? (n - p0) : (uint64_t)KH_TILE);
+        __syncthreads();  // s_map ready / previous tile consumed
+        if (tid == 0) s_drange[0] = doc_upper(doc_start, 0, ndocs - 1, p0);
+        if (tid == 64) s_drange[1] = doc_upper(doc_start, 0, ndocs - 1, p0 + cnt - 1);
+        for (uint32_t i = tid * 16; i < KH_TILE + KG_LOOK; i += 256 * 16) {
+            const uint64_t g = p0 + i;
+            uint32_t x[4];
+            if (padded ? (g < n + KG_LOOK) : (g + 16 <= n)) {
+                const uint4 w = *reinterpret_cast<const uint4*>(text + g);
+                x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        x[q] |= (uint32_t)((g + 4 * q + b < n) ? text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                x[q] = (uint32_t)s_map[x[q] & 0xFF] | ((uint32_t)s_map[(x[q] >> 8) & 0xFF] << 8) |
+                       ((uint32_t)s_map[(x[q] >> 16) & 0xFF] << 16) | ((uint32_t)s_map[x[q] >> 24] << 24);
+            *reinterpret_cast<uint4*>(&s_code[i]) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        __syncthreads();
+        const uint32_t q0 = tid * KH3_PER;
+        if (q0 >= cnt) continue;
+        const uint64_t dhi = s_drange[1];
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_code);
+        const uint64_t pq = p0 + q0;
+        uint64_t d = doc_upper(doc_start, s_drange[0], dhi, pq);
+        uint64_t dend = doc_start[d + 1];
+        const uint64_t dend2 = d + 2 <= ndocs ? doc_start[d + 2] : ~0ull;
+        constexpr uint32_t REACH = KH3_PER + NSYM;
+        const uint32_t E = dend - pq < (1ull << 20) ? (uint32_t)(dend - pq) : (1u << 20);  // positions left in this document
+        const bool fast = q0 + KH3_PER <= cnt && (E >= REACH || dend2 - pq >= (uint64_t)REACH);
+        if (fast) {
+            uint32_t w[12];
+            {
+                const uint4 a = *reinterpret_cast<const uint4*>(&s_code[q0]);
+                const uint4 b = *reinterpret_cast<const uint4*>(&s_code[q0 + 16]);
+                const uint4 c = *reinterpret_cast<const uint4*>(&s_code[q0 + 32]);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+                w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+            }
+            auto code = [&](int t) -> uint32_t { return (w[t >> 2] >> (8 * (t & 3))) & 0xFFu; };
+            uint32_t G[NG];
+#pragma unroll
+            for (int t = 0; t < NG; ++t) G[t] = __umul24(__umul24(code(t), kbase) + code(t + 1), kbase) + code(t + 2);
+#pragma unroll
+            for (int t = 0; t < KH3_PER; ++t) {
+                // the keys of the nsym - 1 positions in front of the document end are counted below
+                if ((uint32_t)(E - 1u - (uint32_t)t) >= (uint32_t)(NSYM - 1)) {
+                    uint64_t key = G[t];
+#pragma unroll
+                    for (int k = 1; k < P; ++k) key = key * W + G[t + 3 * k];
+                    count(key);
+                }
+            }
+            if (E < REACH) {
+                const uint32_t lo = E > (uint32_t)(NSYM - 1) ? E - (uint32_t)(NSYM - 1) : 0u;
+                const uint32_t hi = E < (uint32_t)KH3_PER ? E : (uint32_t)KH3_PER;
+                for (uint32_t t = lo; t < hi; ++t) count(rs_pack_key(s_words, q0 + t, NSYM, kbase, E - t));
+            }
+        } else {
+            const uint32_t qe = q0 + KH3_PER < cnt ? q0 + KH3_PER : cnt;
+            for (uint32_t li = q0; li < qe; ++li) {
+                const uint64_t p = p0 + li;
+                if (p >= dend) {  // next non-empty document
+                    do { ++d; dend = doc_start[d + 1]; } while (p >= dend);
+                }
+                count(rs_pack_key(s_words, li, NSYM, kbase, dend - p < (1ull << 30) ? (uint32_t)(dend - p) : (1u << 30)));
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < npass; ++p)
+        if (s_hist[p][tid]) atomicAdd(&hist[p * 256 + tid], (unsigned long long)s_hist[p][tid]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // group flags: bit0 = first entry of a group of equal prefixes, bit1 = still unresolved
 // ---------------------------------------------------------------------------------------------
@@ -1164,9 +1280,19 @@ void build_typed(Index& ix, bool big) {
         CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
         const int grid = (int)std::min<uint64_t>(ceil_div(n, KH_TILE), 256 * 8);
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
-                           (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
-                           d_kh.as<unsigned long long>(), hyb_w, hyb_magic);
+        const bool by3 = ix.keyhist3 && hyb_w == 0 && nsym % 3 == 0 && nsym >= 6 && nsym <= 15;
+#define CDB_KH3(PARTS)                                                                                              \
+    hipLaunchKernelGGL((sa_keyhist3_kernel<PARTS>), dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n, \
+                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>())
+        if (by3 && nsym == 6) CDB_KH3(2);
+        else if (by3 && nsym == 9) CDB_KH3(3);
+        else if (by3 && nsym == 12) CDB_KH3(4);
+        else if (by3 && nsym == 15) CDB_KH3(5);
+        else
+            hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
+                               (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
+                               d_kh.as<unsigned long long>(), hyb_w, hyb_magic);
+#undef CDB_KH3
         ix.prof.end(t, "sa_keyhist", n, s);
         h_hist.assign((size_t)npass * 256, 0);
         CDB_HIP(hipMemcpyAsync(h_hist.data(), d_kh.p, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -1756,6 +1882,7 @@ void build_typed(Index& ix, bool big) {
         if (st.rounds > 80) throw Error("suffix-array refinement did not converge (internal error)");
     }
     if (ix.debug_fail_build) throw Error("debug: build failure requested (test hook)");
+    if (ix.debug_starve_group && !ix.rws.plain_order) throw Error("radix sort look-back timed out (test hook)");
     st.final_depth = h;
     st.sort_passes = ss.passes_run;
     st.sort_passes_skipped = ss.passes_skipped;

@@ -513,6 +513,42 @@ def test_concurrent_queries_same_handle(G):
     assert not errs
 
 
+@pytest.mark.parametrize("kh3", [1, 0])
+def test_key_histograms_by_parts_match_rolling_keys(G, kh3):
+    # dense keys of 3 P symbols take their digit histograms from 24-bit part arithmetic (sa_keyhist3_kernel); threads
+    # that meet one document end redo the few keys in front of it, threads that meet several (tiny, empty documents)
+    # walk position by position; keyhist3 = 0 is the rolling 64-bit sweep.  A wrong count breaks the sort.
+    seen = set()
+    for blob, ds, opts in ((W.ascii_corpus(6000, 350, seed=21) + (dict(initial_passes=0),)),
+                           (W.ascii_corpus(700, 1024, seed=5) + (dict(),)),
+                           (W.ragged_corpus(20000, 90, seed=15, empty_every=13) + (dict(),)),
+                           (W.ragged_corpus(60000, 7, seed=3, empty_every=3) + (dict(),)),
+                           (W.zipf_corpus(2000, 256, seed=2) + (dict(),)),
+                           (W.ascii_corpus(2000, 500, seed=8, lo=0x41, hi=0x43) + (dict(),))):
+        pats = W.sample_patterns(blob, ds, 200, 1, 12, seed=11)
+        g, _ = _check_parity(G, blob, ds, patterns=pats, key_coding=2, keyhist3=kh3)
+        seen.add(int(g.stat("key_symbols")))
+    assert any(k in (6, 9, 12, 15) for k in seen), seen
+
+
+def test_xcd_tile_order_and_fallback_to_plain_tickets(G):
+    # the big-tile passes hand their tiles out in XCD-aware order (radix_sort.h: RS_GROUP); a pass that starves ends in
+    # the bounded look-back timeout and the build is redone in plain ticket order (test hook: reported once)
+    blob, ds = W.ragged_corpus(9000, 300, seed=31, empty_every=17)
+    pats = W.sample_patterns(blob, ds, 200, 2, 12, seed=4)
+    g, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=31)
+    assert g.stat("group_fallbacks") == 0
+    g, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=31, debug_starve_group=1)
+    assert g.stat("group_fallbacks") == 1
+    g.build()                                   # the handle stays in plain order: no second fallback
+    assert g.stat("group_fallbacks") == 1
+    _check_parity(G, blob, ds, patterns=pats, sort_variant=31, plain_tile_order=1)
+    blob, ds = W.ascii_corpus(9000, 1024, seed=9)     # 9 Mi suffixes: the configuration the size rule picks itself
+    g, _ = _check_parity(G, blob, ds)
+    v = g.verify()
+    assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0
+
+
 def test_failed_build_leaves_index_unbuilt(G):
     # a build that cannot complete (test hook: it throws after its sorts) must leave a queryable "never built" index
     # behind, not a half-built one
