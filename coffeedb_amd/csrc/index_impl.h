@@ -26,6 +26,7 @@ struct BuildStats {
     int key_layout = 0;          // sort records: 0 = (u64 key, entry), 1 = (u32 key, entry), 2 / 3 = (u32 key, entry, u8 / u16 low digits)
     int dense_keys = 0;          // initial keys in base (alphabet + 1) instead of bit-aligned symbols
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
+    int bucket_low_digits = 0;   // ... low digits (bytes) carried beside the 32-bit bucket key
     int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
     int hybrid = 0;              // hybrid initial sort: global passes before the LDS bucket sort (0 = plain LSD sort,
                                  // -1 = tried, a bucket did not fit, redone by the plain sort)
@@ -116,6 +117,7 @@ struct Index {
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;
+    bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)

@@ -892,9 +892,8 @@ struct SortStats {
 
 // kernel configurations (radix_sort's `variant`) that have a generated first pass
 inline bool rs_variant_has_gen(int v) {
-    return v == 0 || v == 21 || v == 26 || v == 1 || v == 31 || v == 33 || v == 36 || v == 32 || (v >= 51 && v <= 59);
+    return v == 0 || v == 21 || v == 26 || v == 1 || v == 31 || v == 33 || v == 36 || v == 32;
 }
-inline bool rs_variant_experimental(int v) { return v >= 51 && v <= 59; }
 
 struct SortPlan {
     int npass, begin_bit;
@@ -1024,7 +1023,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
                                Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e,
                                ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift, bsa);
-            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : "_w16") : "") + "_t" + std::to_string(TILE)).c_str(),
+            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) : "") + "_t" + std::to_string(TILE)).c_str(),
                      2 * n * pair_bytes, s);
         }
         cur ^= 1;
@@ -1073,25 +1072,8 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
         return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
                                                                  stats, dbits, h_hist_in, gen);                       \
     CDB_RS(__VA_ARGS__)
-        if (rs_variant_experimental(variant) && (!atomrank || sizeof(V) != 4 || sizeof(K) != 4)) variant = atomrank ? 31 : 21;
-        if (variant >= 61 && variant <= 63 && !atomrank) variant = 21;
         if (gen && !rs_variant_has_gen(variant))
             throw Error("radix_sort: this kernel configuration has no generated first pass (internal)");
-        if constexpr (sizeof(K) == 4 && sizeof(V) == 4) {
-            switch (variant) {
-                // experiments (A/B through the `sort_variant` option; one-atomic ranking, 4-byte keys and values only)
-                case 51: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 8, false, true);          // look-back window 8
-                case 52: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 16, false, true);         // look-back window 16
-                case 53: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 4, false, true, false);   // tile id = blockIdx.x
-                case 54: CDB_RS_GEN(16, true, true, 1024, false, 1, 0, 8, false, true, false);
-                case 55: CDB_RS_GEN(24, true, true, 512, false, 4, 0, 4, false, true);           // 12 Ki-key tile, 2 WG/CU
-                case 56: CDB_RS_GEN(20, true, true, 512, false, 4, 0, 4, false, true);           // 10 Ki-key tile, 2 WG/CU
-                case 57: CDB_RS_GEN(24, true, true, 512, false, 4, 0, 8, false, true, false);
-                case 58: CDB_RS_GEN(16, true, true, 1024, false, 1, 8, 4, false, true);          // look-back depth counters
-                case 59: CDB_RS_GEN(16, true, true, 1024, false, 1, 8, 16, false, true);
-                default: break;
-            }
-        }
         switch (variant) {
             // production configurations: IPT, REUSE, EARLYV, NT, NONTEMP, MINW, ABL, LB
             default:
@@ -1104,14 +1086,10 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
             case 36: CDB_RS_GEN(18, true, true, 256, false, 1, 0, 4, false, true);
             case 32: CDB_RS_GEN(15, true, true, 256, false, 1, 0, 1, false, true);
             // kept for A/B measurements (tools/sort_bench.py): the first version and the LDS-DMA load path; the other
-            // design points that were measured (tile shapes, look-back depths, non-temporal accesses, timing
-            // ablations) are recorded in DESIGN.md §4.1
+            // design points that were measured (tile shapes, look-back depths, tile orders, non-temporal accesses, timing
+            // ablations) are recorded in DESIGN.md §4.1 and can be re-run with tools/experiments/pass_bench.hip
             case 4: CDB_RS(15, false, false, 256, false, 1, 0, 1);        // round-1 first version
             case 41: CDB_RS(16, true, true, 1024, false, 1, 0, 4, true);  // 16 Ki tile, LDS-DMA loads, ballot ranking
-            // timing-only ablations of the production tile (WRONG results; tools/sort_bench.py)
-            case 61: CDB_RS(16, true, true, 1024, false, 1, 1, 4, false, true);  // no look-back
-            case 62: CDB_RS(16, true, true, 1024, false, 1, 2, 4, false, true);  // linear write-out
-            case 63: CDB_RS(16, true, true, 1024, false, 1, 3, 4, false, true);  // both
         }
 #undef CDB_RS
 #undef CDB_RS_GEN
@@ -1144,7 +1122,10 @@ template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
                      W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
                      const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const BStartArgs* bstart = nullptr,
-                     const unsigned long long* d_hist = nullptr) {
+                     const unsigned long long* d_hist = nullptr, int lead_digits = -1) {
+    // lead_digits: sort digits in the auxiliary array of materialised records (default: every byte of W); the bytes
+    // above them are carried along untouched (the bucket-wise build keeps bits 32..39 of its entries there)
+    const int lead_in = lead_digits >= 0 ? lead_digits : (int)sizeof(W);
     const bool atomrank = rs_atomic_rank_ok(s);
     // 8-byte values: a 12 Ki-key tile keeps staging + auxiliary bytes inside the 160 KB of LDS
     constexpr int IPT_BIG = sizeof(V) == 8 ? 12 : 16;
@@ -1154,29 +1135,16 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
     if (variant == 31 && (!ws.allow_group || ws.plain_order)) variant = 33;
     if (!atomrank && variant == 33) variant = 21;
     if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
-    if (rs_variant_experimental(variant) && (!atomrank || sizeof(V) != 4)) variant = atomrank ? 31 : 21;
 #define CDB_RS_SPLIT(...)                                                                                              \
-    if (gen)                                                                                                           \
-        return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin,   \
-                                                                           hi_bits, stats, dbits, h_hist, gen, w0, w1,  \
-                                                                           0, bstart);                                  \
+    if constexpr (sizeof(W) <= 2) { /* (a generated first pass produces one or two low digits) */                      \
+        if (gen)                                                                                                       \
+            return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n,          \
+                                                                               key_begin, hi_bits, stats, dbits,        \
+                                                                               h_hist, gen, w0, w1, 0, bstart);         \
+    }                                                                                                                  \
     return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin, hi_bits, \
                                                                      stats, dbits, h_hist, (const NoGen*)nullptr, w0, w1, \
-                                                                     (int)sizeof(W), bstart, d_hist)
-    if constexpr (sizeof(V) == 4) {
-        switch (variant) {
-            case 51: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 8, false, true);
-            case 52: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 16, false, true);
-            case 53: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4, false, true, false);
-            case 54: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 8, false, true, false);
-            case 55: CDB_RS_SPLIT(24, true, true, 512, false, 4, 0, 4, false, true);
-            case 56: CDB_RS_SPLIT(20, true, true, 512, false, 4, 0, 4, false, true);
-            case 57: CDB_RS_SPLIT(24, true, true, 512, false, 4, 0, 8, false, true, false);
-            case 58: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 8, 4, false, true);
-            case 59: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 8, 16, false, true);
-            default: break;
-        }
-    }
+                                                                     lead_in, bstart, d_hist)
     switch (variant) {
         default:
         case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);

@@ -487,8 +487,9 @@ __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __r
                                                              bool flags_aligned) {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
+    const uint64_t lmask = (1ull << low_bits) - 1ull;  // (bytes of W above the digits carry other data: packed entries)
     auto full = [&](uint64_t i) -> uint64_t {
-        return low ? (((uint64_t)k32[i] << low_bits) | (uint64_t)low[i]) : (uint64_t)k32[i];
+        return low ? (((uint64_t)k32[i] << low_bits) | ((uint64_t)low[i] & lmask)) : (uint64_t)k32[i];
     };
     uint64_t k[6];
     if (i0 + 4 <= n) {
@@ -497,10 +498,11 @@ __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __r
         W l4[4] = {};
         if (low) {
             if constexpr (sizeof(W) == 1) *reinterpret_cast<uint32_t*>(l4) = *reinterpret_cast<const uint32_t*>(low + i0);
-            else *reinterpret_cast<uint2*>(l4) = *reinterpret_cast<const uint2*>(low + i0);
+            else if constexpr (sizeof(W) == 2) *reinterpret_cast<uint2*>(l4) = *reinterpret_cast<const uint2*>(low + i0);
+            else *reinterpret_cast<uint4*>(l4) = *reinterpret_cast<const uint4*>(low + i0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | (uint64_t)l4[q]) : (uint64_t)hi[q];
+        for (int q = 0; q < 4; ++q) k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | ((uint64_t)l4[q] & lmask)) : (uint64_t)hi[q];
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? full(i0 + q) : 0;
@@ -643,6 +645,68 @@ __global__ __launch_bounds__(256) void sa_bucket_records_kernel(const V* __restr
     unsigned long long* h = hist + (size_t)(it.bucket - bucket0) * 8 * 256;
     for (int p = 0; p < npass; ++p)
         if (s_hist[p][threadIdx.x]) atomicAdd(&h[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
+}
+
+// The same records with PACKED entries (entries below 2^40, i.e. every corpus that fits a GPU): the sorts of a
+// bucket then move (u32 key, u32 entry bits 0..31, W = low digits | entry bits 32..39 above them) — 9 to 12 bytes per
+// suffix and pass instead of 13 to 16 with 8-byte entries — and sa_assemble_entries_kernel puts the sorted
+// entries back together.
+template <typename W>
+__global__ __launch_bounds__(256) void sa_bucket_records_packed_kernel(const uint64_t* __restrict__ ent,
+                                                                       const BucketItem* __restrict__ items,
+                                                                       const uint8_t* __restrict__ text, uint64_t n,
+                                                                       const uint64_t* __restrict__ doc_start,
+                                                                       const uint16_t* __restrict__ symmap, int bits,
+                                                                       uint64_t mask, int nsym, uint32_t kbase, int low_bits,
+                                                                       int npass, uint64_t gstart, uint32_t bucket0,
+                                                                       uint32_t* __restrict__ k32, W* __restrict__ low,
+                                                                       uint32_t* __restrict__ elo,
+                                                                       unsigned long long* __restrict__ hist) {
+    __shared__ uint16_t s_map[256];
+    __shared__ uint32_t s_hist[8][256];
+    s_map[threadIdx.x] = symmap[threadIdx.x];
+    for (int p = 0; p < npass; ++p) s_hist[p][threadIdx.x] = 0;
+    __syncthreads();
+    const BucketItem it = items[blockIdx.x];
+    for (uint32_t r = threadIdx.x; r < it.count; r += 256) {
+        const uint64_t i = it.begin + r;
+        const uint64_t e = ent[i];
+        const uint64_t d = e & mask;
+        const uint64_t pos = doc_start[d] + (e >> bits);
+        const uint64_t rem = doc_start[d + 1] - pos;
+        uint64_t key = 0;
+        if (pos + 24 <= n) {  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
+            uint64_t w = *reinterpret_cast<const u64_unaligned*>(text + pos + 1);
+            for (int k = 1; k < nsym && k <= 8; ++k) {
+                key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                w >>= 8;
+            }
+            if (nsym > 9) {
+                w = *reinterpret_cast<const u64_unaligned*>(text + pos + 9);
+                for (int k = 9; k < nsym; ++k) {
+                    key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+                    w >>= 8;
+                }
+            }
+        } else {
+            for (int k = 1; k < nsym; ++k) key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull);
+        }
+        k32[i - gstart] = (uint32_t)(key >> low_bits);
+        low[i - gstart] = (W)((key & ((1ull << low_bits) - 1ull)) | ((e >> 32) << low_bits));
+        elo[i - gstart] = (uint32_t)e;
+        for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    unsigned long long* h = hist + (size_t)(it.bucket - bucket0) * 8 * 256;
+    for (int p = 0; p < npass; ++p)
+        if (s_hist[p][threadIdx.x]) atomicAdd(&h[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
+}
+
+template <typename W>
+__global__ __launch_bounds__(256) void sa_assemble_entries_kernel(const uint32_t* __restrict__ elo, const W* __restrict__ low,
+                                                                  int hi_shift, uint64_t cnt, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt) out[i] = ((uint64_t)((uint32_t)low[i] >> hi_shift) << 32) | (uint64_t)elo[i];
 }
 
 struct FlagIn {
@@ -1582,12 +1646,17 @@ void build_typed(Index& ix, bool big) {
         }
         // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
         //  symbols, the grouped gather and no separate histogram pass)
-        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : (bbits <= 56 ? 0 : -1)));
-        const bool bwide = bbits > 48 && bbits <= 56;
+        // packed entries (sa_bucket_records_packed_kernel): 8-byte entries below 2^40 travel as u32 + one byte on top of the
+        // low digits; up to three low digits then keep every key of <= 56 bits in (u32, u32, u8 / u16 / u32) records
+        const bool packed = sizeof(V) == 8 && ix.pack_entries && (int)ix.bits + ix.off_bits <= 40 && ix.narrow_keys && nsym > 1 &&
+                            bbits <= 56;
+        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : (bbits <= 56 ? (packed ? 24 : 0) : -1)));
+        const bool bwide = !packed && bbits > 48 && bbits <= 56;
         // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
         //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
         const bool brecords = ix.narrow_keys && blow >= 0 && nsym > 1;  // (codes up to 256 are u16 in the record kernel)
-        st.key_layout = brecords ? (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3))) : 0;
+        st.bucket_low_digits = brecords && blow > 0 ? blow / 8 : 0;
+        st.key_layout = brecords ? (packed ? 5 : (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3)))) : 0;
         if (brecords) {
             const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
             const int bpass = (int)ceil_div(bbits, 8);
@@ -1628,19 +1697,27 @@ void build_typed(Index& ix, bool big) {
             CDB_HIP(hipMemGetInfo(&fre, &tot));
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
             // (the third entry buffer is a luxury: without it an odd number of passes costs a copy back)
-            const bool third = avail > (double)maxb * (2.0 * (keyb + lowb) + 2 * sizeof(V)) * 1.15;
-            const double scratch = (double)maxb * (keyb + lowb + (third ? 2 : 1) * sizeof(V)) +
-                                   (third ? (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1) : 0.0);
-            uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / (keyb + lowb));
+            const int auxb = packed ? (lowb == 0 ? 1 : (lowb == 1 ? 2 : 4)) : lowb;  // bytes of the auxiliary array per suffix
+            const int recb = keyb + auxb + (packed ? 4 : 0);                         // record bytes per suffix of a group
+            const bool third = !packed && avail > (double)maxb * (2.0 * (keyb + lowb) + 2 * sizeof(V)) * 1.15;
+            const double scratch = packed ? (double)maxb * recb
+                                          : (double)maxb * (keyb + lowb + (third ? 2 : 1) * sizeof(V)) +
+                                                (third ? (double)(n / 32) * (sizeof(I) + 16 + 2 * sizeof(V) + 1) : 0.0);
+            uint64_t gcap = (uint64_t)std::max(0.0, (avail - scratch) * 0.85 / recb);
             if (ix.bucket_group_limit) gcap = std::min<uint64_t>(gcap, ix.bucket_group_limit);
             gcap = std::max<uint64_t>(std::min<uint64_t>(gcap, n), maxb);
-            DevBuf k32g, lowg, k32t, lowt, ET, EX, d_bh, d_items;
+            DevBuf k32g, lowg, k32t, lowt, ET, EX, elog, elot, d_bh, d_items;
             k32g.alloc(gcap * keyb);
-            if (lowb) lowg.alloc(gcap * lowb);
+            if (auxb) lowg.alloc(gcap * auxb);
             k32t.alloc(maxb * keyb);
-            if (lowb) lowt.alloc(maxb * lowb);
-            ET.alloc(maxb * sizeof(V));
-            if (third) EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
+            if (auxb) lowt.alloc(maxb * auxb);
+            if (packed) {
+                elog.alloc(gcap * sizeof(uint32_t));
+                elot.alloc(maxb * sizeof(uint32_t));
+            } else {
+                ET.alloc(maxb * sizeof(V));
+                if (third) EX.alloc(maxb * sizeof(V));  // third entry buffer: an odd number of passes still ends in place (radix_sort.h)
+            }
             std::vector<uint64_t> bh;
             std::vector<BucketItem> items;
             auto run_group = [&](auto wtag, auto ktag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1)
@@ -1702,10 +1779,66 @@ void build_typed(Index& ix, bool big) {
                                            flags.as<uint8_t>() + start, (start & 3) == 0);
                 }
             };
+            auto run_group_packed = [&](auto wtag, uint32_t b0, uint32_t b1) {  // buckets [b0, b1), packed entries
+                using W = decltype(wtag);
+                if constexpr (sizeof(V) == 8) {
+                    const uint64_t gstart = bstart[b0];
+                    const uint32_t gb = b1 - b0;
+                    d_bh.ensure((size_t)gb * 8 * 256 * sizeof(uint64_t));
+                    CDB_HIP(hipMemsetAsync(d_bh.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
+                    items.clear();
+                    for (uint32_t x = 0; x < nch; ++x)      // text chunk major: the group's buckets share the cached text
+                        for (uint32_t b = b0; b < b1; ++b) {
+                            const uint64_t lo = bounds[(size_t)b * (nch + 1) + x], hi = bounds[(size_t)b * (nch + 1) + x + 1];
+                            for (uint64_t o = lo; o < hi; o += BR_ITEM)
+                                items.push_back(BucketItem{(unsigned long long)o, (uint32_t)std::min<uint64_t>(BR_ITEM, hi - o), b});
+                        }
+                    st.gather_items += items.size();
+                    if (!items.empty()) {
+                        d_items.ensure(items.size() * sizeof(BucketItem));
+                        CDB_HIP(hipMemcpyAsync(d_items.p, items.data(), items.size() * sizeof(BucketItem), hipMemcpyHostToDevice, s));
+                        int t = ix.prof.begin(s);
+                        hipLaunchKernelGGL((sa_bucket_records_packed_kernel<W>), dim3((unsigned)items.size()), dim3(256), 0, s,
+                                           (const uint64_t*)E.as<uint64_t>(), (const BucketItem*)d_items.as<BucketItem>(), text, n,
+                                           doc_start, (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase,
+                                           blow, bpass, gstart, b0, k32g.as<uint32_t>(), lowg.as<W>(), elog.as<uint32_t>(),
+                                           d_bh.as<unsigned long long>());
+                        ix.prof.end(t, "sa_bucket_records", (bstart[b1] - gstart) * ((uint64_t)nsym + recb + sizeof(V)), s);
+                    }
+                    CDB_HIP(hipStreamSynchronize(s));  // (protects `items`, rebuilt for the next group)
+                    for (uint32_t b = b0; b < b1; ++b) {
+                        const uint64_t start = bstart[b], cnt = bstart[b + 1] - start;
+                        uint32_t* kb = k32g.as<uint32_t>() + (start - gstart);
+                        uint32_t* vb = elog.as<uint32_t>() + (start - gstart);
+                        W* lb = lowg.as<W>() + (start - gstart);
+                        int r = 0, vr = 0;
+                        if (bpass > 0 && cnt > 1) {
+                            const unsigned long long* hb = d_bh.as<unsigned long long>() + (size_t)(b - b0) * 8 * 256;
+                            ix.rws.value_spare = nullptr;
+                            r = radix_sort_split<uint32_t, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), vb, elot.as<uint32_t>(), lb,
+                                                              lowt.as<W>(), cnt, bbits - blow, &ss, ix.sort_variant, 8,
+                                                              (const uint64_t*)nullptr, (const TextGen*)nullptr, 0,
+                                                              (const BStartArgs*)nullptr, hb, lowb);
+                            vr = ix.rws.value_result;
+                        }
+                        const W* ls = r ? lowt.as<W>() : lb;
+                        int t = ix.prof.begin(s);
+                        hipLaunchKernelGGL(sa_assemble_entries_kernel<W>, dim3((unsigned)ceil_div(cnt, 256)), dim3(256), 0, s,
+                                           (const uint32_t*)(vr ? elot.as<uint32_t>() : vb), ls, blow, cnt, E.as<uint64_t>() + start);
+                        ix.prof.end(t, "sa_assemble_entries", cnt * (4 + sizeof(W) + 8), s);
+                        hipLaunchKernelGGL(sa_initflags32_kernel<W>, dim3((unsigned)ceil_div(cnt, 1024)), dim3(256), 0, s,
+                                           (const uint32_t*)(r ? k32t.as<uint32_t>() : kb), lowb ? ls : (const W*)nullptr, blow, cnt,
+                                           bbase, bmagic, flags.as<uint8_t>() + start, (start & 3) == 0);
+                    }
+                }
+            };
             for (uint32_t b0 = 0; b0 < nb;) {
                 uint32_t b1 = b0 + 1;
                 while (b1 < nb && bstart[b1 + 1] - bstart[b0] <= gcap) ++b1;
-                if (bwide) run_group(NoVal{}, uint64_t{}, b0, b1);
+                if (packed && lowb == 0) run_group_packed(uint8_t{}, b0, b1);
+                else if (packed && lowb == 1) run_group_packed(uint16_t{}, b0, b1);
+                else if (packed) run_group_packed(uint32_t{}, b0, b1);
+                else if (bwide) run_group(NoVal{}, uint64_t{}, b0, b1);
                 else if (blow == 0) run_group(NoVal{}, uint32_t{}, b0, b1);
                 else if (blow == 8) run_group(uint8_t{}, uint32_t{}, b0, b1);
                 else run_group(uint16_t{}, uint32_t{}, b0, b1);

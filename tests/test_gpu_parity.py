@@ -185,6 +185,36 @@ def test_big_corpus_code_path_at_small_size(G, force_doubling, group_limit):
     assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
 
 
+def _wide_entry_docs(nsmall, small_len, big_len):
+    """document table whose entries need more than 32 bits: many small documents and one long one"""
+    lens = np.full(nsmall, small_len, dtype=np.uint64)
+    lens[nsmall // 3] = big_len
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+
+
+@pytest.mark.parametrize("pack", [1, 0])
+def test_bucket_sorts_with_packed_entries(G, pack):
+    # bucket-wise build with 8-byte entries: the bucket sorts move (u32 key, u32 entry bits 0..31, low digits | entry
+    # bits 32..39) and the entries are put back together afterwards (pack_entries = 0: (key, u64 entry) records).
+    # Alphabets of 3 / 26 / 95 / 200 / 256 byte values give bucket keys with zero to three low digits.
+    layouts = set()
+    for seed, (lo, hi), initial in ((17, (0x61, 0x63), 0), (5, (0x61, 0x7A), 0), (6, (0x20, 0x7E), 0), (7, (0x20, 0xE7), 0),
+                                    (8, (0x00, 0xFF), 0), (9, (0x20, 0x7E), 7), (10, (0x00, 0xFF), 8), (11, (0x20, 0x7E), 6),
+                                    (12, (0x00, 0xFF), 6)):
+        ds = _wide_entry_docs(40000, 3, 70000)
+        blob = W.random_bytes(int(ds[-1]), seed, lo, hi)
+        pats = W.sample_patterns(blob, ds, 150, 1, 8, seed=12, miss_frac=0)
+        opts = dict(force_big_path=1, pack_entries=pack)
+        if initial:
+            opts["initial_passes"] = initial
+        for group_limit in (0, 30000):
+            g, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, **opts)
+            assert g.sa_width == 8 and g.stat("bucketed") == 1
+            layouts.add((int(g.stat("key_layout")), int(g.stat("bucket_low_digits"))))
+    assert (5 in {l for l, _ in layouts}) == bool(pack), layouts
+    assert not pack or {d for _, d in layouts} == {0, 1, 2, 3}, layouts   # u8 / u16 / u32 auxiliary arrays
+
+
 def test_test_string_shape_property(G):
     # test/test-string.py shape (a-z, 3-char keywords) scaled to 300 x 5000, brute-force oracle
     from oracle import brute_count
