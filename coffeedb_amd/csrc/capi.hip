@@ -1184,6 +1184,8 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = value != 0;
+    else if (!std::strcmp(name, "self_check")) ix.self_check = value != 0;
+    else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
     else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
@@ -1212,7 +1214,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"hybrid", (double)b.hybrid}, {"hybrid_largest_bucket", (double)b.hybrid_largest_bucket}, {"hybrid_estimate", (double)b.hybrid_estimate}, {"hybrid_retries", (double)b.hybrid_retries}, {"group_fallbacks", (double)h->ix.group_fallbacks},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"hybrid", (double)b.hybrid}, {"hybrid_largest_bucket", (double)b.hybrid_largest_bucket}, {"hybrid_estimate", (double)b.hybrid_estimate}, {"hybrid_retries", (double)b.hybrid_retries}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

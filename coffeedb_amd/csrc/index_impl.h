@@ -121,6 +121,10 @@ struct Index {
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
+    bool self_check = true;           // spot check of random adjacent pairs after every build (verify.hip); a failure makes
+                                      // the build fall back to the ballot ranking once, then fail
+    int self_check_fallbacks = 0;
+    bool debug_fail_self_check = false;  // test hook: the first spot check of a build reports a failure
     bool debug_starve_group = false;  // test hook: a build in XCD-aware tile order reports a look-back timeout once
     bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
@@ -150,6 +154,7 @@ void build_suffix_array(Index& ix);
 
 // verify.hip — out = {inversions, tie-order violations, wrapped sum of entries, invalid entries, expected sum}
 void verify_suffix_array(Index& ix, uint64_t out[5]);
+void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // verify.hip: the check behind every build
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
 // out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,
 // equal suffixes not ascending by document}

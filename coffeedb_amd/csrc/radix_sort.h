@@ -803,9 +803,23 @@ static __global__ __launch_bounds__(256) void rs_lane_order_probe_kernel(uint32_
 }
 
 // true when the device passed the probe (cached per device; CDB_RANK=ballot forces the ballot ranking)
+struct RsRankCache {
+    std::mutex mu;
+    std::map<int, bool> ok;
+    static RsRankCache& get() {
+        static RsRankCache c;
+        return c;
+    }
+};
+// the builds' spot check failed with the one-atomic ranking in use: this process ranks with ballots on that device
+inline void rs_atomic_rank_disable(int dev) {
+    RsRankCache& c = RsRankCache::get();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.ok[dev] = false;
+}
 inline bool rs_atomic_rank_ok(hipStream_t s) {
-    static std::mutex mu;
-    static std::map<int, bool> cache;
+    std::mutex& mu = RsRankCache::get().mu;
+    std::map<int, bool>& cache = RsRankCache::get().ok;
     int dev = 0;
     CDB_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mu);

@@ -2085,6 +2085,43 @@ void build_suffix_array(Index& ix) {
     }
     CDB_HIP(hipStreamSynchronize(ix.stream));
     ix.prof.resolve();
+    // Spot check of the finished array (verify.hip).  The stable ranking of the passes rests on observed LDS behaviour
+    // (radix_sort.h: one-atomic ranking, self-tested per device); should a build ever come out wrong, this process
+    // switches the device to the ballot ranking, rebuilds once, and fails loudly if that does not help either.
+    if (ix.self_check && ix.size >= 2) {
+        uint64_t sc[2] = {0, 0};
+        auto check = [&]() {
+            spot_check_suffix_array(ix, 1u << 15, sc);
+            if (ix.debug_fail_self_check && ix.self_check_fallbacks == 0) sc[0] += 1;
+            return sc[0] == 0 && sc[1] == 0;
+        };
+        if (!check()) {
+            const bool was_atomic = rs_atomic_rank_ok(ix.stream);
+            if (was_atomic && !ix.debug_fail_self_check) rs_atomic_rank_disable(ix.device);  // (the test hook leaves the device alone)
+            ix.self_check_fallbacks += 1;
+            try {
+                run();
+                CDB_HIP(hipStreamSynchronize(ix.stream));
+                ix.prof.resolve();
+            } catch (...) {
+                (void)hipStreamSynchronize(ix.stream);
+                ix.prof.resolve();
+                ix.d_sa.release();
+                ix.drop_keys();
+                ix.width = 0;
+                ix.size = 0;
+                throw;
+            }
+            if (!check()) {
+                ix.d_sa.release();
+                ix.drop_keys();
+                ix.width = 0;
+                ix.size = 0;
+                throw Error("suffix array self-check failed: " + std::to_string(sc[0]) + " pairs out of order, " + std::to_string(sc[1]) +
+                            " invalid entries among the sampled pairs (internal error)");
+            }
+        }
+    }
     ix.bstats.build_ms = now_ms() - t0;
 }
 

@@ -71,6 +71,45 @@ __global__ __launch_bounds__(256) void sa_entry_check_kernel(const V* __restrict
     if (b) atomicAdd(bad, b);
 }
 
+// Spot check behind every build (option self_check, default on): `samples` pseudo-random adjacent pairs of the finished
+// array are compared the plain way.  A stable LSD sort whose ranking went wrong anywhere leaves inversions scattered
+// over the whole array, so a few ten thousand pairs notice what the per-device self-test of the one-atomic ranking
+// (radix_sort.h) could miss; the cost is a few microseconds.  Rules as in sa_verify_reference_kernel, minus the one
+// that needs bucket sizes: equal suffixes ascend by document; a suffix that is a prefix of its neighbour comes first;
+// first differing bytes of the same sign class ascend; a byte >= 0x80 against one < 0x80 must ascend only when the array
+// is in plain unsigned order (`plain`), otherwise that pair is skipped (the reference's order depends on bucket sizes).
+template <typename V>
+__global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict__ sa, uint64_t n,
+                                                            const uint8_t* __restrict__ text,
+                                                            const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
+                                                            uint64_t mask, uint32_t samples, uint64_t seed, bool plain,
+                                                            unsigned long long* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= samples || n < 2) return;
+    uint64_t h = seed + 0x9E3779B97F4A7C15ull * (t + 1);
+    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+    h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+    h ^= h >> 31;
+    const uint64_t i = 1 + h % (n - 1);
+    const V ea = sa[i - 1], eb = sa[i];
+    const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits, db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
+    if (da >= ndocs || db >= ndocs || oa >= doc_start[da + 1] - doc_start[da] || ob >= doc_start[db + 1] - doc_start[db]) {
+        atomicAdd(&out[1], 1ull);
+        return;
+    }
+    const uint8_t* pa = text + doc_start[da] + oa;
+    const uint8_t* pb = text + doc_start[db] + ob;
+    const uint64_t la = doc_start[da + 1] - doc_start[da] - oa, lb = doc_start[db + 1] - doc_start[db] - ob;
+    const uint64_t len = la < lb ? la : lb;
+    const uint64_t cap = len < 4096 ? len : 4096;  // (long common prefixes — duplicate documents — are taken on trust)
+    uint64_t l = 0;
+    while (l < cap && pa[l] == pb[l]) ++l;
+    bool bad = false;
+    if (l == len) bad = la > lb || (la == lb && da >= db);
+    else if (l < cap) bad = pa[l] > pb[l] && (plain || ((pa[l] ^ pb[l]) & 0x80u) == 0);
+    if (bad) atomicAdd(&out[0], 1ull);
+}
+
 // ---- the REFERENCE's order --------------------------------------------------------------
 // For text with bytes >= 0x80 the reference's array is not globally sorted: a radix node (bucket of more than
 // chuck_size = max(4096, n / 256) suffixes, index.cpp:96-126,218) lays its children out by
@@ -219,6 +258,27 @@ uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint6
     CDB_HIP(hipMemcpyAsync(&bad, d_bad.p, sizeof(bad), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
     return bad;
+}
+
+// pairs out of order / invalid entries among `samples` random adjacent pairs (see sa_spot_check_kernel)
+void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    if (ix.size < 2 || ix.width == 0) return;
+    hipStream_t s = ix.stream;
+    DevBuf d_out;
+    d_out.alloc(2 * sizeof(uint64_t));
+    CDB_HIP(hipMemsetAsync(d_out.p, 0, 2 * sizeof(uint64_t), s));
+    const unsigned grid = (unsigned)ceil_div(samples, 256);
+    if (ix.width == 4)
+        hipLaunchKernelGGL((sa_spot_check_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
+                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask,
+                           samples, ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL((sa_spot_check_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(),
+                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask,
+                           samples, ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
+    CDB_HIP(hipMemcpyAsync(out, d_out.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
 }
 
 void verify_suffix_array(Index& ix, uint64_t out[5]) {

@@ -579,6 +579,19 @@ def test_xcd_tile_order_and_fallback_to_plain_tickets(G):
     assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0
 
 
+def test_build_self_check_and_its_fallback(G):
+    # every build ends with a spot check of random adjacent pairs (verify.hip); a failure (test hook: reported once) makes
+    # the build run again — in production with the ballot ranking — and only a second failure is an error
+    for blob, ds in (W.ascii_corpus(3000, 333, seed=2), W.ascii_corpus(500, 300, seed=3, lo=0x00, hi=0xFF),
+                     W.ragged_corpus(5000, 40, seed=4, empty_every=5)):
+        pats = W.sample_patterns(blob, ds, 100, 1, 8, seed=2, miss_frac=0)
+        g, _ = _check_parity(G, blob, ds, patterns=pats)
+        assert g.stat("self_check_fallbacks") == 0
+        g, _ = _check_parity(G, blob, ds, patterns=pats, debug_fail_self_check=1)
+        assert g.stat("self_check_fallbacks") == 1
+        _check_parity(G, blob, ds, patterns=pats, self_check=0)
+
+
 def test_failed_build_leaves_index_unbuilt(G):
     # a build that cannot complete (test hook: it throws after its sorts) must leave a queryable "never built" index
     # behind, not a half-built one
