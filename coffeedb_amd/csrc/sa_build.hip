@@ -668,33 +668,55 @@ __global__ __launch_bounds__(256) void sa_bucket_records_packed_kernel(const uin
     for (int p = 0; p < npass; ++p) s_hist[p][threadIdx.x] = 0;
     __syncthreads();
     const BucketItem it = items[blockIdx.x];
-    for (uint32_t r = threadIdx.x; r < it.count; r += 256) {
-        const uint64_t i = it.begin + r;
-        const uint64_t e = ent[i];
-        const uint64_t d = e & mask;
-        const uint64_t pos = doc_start[d] + (e >> bits);
-        const uint64_t rem = doc_start[d + 1] - pos;
-        uint64_t key = 0;
-        if (pos + 24 <= n) {  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
-            uint64_t w = *reinterpret_cast<const u64_unaligned*>(text + pos + 1);
-            for (int k = 1; k < nsym && k <= 8; ++k) {
-                key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
-                w >>= 8;
-            }
-            if (nsym > 9) {
-                w = *reinterpret_cast<const u64_unaligned*>(text + pos + 9);
-                for (int k = 9; k < nsym; ++k) {
-                    key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[w & 0xff] : 0ull);
+    // Four entries per thread and round, stage by stage: entry -> document table -> text window are dependent loads,
+    // and the four chains of a thread are in flight together.
+    constexpr int U = 4;
+    for (uint32_t r0 = threadIdx.x; r0 < it.count; r0 += 256 * U) {
+        uint64_t e[U], pos[U], rem[U], w0[U], w1[U];
+        bool live[U], windowed[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = r0 + 256u * u < it.count;
+            e[u] = live[u] ? ent[it.begin + r0 + 256u * u] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t d = live[u] ? (e[u] & mask) : 0ull;
+            const uint64_t ds = doc_start[d], de = doc_start[d + 1];
+            pos[u] = ds + (e[u] >> bits);
+            rem[u] = de - pos[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            windowed[u] = live[u] && pos[u] + 24 <= n;  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
+            w0[u] = windowed[u] ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 1) : 0ull;
+            w1[u] = windowed[u] && nsym > 9 ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 9) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            uint64_t key = 0;
+            if (windowed[u]) {
+                uint64_t w = w0[u];
+                for (int k = 1; k < nsym && k <= 8; ++k) {
+                    key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[w & 0xff] : 0ull);
                     w >>= 8;
                 }
+                w = w1[u];
+                for (int k = 9; k < nsym; ++k) {
+                    key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[w & 0xff] : 0ull);
+                    w >>= 8;
+                }
+            } else {
+                for (int k = 1; k < nsym; ++k)
+                    key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[text[pos[u] + k]] : 0ull);
             }
-        } else {
-            for (int k = 1; k < nsym; ++k) key = key * kbase + ((uint64_t)k < rem ? (uint64_t)s_map[text[pos + k]] : 0ull);
+            const uint64_t i = it.begin + r0 + 256u * u;
+            k32[i - gstart] = (uint32_t)(key >> low_bits);
+            low[i - gstart] = (W)((key & ((1ull << low_bits) - 1ull)) | ((e[u] >> 32) << low_bits));
+            elo[i - gstart] = (uint32_t)e[u];
+            for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
         }
-        k32[i - gstart] = (uint32_t)(key >> low_bits);
-        low[i - gstart] = (W)((key & ((1ull << low_bits) - 1ull)) | ((e >> 32) << low_bits));
-        elo[i - gstart] = (uint32_t)e;
-        for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
     }
     __syncthreads();
     unsigned long long* h = hist + (size_t)(it.bucket - bucket0) * 8 * 256;
