@@ -83,6 +83,23 @@ def test_query_before_build_returns_nothing(G):
     assert ix.query(b"a") == []  # reference reads uninitialised state here; we return {}
 
 
+def test_second_restatement_fixtures(G, golden_dir):
+    # tests/golden/model_cases.json (fixture classes (3)-(6) of SURVEY.md §8(c), from the pure-Python reading of index.cpp
+    # in tests/ref_model.py): the GPU path against committed hashes and rows, no oracle involved
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_model_fixtures", os.path.join(golden_dir, "make_model_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(golden_dir, "model_cases.json")))["cases"]
+    for name, (blob, ds, ids) in mod.cases().items():
+        w = want[name]
+        g = _gpu(G, blob, ds, ids)
+        assert (g.size, g.bits, g.mask, g.sa_width) == (w["size"], w["bits"], w["mask"], w["width"]), name
+        assert mod.sa_hash(g.sa(), g.sa_width) == w["sa_sha256"], name
+        for kw, rows in w["queries"].items():
+            assert g.query(bytes.fromhex(kw)) == [tuple(r) for r in rows], (name, kw)
+
+
 def test_c0_full(G):
     # BASELINE config 0: 10k docs x 256 B printable ASCII, 1k patterns len 4-16 (+10 % misses)
     blob, ds = W.ascii_corpus(10000, 256, seed=12345)

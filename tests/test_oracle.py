@@ -141,3 +141,60 @@ def test_batch_matches_single():
         got = list(zip(ids[int(rp[j]):int(rp[j + 1])].tolist(), cnt[int(rp[j]):int(rp[j + 1])].tolist()))
         assert got == want
     assert hits == int(cnt.sum())
+
+
+def _model_cases():
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_model_fixtures", os.path.join(here, "golden", "make_model_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_oracle_matches_the_second_restatement_fixtures(golden_dir):
+    # tests/golden/model_cases.json: canonical suffix arrays (SHA-256) and keyword rows of the fixture classes (3)-(6) of
+    # SURVEY.md §8(c) — radix nodes over several levels, ragged documents, bytes >= 0x80 (signed child order, unsigned
+    # leaves: the array is not globally sorted and some counts are "wrong" exactly like the reference's), the u32 / u64
+    # width boundary — computed by tests/ref_model.py, a pure-Python reading of index.cpp that shares no code with
+    # oracle/cpu_ref.cpp.
+    mod = _model_cases()
+    with open(os.path.join(golden_dir, "model_cases.json")) as f:
+        want = json.load(f)["cases"]
+    for name, (blob, ds, ids) in mod.cases().items():
+        w = want[name]
+        ix = OracleIndex()
+        ix.add_bulk(ids, blob, ds)
+        ix.build()
+        ix.canonicalize()
+        assert (ix.size, ix.bits, ix.mask, ix.sa_width) == (w["size"], w["bits"], w["mask"], w["width"]), name
+        assert mod.sa_hash(ix.sa(), ix.sa_width) == w["sa_sha256"], name
+        for kw, rows in w["queries"].items():
+            assert ix.query(bytes.fromhex(kw)) == [tuple(r) for r in rows], (name, kw)
+    assert want["width_32_bits_u32"]["width"] == 4 and want["width_33_bits_u64"]["width"] == 8
+
+
+def test_second_restatement_agrees_on_random_small_inputs():
+    # the model itself, run live on small random inputs (several alphabets, empty documents, duplicate documents, a
+    # thread count sweep on the oracle side): entry-for-entry equal arrays and equal rows
+    from ref_model import RefModel
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        nd = int(rng.integers(1, 40))
+        lo, hi = [(0x61, 0x62), (0x61, 0x7A), (0x00, 0xFF), (0x7E, 0x81)][trial % 4]
+        docs = [bytes(rng.integers(lo, hi + 1, size=int(rng.integers(0, 400)), dtype=np.uint8)) for _ in range(nd)]
+        if trial % 3 == 0 and nd > 2:
+            docs[1] = docs[0]
+        if sum(len(d) for d in docs) == 0:
+            continue
+        ids = (rng.permutation(nd) * 5 - 7).tolist()
+        m = RefModel(ids, docs)
+        ix = _mk(docs, ids)
+        ix.canonicalize()
+        assert (ix.size, ix.bits, ix.mask, ix.sa_width) == (m.size, m.bits, m.mask, m.width)
+        assert ix.sa().tolist() == m.sa
+        text = b"".join(docs)
+        for _ in range(25):
+            a = int(rng.integers(0, len(text)))
+            kw = text[a:a + int(rng.integers(1, 6))]
+            assert ix.query(kw) == m.query(kw), kw
