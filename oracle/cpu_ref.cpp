@@ -9,6 +9,9 @@
 //   * test/test-string.py:14-19,52-56  overlapping brute-force count per document (property oracle)
 //   * SURVEY.md §8c golden vectors recorded from the unmodified reference (full SA of the README
 //     corpus, empty index, empty doc + duplicate id) — committed under tests/golden/.
+//   * tests/golden/model_cases.json — canonical arrays (SHA-256) and keyword rows for radix nodes over several
+//     levels, ragged documents, bytes >= 0x80 and the u32 / u64 width boundary, from an independent pure-Python
+//     restatement of index.cpp (tests/ref_model.py); not outputs of the reference binary.
 // The reference itself cannot be compiled in this image without a stand-in <format> header
 // (progress_bar.h:10 includes <format>; g++ 11.4 / ROCm clang 22 do not ship it), so no oracle/_ref
 // build exists; see DESIGN.md "Oracle".
