@@ -771,6 +771,41 @@ def test_build_while_another_handle_serves_queries(G):
     assert not errors, errors[0]
 
 
+def test_concurrent_builds_in_xcd_tile_order(G):
+    # Four handles build at the same time on one GPU, every big-tile pass in XCD-aware order: their kernels share the
+    # CUs, so a pass may find fewer workgroups resident than its tile reservation needs (radix_sort.h: RS_GROUP).  Either
+    # it still gets through or it ends in the bounded look-back timeout and the build is redone in plain ticket order;
+    # every build must come out right either way, and none may hang.
+    import threading
+    import time
+    corpora = [W.ascii_corpus(2500, 1024, seed=60 + k) for k in range(4)]
+    oracles = [_oracle(b, d, np.arange(len(d) - 1, dtype=np.int64)) for b, d in corpora]
+    errors, fallbacks = [], []
+
+    def work(k):
+        try:
+            blob, ds = corpora[k]
+            g = G()
+            g.set_option("sort_variant", 31)
+            g.add_bulk(np.arange(len(ds) - 1, dtype=np.int64), blob, ds)
+            for _ in range(3):
+                g.build()
+                assert np.array_equal(g.sa(), oracles[k].sa())
+            fallbacks.append(g.stat("group_fallbacks"))
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    t0 = time.time()
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a build hangs"
+    assert not errors, errors[0]
+    assert len(fallbacks) == 4 and time.time() - t0 < 240
+
+
 def test_add_after_load_and_device_builds_rebuilds_the_whole_column(G, tmp_path):
     # restart flow: cdb_load, then more documents, then a rebuild — the loaded column must come back from the device
     # (cdb_add after cdb_load / cdb_build_device / cdb_build_resident used to corrupt the staging tables)
