@@ -94,6 +94,40 @@ __device__ __forceinline__ uint64_t bs_lower_bound(const P* __restrict__ bstart,
 // ---- sorting inside a wavefront: a bitonic network over 64 * R values held R per lane (element r * 64 + lane) ------
 // Exchanges between lanes are shuffles, exchanges across 64-element blocks are register pairs: no LDS traffic, no
 // barriers.  Ascending order; callers pad with all-ones.
+// value of lane ^ Q without the LDS crossbar: DPP controls inside a row of 16 lanes (quad permutations, row rotation,
+// half-row mirror), v_permlane16/32_swap across rows — one or two full-rate vector instructions instead of a
+// ds_bpermute (gfx950; tools/experiments/dpp/xor_partner_test.hip checks every pattern)
+template <int Q>
+__device__ __forceinline__ uint32_t bs_xor_partner(uint32_t x, int lane) {
+    if constexpr (Q == 1) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    } else if constexpr (Q == 2) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    } else if constexpr (Q == 4) {
+        const int t = __builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);     // row_half_mirror: lane ^ 7
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);        // quad_perm [3,2,1,0]: lane ^ 3
+    } else if constexpr (Q == 8) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true);  // row_ror:8
+    } else if constexpr (Q == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        static_assert(Q == 32, "lane distance inside a wavefront");
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+__device__ __forceinline__ uint32_t bs_xor_partner_q(uint32_t x, int q, int lane) {  // (q is a constant after unrolling)
+    switch (q) {
+        case 1: return bs_xor_partner<1>(x, lane);
+        case 2: return bs_xor_partner<2>(x, lane);
+        case 4: return bs_xor_partner<4>(x, lane);
+        case 8: return bs_xor_partner<8>(x, lane);
+        case 16: return bs_xor_partner<16>(x, lane);
+        default: return bs_xor_partner<32>(x, lane);
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void bs_wave_sort(uint32_t (&v)[R], int lane) {
 #pragma unroll
@@ -116,7 +150,7 @@ __device__ __forceinline__ void bs_wave_sort(uint32_t (&v)[R], int lane) {
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const uint32_t o = __shfl_xor(v[r], q);
+                    const uint32_t o = bs_xor_partner_q(v[r], q, lane);
                     const bool up = (((r * 64) | lane) & k) == 0;
                     const bool lower = (lane & q) == 0;
                     const uint32_t mn = v[r] < o ? v[r] : o, mx = v[r] < o ? o : v[r];
@@ -457,9 +491,12 @@ __device__ __forceinline__ void bs_wave_round(uint32_t* __restrict__ k32, V* __r
             const V t = bs_shfl_any<V>(e[q], (int)(idx & 63u));
             o = (idx >> 6) == (uint32_t)q ? t : o;
         }
-        uint32_t pv = __shfl_up(v[r], 1), nv = __shfl_down(v[r], 1);
-        if (r > 0) { const uint32_t x = __shfl(v[r - 1], 63); if (lane == 0) pv = x; }
-        if (r + 1 < R) { const uint32_t x = __shfl(v[r + 1], 0); if (lane == 63) nv = x; }
+        // neighbours in sorted order: whole-wave shifts by one lane (DPP wave_shr:1 / wave_shl:1), the lanes at the ends
+        // take the edge values of the neighbouring register
+        uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)v[r], (int)v[r], 0x138, 0xF, 0xF, false);
+        uint32_t nv = (uint32_t)__builtin_amdgcn_update_dpp((int)v[r], (int)v[r], 0x130, 0xF, 0xF, false);
+        if (r > 0) { const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v[r - 1], 63); if (lane == 0) pv = x; }
+        if (r + 1 < R) { const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v[r + 1], 0); if (lane == 63) nv = x; }
         if (i < m) {
             const uint32_t lkx = v[r] >> 8;
             const bool head = i == 0 || (pv >> 8) != lkx;

@@ -329,7 +329,8 @@ template <int P>
 __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restrict__ text,
                                                           const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                           uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
-                                                          int npass, bool padded, unsigned long long* __restrict__ hist) {
+                                                          int npass, bool padded, unsigned long long* __restrict__ hist,
+                                                          uint64_t hyb_w, uint64_t hyb_magic) {
     constexpr int NSYM = 3 * P;
     constexpr int NG = KH3_PER + 3 * (P - 1);  // G values a thread needs
     static_assert(NG + 2 <= 48, "window of three 16-byte reads");
@@ -343,6 +344,11 @@ __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restr
     const uint32_t W = kbase * kbase * kbase;
     const uint64_t tiles = (n + KH_TILE - 1) / KH_TILE;
     auto count = [&](uint64_t key) {
+        if (hyb_w) {  // hybrid sort: the passes run over the digits of the bucket number b = key / w
+            uint64_t b = __umul64hi(key, hyb_magic);
+            if (key - b * hyb_w >= hyb_w) b += 1;
+            key = b;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (q < npass) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
@@ -1366,10 +1372,11 @@ void build_typed(Index& ix, bool big) {
         CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
         const int grid = (int)std::min<uint64_t>(ceil_div(n, KH_TILE), 256 * 8);
         int t = ix.prof.begin(s);
-        const bool by3 = ix.keyhist3 && hyb_w == 0 && nsym % 3 == 0 && nsym >= 6 && nsym <= 15;
+        const bool by3 = ix.keyhist3 && nsym % 3 == 0 && nsym >= 6 && nsym <= 15;
 #define CDB_KH3(PARTS)                                                                                              \
     hipLaunchKernelGGL((sa_keyhist3_kernel<PARTS>), dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n, \
-                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>())
+                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>(), \
+                       hyb_w, hyb_magic)
         if (by3 && nsym == 6) CDB_KH3(2);
         else if (by3 && nsym == 9) CDB_KH3(3);
         else if (by3 && nsym == 12) CDB_KH3(4);
