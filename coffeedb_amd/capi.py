@@ -20,7 +20,7 @@ EXPORTS = [
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
-    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference",
+    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge",
@@ -593,6 +593,18 @@ def debug_radix_sort(d_keys_ptr, d_vals_ptr, n, val_bytes, key_bits, variant=0, 
     if rc != 0:
         raise RuntimeError(f"cdb_debug_radix_sort failed ({rc})")
     return ms.value, passes.value
+
+
+def layout_rule(ndocs, longest):
+    """(bits, mask, width, off_bits) of the reference's entry layout, or RuntimeError with the reference's message."""
+    lib = load_library()
+    lib.cdb_layout_rule.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    bits, mask, width, off = C.c_uint64(0), C.c_uint64(0), C.c_int(0), C.c_int(0)
+    err = C.create_string_buffer(256)
+    if lib.cdb_layout_rule(ndocs, longest, C.byref(bits), C.byref(mask), C.byref(width), C.byref(off), err, 256) != 0:
+        raise RuntimeError(err.value.decode())
+    return bits.value, mask.value, width.value, off.value
 
 
 def raw_record_find_string(record: bytes, key: bytes):

@@ -1327,6 +1327,24 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
     }
 }
 
+int cdb_layout_rule(uint64_t ndocs, uint64_t longest, uint64_t* bits, uint64_t* mask, int* width, int* off_bits, char* err,
+                    size_t err_cap) {
+    try {
+        const Layout L = layout_from(ndocs, 0, longest);
+        if (bits) *bits = L.bits;
+        if (mask) *mask = L.mask;
+        if (width) *width = L.width;
+        if (off_bits) *off_bits = L.off_bits;
+        return CDB_OK;
+    } catch (const std::exception& e) {
+        if (err && err_cap) {
+            std::strncpy(err, e.what(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return CDB_E_INVALID;
+    }
+}
+
 void cdb_release_cached_memory(void) {
     DevPool::get().trim();
     HostPool::get().trim();

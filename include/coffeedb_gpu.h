@@ -323,6 +323,15 @@ int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]);
 int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int val_bytes, int key_bits,
                          int variant, double* onesweep_ms, int* passes);
 
+/* The build prologue's layout rule as a pure host function (no device, no handle): entry layout of an index over
+ * `ndocs` documents whose longest has `longest` bytes — index.cpp:182-208: masks grown by `mask = (mask << 1) + 1`,
+ * bits = popcount, 4-byte entries while bits + offset bits <= 32.  Returns CDB_OK and fills bits / mask / width /
+ * off_bits, or CDB_E_INVALID with the reference's own message in `err` (index.cpp:195-200: "The amount of data
+ * exceeds the maximum range that CoffeeDB can handle" beyond 64 bits, "The number of objects exceeds ..." beyond 2^32
+ * documents).  What cdb_build* apply before they touch the device. */
+int cdb_layout_rule(uint64_t ndocs, uint64_t longest, uint64_t* bits, uint64_t* mask, int* width, int* off_bits,
+                    char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

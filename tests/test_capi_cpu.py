@@ -94,3 +94,20 @@ def test_sharded_and_bulk_entry_points_refuse_cleanly_without_gpu(lib):
     assert lib.cdb_comm_merge(None, None, None) == 1
     lib.cdb_shards_destroy(None)
     lib.cdb_comm_destroy(None)
+
+
+def test_layout_rule_and_capacity_limit_messages(lib):
+    # index.cpp:182-208 through the host-only entry cdb_layout_rule — what every cdb_build* applies first.  The two
+    # capacity limits (index.cpp:195-200) cannot be reached with real data on one machine; their messages are the
+    # reference's own strings.
+    assert capi.layout_rule(3, 8) == (2, 3, 4, 4)                 # README corpus: 3 docs -> mask 3; longest 8 -> mask 15
+    assert capi.layout_rule(0, 0) == (1, 1, 4, 1)                 # empty index: bits = 1 (SURVEY §8c golden vector 2)
+    assert capi.layout_rule(1 << 20, 1024) == (21, (1 << 21) - 1, 4, 11)   # C1: 21 + 11 = 32 bits -> u32 entries
+    assert capi.layout_rule(1 << 20, 1025) == (21, (1 << 21) - 1, 4, 11)   # mask 2047 still covers 1025
+    assert capi.layout_rule(1 << 20, 2048) == (21, (1 << 21) - 1, 8, 12)   # 33 bits -> u64 entries
+    assert capi.layout_rule(1 << 23, 1024) == (24, (1 << 24) - 1, 8, 11)   # C2
+    assert capi.layout_rule((1 << 32) - 1, 4)[0] == 32
+    with pytest.raises(RuntimeError, match="The number of objects exceeds the maximum range that CoffeeDB can handle"):
+        capi.layout_rule((1 << 32) + 1, 4)
+    with pytest.raises(RuntimeError, match="The amount of data exceeds the maximum range that CoffeeDB can handle"):
+        capi.layout_rule(1 << 31, 1 << 33)                        # 32 + 34 bits
