@@ -1316,6 +1316,21 @@ void build_typed(Index& ix, bool big) {
         // the bucket-wise sort partitions by the FIRST symbol and gathers the keys behind it bucket by bucket
         nsym = std::min(nsym, HC_MAXSYM);  // (the record gather reads two 8-byte windows behind the first symbol)
         dbits = std::min(symbits, 8);
+        // Symbols that ride along for free: a bucket's key is the dense number of the nsym - 1 symbols behind the first,
+        // sorted in whole 8-bit passes — one more symbol that still fits the last pass costs nothing and leaves fewer
+        // suffixes unresolved (8 GiB of Zipf text: 10 instead of 9 symbols in the same 7 passes).
+        if (ix.narrow_keys && ix.initial_passes == 0 && nsym > 1) {
+            auto bits_of = [&](int k) {  // bits of (alphabet + 1)^k - 1; 999 beyond 56 bits
+                unsigned __int128 v = 1;
+                for (int i = 0; i < k; ++i) {
+                    v *= (unsigned)sigma + 1u;
+                    if (v > ((unsigned __int128)1 << 56)) return 999;
+                }
+                return bit_width64((uint64_t)(v - 1));
+            };
+            const int passes = (int)ceil_div(bits_of(nsym - 1), 8);
+            while (bits_of(nsym - 1) <= 56 && nsym < HC_MAXSYM && bits_of(nsym) <= 8 * passes) ++nsym;
+        }
     }
     // Key coding.  Bit-aligned symbols (base 2^symbits) waste log2(2^symbits / (alphabet + 1)) bits per
     // symbol; the dense base-(alphabet + 1) number is used when it saves a whole radix pass (95-symbol
