@@ -262,6 +262,18 @@ int cdb_create(cdb_index** out, int device) {
         return CDB_E_DEVICE;
     }
     *out = h;
+    if (const char* e = std::getenv("CDB_OPTIONS")) {  // test / measurement hook: "name=value,name=value" applied to every new handle
+        std::string all(e);
+        size_t at = 0;
+        while (at < all.size()) {
+            size_t end = all.find(',', at);
+            if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(at, end - at);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) (void)cdb_set_option(h, kv.substr(0, eq).c_str(), std::atoll(kv.c_str() + eq + 1));
+            at = end + 1;
+        }
+    }
     return CDB_OK;
 }
 
