@@ -490,36 +490,58 @@ template <typename W>
 __global__ __launch_bounds__(256) void sa_initflags32_kernel(const uint32_t* __restrict__ k32,
                                                              const W* __restrict__ low, int low_bits, uint64_t n,
                                                              uint32_t kbase, uint64_t kmagic, uint8_t* __restrict__ flags,
-                                                             bool flags_aligned) {
-    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= n) return;
-    const uint64_t lmask = (1ull << low_bits) - 1ull;  // (bytes of W above the digits carry other data: packed entries)
-    auto full = [&](uint64_t i) -> uint64_t {
-        return low ? (((uint64_t)k32[i] << low_bits) | ((uint64_t)low[i] & lmask)) : (uint64_t)k32[i];
-    };
-    uint64_t k[6];
-    if (i0 + 4 <= n) {
-        const uint4 a = *reinterpret_cast<const uint4*>(k32 + i0);
-        const uint32_t hi[4] = {a.x, a.y, a.z, a.w};
-        W l4[4] = {};
-        if (low) {
-            if constexpr (sizeof(W) == 1) *reinterpret_cast<uint32_t*>(l4) = *reinterpret_cast<const uint32_t*>(low + i0);
-            else if constexpr (sizeof(W) == 2) *reinterpret_cast<uint2*>(l4) = *reinterpret_cast<const uint2*>(low + i0);
-            else *reinterpret_cast<uint4*>(l4) = *reinterpret_cast<const uint4*>(low + i0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | ((uint64_t)l4[q] & lmask)) : (uint64_t)hi[q];
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? full(i0 + q) : 0;
+                                                             bool flags_aligned, U2* __restrict__ tile_sums = nullptr) {
+    // tile_sums (optional; `flags` is then the whole array): per scan tile of SC_TILE flags the number of unresolved
+    // entries and of unresolved group heads — the sums the first compaction would otherwise re-read every flag for
+    __shared__ uint32_t s_sum[2];
+    if (tile_sums) {  // (uniform)
+        if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
+        __syncthreads();
     }
-    k[0] = i0 > 0 ? full(i0 - 1) : ~k[1];
-    k[5] = i0 + 4 < n ? full(i0 + 4) : 0;
-    const uint32_t out = sa_flags_of(k, i0, n, kbase, kmagic);
-    if (flags_aligned && i0 + 4 <= n) {
-        *reinterpret_cast<uint32_t*>(flags + i0) = out;
-    } else {
-        for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 < n) {
+        const uint64_t lmask = (1ull << low_bits) - 1ull;  // (bytes of W above the digits carry other data: packed entries)
+        auto full = [&](uint64_t i) -> uint64_t {
+            return low ? (((uint64_t)k32[i] << low_bits) | ((uint64_t)low[i] & lmask)) : (uint64_t)k32[i];
+        };
+        uint64_t k[6];
+        if (i0 + 4 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4*>(k32 + i0);
+            const uint32_t hi[4] = {a.x, a.y, a.z, a.w};
+            W l4[4] = {};
+            if (low) {
+                if constexpr (sizeof(W) == 1) *reinterpret_cast<uint32_t*>(l4) = *reinterpret_cast<const uint32_t*>(low + i0);
+                else if constexpr (sizeof(W) == 2) *reinterpret_cast<uint2*>(l4) = *reinterpret_cast<const uint2*>(low + i0);
+                else *reinterpret_cast<uint4*>(l4) = *reinterpret_cast<const uint4*>(low + i0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[1 + q] = low ? (((uint64_t)hi[q] << low_bits) | ((uint64_t)l4[q] & lmask)) : (uint64_t)hi[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[1 + q] = i0 + q < n ? full(i0 + q) : 0;
+        }
+        k[0] = i0 > 0 ? full(i0 - 1) : ~k[1];
+        k[5] = i0 + 4 < n ? full(i0 + 4) : 0;
+        const uint32_t out = sa_flags_of(k, i0, n, kbase, kmagic);
+        if (flags_aligned && i0 + 4 <= n) {
+            *reinterpret_cast<uint32_t*>(flags + i0) = out;
+        } else {
+            for (int q = 0; q < 4 && i0 + q < n; ++q) flags[i0 + q] = (uint8_t)(out >> (8 * q));
+        }
+        if (tile_sums) {
+            const uint32_t unres = (out >> 1) & 0x01010101u;  // (sa_flags_of leaves the bytes behind n zero)
+            const uint32_t a = __popc(unres), b = __popc(unres & out);
+            if (a) atomicAdd(&s_sum[0], a);
+            if (b) atomicAdd(&s_sum[1], b);
+        }
+    }
+    if (tile_sums) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_sum[0]) {  // (a workgroup's 1024 flags lie inside one scan tile)
+            U2* t = tile_sums + ((uint64_t)blockIdx.x * 1024) / SC_TILE;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&t->a), (unsigned long long)s_sum[0]);
+            if (s_sum[1]) atomicAdd(reinterpret_cast<unsigned long long*>(&t->b), (unsigned long long)s_sum[1]);
+        }
     }
 }
 
@@ -1921,20 +1943,29 @@ void build_typed(Index& ix, bool big) {
         st.bucketed = 1;
         sa_buf = std::move(E);
     }
+    bool tile_sums_ready = false;  // the flag kernel has left the raw tile sums of the first compaction in scan_partials
     if (!big && !flags_done) {  // (the bucket-wise and the hybrid sort write the flags themselves)
         int t = ix.prof.begin(s);
         if (layout == WIDE)
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
                                (const uint64_t*)sorted_keys.as<uint64_t>(), n, kbase, kmagic, flags.as<uint8_t>(), true);
-        else if (layout == SPLIT2)
-            hipLaunchKernelGGL(sa_initflags32_kernel<uint16_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                               (const uint32_t*)sorted_k32.as<uint32_t>(), (const uint16_t*)sorted_low.as<uint16_t>(), low_bits, n,
-                               kbase, kmagic, flags.as<uint8_t>(), true);
-        else
-            hipLaunchKernelGGL(sa_initflags32_kernel<uint8_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
-                               (const uint32_t*)sorted_k32.as<uint32_t>(),
-                               layout == SPLIT ? (const uint8_t*)sorted_low.as<uint8_t>() : (const uint8_t*)nullptr, low_bits, n,
-                               kbase, kmagic, flags.as<uint8_t>(), true);
+        else {
+            // (the flag kernel leaves the per-tile counts of unresolved entries for the first compaction: no second sweep
+            //  over the flags for them)
+            const uint64_t nbt = ceil_div(n, (uint64_t)SC_TILE);
+            ix.scan_partials.ensure(scan_partials_slots(nbt) * sizeof(U2));
+            CDB_HIP(hipMemsetAsync(ix.scan_partials.p, 0, nbt * sizeof(U2), s));
+            tile_sums_ready = true;
+            if (layout == SPLIT2)
+                hipLaunchKernelGGL(sa_initflags32_kernel<uint16_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+                                   (const uint32_t*)sorted_k32.as<uint32_t>(), (const uint16_t*)sorted_low.as<uint16_t>(), low_bits,
+                                   n, kbase, kmagic, flags.as<uint8_t>(), true, ix.scan_partials.as<U2>());
+            else
+                hipLaunchKernelGGL(sa_initflags32_kernel<uint8_t>, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
+                                   (const uint32_t*)sorted_k32.as<uint32_t>(),
+                                   layout == SPLIT ? (const uint8_t*)sorted_low.as<uint8_t>() : (const uint8_t*)nullptr, low_bits,
+                                   n, kbase, kmagic, flags.as<uint8_t>(), true, ix.scan_partials.as<U2>());
+        }
         ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : 5 + low_bytes), s);
     }
     CDB_HIP(hipStreamSynchronize(s));
@@ -1974,7 +2005,9 @@ void build_typed(Index& ix, bool big) {
             if (still == 0) break;
         }
         CDB_HIP(hipMemsetAsync(d_open.p, 0, sizeof(uint64_t), s));
-        const U2 tot = scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+        const U2 tot = tile_sums_ready ? scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0})
+                                       : scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+        tile_sums_ready = false;
         const uint64_t m = tot.a, G = tot.b;
         if (st.rounds == 0) st.unresolved_initial = m;
         st.unresolved_max = std::max(st.unresolved_max, m);

@@ -205,6 +205,18 @@ T scan_totals(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T ident
     return total;
 }
 
+// Phase 1 when the producer of the data has already left the raw tile sums in `partials` (slots 0 .. nb - 1, same tile
+// geometry): only the scan of the partials and the grand total remain.
+template <typename T, typename Op>
+T scan_totals_from_partials(hipStream_t s, DevBuf& partials, uint64_t n, Op op, T identity) {
+    const uint64_t nb = ceil_div(n, SC_TILE);
+    scan_partials_inplace<T, Op>(s, partials, nb, op, identity);
+    T total;
+    CDB_HIP(hipMemcpyAsync(&total, partials.as<T>() + nb, sizeof(T), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    return total;
+}
+
 // Phase 1 without the host round trip: partials[nb] holds the grand total on the device only.
 template <typename T, typename In, typename Op>
 void scan_totals_device(hipStream_t s, DevBuf& partials, In in, uint64_t n, Op op, T identity) {
