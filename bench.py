@@ -535,7 +535,12 @@ def main():
             lat.sort()
             out["single_query_us"] = {"median": round(lat[len(lat) // 2], 2), "p10": round(lat[len(lat) // 10], 2),
                                       "p90": round(lat[(len(lat) * 9) // 10], 2), "keywords": len(kws),
-                                      "note": "cdb_query through the Python ctypes binding (adds ~2 us), 8-byte keywords, one caller"}
+                                      "note": "cdb_query through the Python ctypes binding, 8-byte keywords, one caller"}
+            c_us = np.sort(g.query_latency_us(kws, reps=32))
+            out["single_query_us"]["c_caller"] = {"median": round(float(c_us[len(c_us) // 2]), 2), "p10": round(float(c_us[len(c_us) // 10]), 2),
+                                                  "p90": round(float(c_us[(len(c_us) * 9) // 10]), 2),
+                                                  "note": "the same calls timed inside the library (cdb_debug_query_latency): what a C++ caller "
+                                                          "such as database.cpp:392 sees; median over 32 calls per keyword"}
         except Exception as e:  # noqa: BLE001
             out["single_query_us"] = {"error": repr(e)[:200]}
     extra = args.configs

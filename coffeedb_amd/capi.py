@@ -20,7 +20,7 @@ EXPORTS = [
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
-    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule",
+    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule", "cdb_debug_query_latency",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge",
@@ -381,6 +381,16 @@ class GpuStringIndex:
         out = (C.c_uint64 * 4)()
         self._check(self._lib.cdb_debug_verify_reference(self._h, out))
         return {"violations": out[0], "mixed_pairs": out[1], "radix_node_pairs": out[2], "tie_violations": out[3]}
+
+    def query_latency_us(self, keywords, reps=32):
+        """median microseconds per cdb_query call of every keyword, measured inside the library (no binding overhead)"""
+        blob = b"".join(keywords)
+        offs = np.zeros(len(keywords) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(k) for k in keywords])
+        out = np.zeros(len(keywords), dtype=np.float64)
+        self._lib.cdb_debug_query_latency.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self._check(self._lib.cdb_debug_query_latency(self._h, blob, _ptr(offs), len(keywords), reps, _ptr(out)))
+        return out
 
     def set_option(self, name, value):
         self._check(self._lib.cdb_set_option(self._h, name.encode(), int(value)))

@@ -1339,6 +1339,28 @@ int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int
     }
 }
 
+int cdb_debug_query_latency(cdb_index* h, const char* blob, const uint64_t* offsets, size_t nkw, int reps, double* us_out) {
+    if (!h || !blob || !offsets || !us_out || reps < 1) return CDB_E_INVALID;
+    std::vector<double> t((size_t)reps);
+    for (size_t k = 0; k < nkw; ++k) {
+        const char* kw = blob + offsets[k];
+        const size_t len = (size_t)(offsets[k + 1] - offsets[k]);
+        for (int r = 0; r < reps; ++r) {
+            int64_t *ids = nullptr, *counts = nullptr;
+            size_t rows = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = cdb_query(h, kw, len, &ids, &counts, &rows);
+            t[(size_t)r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (rc != CDB_OK) return rc;
+            cdb_free(ids);
+            cdb_free(counts);
+        }
+        std::sort(t.begin(), t.end());
+        us_out[k] = t[t.size() / 2];
+    }
+    return CDB_OK;
+}
+
 int cdb_layout_rule(uint64_t ndocs, uint64_t longest, uint64_t* bits, uint64_t* mask, int* width, int* off_bits, char* err,
                     size_t err_cap) {
     try {

@@ -323,6 +323,12 @@ int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]);
 int cdb_debug_radix_sort(int device, void* d_keys, void* d_vals, uint64_t n, int val_bytes, int key_bits,
                          int variant, double* onesweep_ms, int* passes);
 
+/* Measurement hook: wall time of `reps` back-to-back cdb_query calls for each of `nkw` keywords (blob + offsets like
+ * cdb_query_batch), taken inside the library with a steady clock — what a C++ caller such as database.cpp:392 sees,
+ * without a language binding in between.  us_out[nkw] receives the MEDIAN microseconds per call of every keyword;
+ * results are freed immediately. */
+int cdb_debug_query_latency(cdb_index* h, const char* blob, const uint64_t* offsets, size_t nkw, int reps, double* us_out);
+
 /* The build prologue's layout rule as a pure host function (no device, no handle): entry layout of an index over
  * `ndocs` documents whose longest has `longest` bytes — index.cpp:182-208: masks grown by `mask = (mask << 1) + 1`,
  * bits = popcount, 4-byte entries while bits + offset bits <= 32.  Returns CDB_OK and fills bits / mask / width /
