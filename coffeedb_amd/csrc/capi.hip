@@ -1191,6 +1191,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "sort_variant")) ix.sort_variant = (int)value;
     else if (!std::strcmp(name, "keyhist3")) ix.keyhist3 = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
+    else if (!std::strcmp(name, "search_lanes")) ix.search_lanes = (value == 1 || value == 8) ? (int)value : 0;
     else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;

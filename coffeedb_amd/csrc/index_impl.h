@@ -117,6 +117,7 @@ struct Index {
     bool force_doubling = false;
     int initial_passes = 0;
     int sort_variant = 0;
+    int search_lanes = 0;      // lanes per keyword in the fast batched search: 0 = by batch size, 1 or 8
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)

@@ -144,7 +144,11 @@ __device__ __forceinline__ int kw_le_pivot(uint64_t khi, uint64_t klo, uint64_t 
     return 2;
 }
 
-template <typename V>
+// G = lanes per keyword.  G = 1: plain bisection below the pivot levels.  G = 8: the lanes of a group probe G slots per
+// round, which split the range G + 1 ways — log9 instead of log2 rounds of DEPENDENT loads (6 instead of 19 below the
+// pivot levels at 2^30 suffixes) for G times the loads: the better trade while a batch is too small to fill the GPU
+// with one thread per keyword.  The array is sorted, so every search strategy finds the same bounds.
+template <typename V, int G>
 __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict__ sa, uint64_t n,
                                                             const uint8_t* __restrict__ text,
                                                             const uint64_t* __restrict__ doc_start, int bits,
@@ -165,13 +169,17 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     for (int i = threadIdx.x; levels > 0 && i < (1 << levels); i += 256) s_piv[i] = piv[i];
     if (keys) s_code[threadIdx.x] = symmap[threadIdx.x];
     __syncthreads();
-    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t j = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (j >= npat) return;
+    const int sub = (int)(threadIdx.x & (G - 1));             // this lane's place in its group
+    const int gshift = (int)((threadIdx.x & 63) & ~(G - 1));  // first lane of the group inside the wavefront
     const uint8_t* k = blob + offs[j];
     const uint64_t m = offs[j + 1] - offs[j];
     if (m == 0 || offs[j + 1] < offs[j]) {  // empty pattern (device batches are not pre-validated): no rows
-        left_out[j] = 0;
-        hits_out[j] = 0;
+        if (sub == 0) {
+            left_out[j] = 0;
+            hits_out[j] = 0;
+        }
         return;
     }
     uint64_t kw[2] = {0, 0};
@@ -189,8 +197,10 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     if (keys)
         for (uint64_t q = kc; q < m; ++q) absent |= s_code[k[q]] == 0;
     if (absent) {
-        left_out[j] = 0;
-        hits_out[j] = 0;
+        if (sub == 0) {
+            left_out[j] = 0;
+            hits_out[j] = 0;
+        }
         return;
     }
     // keys are numbers in base kbase: the suffixes starting with the keyword's first kc symbols are exactly
@@ -232,10 +242,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
     // ---- lower bound (index.cpp:260-274), first `levels` levels from LDS
     int64_t L = 0, R = (int64_t)n - 1;
     uint32_t id = 1;
-    while (L < R) {
-        const int64_t M = L + (R - L) / 2;
-        int le = 2;
-        if (levels > 0 && id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
+    auto le_at = [&](int64_t M, int le) -> bool {  // keyword <= suffix(M)?  (le = 2: not decided by a pivot)
         if (le == 2 && keys) {
             const int c = key_cmp(M);
             if (c != 0) le = c > 0 ? 1 : 0;
@@ -248,7 +255,39 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
             const int c = cmp_common(k, m, sp, sl);
             le = (c < 0 || (c == 0 && m <= sl)) ? 1 : 0;
         }
-        if (le) { R = M; id = 2 * id; } else { L = M + 1; id = 2 * id + 1; }
+        return le != 0;
+    };
+    while (L < R && (G == 1 || (levels > 0 && id < (1u << levels)))) {  // (G > 1: the pivot levels only; every lane alike)
+        const int64_t M = L + (R - L) / 2;
+        int le = 2;
+        if (levels > 0 && id < (1u << levels)) le = kw_le_pivot(kw[0], kw[1], m, s_piv[id]);
+        if (le_at(M, le)) { R = M; id = 2 * id; } else { L = M + 1; id = 2 * id + 1; }
+    }
+    if constexpr (G > 1) {
+        for (;;) {
+            const bool open = L < R;
+            if (!__any(open)) break;  // (wave-uniform: groups that are done idle through the remaining rounds)
+            const int64_t span = R - L;
+            const bool narrow = span <= (int64_t)G;  // the last round probes consecutive slots; slot R is the saturated answer
+            bool le = false;
+            if (open) {
+                const int64_t M = narrow ? L + sub : L + (span * (sub + 1)) / (G + 1);
+                le = M >= R ? true : le_at(M, 2);
+            }
+            const uint32_t gb = (uint32_t)((__ballot(le) >> gshift) & ((1ull << G) - 1ull));
+            if (open) {
+                const int f = gb ? __ffs((int)gb) - 1 : G;
+                if (narrow) {
+                    L = R = L + f;  // (f <= span: the lane on slot R always answers "le")
+                } else if (f == G) {
+                    L = L + (span * G) / (G + 1) + 1;
+                } else {
+                    const int64_t r2 = L + (span * (f + 1)) / (G + 1);
+                    if (f > 0) L = L + (span * f) / (G + 1) + 1;
+                    R = r2;
+                }
+            }
+        }
     }
     const int64_t left = L;
     // ---- prefix upper bound (index.cpp:275-287) by galloping from `left`
@@ -270,6 +309,26 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
             if (is_prefix(M)) A = M; else B = M - 1;
         }
         right = A + 1;
+    } else if (G > 1) {
+        // the group probes the G slots from `left` on at once; only a run of matches longer than that gallops on
+        // (every lane of the group alike: the same addresses, no divergence inside the group)
+        const int64_t M = left + sub;
+        const bool pf = M < (int64_t)n && is_prefix(M);
+        const uint32_t gb = (uint32_t)((__ballot(!pf) >> gshift) & ((1ull << G) - 1ull));
+        if (gb) {
+            right = left + (__ffs((int)gb) - 1);
+        } else {
+            int64_t good = left + G - 1, step = 1, bad = (int64_t)n;
+            while (good + step < (int64_t)n) {
+                if (is_prefix(good + step)) { good += step; step <<= 1; }
+                else { bad = good + step; break; }
+            }
+            while (good + 1 < bad) {
+                const int64_t mid = good + (bad - good) / 2;
+                if (is_prefix(mid)) good = mid; else bad = mid;
+            }
+            right = good + 1;
+        }
     } else if (n > 0 && is_prefix(left)) {
         int64_t good = left, step = 1, bad = (int64_t)n;
         while (good + step < (int64_t)n) {
@@ -282,8 +341,10 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
         }
         right = good + 1;
     }
-    left_out[j] = left;
-    hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
+    if (sub == 0) {
+        left_out[j] = left;
+        hits_out[j] = right > left ? (uint64_t)(right - left) : 0ull;
+    }
 }
 
 struct OpSumMax {  // (a, b) = (sum, max)
@@ -491,7 +552,12 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
                                ix.d_text, doc_start, (int)ix.bits, ix.mask, levels, ix.d_pivots.as<Pivot>());
             ix.pivot_levels = levels;
         }
-        hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+        // a group of 8 lanes per keyword for SMALL batches (coalesced single queries, a few thousand keywords), where the
+        // chain of dependent probes is the cost: 1000 keywords 0.090 -> 0.055 ms; from ~10^4 keywords on the random loads
+        // themselves are (10^5 keywords: 0.17 ms with one lane, 0.34 ms with eight).  search_lanes: 0 = by batch size
+        const bool wide = ix.search_lanes == 8 || (ix.search_lanes == 0 && npat <= 4096);
+        auto kern = wide ? q_search_fast_kernel<V, 8> : q_search_fast_kernel<V, 1>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(npat * (wide ? 8 : 1), 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)ix.d_pivots.as<Pivot>(),
                            ix.pivot_levels,
                            ix.key_nsym && ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
@@ -500,7 +566,7 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
                            ix.key_low_bytes, (const uint16_t*)ix.d_symmap_q.as<uint16_t>(), ix.key_nsym, ix.key_base, false,
                            ix.q_left.as<int64_t>(), ix.q_right.as<uint64_t>());
     } else if (!ix.sa_sorted && ix.use_fast_search && ix.key_nsym) {
-        hipLaunchKernelGGL((q_search_fast_kernel<V>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
+        hipLaunchKernelGGL((q_search_fast_kernel<V, 1>), dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, sa, ix.size, ix.d_text,
                            doc_start, (int)ix.bits, ix.mask, d_blob, d_offs, npat, (const Pivot*)nullptr, 0,
                            ix.d_keys.p ? (const uint64_t*)ix.d_keys.as<uint64_t>() : (const uint64_t*)nullptr,
                            ix.d_keys32.p ? (const uint32_t*)ix.d_keys32.as<uint32_t>() : (const uint32_t*)nullptr,

@@ -688,6 +688,21 @@ def test_resident_build_equals_host_table_build(G, tmp_path):
     assert np.array_equal(g.sa(), o.sa())
 
 
+def test_search_with_eight_lanes_per_keyword(G):
+    # small batches search with a group of 8 lanes per keyword (9-ary rounds below the pivot levels); any batch can be
+    # forced either way, and both must return the reference's rows
+    for blob, ds in (W.ascii_corpus(6000, 350, seed=21), W.ragged_corpus(20000, 90, seed=15, empty_every=13),
+                     W.ascii_corpus(2000, 500, seed=8, lo=0x41, hi=0x43), W.zipf_corpus(2000, 256, seed=2)):
+        ids = np.arange(len(ds) - 1, dtype=np.int64)
+        o = _oracle(blob, ds, ids)
+        pats = W.sample_patterns(blob, ds, 700, 1, 24, seed=5)
+        want = o.query_batch(*pats, nthreads=4)
+        for lanes in (8, 1, 0):
+            g = _gpu(G, blob, ds, ids, search_lanes=lanes, reference_compat=0)
+            got = g.query_batch(*pats)
+            assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])), lanes
+
+
 def test_single_keyword_wavefront_path(G):
     # a lone cdb_query is answered by one wavefront (64-ary search + in-register rows); it must agree with the
     # batched pipeline and the oracle for every kind of keyword, and hand over to the batch path when the
