@@ -688,6 +688,16 @@ def test_resident_build_equals_host_table_build(G, tmp_path):
     assert np.array_equal(g.sa(), o.sa())
 
 
+def test_query_latency_probe_entry(G):
+    # cdb_debug_query_latency times lone cdb_query calls inside the library (bench.py: single_query_us.c_caller)
+    blob, ds = W.ascii_corpus(3000, 333, seed=2)
+    g = _gpu(G, blob, ds, np.arange(3000, dtype=np.int64))
+    us = g.query_latency_us([bytes(blob[10:16]), bytes(blob[500:503]), b"\x7f\x7f"], reps=8)
+    assert us.shape == (3,) and np.all(us > 0) and np.all(us < 1e6)
+    with pytest.raises(RuntimeError, match="Empty keywords are not allowed"):
+        g.query_latency_us([b"ab", b""], reps=2)
+
+
 def test_search_with_eight_lanes_per_keyword(G):
     # small batches search with a group of 8 lanes per keyword (9-ary rounds below the pivot levels); any batch can be
     # forced either way, and both must return the reference's rows
