@@ -186,6 +186,41 @@ struct BStartArgs {
     int lead_bits = 0;
 };
 
+// Segmented passes (the bucket-wise build of corpora >= 2^32, sa_build.hip): ONE launch sorts every first-symbol
+// bucket ("segment") of a bucket group on its own — a tile belongs to exactly one segment (tile_seg), takes its digit
+// starts from that segment's table, and the look-back chain restarts at the segment's first tile.  Replaces one
+// launch per bucket and pass (~1000 launches per 4 GiB build) by one launch per pass.
+struct NoSeg {};
+struct SegInfo {
+    unsigned long long begin, end;  // element range of the segment inside the group's record buffers
+    uint32_t tile_begin, pad;       // its first tile
+};
+struct SegArgs {
+    const uint32_t* tile_seg = nullptr;  // [tiles] segment of every tile
+    const SegInfo* segs = nullptr;
+    uint32_t tiles = 0;                  // tiles of all segments together
+    uint32_t start_stride = 0;           // digit starts of segment g at digit_start[g * start_stride + d]
+};
+// The LAST pass of a segmented sort of packed bucket records writes the finished suffix-array entries and their
+// group flags instead of the records: entry = (aux >> hi_shift) << 32 | value, flag bit0 = first of a group of equal
+// keys, bit1 = still unresolved (sa_build.hip: sa_flags_of).  A tile sees the neighbours of all its elements except
+// across the ends of its per-digit runs, whose true neighbours sit in other tiles: those elements get provisional
+// flags (head / tail assumed), every (tile, digit) run leaves an edge record, and rs_seg_edge_fix_kernel settles them.
+struct SegEdge {
+    unsigned long long first, last;  // full keys of the run's first and last element
+    unsigned long long pos;          // output slot (inside the group) of the run's first element
+    uint32_t cnt, pad;
+};
+struct SegFinalArgs : SegArgs {
+    uint64_t* eout = nullptr;   // entries of the group (already offset to the group's first slot)
+    uint8_t* flags = nullptr;   // ... and its flags
+    SegEdge* edges = nullptr;   // [tiles][256]
+    int hi_shift = 0;           // entry bits 32.. sit above this many bits of the auxiliary word
+    int low_bits = 0;           // key = (k32 << low_bits) | (aux & (2^low_bits - 1))
+    uint32_t kbase = 2;
+    unsigned long long kmagic = 0;
+};
+
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
 // in byte i): Horner over the first nsym (<= 16) codes in base `base`, first symbol most significant; codes
 // at or behind the end of the document (rem symbols left) count as 0.  Four codes at a time are combined
@@ -238,13 +273,17 @@ static __global__ __launch_bounds__(256) void rs_tiledoc_kernel(const uint64_t* 
 // W (optional, u8 or u16) = auxiliary low digits of a split key that travel with the pair (TextGen::low_bits);
 // aux_shift >= 0 makes this pass sort on (aux >> aux_shift) & dmask instead of a key digit (the leading
 // passes of a split sort: the first, generated one, and for two low digits the one after it).
-template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal>
+template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W = NoVal, typename Seg = NoSeg>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
     uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen(),
-    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr, int aux_shift = -1, BStartArgs bs = BStartArgs()) {
+    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr, int aux_shift = -1, BStartArgs bs = BStartArgs(),
+    Seg seg = Seg()) {
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
+    constexpr bool SEG = !std::is_same<Seg, NoSeg>::value;
+    constexpr bool FINAL = std::is_same<Seg, SegFinalArgs>::value;
+    static_assert(!SEG || (!GEN && Cfg::REUSE && !Cfg::DMA), "segmented passes: materialised records, shared staging");
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
     using WS = typename std::conditional<HAS_W, W, uint8_t>::type;
@@ -292,11 +331,21 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
     const uint64_t tile = (Cfg::TICKET || Cfg::GROUP > 0) ? (uint64_t)s_tile : (uint64_t)blockIdx.x;
-    const uint64_t base = tile * TILE;
-    if constexpr (Cfg::GROUP > 0) {
+    uint64_t base = tile * TILE;
+    uint64_t tile0 = 0;     // first tile of the look-back chain this tile belongs to
+    uint64_t seg_n = n;     // end of the element range the tile may read
+    uint32_t sg = 0;
+    if constexpr (SEG) {
+        if (tile >= (uint64_t)seg.tiles) return;  // (the grid is rounded up to whole tile groups)
+        sg = seg.tile_seg[tile];
+        const SegInfo si = seg.segs[sg];
+        tile0 = si.tile_begin;
+        base = si.begin + (tile - tile0) * TILE;
+        seg_n = si.end;
+    } else if constexpr (Cfg::GROUP > 0) {
         if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
     }
-    const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
+    const uint32_t valid = (uint32_t)((seg_n - base) < (uint64_t)TILE ? (seg_n - base) : (uint64_t)TILE);
 
     // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
     K key[IPT];
@@ -610,7 +659,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         // real (in-range) count of this digit: padding only ever sits in digit 255
         real = d == 255 ? (uint64_t)cnt - (uint64_t)(TILE - valid) : (uint64_t)cnt;
         // publish the aggregate as early as possible: successors can already add it up
-        rs_st_status(my, tag | ((tile == 0 ? 2ull : 1ull) << 54) | real);
+        rs_st_status(my, tag | ((tile == tile0 ? 2ull : 1ull) << 54) | real);
         // exclusive scan of cnt over the 256 digits: wave scan, then across the 4 digit-owning waves
         incl = cnt;
 #pragma unroll
@@ -662,7 +711,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // the walk gets ever longer.  LB predecessors are therefore fetched per round trip and consumed
     // nearest-first up to the first inclusive prefix.
     uint64_t excl = 0;
-    if (tid < 256 && tile != 0 && !(Cfg::ABL & 1)) {
+    if (tid < 256 && tile != tile0 && !(Cfg::ABL & 1)) {
         constexpr int LB = Cfg::LB;
         int64_t p = (int64_t)tile - 1;
         uint32_t spins = 0;
@@ -671,7 +720,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             uint64_t sw[LB];
 #pragma unroll
             for (int k = 0; k < LB; ++k)
-                sw[k] = p - k >= 0 ? rs_ld_status(status + (uint64_t)(p - k) * 256 + d) : 0ull;
+                sw[k] = p - k >= (int64_t)tile0 ? rs_ld_status(status + (uint64_t)(p - k) * 256 + d) : 0ull;
             int used = 0;
             bool open = true;
 #pragma unroll
@@ -687,7 +736,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 atomicAdd(err + 1, (uint32_t)used);
                 atomicAdd(err + 2, 1u);
             }
-            p -= used;  // tile 0 always publishes an inclusive prefix, so p never underflows
+            p -= used;  // the chain's first tile always publishes an inclusive prefix, so p never underflows
             if (used == 0) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > RS_SPIN_LIMIT) {
@@ -700,8 +749,29 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         }
         rs_st_status(my, tag | (2ull << 54) | (excl + real));
     }
-    if (tid < 256) s_gbase[d] = (Cfg::ABL & 2) ? base : (uint64_t)digit_start[d] + excl - (uint64_t)tstart;
+    uint64_t dstart = 0;
+    if (tid < 256) {
+        if constexpr (SEG) dstart = (uint64_t)digit_start[(size_t)sg * seg.start_stride + d];
+        else dstart = (uint64_t)digit_start[d];
+        s_gbase[d] = (Cfg::ABL & 2) ? base : dstart + excl - (uint64_t)tstart;
+    }
     __syncthreads();
+    if constexpr (FINAL) {
+        if (tid < 256) {  // edge record of this tile's run of digit d (the sorted keys sit in LDS until the next barrier)
+            SegEdge e;
+            e.first = e.last = 0;
+            e.pos = dstart + excl;
+            e.cnt = (uint32_t)real;
+            e.pad = 0;
+            if (real) {
+                const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
+                const uint32_t a = tstart, b = tstart + (uint32_t)real - 1u;
+                e.first = ((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask);
+                e.last = ((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask);
+            }
+            seg.edges[tile * 256 + d] = e;
+        }
+    }
 
     // ---- coalesced write-out: consecutive lanes -> consecutive slots of one digit run
     if constexpr (!REUSE) {
@@ -726,6 +796,19 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const K k = s_keys[i];
                 const uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
                 dig[j] = (uint8_t)dd;
+                if constexpr (FINAL) {
+                    // group flags from the neighbours in the sorted tile (equal keys have equal digits, so the ends of
+                    // a digit run come out as head / tail: provisional there, settled by rs_seg_edge_fix_kernel)
+                    const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
+                    const uint64_t kc = ((uint64_t)k << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i : 0] & lmask);
+                    bool head = true, tail = true;
+                    if (i > 0) head = (((uint64_t)s_keys[i - 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i - 1 : 0] & lmask)) != kc;
+                    if (i + 1 < valid) tail = (((uint64_t)s_keys[i + 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i + 1 : 0] & lmask)) != kc;
+                    const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
+                                                      : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
+                    seg.flags[s_gbase[dd] + i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+                    continue;
+                }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
                 if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
                 if constexpr (HAS_W && sizeof(K) == 4) {
@@ -753,9 +836,55 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t i = j * NT + tid;
-            if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
+            if constexpr (FINAL) {
+                if (i < valid)
+                    seg.eout[s_gbase[dig[j]] + i] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
+            } else {
+                if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
+            }
         }
     }
+}
+
+// Settles the provisional flags at the ends of the per-digit runs of a segmented final pass: for every run (tile t,
+// digit d) the run in front of it in the output is the nearest earlier tile of the same segment that holds digit d
+// — its last element sits right in front of this run's first.  Equal keys there: the first element is no group head,
+// and both elements belong to an unresolved group unless the key ends inside the document.
+static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEdge* __restrict__ edges, const uint32_t* __restrict__ tile_seg,
+                                                                     const SegInfo* __restrict__ segs, uint32_t tiles,
+                                                                     uint8_t* __restrict__ flags, uint32_t kbase, unsigned long long kmagic) {
+    const uint32_t t = blockIdx.x, d = threadIdx.x;
+    if (t >= tiles) return;
+    const SegEdge e = edges[(size_t)t * 256 + d];
+    if (!e.cnt) return;
+    const uint32_t t0 = segs[tile_seg[t]].tile_begin;
+    if (t == t0) return;
+    // largest t' in [t0, t) whose run starts in front of this one (runs of tiles without the digit share its start)
+    uint32_t lo = t0, hi = t;  // invariant: answer (if any) in [lo, hi)
+    if (edges[(size_t)(t - 1) * 256 + d].pos < e.pos) {
+        lo = t - 1;
+    } else {
+        if (edges[(size_t)t0 * 256 + d].pos >= e.pos) return;  // first run of this digit in the segment
+        hi = t - 1;
+        while (hi - lo > 1) {  // pos[lo] < e.pos <= pos[hi]
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (edges[(size_t)mid * 256 + d].pos < e.pos) lo = mid; else hi = mid;
+        }
+    }
+    const SegEdge pe = edges[(size_t)lo * 256 + d];
+    if (pe.last != e.first) return;
+    const bool exhausted = kmagic ? (e.first - __umul64hi(e.first, kmagic) * kbase) == 0 : (e.first & (uint64_t)(kbase - 1u)) == 0;
+    auto patch = [&](unsigned long long slot, uint32_t clear, uint32_t set) {
+        // (the word that holds the byte: `flags` points at the group's first flag, which need not be 4-byte aligned;
+        //  the flag array itself is a 256-byte-aligned device block, so the word lies inside it)
+        const uintptr_t a = reinterpret_cast<uintptr_t>(flags + slot);
+        unsigned int* w = reinterpret_cast<unsigned int*>(a & ~(uintptr_t)3);
+        const uint32_t sh = 8u * (uint32_t)(a & 3u);
+        if (clear) atomicAnd(w, ~(clear << sh));
+        if (set) atomicOr(w, set << sh);
+    };
+    patch(e.pos, 1u, exhausted ? 0u : 2u);       // first of this run: not a head
+    patch(e.pos - 1, 0u, exhausted ? 0u : 2u);   // last of the run in front: not a tail
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1170,6 +1299,113 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
         case 32: CDB_RS_SPLIT(15, true, true, 256, false, 1, 0, 1, false, true);
     }
 #undef CDB_RS_SPLIT
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmented sort of packed bucket records (the bucket-wise build of corpora >= 2^32)
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_SEG_TILE = 16384;  // 1024 threads x 16 records (u32 key, u32 value, W)
+
+// first tile of every segment is known on the host; the tile -> segment map is a search per tile
+static __global__ __launch_bounds__(256) void rs_seg_tilemap_kernel(const SegInfo* __restrict__ segs, uint32_t nseg, uint32_t tiles,
+                                                                    uint32_t* __restrict__ tile_seg) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= tiles) return;
+    uint32_t lo = 0, hi = nseg - 1;  // largest g with segs[g].tile_begin <= t
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (segs[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    tile_seg[t] = lo;
+}
+
+// starts[g][p][d] = first output slot of digit d of pass p inside segment g (hist and starts: [nseg][8][256])
+static __global__ __launch_bounds__(256) void rs_seg_digit_start_kernel(const unsigned long long* __restrict__ hist,
+                                                                        const SegInfo* __restrict__ segs, int npass,
+                                                                        unsigned long long* __restrict__ starts) {
+    __shared__ unsigned long long s[256];
+    const uint32_t g = blockIdx.x;
+    const int t = threadIdx.x;
+    const unsigned long long b0 = segs[g].begin;
+    for (int p = 0; p < npass; ++p) {
+        const unsigned long long c = hist[((size_t)g * 8 + p) * 256 + t];
+        s[t] = c;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const unsigned long long v = t >= off ? s[t - off] : 0;
+            __syncthreads();
+            s[t] += v;
+            __syncthreads();
+        }
+        starts[((size_t)g * 8 + p) * 256 + t] = b0 + s[t] - c;
+        __syncthreads();
+    }
+}
+
+// One stable LSD sort per segment, all segments of a pass in ONE launch.  Records (k32, value, aux) of m elements in
+// buffers 0; `lead` low digits sit in the auxiliary word (sorted first), key_bits bits in k32.  The last pass writes
+// entries and group flags through `fin` (eout / flags / edges filled in by the caller) instead of records.
+// d_hist: digit counts [nseg][8][256], lowest digit first; d_starts: scratch of the same shape.
+template <typename W>
+void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1,
+                          W* w0, W* w1, uint64_t m, const SegInfo* d_segs, const uint32_t* d_tile_seg, uint32_t nseg, uint32_t tiles,
+                          const unsigned long long* d_hist, unsigned long long* d_starts, int key_bits, int lead, SegFinalArgs fin,
+                          SortStats* stats) {
+    if (!rs_atomic_rank_ok(s)) throw Error("radix_sort_segmented: needs the one-atomic ranking (internal)");
+    const int kpass = (int)ceil_div((uint64_t)key_bits, 8);
+    const int npass = kpass + lead;
+    if (npass < 1 || npass > 8 || kpass < 1) throw Error("radix_sort_segmented: unsupported pass count (internal)");
+    const int last_bits = key_bits - 8 * (kpass - 1);
+    const uint32_t last_mask = (1u << last_bits) - 1u;
+    ws.prepare((uint64_t)tiles * RS_SEG_TILE, RS_SEG_TILE, s);
+    hipLaunchKernelGGL(rs_seg_digit_start_kernel, dim3(nseg), dim3(256), 0, s, d_hist, d_segs, npass, d_starts);
+    SegArgs sa;
+    sa.tile_seg = d_tile_seg;
+    sa.segs = d_segs;
+    sa.tiles = tiles;
+    sa.start_stride = 8 * 256;
+    static_cast<SegArgs&>(fin) = sa;
+    const bool grouped = ws.allow_group && !ws.plain_order;
+    using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+    using CfgP = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true>;
+    const uint32_t grid = grouped ? (uint32_t)(ceil_div(tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : tiles;
+    uint32_t* kb[2] = {k0, k1};
+    uint32_t* vb[2] = {v0, v1};
+    W* wb[2] = {w0, w1};
+    int cur = 0;
+    const char* wn = sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32");
+    const size_t rec = 8 + sizeof(W);
+    for (int p = 0; p < npass; ++p) {
+        const uint32_t e = ws.next_epoch(s);
+        const uint32_t dmask = p == npass - 1 ? last_mask : 0xFFu;
+        const int shift = 8 * (p - lead);
+        const int aux_shift = p < lead ? 8 * p : -1;
+        const unsigned long long* dstart = d_starts + (size_t)p * 256;
+        uint32_t* tk = grouped ? ws.xticket_ptr(e) : ws.ticket_ptr(e);
+        int t = prof.begin(s);
+#define CDB_SEG_LAUNCH(CFG, SEGT, SEGV)                                                                                       \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, W, SEGT>), dim3(grid), dim3(1024), 0, s,            \
+                       (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], m, shift, dmask, dstart, \
+                       ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift,     \
+                       BStartArgs(), SEGV)
+        if (p == npass - 1) {
+            if (grouped) CDB_SEG_LAUNCH(CfgG, SegFinalArgs, fin);
+            else CDB_SEG_LAUNCH(CfgP, SegFinalArgs, fin);
+            prof.end(t, (std::string("rs_seg_final") + wn + "_t16384").c_str(), m * (rec + 9), s);
+        } else {
+            if (grouped) CDB_SEG_LAUNCH(CfgG, SegArgs, sa);
+            else CDB_SEG_LAUNCH(CfgP, SegArgs, sa);
+            prof.end(t, (std::string("rs_seg_k32_v32") + wn + "_t16384").c_str(), 2 * m * rec, s);
+        }
+#undef CDB_SEG_LAUNCH
+        cur ^= 1;
+        if (stats) stats->passes_run++;
+    }
+    int t = prof.begin(s);
+    hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(tiles), dim3(256), 0, s, (const SegEdge*)fin.edges, d_tile_seg, d_segs, tiles,
+                       fin.flags, fin.kbase, fin.kmagic);
+    prof.end(t, "rs_seg_edge_fix", (uint64_t)tiles * 256 * sizeof(SegEdge), s);
+    CDB_HIP(hipGetLastError());
 }
 
 }  // namespace cdb

@@ -752,6 +752,152 @@ __global__ __launch_bounds__(256) void sa_bucket_records_packed_kernel(const uin
         if (s_hist[p][threadIdx.x]) atomicAdd(&h[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
 }
 
+// ---- device-side planning of the record gather + a persistent, XCD-aware gather (segmented bucket-wise build) ----
+// The work items of a bucket group are (bucket, <= BR_ITEM consecutive entries of it inside one text chunk), walked in
+// text-chunk order so that the chunk sits in the L2 while every bucket reads it.  The 8 XCDs have private L2s, so the
+// chunks are dealt out to them round robin: list x = the chunks x, x + 8, ... (chunk-major, bucket-minor), and only the
+// workgroups running on XCD x (blockIdx % 8, as dispatched) draw from list x — a chunk crosses the fabric once instead
+// of once per XCD.  Item lists are laid out on the device (no host loop over millions of items, no copy of the bounds
+// back to the host, no synchronisation per group).
+//   cells of list x: c = ci * gb + bi  <->  chunk x + 8 ci, bucket b0 + bi;  cell_base[x] = cells in front of list x
+struct GatherPlan {
+    uint32_t cell_base[9];
+};
+
+// block x scans the item counts of its list: cell_off[cell_base[x] + c] = items in front of cell c, list_len[x] = total
+__global__ __launch_bounds__(1024) void sa_gather_plan_kernel(const unsigned long long* __restrict__ bounds, uint32_t nch, uint32_t b0,
+                                                              uint32_t gb, GatherPlan plan, uint32_t* __restrict__ cell_off,
+                                                              uint32_t* __restrict__ list_len) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t x = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cells = plan.cell_base[x + 1] - plan.cell_base[x];
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < cells; c0 += 1024) {
+        const uint32_t c = c0 + tid;
+        uint32_t v = 0;
+        if (c < cells) {
+            const uint32_t ch = x + 8u * (c / gb), b = b0 + c % gb;
+            const unsigned long long lo = bounds[(size_t)b * (nch + 1) + ch], hi = bounds[(size_t)b * (nch + 1) + ch + 1];
+            v = (uint32_t)((hi - lo + BR_ITEM - 1) / BR_ITEM);
+        }
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += y;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (uint32_t w = 0; w < wave; ++w) pre += s_w[w];
+        if (c < cells) cell_off[plan.cell_base[x] + c] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) list_len[x] = s_carry;
+}
+
+// one thread per cell writes the cell's items; items of list x start behind the lists in front of it
+__global__ __launch_bounds__(256) void sa_gather_emit_kernel(const unsigned long long* __restrict__ bounds, uint32_t nch, uint32_t b0,
+                                                             uint32_t gb, GatherPlan plan, const uint32_t* __restrict__ cell_off,
+                                                             const uint32_t* __restrict__ list_len, BucketItem* __restrict__ items) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= plan.cell_base[8]) return;
+    uint32_t x = 0;
+    while (t >= plan.cell_base[x + 1]) ++x;
+    const uint32_t c = t - plan.cell_base[x];
+    uint32_t at = cell_off[t];
+    for (uint32_t y = 0; y < x; ++y) at += list_len[y];
+    const uint32_t ch = x + 8u * (c / gb), b = b0 + c % gb;
+    const unsigned long long lo = bounds[(size_t)b * (nch + 1) + ch], hi = bounds[(size_t)b * (nch + 1) + ch + 1];
+    for (unsigned long long o = lo; o < hi; o += BR_ITEM, ++at)
+        items[at] = BucketItem{o, (uint32_t)((hi - o) < (unsigned long long)BR_ITEM ? (hi - o) : (unsigned long long)BR_ITEM), b};
+}
+
+// the gather of sa_bucket_records_packed_kernel, persistent: workgroup w serves list w % 8 until it is empty
+template <typename W>
+__global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint64_t* __restrict__ ent, const BucketItem* __restrict__ items,
+                                                                      const uint32_t* __restrict__ list_len, uint32_t* __restrict__ tickets,
+                                                                      const uint8_t* __restrict__ text, uint64_t n,
+                                                                      const uint64_t* __restrict__ doc_start,
+                                                                      const uint16_t* __restrict__ symmap, int bits, uint64_t mask, int nsym,
+                                                                      uint32_t kbase, int low_bits, int npass, uint64_t gstart,
+                                                                      uint32_t bucket0, uint32_t* __restrict__ k32, W* __restrict__ low,
+                                                                      uint32_t* __restrict__ elo, unsigned long long* __restrict__ hist) {
+    __shared__ uint16_t s_map[256];
+    __shared__ uint32_t s_hist[8][256];
+    __shared__ uint32_t s_slot;
+    const uint32_t x = blockIdx.x & 7u;
+    s_map[threadIdx.x] = symmap[threadIdx.x];
+    uint32_t first = 0;
+    for (uint32_t y = 0; y < x; ++y) first += list_len[y];
+    const uint32_t len = list_len[x];
+    constexpr int U = 4;
+    for (;;) {
+        __syncthreads();  // (s_map ready / previous item's histogram flushed)
+        if (threadIdx.x == 0) s_slot = atomicAdd(tickets + x, 1u);
+        for (int p = 0; p < npass; ++p) s_hist[p][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t slot = s_slot;
+        if (slot >= len) break;
+        const BucketItem it = items[first + slot];
+        for (uint32_t r0 = threadIdx.x; r0 < it.count; r0 += 256 * U) {
+            uint64_t e[U], pos[U], rem[U], w0[U], w1[U];
+            bool live[U], windowed[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                live[u] = r0 + 256u * u < it.count;
+                e[u] = live[u] ? ent[it.begin + r0 + 256u * u] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t d = live[u] ? (e[u] & mask) : 0ull;
+                const uint64_t ds = doc_start[d], de = doc_start[d + 1];
+                pos[u] = ds + (e[u] >> bits);
+                rem[u] = de - pos[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                windowed[u] = live[u] && pos[u] + 24 <= n;  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
+                w0[u] = windowed[u] ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 1) : 0ull;
+                w1[u] = windowed[u] && nsym > 9 ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 9) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u]) continue;
+                uint64_t key = 0;
+                if (windowed[u]) {
+                    uint64_t w = w0[u];
+                    for (int k = 1; k < nsym && k <= 8; ++k) {
+                        key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[w & 0xff] : 0ull);
+                        w >>= 8;
+                    }
+                    w = w1[u];
+                    for (int k = 9; k < nsym; ++k) {
+                        key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[w & 0xff] : 0ull);
+                        w >>= 8;
+                    }
+                } else {
+                    for (int k = 1; k < nsym; ++k)
+                        key = key * kbase + ((uint64_t)k < rem[u] ? (uint64_t)s_map[text[pos[u] + k]] : 0ull);
+                }
+                const uint64_t i = it.begin + r0 + 256u * u;
+                k32[i - gstart] = (uint32_t)(key >> low_bits);
+                low[i - gstart] = (W)((key & ((1ull << low_bits) - 1ull)) | ((e[u] >> 32) << low_bits));
+                elo[i - gstart] = (uint32_t)e[u];
+                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+            }
+        }
+        __syncthreads();
+        unsigned long long* h = hist + (size_t)(it.bucket - bucket0) * 8 * 256;
+        for (int p = 0; p < npass; ++p)
+            if (s_hist[p][threadIdx.x]) atomicAdd(&h[p * 256 + threadIdx.x], (unsigned long long)s_hist[p][threadIdx.x]);
+    }
+}
+
 template <typename W>
 __global__ __launch_bounds__(256) void sa_assemble_entries_kernel(const uint32_t* __restrict__ elo, const W* __restrict__ low,
                                                                   int hi_shift, uint64_t cnt, uint64_t* __restrict__ out) {
@@ -1755,16 +1901,132 @@ void build_typed(Index& ix, bool big) {
             hipLaunchKernelGGL((sa_bucket_bounds_kernel<V>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
                                (const V*)E.as<V>(), (const unsigned long long*)d_bstart.as<unsigned long long>(), nb, nch, chunk,
                                doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
-            std::vector<uint64_t> bounds((size_t)nb * (nch + 1));
-            CDB_HIP(hipMemcpyAsync(bounds.data(), d_bounds.p, bounds.size() * 8, hipMemcpyDeviceToHost, s));
-            CDB_HIP(hipStreamSynchronize(s));
             // groups of consecutive buckets whose records (4 + lowb bytes per suffix) fit the memory left
             size_t fre = 0, tot = 0;
             CDB_HIP(hipMemGetInfo(&fre, &tot));
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
-            // (the third entry buffer is a luxury: without it an odd number of passes costs a copy back)
             const int auxb = packed ? (lowb == 0 ? 1 : (lowb == 1 ? 2 : 4)) : lowb;  // bytes of the auxiliary array per suffix
             const int recb = keyb + auxb + (packed ? 4 : 0);                         // record bytes per suffix of a group
+            // ---- segmented form (round 3): ONE launch per radix pass sorts every bucket of a group (radix_sort.h:
+            // radix_sort_segmented), the last pass writes entries + group flags itself, the gather is planned on the
+            // device and XCD-aware, and nothing in the group loop waits for the host.  Needs two record buffers per
+            // group (the passes ping-pong over the whole group) and a bucket is never split across groups.
+            uint64_t seg_cap = 0;
+            if (packed && ix.segmented_sort && sizeof(V) == 8 && rs_atomic_rank_ok(s)) {
+                const double per = 2.0 * recb + 1.0;  // + edge records (32 B per tile and digit)
+                uint64_t cap = (uint64_t)std::max(0.0, avail * 0.85 / per);
+                if (cap >= maxb) {
+                    if (ix.bucket_group_limit) cap = std::max<uint64_t>(std::min<uint64_t>(cap, ix.bucket_group_limit), maxb);
+                    seg_cap = std::min<uint64_t>(cap, n);
+                }
+            }
+            auto run_segmented = [&](auto wtag) {
+                using W = decltype(wtag);
+                if constexpr (sizeof(V) == 8) {
+                    struct Group {
+                        uint32_t b0, b1, tiles, cells;
+                        uint64_t gstart, elems;
+                        GatherPlan plan;
+                    };
+                    std::vector<Group> groups;
+                    std::vector<SegInfo> h_segs(nb);
+                    uint32_t max_tiles = 0, max_gb = 0, max_cells = 0;
+                    uint64_t max_items = 0;
+                    for (uint32_t b0 = 0; b0 < nb;) {
+                        uint32_t b1 = b0 + 1;
+                        while (b1 < nb && bstart[b1 + 1] - bstart[b0] <= seg_cap) ++b1;
+                        Group g;
+                        g.b0 = b0;
+                        g.b1 = b1;
+                        g.gstart = bstart[b0];
+                        g.elems = bstart[b1] - bstart[b0];
+                        uint32_t tiles = 0;
+                        for (uint32_t b = b0; b < b1; ++b) {
+                            h_segs[b] = SegInfo{(unsigned long long)(bstart[b] - g.gstart), (unsigned long long)(bstart[b + 1] - g.gstart), tiles, 0u};
+                            tiles += (uint32_t)ceil_div(bstart[b + 1] - bstart[b], (uint64_t)RS_SEG_TILE);
+                        }
+                        g.tiles = tiles;
+                        const uint32_t gb = b1 - b0;
+                        g.plan.cell_base[0] = 0;
+                        for (uint32_t x = 0; x < 8; ++x) g.plan.cell_base[x + 1] = g.plan.cell_base[x] + (x < nch ? (nch - x + 7) / 8 : 0u) * gb;
+                        g.cells = g.plan.cell_base[8];
+                        max_tiles = std::max(max_tiles, tiles);
+                        max_gb = std::max(max_gb, gb);
+                        max_cells = std::max(max_cells, g.cells);
+                        max_items = std::max<uint64_t>(max_items, g.elems / BR_ITEM + g.cells + 8);
+                        groups.push_back(g);
+                        b0 = b1;
+                    }
+                    uint64_t max_elems = 0;
+                    for (const Group& g : groups) max_elems = std::max(max_elems, g.elems);
+                    DevBuf kb[2], eb[2], wb[2], edges, d_starts, d_segs, tile_seg, cell_off, lists, d_items2, d_bh2;
+                    for (int q = 0; q < 2; ++q) {
+                        kb[q].alloc(max_elems * sizeof(uint32_t));
+                        eb[q].alloc(max_elems * sizeof(uint32_t));
+                        wb[q].alloc(max_elems * sizeof(W));
+                    }
+                    edges.alloc((size_t)max_tiles * 256 * sizeof(SegEdge));
+                    d_starts.alloc((size_t)max_gb * 8 * 256 * sizeof(uint64_t));
+                    d_bh2.alloc((size_t)max_gb * 8 * 256 * sizeof(uint64_t));
+                    d_segs.alloc((size_t)nb * sizeof(SegInfo));
+                    tile_seg.alloc((size_t)max_tiles * sizeof(uint32_t));
+                    cell_off.alloc((size_t)max_cells * sizeof(uint32_t));
+                    lists.alloc(groups.size() * 16 * sizeof(uint32_t));  // per group: 8 list lengths, 8 tickets
+                    d_items2.alloc((size_t)max_items * sizeof(BucketItem));
+                    st.alloc_ms += now_ms() - ta;
+                    CDB_HIP(hipMemcpyAsync(d_segs.p, h_segs.data(), (size_t)nb * sizeof(SegInfo), hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipMemsetAsync(lists.p, 0, groups.size() * 16 * sizeof(uint32_t), s));
+                    const unsigned long long* bnd = d_bounds.as<unsigned long long>();
+                    for (size_t gi = 0; gi < groups.size(); ++gi) {
+                        const Group& g = groups[gi];
+                        const uint32_t gb = g.b1 - g.b0;
+                        uint32_t* list_len = lists.as<uint32_t>() + gi * 16;
+                        uint32_t* tickets = list_len + 8;
+                        CDB_HIP(hipMemsetAsync(d_bh2.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
+                        int t = ix.prof.begin(s);
+                        hipLaunchKernelGGL(sa_gather_plan_kernel, dim3(8), dim3(1024), 0, s, bnd, nch, g.b0, gb, g.plan, cell_off.as<uint32_t>(),
+                                           list_len);
+                        hipLaunchKernelGGL(sa_gather_emit_kernel, dim3((unsigned)ceil_div(g.cells, 256)), dim3(256), 0, s, bnd, nch, g.b0, gb,
+                                           g.plan, (const uint32_t*)cell_off.as<uint32_t>(), (const uint32_t*)list_len,
+                                           d_items2.as<BucketItem>());
+                        ix.prof.end(t, "sa_gather_plan", (uint64_t)g.cells * 24 + (g.elems / BR_ITEM) * sizeof(BucketItem), s);
+                        t = ix.prof.begin(s);
+                        hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(256 * 8), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
+                                           (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
+                                           (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
+                                           g.b0, kb[0].as<uint32_t>(), wb[0].as<W>(), eb[0].as<uint32_t>(), d_bh2.as<unsigned long long>());
+                        ix.prof.end(t, "sa_bucket_records", g.elems * ((uint64_t)nsym + recb + sizeof(V)), s);
+                        st.gather_items += g.elems / BR_ITEM;
+                        hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
+                                           (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
+                        SegFinalArgs fin;
+                        fin.eout = E.as<uint64_t>() + g.gstart;
+                        fin.flags = flags.as<uint8_t>() + g.gstart;
+                        fin.edges = edges.as<SegEdge>();
+                        fin.hi_shift = blow;
+                        fin.low_bits = blow;
+                        fin.kbase = bbase;
+                        fin.kmagic = bmagic;
+                        radix_sort_segmented<W>(s, ix.rws, ix.prof, kb[0].as<uint32_t>(), kb[1].as<uint32_t>(), eb[0].as<uint32_t>(),
+                                                eb[1].as<uint32_t>(), wb[0].as<W>(), wb[1].as<W>(), g.elems,
+                                                (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), (const uint32_t*)tile_seg.as<uint32_t>(), gb,
+                                                g.tiles, (const unsigned long long*)d_bh2.as<unsigned long long>(),
+                                                d_starts.as<unsigned long long>(), bbits - blow, lowb, fin, &ss);
+                        st.bucket_groups++;
+                    }
+                    CDB_HIP(hipStreamSynchronize(s));  // (h_segs and the group scratch go out of scope)
+                    st.segmented = 1;
+                }
+            };
+            if (seg_cap) {
+                if (lowb == 0) run_segmented(uint8_t{});
+                else if (lowb == 1) run_segmented(uint16_t{});
+                else run_segmented(uint32_t{});
+            } else {
+            std::vector<uint64_t> bounds((size_t)nb * (nch + 1));
+            CDB_HIP(hipMemcpyAsync(bounds.data(), d_bounds.p, bounds.size() * 8, hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            // (the third entry buffer is a luxury: without it an odd number of passes costs a copy back)
             const bool third = !packed && avail > (double)maxb * (2.0 * (keyb + lowb) + 2 * sizeof(V)) * 1.15;
             const double scratch = packed ? (double)maxb * recb
                                           : (double)maxb * (keyb + lowb + (third ? 2 : 1) * sizeof(V)) +
@@ -1911,6 +2173,7 @@ void build_typed(Index& ix, bool big) {
                 st.bucket_groups++;
                 b0 = b1;
             }
+            }  // (per-bucket launches)
         } else {
         KT[0].alloc(maxb * sizeof(uint64_t));
         if (nsym > 1 && maxb > 1) {

@@ -209,7 +209,7 @@ def _wide_entry_docs(nsmall, small_len, big_len):
     return np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
 
 
-@pytest.mark.parametrize("pack", [1, 0])
+@pytest.mark.parametrize("pack", [1, 0, 2])
 def test_bucket_sorts_with_packed_entries(G, pack):
     # bucket-wise build with 8-byte entries: the bucket sorts move (u32 key, u32 entry bits 0..31, low digits | entry
     # bits 32..39) and the entries are put back together afterwards (pack_entries = 0: (key, u64 entry) records).
@@ -221,15 +221,39 @@ def test_bucket_sorts_with_packed_entries(G, pack):
         ds = _wide_entry_docs(40000, 3, 70000)
         blob = W.random_bytes(int(ds[-1]), seed, lo, hi)
         pats = W.sample_patterns(blob, ds, 150, 1, 8, seed=12, miss_frac=0)
-        opts = dict(force_big_path=1, pack_entries=pack)
+        # pack = 2: packed entries sorted bucket by bucket (round 2); pack = 1: segmented passes (round 3: one launch per
+        # pass for all buckets of a group, entries and group flags written by the last pass)
+        opts = dict(force_big_path=1, pack_entries=int(pack > 0), segmented_sort=int(pack == 1))
         if initial:
             opts["initial_passes"] = initial
         for group_limit in (0, 30000):
             g, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, **opts)
-            assert g.sa_width == 8 and g.stat("bucketed") == 1
+            assert g.sa_width == 8 and g.stat("bucketed") == 1 and g.stat("segmented") == int(pack == 1)
             layouts.add((int(g.stat("key_layout")), int(g.stat("bucket_low_digits"))))
     assert (5 in {l for l, _ in layouts}) == bool(pack), layouts
     assert not pack or {d for _, d in layouts} == {0, 1, 2, 3}, layouts   # u8 / u16 / u32 auxiliary arrays
+
+
+@pytest.mark.parametrize("plain_order", [0, 1])
+def test_segmented_bucket_sort_groups_across_tiles(G, plain_order):
+    # segmented passes of the bucket-wise build: groups of equal keys that straddle the ends of a tile's per-digit
+    # runs get their flags from the edge records (radix_sort.h: rs_seg_edge_fix_kernel).  Tiny alphabets and repeated
+    # documents put thousands of equal keys in a row, buckets of several 16 Ki tiles, several bucket groups.
+    for seed, (lo, hi), reps in ((3, (0x61, 0x62), 1), (4, (0x61, 0x63), 3), (5, (0x41, 0x44), 2)):
+        ds = _wide_entry_docs(40000, 4, 70000)
+        blob = W.random_bytes(int(ds[-1]), seed, lo, hi)
+        if reps > 1:                                   # repeated stretches: equal suffixes from different documents
+            blob[60000:120000] = blob[0:60000]
+        pats = W.sample_patterns(blob, ds, 120, 1, 10, seed=12, miss_frac=0)
+        for group_limit in (0, 70000):
+            for initial in (0, 2):
+                opts = dict(force_big_path=1, plain_tile_order=plain_order, bucket_group_limit=group_limit)
+                if initial:
+                    opts["initial_passes"] = initial
+                g, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
+                assert g.sa_width == 8 and g.stat("segmented") == 1
+                v = g.verify()
+                assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0
 
 
 def test_test_string_shape_property(G):
