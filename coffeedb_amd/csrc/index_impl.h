@@ -28,6 +28,7 @@ struct BuildStats {
     int bucketed = 0;            // streamed bucket-wise initial sort (corpora >= 2^32)
     int bucket_low_digits = 0;   // ... low digits (bytes) carried beside the 32-bit bucket key
     int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
+    int root_folded = 0;         // ... first-symbol buckets laid out in the reference's root order (bytes >= 0x80 first)
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     int hybrid = 0;              // hybrid initial sort: global passes before the LDS bucket sort (0 = plain LSD sort,
                                  // -1 = tried, a bucket did not fit, redone by the plain sort)
@@ -119,6 +120,7 @@ struct Index {
     int initial_passes = 0;
     int sort_variant = 0;
     int search_lanes = 0;      // lanes per keyword in the fast batched search: 0 = by batch size, 1 or 8
+    bool fold_root = true;       // bucket-wise build under reference_compat: bucket order = the reference's root child order
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8

@@ -219,6 +219,7 @@ struct SegFinalArgs : SegArgs {
     int low_bits = 0;           // key = (k32 << low_bits) | (aux & (2^low_bits - 1))
     uint32_t kbase = 2;
     unsigned long long kmagic = 0;
+    int abl = 0;                // timing experiments only (WRONG results): 1 = no flag stores, 2 = no entry stores, 4 = no neighbour compares
 };
 
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
@@ -802,11 +803,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
                     const uint64_t kc = ((uint64_t)k << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i : 0] & lmask);
                     bool head = true, tail = true;
+                    if (!(seg.abl & 4)) {
                     if (i > 0) head = (((uint64_t)s_keys[i - 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i - 1 : 0] & lmask)) != kc;
                     if (i + 1 < valid) tail = (((uint64_t)s_keys[i + 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i + 1 : 0] & lmask)) != kc;
+                    }
                     const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
                                                       : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
-                    seg.flags[s_gbase[dd] + i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+                    if (!(seg.abl & 1)) seg.flags[s_gbase[dd] + i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
                     continue;
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         for (int j = 0; j < IPT; ++j) {
             const uint32_t i = j * NT + tid;
             if constexpr (FINAL) {
-                if (i < valid)
+                if (i < valid && !(seg.abl & 2))
                     seg.eout[s_gbase[dig[j]] + i] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
             } else {
                 if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);

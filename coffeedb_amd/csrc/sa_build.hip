@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint
                                                                       const uint16_t* __restrict__ symmap, int bits, uint64_t mask, int nsym,
                                                                       uint32_t kbase, int low_bits, int npass, uint64_t gstart,
                                                                       uint32_t bucket0, uint32_t* __restrict__ k32, W* __restrict__ low,
-                                                                      uint32_t* __restrict__ elo, unsigned long long* __restrict__ hist) {
+                                                                      uint32_t* __restrict__ elo, unsigned long long* __restrict__ hist,
+                                                                      int abl) {
     __shared__ uint16_t s_map[256];
     __shared__ uint32_t s_hist[8][256];
     __shared__ uint32_t s_slot;
@@ -855,6 +856,11 @@ __global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint64_t d = live[u] ? (e[u] & mask) : 0ull;
+                if (abl & 2) {  // (timing experiment: no document table)
+                    pos[u] = (e[u] >> bits) + d * 1024;
+                    rem[u] = 1u << 20;
+                    continue;
+                }
                 const uint64_t ds = doc_start[d], de = doc_start[d + 1];
                 pos[u] = ds + (e[u] >> bits);
                 rem[u] = de - pos[u];
@@ -862,6 +868,11 @@ __global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 windowed[u] = live[u] && pos[u] + 24 <= n;  // symbols 1 .. nsym-1 from two 8-byte windows behind the first byte
+                if (abl & 4) {  // (timing experiment: no text)
+                    w0[u] = e[u] * 0x9E3779B97F4A7C15ull;
+                    w1[u] = w0[u] >> 7;
+                    continue;
+                }
                 w0[u] = windowed[u] ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 1) : 0ull;
                 w1[u] = windowed[u] && nsym > 9 ? *reinterpret_cast<const u64_unaligned*>(text + pos[u] + 9) : 0ull;
             }
@@ -887,8 +898,9 @@ __global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint
                 const uint64_t i = it.begin + r0 + 256u * u;
                 k32[i - gstart] = (uint32_t)(key >> low_bits);
                 low[i - gstart] = (W)((key & ((1ull << low_bits) - 1ull)) | ((e[u] >> 32) << low_bits));
-                elo[i - gstart] = (uint32_t)e[u];
-                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+                if (!(abl & 8)) elo[i - gstart] = (uint32_t)e[u];
+                if (!(abl & 1))
+                    for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
             }
         }
         __syncthreads();
@@ -1169,8 +1181,10 @@ __global__ __launch_bounds__(256) void compat_reverse_kernel(V* __restrict__ x, 
     }
 }
 
+// roots (optional): the bucket-wise build already laid its first-symbol buckets out in the reference's root order —
+// the walk starts one level down, with those buckets as nodes
 template <typename V>
-void apply_reference_order(Index& ix, V* sa) {
+void apply_reference_order(Index& ix, V* sa, const std::vector<CompatBucket>* roots = nullptr) {
     hipStream_t s = ix.stream;
     const uint64_t n = ix.size;
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
@@ -1178,10 +1192,20 @@ void apply_reference_order(Index& ix, V* sa) {
     if (n <= chuck) return;
     DevBuf d_buckets, d_bounds;
     uint64_t depth = 0;
+    if (roots) {
+        level.clear();
+        for (const CompatBucket& b : *roots)
+            if (b.hi - b.lo > chuck) level.push_back(b);
+        depth = 1;
+    }
+    uint64_t moved = 0;  // elements reversed (each one read and written)
+    const int tprof = ix.prof.begin(s);
     auto reverse = [&](uint64_t at, uint64_t len) {
-        if (len > 1)
+        if (len > 1) {
             hipLaunchKernelGGL((compat_reverse_kernel<V>), dim3((unsigned)std::min<uint64_t>(ceil_div(len / 2, 256), 1u << 20)), dim3(256),
                                0, s, sa + at, len);
+            moved += len;
+        }
     };
     while (!level.empty()) {
         const size_t nb = level.size();
@@ -1217,6 +1241,7 @@ void apply_reference_order(Index& ix, V* sa) {
         ++depth;
     }
     ix.bstats.compat_depth = depth;
+    ix.prof.end(tprof, "sa_compat_rotate", 2 * moved * sizeof(V), s);
     CDB_HIP(hipStreamSynchronize(s));
 }
 
@@ -1243,7 +1268,7 @@ struct CompatNode {
 
 // returns false (nothing done) when the scratch array cannot be had; sa_buf is replaced by the reordered array
 template <typename V>
-bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
+bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, const std::vector<CompatBucket>* roots = nullptr) {
     hipStream_t s = ix.stream;
     const uint64_t n = ix.size;
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
@@ -1270,6 +1295,15 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
     };
     DevBuf d_buckets, d_bounds, d_segs;
     uint64_t depth = 0;
+    if (roots) {  // first-symbol buckets already in the reference's root order: they stay where they are
+        level.clear();
+        for (const CompatBucket& b : *roots) {
+            if (b.hi - b.lo > chuck) level.push_back(CompatNode{b.lo, b.hi, b.lo});
+            else emit(b.lo, b.lo, b.hi - b.lo);
+        }
+        depth = 1;
+    }
+    const uint64_t rotations_before = ix.bstats.compat_rotations;
     std::vector<CompatBucket> cb;
     while (!level.empty()) {
         const size_t nb = level.size();
@@ -1322,6 +1356,7 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf) {
         ++depth;
     }
     ix.bstats.compat_depth = depth;
+    if (ix.bstats.compat_rotations == rotations_before) return true;  // every node had its children on one side: nothing moves
     if (!segs.empty()) {
         d_segs.alloc(segs.size() * sizeof(CompatSeg));
         CDB_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(CompatSeg), hipMemcpyHostToDevice, s));
@@ -1543,6 +1578,7 @@ void build_typed(Index& ix, bool big) {
 
     // ---- 2 + 3. keys + entries, initial sort
     DevBuf sorted_keys, sa_buf, flags;
+    std::vector<CompatBucket> folded_roots;  // bucket-wise build in the reference's root order: the first-symbol buckets
     SortStats ss;
     const bool fused = big || (ix.fuse_keygen && (dense || dbits == symbits) && nsym <= HC_MAXSYM &&
                                rs_variant_has_gen(ix.sort_variant));
@@ -1822,13 +1858,30 @@ void build_typed(Index& ix, bool big) {
         // Every position starts a suffix, and a suffix is never empty: the first symbol is never "end of document", so
         // the partition digit is code - 1 (0 .. alphabet - 1: 8 bits even for all 256 byte values, where the codes
         // 1 .. 256 themselves need 9) and its histogram is simply the byte histogram.
+        // Bucket order = ascending code, or — reference_compat order on text with bytes >= 0x80 — the reference's child
+        // order of the ROOT radix node (index.h:66-73: bytes 0x80..0xFF in front of 0x00..0x7F): the first-symbol buckets
+        // then sit where apply_reference_order's root rotation (three reversals of the whole array) would put them.
+        const bool root_folded = ix.reference_compat && high_bytes && ix.fold_root && n > std::max<uint64_t>(4096, n / 256);
+        std::vector<int> border;  // symbol codes in bucket order
+        if (root_folded) {
+            for (int b = 128; b < 256; ++b)
+                if (h_map[b]) border.push_back(h_map[b]);
+            for (int b = 0; b < 128; ++b)
+                if (h_map[b]) border.push_back(h_map[b]);
+        } else {
+            for (int c = 1; c <= sigma; ++c) border.push_back(c);
+        }
         std::vector<uint64_t> first_by_code(258, 0), first_digit(256, 0);
         uint16_t h_map_first[256];
-        for (int b = 0; b < 256; ++b) {
-            h_map_first[b] = h_map[b] ? (uint16_t)(h_map[b] - 1) : (uint16_t)0;
-            if (h_map[b]) {
-                first_by_code[h_map[b]] = h_counts[b];
-                first_digit[h_map[b] - 1] = h_counts[b];
+        {
+            int slot_of_code[258] = {0};
+            for (int k = 0; k < sigma; ++k) slot_of_code[border[k]] = k;
+            for (int b = 0; b < 256; ++b) {
+                h_map_first[b] = h_map[b] ? (uint16_t)slot_of_code[h_map[b]] : (uint16_t)0;
+                if (h_map[b]) {
+                    first_by_code[h_map[b]] = h_counts[b];
+                    first_digit[slot_of_code[h_map[b]]] = h_counts[b];
+                }
             }
         }
         const uint64_t* h_first = first_by_code.data();  // (indexed by symbol code 1 .. alphabet)
@@ -1843,6 +1896,14 @@ void build_typed(Index& ix, bool big) {
                                       &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
         uint64_t maxb = 0;
         for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
+        if (root_folded) {
+            uint64_t at = 0;
+            for (int k = 0; k < sigma; ++k) {
+                folded_roots.push_back(CompatBucket{(unsigned long long)at, (unsigned long long)(at + h_first[border[k]])});
+                at += h_first[border[k]];
+            }
+            st.root_folded = 1;
+        }
         // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
         // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort
         // path when it fits 32 bits + one or two low digits: (u32, entry, u8 / u16) instead of (u64, entry).
@@ -1875,21 +1936,9 @@ void build_typed(Index& ix, bool big) {
             const int lowb = blow / 8;
             const int keyb = bwide ? 8 : 4;  // bytes of the key part of a record
             // non-empty buckets and their entry ranges
-            std::vector<uint64_t> bstart;  // [nb + 1]
-            for (int c = 1; c <= sigma; ++c)
-                if (h_first[c]) bstart.push_back(0);
-            const uint32_t nb = (uint32_t)bstart.size();
-            bstart.push_back(0);
-            {
-                uint64_t acc = 0;
-                uint32_t b = 0;
-                for (int c = 1; c <= sigma; ++c)
-                    if (h_first[c]) {
-                        bstart[b++] = acc;
-                        acc += h_first[c];
-                    }
-                bstart[nb] = acc;
-            }
+            const uint32_t nb = (uint32_t)sigma;  // (every code stands for a byte that occurs)
+            std::vector<uint64_t> bstart(nb + 1, 0);  // entry ranges of the buckets, in bucket order
+            for (uint32_t b = 0; b < nb; ++b) bstart[b + 1] = bstart[b] + h_first[border[b]];
             // where every bucket crosses the text chunks: 2 MiB, so that the chunk all concurrent work items read
             // fits every XCD's 4 MB L2
             const uint64_t chunk = 2ull << 20;  // (measured at 8 GiB: 1 MiB 61 ms, 2 MiB 60, 4 MiB 62, 16 MiB 88, 32 MiB 97)
@@ -1994,7 +2043,8 @@ void build_typed(Index& ix, bool big) {
                         hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(256 * 8), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
-                                           g.b0, kb[0].as<uint32_t>(), wb[0].as<W>(), eb[0].as<uint32_t>(), d_bh2.as<unsigned long long>());
+                                           g.b0, kb[0].as<uint32_t>(), wb[0].as<W>(), eb[0].as<uint32_t>(), d_bh2.as<unsigned long long>(),
+                                           getenv("CDB_GATHER_ABL") ? std::atoi(getenv("CDB_GATHER_ABL")) : 0);
                         ix.prof.end(t, "sa_bucket_records", g.elems * ((uint64_t)nsym + recb + sizeof(V)), s);
                         st.gather_items += g.elems / BR_ITEM;
                         hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
@@ -2007,6 +2057,7 @@ void build_typed(Index& ix, bool big) {
                         fin.low_bits = blow;
                         fin.kbase = bbase;
                         fin.kmagic = bmagic;
+                        if (const char* ab = getenv("CDB_SEG_ABL")) fin.abl = std::atoi(ab);
                         radix_sort_segmented<W>(s, ix.rws, ix.prof, kb[0].as<uint32_t>(), kb[1].as<uint32_t>(), eb[0].as<uint32_t>(),
                                                 eb[1].as<uint32_t>(), wb[0].as<W>(), wb[1].as<W>(), g.elems,
                                                 (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), (const uint32_t*)tile_seg.as<uint32_t>(), gb,
@@ -2181,8 +2232,8 @@ void build_typed(Index& ix, bool big) {
             ET.alloc(maxb * sizeof(V));
         }
         uint64_t start = 0;
-        for (int c = 1; c <= sigma; ++c) {
-            const uint64_t cnt = h_first[c];
+        for (int k = 0; k < sigma; ++k) {
+            const uint64_t cnt = h_first[border[k]];
             if (!cnt) continue;
             V* eb = E.as<V>() + start;
             int t = ix.prof.begin(s);
@@ -2368,9 +2419,10 @@ void build_typed(Index& ix, bool big) {
         std::memcpy(ix.h_symmap_q, h_map, sizeof(h_map));
     }
     if (ix.reference_compat && high_bytes) {
-        if (!apply_reference_order_oop<V>(ix, sa_buf)) {
-            apply_reference_order<V>(ix, sa);  // in place when no second array fits
-            ix.drop_keys();                    // ... which moves the entries away from their keys
+        const std::vector<CompatBucket>* roots = folded_roots.empty() ? nullptr : &folded_roots;
+        if (!apply_reference_order_oop<V>(ix, sa_buf, roots)) {
+            apply_reference_order<V>(ix, sa, roots);  // in place when no second array fits
+            ix.drop_keys();                           // ... which moves the entries away from their keys
         }
     }
     ix.d_sa = std::move(sa_buf);

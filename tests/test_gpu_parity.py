@@ -658,9 +658,11 @@ def test_bucket_wise_path_with_all_256_byte_values(G):
         blob, ds = W.ascii_corpus(*shape, seed=seed, lo=0x00, hi=0xFF)
         assert len(np.unique(blob)) == 256
         pats = W.sample_patterns(blob, ds, 200, 1, 3, seed=2, miss_frac=0)
-        for group_limit in (0, 5000):
-            g, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, bucket_group_limit=group_limit)
-            assert g.stat("bucketed") == 1
+        for group_limit, fold in ((0, 1), (5000, 1), (0, 0)):
+            # fold_root: the first-symbol buckets are laid out in the reference's root order (0x80..0xFF first) by the
+            # partition pass itself; 0 = plain order + the generic root rotation afterwards
+            g, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, bucket_group_limit=group_limit, fold_root=fold)
+            assert g.stat("bucketed") == 1 and g.stat("root_folded") == fold
         plain = _gpu(G, blob, ds, np.arange(len(ds) - 1, dtype=np.int64), force_big_path=1, reference_compat=0, narrow_keys=0)
         v = plain.verify()                                         # plain unsigned order (the oracle restates the reference's)
         assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
