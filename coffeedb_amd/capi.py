@@ -16,14 +16,16 @@ LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
 _LIB = None
 
 EXPORTS = [
-    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_view", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule", "cdb_debug_query_latency",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
-    "cdb_shards_transport", "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge",
+    "cdb_shards_transport", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
+    "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge", "cdb_comm_merge_counts",
+    "cdb_comm_world", "cdb_comm_transport",
 ]
 
 
@@ -44,6 +46,11 @@ class CdbHits(C.Structure):
 class CdbDeviceResult(C.Structure):
     _fields_ = [("npat", C.c_uint64), ("nrows", C.c_uint64), ("nhits", C.c_uint64),
                 ("d_row_ptr", C.c_void_p), ("d_ids", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+class CdbShardSlice(C.Structure):
+    _fields_ = [("npat", C.c_uint64), ("nrows_total", C.c_uint64), ("nrows_local", C.c_uint64),
+                ("d_row_ptr", C.c_void_p), ("d_row_base", C.c_void_p)]
 
 
 class CdbKeyQuery(C.Structure):
@@ -165,6 +172,17 @@ def load_library():
     lib.cdb_comm_last_error.argtypes = [vp]
     lib.cdb_comm_last_error.restype = cp
     lib.cdb_comm_merge.argtypes = [vp, C.POINTER(CdbDeviceResult), C.POINTER(CdbDeviceResult)]
+    lib.cdb_comm_merge_counts.argtypes = [vp, C.POINTER(CdbDeviceResult), C.POINTER(CdbShardSlice)]
+    lib.cdb_comm_world.argtypes = [vp]
+    lib.cdb_comm_transport.argtypes = [vp]
+    lib.cdb_comm_transport.restype = cp
+    lib.cdb_build_view.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_shards_query_batch_offsets.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult), C.POINTER(CdbHits)]
+    lib.cdb_shards_query_and.argtypes = [C.POINTER(CdbKeyQuery), C.c_int, C.c_int, i64, i64, u64, C.POINTER(C.POINTER(i64)),
+                                         C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
+    lib.cdb_shards_add_raw_dir.argtypes = [vp, cp, cp, C.POINTER(u64), C.POINTER(u64)]
+    lib.cdb_shards_save.argtypes = [vp, cp]
+    lib.cdb_shards_load.argtypes = [vp, cp]
     _LIB = lib
     return lib
 
@@ -208,6 +226,14 @@ class GpuStringIndex:
 
     def build(self):
         self._check(self._lib.cdb_build(self._h))
+
+    def build_view(self, ids, blob, doc_start):
+        """cdb_build_view: build straight from the caller's host column (no staging copy inside the handle)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+        assert len(doc_start) == len(ids) + 1
+        self._check(self._lib.cdb_build_view(self._h, _ptr(ids), _ptr(blob) if len(blob) else None, _ptr(doc_start), len(ids)))
 
     def add_raw_record(self, key: bytes, record: bytes):
         self._check(self._lib.cdb_add_raw_record(self._h, key, record, len(record)))
@@ -524,6 +550,29 @@ class GpuShards:
         return (ad(r.row_ptr, npat + 1, np.uint64, own), ad(r.ids, nrows, np.int64, own), ad(r.counts, nrows, np.int64, own),
                 int(r.nhits))
 
+    def query_batch_offsets(self, blob, offsets):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        npat = len(offsets) - 1
+        r, hx = CdbResult(), CdbHits()
+        self._check(self._lib.cdb_shards_query_batch_offsets(self._h, _ptr(blob), _ptr(offsets), npat, C.byref(r), C.byref(hx)))
+        own = GpuStringIndex._Owner(self._lib, ("cdb_result_free", r), ("cdb_hits_free", hx))
+        nrows, nhits = int(r.nrows), int(r.nhits)
+        ad = GpuStringIndex._adopt
+        return (ad(r.row_ptr, npat + 1, np.uint64, own), ad(r.ids, nrows, np.int64, own), ad(r.counts, nrows, np.int64, own),
+                ad(hx.hit_ptr, nrows + 1, np.uint64, own), ad(hx.offsets, nhits, np.uint64, own))
+
+    def add_raw_dir(self, directory, key: bytes):
+        nrec, nadd = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.cdb_shards_add_raw_dir(self._h, os.fsencode(directory), key, C.byref(nrec), C.byref(nadd)))
+        return nrec.value, nadd.value
+
+    def save(self, path):
+        self._check(self._lib.cdb_shards_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        self._check(self._lib.cdb_shards_load(self._h, os.fsencode(path)))
+
 
 class ShardComm:
     """cdb_comm: one rank of a one-process-per-GPU group; merge() is collective."""
@@ -551,6 +600,16 @@ class ShardComm:
             raise RuntimeError(self._lib.cdb_comm_last_error(self._h).decode(errors="replace"))
         return out
 
+    def merge_counts(self, local: "CdbDeviceResult"):
+        """Counts-only collective: merged row_ptr + this rank's first merged row per pattern (device arrays)."""
+        out = CdbShardSlice()
+        if self._lib.cdb_comm_merge_counts(self._h, C.byref(local), C.byref(out)) != 0:
+            raise RuntimeError(self._lib.cdb_comm_last_error(self._h).decode(errors="replace"))
+        return out
+
+    world = property(lambda s: s._lib.cdb_comm_world(s._h))
+    transport = property(lambda s: s._lib.cdb_comm_transport(s._h).decode())
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.cdb_comm_destroy(self._h)
@@ -560,9 +619,11 @@ class ShardComm:
 
 
 def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):
-    """AND across keys on the device (cdb_query_and).  keys: (GpuStringIndex, [keywords]) for a string column or
-    (None, [(id, count), ...]) for rows resolved elsewhere (ascending id).  Returns [(id, summed count), ...]."""
+    """AND across keys on the device (cdb_query_and / cdb_shards_query_and).  keys: (GpuStringIndex or GpuShards,
+    [keywords]) for a string column or (None, [(id, count), ...]) for rows resolved elsewhere (ascending id).  Returns
+    [(id, summed count), ...]."""
     lib = load_library()
+    sharded = any(isinstance(ix, GpuShards) for ix, _ in keys)
     arr = (CdbKeyQuery * len(keys))()
     keep = []
     lead = None
@@ -585,9 +646,11 @@ def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):
             arr[k].counts = rc.ctypes.data if len(rc) else None
             arr[k].nrows = len(ri)
     ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
-    rc_ = lib.cdb_query_and(arr, len(keys), 1 if ranked else 0, int(lo), int(hi), int(limit), C.byref(ids), C.byref(cnt), C.byref(n))
+    fn = lib.cdb_shards_query_and if sharded else lib.cdb_query_and  # (cdb_shards_key_query has cdb_key_query's layout)
+    rc_ = fn(arr, len(keys), 1 if ranked else 0, int(lo), int(hi), int(limit), C.byref(ids), C.byref(cnt), C.byref(n))
     if rc_ != 0:
-        raise RuntimeError(lib.cdb_last_error(lead._h).decode(errors="replace") if lead is not None else "cdb_query_and: no string key")
+        err = lib.cdb_shards_last_error if sharded else lib.cdb_last_error
+        raise RuntimeError(err(lead._h).decode(errors="replace") if lead is not None else "cdb_query_and: no string key")
     out = [(ids[i], cnt[i]) for i in range(n.value)]
     lib.cdb_free(ids)
     lib.cdb_free(cnt)

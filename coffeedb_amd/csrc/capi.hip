@@ -409,6 +409,19 @@ int cdb_add_raw_dir(cdb_index* h, const char* dir, const char* key, uint64_t* re
     if (added) *added = 0;
     return guarded(h, [&] {
         Index& ix = h->ix;
+        ensure_host_staging(ix);
+        uint64_t nrec = 0, nadd = 0;
+        cdb::read_raw_dir(dir, key, ix.ids, ix.doc_start, ix.host_text, nrec, nadd);
+        if (records) *records = nrec;
+        if (added) *added = nadd;
+    });
+}
+}  // extern "C"
+
+// every record file of `dir` (ascending name order) appended to a staged column; all or nothing
+void cdb::read_raw_dir(const char* dir, const char* key, std::vector<int64_t>& ids, std::vector<uint64_t>& doc_start, std::string& text,
+                       uint64_t& nrec, uint64_t& nadd) {
+    {
         DIR* d = opendir(dir);
         if (!d) throw Error(std::string("Cannot open directory: ") + dir);
         std::vector<std::string> names;
@@ -418,10 +431,9 @@ int cdb_add_raw_dir(cdb_index* h, const char* dir, const char* key, uint64_t* re
         }
         closedir(d);
         std::sort(names.begin(), names.end());
-        ensure_host_staging(ix);
-        const size_t mark_ids = ix.ids.size(), mark_text = ix.host_text.size();
+        const size_t mark_ids = ids.size(), mark_text = text.size();
         std::vector<char> buf;
-        uint64_t nrec = 0, nadd = 0;
+        nrec = nadd = 0;
         try {
             for (const std::string& name : names) {
                 const std::string path = std::string(dir) + "/" + name;
@@ -440,21 +452,21 @@ int cdb_add_raw_dir(cdb_index* h, const char* dir, const char* key, uint64_t* re
                 if (r < 0) throw Error("malformed raw record: " + path);
                 ++nrec;
                 if (r == 0) continue;  // the object has no string value under this key
-                ix.host_text.append(v, vl);
-                ix.ids.push_back(id);
-                ix.doc_start.push_back(ix.host_text.size());
+                text.append(v, vl);
+                ids.push_back(id);
+                doc_start.push_back(text.size());
                 ++nadd;
             }
         } catch (...) {  // all or nothing: a half-read directory must not leave a partial column behind
-            ix.ids.resize(mark_ids);
-            ix.doc_start.resize(mark_ids + 1);
-            ix.host_text.resize(mark_text);
+            ids.resize(mark_ids);
+            doc_start.resize(mark_ids + 1);
+            text.resize(mark_text);
             throw;
         }
-        if (records) *records = nrec;
-        if (added) *added = nadd;
-    });
+    }
 }
+
+extern "C" {
 
 // ---- f4: persistence of a built index (the reference rebuilds every index at start, server.cpp:44) ----
 namespace {
@@ -572,6 +584,7 @@ int cdb_build(cdb_index* h) {
         DeviceScope dscope(ix);
         const Layout L = layout_of(ix.doc_start, ix.ids.size());  // throws the reference's capacity errors: nothing changed yet
         const uint64_t n = L.size;
+        bool committed = false;  // a failure before the commit point (allocation, upload) leaves the previous index serving
         try {
             DevBuf text, d_start, d_ids;
             text.alloc(n + TEXT_PAD);
@@ -579,6 +592,7 @@ int cdb_build(cdb_index* h) {
             const double tu = wall_ms();
             upload_pageable(text.p, ix.host_text.data(), n, ix.stream, ix.device);
             upload_tables(ix, ix.doc_start, ix.ids, L.ndocs, d_start, d_ids);
+            committed = true;
             reset_unbuilt(ix);  // (waits for the stream: the old arrays are idle; ix.mu keeps queries out)
             ix.host_upload_ms = wall_ms() - tu;
             commit_layout(ix, L);
@@ -589,7 +603,8 @@ int cdb_build(cdb_index* h) {
             ix.d_ids = std::move(d_ids);
             build_suffix_array(ix);
         } catch (...) {
-            reset_unbuilt(ix);
+            if (committed) reset_unbuilt(ix);
+            else (void)hipStreamSynchronize(ix.stream);
             throw;
         }
         // the staging copy has done its job (database.cpp builds a fresh index object per build and never adds to a
@@ -627,9 +642,11 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
             hstart[d + 1] = doc_start[d + 1] - first;
         }
         const Layout L = layout_of(hstart, ndocs);
+        bool committed = false;
         try {
             DevBuf d_start, d_ids;
             upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
+            committed = true;
             reset_unbuilt(ix);
             commit_layout(ix, L);
             ix.ids.swap(hid);
@@ -644,7 +661,59 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
             ix.d_ids = std::move(d_ids);
             build_suffix_array(ix);
         } catch (...) {
+            if (committed) reset_unbuilt(ix);
+            else (void)hipStreamSynchronize(ix.stream);
+            throw;
+        }
+    });
+}
+
+/* cdb_build_view: build straight from the caller's host column — what string_index really holds (index.h:58:
+ * non-owning string_views into database.cpp's map, database.cpp:262-264) — without the staging copy of cdb_add_bulk
+ * (a memcpy into fresh pages: 180 ms per GiB, 3x the build it feeds).  The column goes to the device through the
+ * chunked pinned upload; afterwards the handle owns device copies only (cdb_add* fetch them back when needed). */
+int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs) {
+    if (!h || (ndocs && (!ids || !doc_start || (!blob && doc_start[ndocs] > doc_start[0])))) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        DeviceScope dscope(ix);
+        const uint64_t first = ndocs ? doc_start[0] : 0;
+        std::vector<int64_t> hid(ids, ids + ndocs);
+        std::vector<uint64_t> hstart(ndocs + 1);
+        hstart[0] = 0;
+        for (uint64_t d = 0; d < ndocs; ++d) {
+            if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+            hstart[d + 1] = doc_start[d + 1] - first;
+        }
+        const Layout L = layout_of(hstart, ndocs);  // (throws the reference's capacity errors: nothing changed yet)
+        const uint64_t n = L.size;
+        bool committed = false;
+        try {
+            DevBuf text, d_start, d_ids;
+            text.alloc(n + TEXT_PAD);
+            CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
+            const double tu = wall_ms();
+            if (n) upload_pageable(text.p, blob + first, n, ix.stream, ix.device);
+            upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
+            committed = true;
             reset_unbuilt(ix);
+            ix.host_upload_ms = wall_ms() - tu;
+            commit_layout(ix, L);
+            ix.ids.swap(hid);
+            ix.doc_start.swap(hstart);
+            ix.host_tables_valid = true;
+            std::string().swap(ix.host_text);
+            ix.host_text_valid = false;  // the column lives on the device (and with the caller)
+            ix.d_text_owned = std::move(text);
+            ix.d_text = ix.d_text_owned.as<uint8_t>();
+            ix.text_padded = true;
+            ix.d_doc_start = std::move(d_start);
+            ix.d_ids = std::move(d_ids);
+            build_suffix_array(ix);
+        } catch (...) {
+            if (committed) reset_unbuilt(ix);
+            else (void)hipStreamSynchronize(ix.stream);
             throw;
         }
     });
@@ -675,7 +744,7 @@ int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_s
         if (out[1]) throw Error("doc_start must be non-decreasing");
         if (first != 0) throw Error("d_doc_start[0] must be 0");
         const Layout L = layout_from(ndocs, total, out[0]);  // bits / mask / size / entry width exactly as index.cpp:182-208
-        try {
+        try {  // (nothing can fail between here and the commit: the tables are already on the device)
             reset_unbuilt(ix);
             commit_layout(ix, L);
             ix.ids.clear();
@@ -847,6 +916,15 @@ int cdb_query_and(const cdb_key_query* keys, int nkeys, int ranked, int64_t corr
     for (int k = 0; k < nkeys; ++k)
         if (keys[k].index && !lead) lead = keys[k].index;
     if (!lead) return CDB_E_INVALID;
+    return cdb::query_and_with_lead(lead, keys, nkeys, ranked, corr_lo, corr_hi, limit, ids, counts, nrows);
+}
+}  // extern "C"
+
+// the merge behind cdb_query_and on `lead`'s device and stream (shards.hip: every key of a sharded AND arrives as a row
+// list resolved by its shards, and the first shard of the first key lends its device)
+int cdb::query_and_with_lead(cdb_index* lead, const cdb_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi,
+                             uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
+    {
     return guarded(lead, [&] {
         Index& ix = lead->ix;
         for (int k = 0; k < nkeys; ++k) {
@@ -928,7 +1006,10 @@ int cdb_query_and(const cdb_key_query* keys, int nkeys, int ranked, int64_t corr
         *counts = hc;
         *nrows = (size_t)r.nrows;
     });
+    }
 }
+
+extern "C" {
 
 int cdb_query_spans(cdb_index* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {
     if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;

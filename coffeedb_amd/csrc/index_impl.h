@@ -155,6 +155,10 @@ struct Index {
 void ensure_host_tables(Index& ix);
 void ensure_host_staging(Index& ix);
 
+// capi.hip — pieces shared with shards.hip
+void read_raw_dir(const char* dir, const char* key, std::vector<int64_t>& ids, std::vector<uint64_t>& doc_start, std::string& text,
+                  uint64_t& nrec, uint64_t& nadd);
+
 // sa_build.hip
 void build_suffix_array(Index& ix);
 
@@ -179,6 +183,12 @@ DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t
                                 bool with_offsets = false);
 // one keyword through the single-wavefront kernel; false = not applicable, use the batched path
 bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
+// ... in two halves (several indexes queried at once, shards.hip): launch, then collect (false = handed over to the
+// batched path); Absent = a byte the text never holds, the answer is empty without a launch (query_single_empty)
+enum class SingleLaunch { NotApplicable, Absent, Launched };
+SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len);
+bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
+void query_single_empty(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
 // highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
 // ix.q_keys0, inclusive span ends -> ix.q_keys1
 struct SpanResult {
@@ -208,3 +218,8 @@ DeviceCsr and_merge_on_device(Index& ix, const std::vector<DeviceRows>& lists, b
 struct cdb_index {
     cdb::Index ix;
 };
+struct cdb_key_query;
+namespace cdb {
+int query_and_with_lead(cdb_index* lead, const cdb_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi,
+                        uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows);
+}

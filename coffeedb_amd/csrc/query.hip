@@ -1392,10 +1392,27 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
 }
 
 // true = answered (rows in freshly malloc'd *ids_out / *counts_out); false = take the batched path
-bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids_out, int64_t** counts_out, size_t* nrows) {
+namespace {
+void single_empty_rows(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows) {
+    *nrows = 0;
+    *ids_out = (int64_t*)std::malloc(8);
+    *counts_out = (int64_t*)std::malloc(8);
+    if (!*ids_out || !*counts_out) {
+        std::free(*ids_out);
+        std::free(*counts_out);
+        *ids_out = *counts_out = nullptr;
+        throw std::bad_alloc();
+    }
+    ix.qstats.nhits = ix.qstats.nrows = 0;
+}
+}  // namespace
+
+// The lone-keyword path in two halves, so that a caller holding several indexes (shards.hip: one per GPU) can have all
+// their kernels in flight before it waits for the first answer.
+SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
     if (!ix.use_single_query || ix.width == 0 || ix.size == 0 || len == 0 || len > 120 ||
         ix.ndocs >= 0xFFFFFFFFull)
-        return false;
+        return SingleLaunch::NotApplicable;
     hipStream_t s = ix.stream;
     if (!ix.h_single) {
         CDB_HIP(hipHostMalloc(&ix.h_single, sizeof(SingleOut), hipHostMallocMapped));
@@ -1415,19 +1432,7 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids
             absent |= c == 0;
             if ((int)q < kc) kwc = kwc * ix.key_base + c;
         }
-        if (absent) {  // a byte the text never holds: the keyword occurs nowhere
-            *nrows = 0;
-            *ids_out = (int64_t*)std::malloc(8);
-            *counts_out = (int64_t*)std::malloc(8);
-            if (!*ids_out || !*counts_out) {
-                std::free(*ids_out);
-                std::free(*counts_out);
-                *ids_out = *counts_out = nullptr;
-                throw std::bad_alloc();
-            }
-            ix.qstats.nhits = ix.qstats.nrows = 0;
-            return true;
-        }
+        if (absent) return SingleLaunch::Absent;  // a byte the text never holds: the keyword occurs nowhere
         for (int q = kc; q < ix.key_nsym; ++q) kpw *= ix.key_base;
         sk.keys64 = ix.d_keys.p ? ix.d_keys.as<uint64_t>() : nullptr;
         sk.keys32 = ix.d_keys32.p ? ix.d_keys32.as<uint32_t>() : nullptr;
@@ -1449,6 +1454,13 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
                            (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
     CDB_HIP(hipGetLastError());
+    return SingleLaunch::Launched;
+}
+
+// false = the kernel handed the keyword over (too many hits for it): use the batched path
+bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows) {
+    hipStream_t s = ix.stream;
+    SingleOut* out = static_cast<SingleOut*>(ix.h_single);
     // The kernel publishes its row count last (system-scope release) into host-mapped memory: the host polls that word
     // instead of paying for hipStreamSynchronize's wake-up (~10 us of the ~20 us a call used to cost).  The stream
     // keeps its order for whatever is launched next; a kernel that never answers (device error) is left to the
@@ -1484,6 +1496,16 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids
     ix.qstats.nrows = out->nrows;
     return true;
 }
+
+bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids_out, int64_t** counts_out, size_t* nrows) {
+    switch (query_single_launch(ix, kw, len)) {
+        case SingleLaunch::NotApplicable: return false;
+        case SingleLaunch::Absent: single_empty_rows(ix, ids_out, counts_out, nrows); return true;
+        default: return query_single_collect(ix, ids_out, counts_out, nrows);
+    }
+}
+
+void query_single_empty(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows) { single_empty_rows(ix, ids_out, counts_out, nrows); }
 
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, bool with_offsets) {
     DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat, with_offsets)

@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <shared_mutex>
 #include <thread>
 
 #include "../../include/coffeedb_gpu.h"
@@ -214,8 +215,7 @@ struct ColSumIn {  // rows of pattern j over all shards
 };
 __global__ __launch_bounds__(64) void sh_rank_offsets_kernel(const uint64_t* __restrict__ flat_ptr, uint64_t npat, int world,
                                                              uint64_t* __restrict__ out /*[world + 1]*/) {
-    const int q = threadIdx.x;
-    if (q <= world) out[q] = flat_ptr[(uint64_t)q * npat];
+    for (int q = threadIdx.x; q <= world; q += 64) out[q] = flat_ptr[(uint64_t)q * npat];  // (any number of ranks)
 }
 // merged row i: its pattern (search in the merged row_ptr), then the shard whose rows of that pattern cover it
 __global__ __launch_bounds__(256) void sh_place_kernel(const uint64_t* __restrict__ g_row_ptr, const uint32_t* __restrict__ all_cnt,
@@ -319,6 +319,54 @@ void merge_core(MergeRank& mr, const cdb_device_result& local, cdb_device_result
     CDB_HIP(hipStreamSynchronize(s));
     merged.d_ids = mr.out_ids.as<int64_t>();
     merged.d_counts = mr.out_cnt.as<int64_t>();
+}
+
+// Counts-only merge for host (or rank-local) consumers ("otherwise each GPU D2H's its slice"): the ranks
+// exchange nothing but their per-pattern row counts; every rank learns the merged row_ptr and where ITS rows of every
+// pattern start in the merged row stream.  No rank ever holds another rank's rows — at C4 (10^7 patterns x 8 shards)
+// the full all-gatherv would put ~10^9 rows on every GPU.
+__global__ __launch_bounds__(256) void sh_base_kernel(const uint64_t* __restrict__ g_row_ptr, const uint32_t* __restrict__ all_cnt,
+                                                      uint64_t npat, int rank, uint64_t* __restrict__ base) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= npat) return;
+    uint64_t b = g_row_ptr[j];
+    for (int q = 0; q < rank; ++q) b += all_cnt[(uint64_t)q * npat + j];
+    base[j] = b;
+}
+
+void merge_counts_core(MergeRank& mr, const cdb_device_result& local, cdb_shard_slice& out) {
+    CDB_HIP(hipSetDevice(mr.device));
+    StreamScope ss(mr.stream);
+    hipStream_t s = mr.stream;
+    const uint64_t npat = local.npat;
+    const int G = mr.world;
+    std::memset(&out, 0, sizeof(out));
+    out.npat = npat;
+    out.nrows_local = local.nrows;
+    mr.g_row_ptr.ensure((npat + 1) * 8);
+    if (npat == 0) {
+        CDB_HIP(hipMemsetAsync(mr.g_row_ptr.p, 0, 8, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        out.d_row_ptr = mr.g_row_ptr.as<uint64_t>();
+        return;
+    }
+    mr.cnt.ensure(npat * 4);
+    mr.all_cnt.ensure((size_t)G * npat * 4);
+    mr.flat_ptr.ensure(npat * 8);  // (here: this rank's row bases)
+    hipLaunchKernelGGL(sh_counts_kernel, dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, local.d_row_ptr, npat, mr.cnt.as<uint32_t>());
+    mr.tr->all_gather(mr.rank, mr.cnt.p, mr.all_cnt.p, npat * 4, s);
+    ColSumIn cin{mr.all_cnt.as<uint32_t>(), npat, G};
+    scan_totals_device<uint64_t>(s, mr.partials, cin, npat, OpAdd{}, (uint64_t)0);
+    scan_apply<uint64_t>(s, mr.partials, cin, npat, OpAdd{}, (uint64_t)0, FlatPtrOut{mr.g_row_ptr.as<uint64_t>(), npat});
+    hipLaunchKernelGGL(sh_base_kernel, dim3((unsigned)ceil_div(npat, 256)), dim3(256), 0, s, (const uint64_t*)mr.g_row_ptr.as<uint64_t>(),
+                       (const uint32_t*)mr.all_cnt.as<uint32_t>(), npat, mr.rank, mr.flat_ptr.as<uint64_t>());
+    uint64_t total = 0;
+    CDB_HIP(hipMemcpyAsync(&total, mr.g_row_ptr.as<uint64_t>() + npat, 8, hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipGetLastError());
+    CDB_HIP(hipStreamSynchronize(s));
+    out.nrows_total = total;
+    out.d_row_ptr = mr.g_row_ptr.as<uint64_t>();
+    out.d_row_base = mr.flat_ptr.as<uint64_t>();
 }
 
 template <typename T, typename F>
@@ -426,11 +474,23 @@ int cdb_comm_merge(cdb_comm* c, const cdb_device_result* local, cdb_device_resul
     return guarded_on(&c->mr, [&] { merge_core(c->mr, *local, *merged); });
 }
 
+int cdb_comm_merge_counts(cdb_comm* c, const cdb_device_result* local, cdb_shard_slice* out) {
+    if (!c || !local || !out) return CDB_E_INVALID;
+    return guarded_on(&c->mr, [&] { merge_counts_core(c->mr, *local, *out); });
+}
+
+int cdb_comm_world(const cdb_comm* c) { return c ? c->mr.world : 0; }
+const char* cdb_comm_transport(const cdb_comm* c) { return (c && c->mr.tr) ? c->mr.tr->name() : "none"; }
+
 }  // extern "C"
 
 // =====================================================================================================================
 // one process, G devices
 // =====================================================================================================================
+// Locking: `state` guards WHICH shard handles exist — builds and loads replace them under the exclusive
+// lock, every query holds it shared for the whole call, so a query never sees a destroyed handle or a half-built set.
+// Device work of one shard is serialised by that shard's own ix.mu; code that holds several of them at once (the
+// lone-keyword fan-out, the device merge) takes them in ascending shard order.
 struct cdb_shards {
     std::vector<int> devices;
     std::vector<cdb_index*> shard;                  // one handle per device slot
@@ -438,14 +498,19 @@ struct cdb_shards {
     std::shared_ptr<Transport> tr;
     int used = 0;                                   // shards holding documents after the last build
     std::vector<uint64_t> bounds;                   // docs [bounds[i], bounds[i+1]) live on shard i
-    // host staging of the whole column (cdb_shards_add*)
+    // host staging of the whole column (cdb_shards_add*): the ONE host copy — builds upload views of it (cdb_build_view)
     std::vector<int64_t> ids;
     std::vector<uint64_t> doc_start{0};
     std::string text;
+    bool staging_valid = true;               // false after cdb_shards_load until the column is fetched back from the shards
     uint64_t max_shard_bytes = 12ull << 30;  // a shard beyond this is split although fewer devices would do
     bool use_all = false;                    // always spread over every device (bench / tests)
+    bool device_merge = false;               // cdb_shards_query_batch merges on the devices (RCCL all-gatherv) instead of the host
+    bool replace_in_place = false;           // build: destroy the serving shards FIRST (a column whose old + new arrays do not
+                                             // fit together; the reference keeps both, database.cpp:276-280)
     std::vector<std::pair<std::string, int64_t>> options;
-    std::mutex mu;
+    std::shared_mutex state;
+    std::mutex staging_mu;                   // add* / build read and write the staged column
     std::mutex err_mu;
     std::string err;
 };
@@ -455,6 +520,10 @@ namespace {
 // runs f(i) for i in [0, n) on n host threads (each shard has its own device, stream and locks); rethrows the first error
 template <typename F>
 void parallel_shards(int n, F&& f) {
+    if (n == 1) {
+        f(0);
+        return;
+    }
     std::vector<std::thread> th;
     std::mutex emu;
     std::string first;
@@ -473,40 +542,123 @@ void parallel_shards(int n, F&& f) {
     if (failed) throw Error(first);
 }
 
-void check_shard(cdb_shards* h, int i, int rc) {
-    if (rc != CDB_OK) throw Error(cdb_last_error(h->shard[i]));
+void check_handle(cdb_index* p, int rc) {
+    if (rc != CDB_OK) throw Error(cdb_last_error(p));
 }
+void check_shard(cdb_shards* h, int i, int rc) { check_handle(h->shard[i], rc); }
 
-// (re)creates the merge ranks and their transport for the first `used` shards
-void setup_merge(cdb_shards* h) {
-    h->ranks.clear();
-    h->tr.reset();
-    const int G = h->used;
+// merge ranks and their transport for the first `used` handles of `shard`
+void make_merge(const std::vector<int>& devices, const std::vector<cdb_index*>& shard, int G,
+                std::vector<std::unique_ptr<MergeRank>>& ranks, std::shared_ptr<Transport>& tr_out) {
+    ranks.clear();
+    tr_out.reset();
     if (G <= 1) return;
     bool distinct = true;
     for (int i = 0; i < G; ++i)
         for (int j = 0; j < i; ++j)
-            if (h->devices[i] == h->devices[j]) distinct = false;
+            if (devices[i] == devices[j]) distinct = false;
     const char* force = std::getenv("CDB_SHARD_TRANSPORT");
     const bool want_rccl = distinct && RcclApi::get().ok() && !(force && std::string(force) == "copy");
     if (want_rccl) {
         auto tr = std::make_shared<RcclTransport>(G);
         tr->comms.assign(G, nullptr);
-        CDB_NCCL(RcclApi::get().CommInitAll(tr->comms.data(), G, h->devices.data()));
+        CDB_NCCL(RcclApi::get().CommInitAll(tr->comms.data(), G, devices.data()));
         for (int i = 0; i < G; ++i) tr->local_rank.push_back(i);
-        h->tr = tr;
+        tr_out = tr;
     } else {
-        h->tr = std::make_shared<LocalTransport>(G);
+        tr_out = std::make_shared<LocalTransport>(G);
     }
     for (int i = 0; i < G; ++i) {
         auto mr = std::make_unique<MergeRank>();
         mr->rank = i;
         mr->world = G;
-        mr->device = h->devices[i];
-        mr->stream = h->shard[i]->ix.stream;  // the shard's own stream: its query results are complete in stream order
-        mr->tr = h->tr;
-        h->ranks.push_back(std::move(mr));
+        mr->device = devices[i];
+        mr->stream = shard[i]->ix.stream;  // the shard's own stream: its query results are complete in stream order
+        mr->tr = tr_out;
+        ranks.push_back(std::move(mr));
     }
+}
+
+// fresh handles for every device slot, with the options set so far
+std::vector<cdb_index*> fresh_handles(cdb_shards* h) {
+    std::vector<cdb_index*> fresh;
+    try {
+        for (size_t i = 0; i < h->devices.size(); ++i) {
+            cdb_index* p = nullptr;
+            if (cdb_create(&p, h->devices[i]) != CDB_OK) throw Error("HIP error: cannot create a shard handle");
+            fresh.push_back(p);
+            for (auto& kv : h->options) (void)cdb_set_option(p, kv.first.c_str(), kv.second);
+        }
+    } catch (...) {
+        for (cdb_index* p : fresh) cdb_destroy(p);
+        throw;
+    }
+    return fresh;
+}
+
+// a new generation of shards takes over (exclusive lock held by the caller); the old handles are destroyed
+void install(cdb_shards* h, std::vector<cdb_index*>& fresh, int used, std::vector<uint64_t>& bounds,
+             std::vector<std::unique_ptr<MergeRank>>& ranks, std::shared_ptr<Transport>& tr) {
+    h->ranks.swap(ranks);   // (the old merge ranks borrow the old handles' streams: they go first)
+    ranks.clear();
+    h->tr.swap(tr);
+    tr.reset();
+    h->shard.swap(fresh);
+    h->used = used;
+    h->bounds.swap(bounds);
+    for (cdb_index* p : fresh) cdb_destroy(p);
+    fresh.clear();
+}
+
+// the column back on the host after cdb_shards_load (the shards hold it on their devices)
+void fetch_staging(cdb_shards* h) {
+    if (h->staging_valid) return;
+    std::vector<int64_t> ids;
+    std::vector<uint64_t> ds{0};
+    std::string text;
+    for (int i = 0; i < h->used; ++i) {
+        Index& ix = h->shard[i]->ix;
+        ensure_host_staging(ix);
+        ids.insert(ids.end(), ix.ids.begin(), ix.ids.end());
+        const uint64_t base = text.size();
+        text.append(ix.host_text);
+        for (size_t d = 1; d < ix.doc_start.size(); ++d) ds.push_back(base + ix.doc_start[d]);
+        std::string().swap(ix.host_text);  // (one host copy: the shard keeps its device copy)
+        ix.host_text_valid = false;
+    }
+    h->ids.swap(ids);
+    h->doc_start.swap(ds);
+    h->text.swap(text);
+    h->staging_valid = true;
+}
+
+// f(t, j0, j1) over [0, n) split into contiguous ranges, on up to T host threads (small n: one)
+template <typename F>
+void parallel_ranges(uint64_t n, int T, F&& f) {
+    T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)T, n >> 16));
+    if (T == 1) {
+        f(0, (uint64_t)0, n);
+        return;
+    }
+    parallel_shards(T, [&](int t) { f(t, n * t / T, n * (t + 1) / T); });
+}
+
+int out_rows(const std::vector<std::pair<int64_t, int64_t>>& rows, int64_t** ids, int64_t** counts, size_t* nrows) {
+    int64_t* oi = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
+    int64_t* oc = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
+    if (!oi || !oc) {
+        std::free(oi);
+        std::free(oc);
+        throw std::bad_alloc();
+    }
+    for (size_t r = 0; r < rows.size(); ++r) {
+        oi[r] = rows[r].first;
+        oc[r] = rows[r].second;
+    }
+    *ids = oi;
+    *counts = oc;
+    *nrows = rows.size();
+    return 0;
 }
 
 }  // namespace
@@ -552,6 +704,11 @@ const char* cdb_shards_last_error(const cdb_shards* h) {
 int cdb_shards_add(cdb_shards* h, int64_t id, const char* value, size_t len) {
     if (!h || (!value && len)) return CDB_E_INVALID;
     return guarded_on(h, [&] {
+        std::lock_guard<std::mutex> g(h->staging_mu);  // (lock order everywhere: staging_mu, then state)
+        {
+            std::shared_lock<std::shared_mutex> st(h->state);
+            fetch_staging(h);
+        }
         h->text.append(value, len);
         h->ids.push_back(id);
         h->doc_start.push_back(h->text.size());
@@ -564,6 +721,11 @@ int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, con
         if (!ndocs) return;
         for (uint64_t d = 0; d < ndocs; ++d)
             if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
+        std::lock_guard<std::mutex> g(h->staging_mu);
+        {
+            std::shared_lock<std::shared_mutex> st(h->state);
+            fetch_staging(h);
+        }
         h->ids.reserve(h->ids.size() + ndocs);
         h->doc_start.reserve(h->doc_start.size() + ndocs);
         const uint64_t base = h->text.size();
@@ -572,6 +734,24 @@ int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, con
             h->ids.push_back(ids[d]);
             h->doc_start.push_back(base + doc_start[d + 1] - doc_start[0]);
         }
+    });
+}
+
+// raw-file ingest (database.cpp:170-275) into the sharded column: cdb_add_raw_dir's reader, all or nothing
+int cdb_shards_add_raw_dir(cdb_shards* h, const char* dir, const char* key, uint64_t* records, uint64_t* added) {
+    if (!h || !dir || !key) return CDB_E_INVALID;
+    if (records) *records = 0;
+    if (added) *added = 0;
+    return guarded_on(h, [&] {
+        std::lock_guard<std::mutex> g(h->staging_mu);
+        {
+            std::shared_lock<std::shared_mutex> st(h->state);
+            fetch_staging(h);
+        }
+        uint64_t nrec = 0, nadd = 0;
+        read_raw_dir(dir, key, h->ids, h->doc_start, h->text, nrec, nadd);
+        if (records) *records = nrec;
+        if (added) *added = nadd;
     });
 }
 
@@ -585,6 +765,15 @@ int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value) {
         h->use_all = value != 0;
         return CDB_OK;
     }
+    if (!std::strcmp(name, "device_merge")) {
+        h->device_merge = value != 0;
+        return CDB_OK;
+    }
+    if (!std::strcmp(name, "replace_in_place")) {
+        h->replace_in_place = value != 0;
+        return CDB_OK;
+    }
+    std::shared_lock<std::shared_mutex> st(h->state);
     for (cdb_index* p : h->shard) {
         const int rc = cdb_set_option(p, name, value);
         if (rc != CDB_OK) {
@@ -597,32 +786,110 @@ int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value) {
     return CDB_OK;
 }
 
+// index.cpp:178-236 over several GPUs.  Transactional: a NEW generation of shard handles is built beside
+// the serving one — database.cpp:276-280 keeps the old index answering until the new one is complete — and takes over
+// under the exclusive lock only when every shard succeeded; a failure leaves the old generation untouched.  The shards
+// upload VIEWS of the one staged column (cdb_build_view): no second host copy per shard.
 int cdb_shards_build(cdb_shards* h) {
     if (!h) return CDB_E_INVALID;
     return guarded_on(h, [&] {
-        std::lock_guard<std::mutex> g(h->mu);
-        const int G = (int)h->shard.size();
+        std::lock_guard<std::mutex> sg(h->staging_mu);  // (the column must not move while the shards upload it)
+        {
+            std::shared_lock<std::shared_mutex> st(h->state);
+            fetch_staging(h);
+        }
+        const int G = (int)h->devices.size();
         const uint64_t nd = h->ids.size(), total = h->doc_start[nd];
         // shard only when the column exceeds what one GPU should hold (north star), unless told to spread anyway
         int used = h->use_all ? G : (int)std::min<uint64_t>((uint64_t)G, std::max<uint64_t>(1, ceil_div(total, h->max_shard_bytes)));
         used = std::max(1, std::min<int>(used, (int)std::max<uint64_t>(nd, 1)));
-        const std::vector<uint64_t> b = shard_bounds(h->doc_start, used);
-        // fresh handles for the shards (a rebuild replaces the whole column, as database.cpp does with new objects)
-        for (int i = 0; i < G; ++i) {
-            cdb_index* fresh = nullptr;
-            if (cdb_create(&fresh, h->devices[i]) != CDB_OK) throw Error("HIP error: cannot create a shard handle");
-            for (auto& kv : h->options) (void)cdb_set_option(fresh, kv.first.c_str(), kv.second);
-            cdb_destroy(h->shard[i]);
-            h->shard[i] = fresh;
+        std::vector<uint64_t> b = shard_bounds(h->doc_start, used);
+        if (h->replace_in_place) {  // the caller accepts an unbuilt window: the old arrays go first
+            std::unique_lock<std::shared_mutex> st(h->state);
+            std::vector<cdb_index*> empty = fresh_handles(h);
+            std::vector<uint64_t> nb{0};
+            std::vector<std::unique_ptr<MergeRank>> nr;
+            std::shared_ptr<Transport> nt;
+            install(h, empty, 0, nb, nr, nt);
         }
-        parallel_shards(used, [&](int i) {
-            const uint64_t d0 = b[i], d1 = b[i + 1];
-            check_shard(h, i, cdb_add_bulk(h->shard[i], h->ids.data() + d0, h->text.data(), h->doc_start.data() + d0, d1 - d0));
-            check_shard(h, i, cdb_build(h->shard[i]));
-        });
-        h->used = used;
-        h->bounds = b;
-        setup_merge(h);
+        std::vector<cdb_index*> fresh = fresh_handles(h);
+        std::vector<std::unique_ptr<MergeRank>> ranks;
+        std::shared_ptr<Transport> tr;
+        try {
+            parallel_shards(used, [&](int i) {
+                const uint64_t d0 = b[i], d1 = b[i + 1];
+                check_handle(fresh[i], cdb_build_view(fresh[i], h->ids.data() + d0, h->text.data(), h->doc_start.data() + d0, d1 - d0));
+            });
+            make_merge(h->devices, fresh, used, ranks, tr);
+        } catch (...) {
+            ranks.clear();
+            tr.reset();
+            for (cdb_index* p : fresh) cdb_destroy(p);
+            throw;
+        }
+        std::unique_lock<std::shared_mutex> st(h->state);
+        install(h, fresh, used, b, ranks, tr);
+    });
+}
+
+// f4 over shards: `path` holds the shard count and document bounds, `path.<i>` shard i's own file (cdb_save)
+namespace {
+constexpr uint64_t SHARDS_MAGIC = 0x3130485344424443ull;  // "CDBDSH01"
+}
+int cdb_shards_save(cdb_shards* h, const char* path) {
+    if (!h || !path) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        std::shared_lock<std::shared_mutex> st(h->state);
+        if (h->used < 1) throw Error("index has not been built");
+        for (int i = 0; i < h->used; ++i) check_shard(h, i, cdb_save(h->shard[i], (std::string(path) + "." + std::to_string(i)).c_str()));
+        FILE* fp = std::fopen(path, "wb");
+        if (!fp) throw Error(std::string("Cannot open file: ") + path);
+        struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+        const uint64_t hd[2] = {SHARDS_MAGIC, (uint64_t)h->used};
+        bool ok = std::fwrite(hd, 8, 2, fp) == 2;
+        ok = ok && std::fwrite(h->bounds.data(), 8, (size_t)h->used + 1, fp) == (size_t)h->used + 1;
+        if (!ok) throw Error(std::string("Cannot write file: ") + path);
+    });
+}
+
+int cdb_shards_load(cdb_shards* h, const char* path) {
+    if (!h || !path) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        std::lock_guard<std::mutex> sg(h->staging_mu);
+        uint64_t hd[2] = {0, 0};
+        std::vector<uint64_t> b;
+        {
+            FILE* fp = std::fopen(path, "rb");
+            if (!fp) throw Error(std::string("Cannot open file: ") + path);
+            struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fp};
+            if (std::fread(hd, 8, 2, fp) != 2 || hd[0] != SHARDS_MAGIC || hd[1] < 1 || hd[1] > 4096)
+                throw Error(std::string("Not a saved sharded index: ") + path);
+            b.resize(hd[1] + 1);
+            if (std::fread(b.data(), 8, b.size(), fp) != b.size()) throw Error(std::string("Truncated index file: ") + path);
+        }
+        const int used = (int)hd[1];
+        if (used > (int)h->devices.size()) throw Error("saved index has more shards than this handle has devices");
+        std::vector<cdb_index*> fresh = fresh_handles(h);
+        std::vector<std::unique_ptr<MergeRank>> ranks;
+        std::shared_ptr<Transport> tr;
+        try {
+            parallel_shards(used, [&](int i) {
+                check_handle(fresh[i], cdb_load(fresh[i], (std::string(path) + "." + std::to_string(i)).c_str()));
+                if (fresh[i]->ix.ndocs != b[i + 1] - b[i]) throw Error(std::string("Corrupt index file (shard bounds): ") + path);
+            });
+            make_merge(h->devices, fresh, used, ranks, tr);
+        } catch (...) {
+            ranks.clear();
+            tr.reset();
+            for (cdb_index* p : fresh) cdb_destroy(p);
+            throw;
+        }
+        std::unique_lock<std::shared_mutex> st(h->state);
+        install(h, fresh, used, b, ranks, tr);
+        h->ids.clear();
+        h->doc_start.assign(1, 0);
+        std::string().swap(h->text);
+        h->staging_valid = false;  // the column lives on the devices (fetched back by the next add / build)
     });
 }
 
@@ -633,41 +900,85 @@ uint64_t cdb_shards_first_doc(const cdb_shards* h, int i) {
 }
 const char* cdb_shards_transport(const cdb_shards* h) { return (h && h->tr) ? h->tr->name() : "none"; }
 
+// One keyword (database.cpp:392): every shard's lone-keyword kernel is in flight before the first answer is awaited
+// (one launch + one poll per shard instead of G complete round trips); shards in order = ascending document index.
 int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows) {
     if (!h || !ids || !counts || !nrows) return CDB_E_INVALID;
     *ids = nullptr;
     *counts = nullptr;
     *nrows = 0;
     return guarded_on(h, [&] {
-        // shards in order = ascending document index; one keyword: the lone-keyword kernel of every shard, concatenated
-        std::vector<int64_t> ri, rc;
-        for (int i = 0; i < std::max(h->used, 1); ++i) {
-            int64_t *pi = nullptr, *pc = nullptr;
+        if (len == 0) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
+        std::shared_lock<std::shared_mutex> st(h->state);
+        const int G = std::max(h->used, 1);
+        struct Part {
+            int64_t *ids = nullptr, *counts = nullptr;
             size_t n = 0;
-            check_shard(h, i, cdb_query(h->shard[i], keyword, len, &pi, &pc, &n));
-            ri.insert(ri.end(), pi, pi + n);
-            rc.insert(rc.end(), pc, pc + n);
-            cdb_free(pi);
-            cdb_free(pc);
+            SingleLaunch state = SingleLaunch::NotApplicable;
+        };
+        std::vector<Part> part(G);
+        struct Cleanup {
+            std::vector<Part>& p;
+            ~Cleanup() { for (auto& x : p) { cdb_free(x.ids); cdb_free(x.counts); } }
+        } cleanup{part};
+        {
+            std::vector<std::unique_lock<std::mutex>> locks;  // ascending shard order
+            for (int i = 0; i < G; ++i) {
+                Index& ix = h->shard[i]->ix;
+                locks.emplace_back(ix.mu);
+                CDB_HIP(hipSetDevice(ix.device));
+                StreamScope ss(ix.stream);
+                part[i].state = query_single_launch(ix, keyword, len);
+            }
+            for (int i = 0; i < G; ++i) {
+                Index& ix = h->shard[i]->ix;
+                if (part[i].state == SingleLaunch::Absent) query_single_empty(ix, &part[i].ids, &part[i].counts, &part[i].n);
+                else if (part[i].state == SingleLaunch::Launched) {
+                    CDB_HIP(hipSetDevice(ix.device));
+                    StreamScope ss(ix.stream);
+                    if (!query_single_collect(ix, &part[i].ids, &part[i].counts, &part[i].n)) part[i].state = SingleLaunch::NotApplicable;
+                }
+            }
         }
-        int64_t* oi = (int64_t*)std::malloc(std::max<size_t>(ri.size(), 1) * 8);
-        int64_t* oc = (int64_t*)std::malloc(std::max<size_t>(ri.size(), 1) * 8);
-        if (!oi || !oc) {
-            std::free(oi);
-            std::free(oc);
-            throw std::bad_alloc();
+        std::vector<std::pair<int64_t, int64_t>> rows;
+        for (int i = 0; i < G; ++i) {
+            if (part[i].state == SingleLaunch::NotApplicable)  // long hit lists, options: the shard's ordinary path
+                check_shard(h, i, cdb_query(h->shard[i], keyword, len, &part[i].ids, &part[i].counts, &part[i].n));
+            for (size_t r = 0; r < part[i].n; ++r) rows.emplace_back(part[i].ids[r], part[i].counts[r]);
         }
-        std::memcpy(oi, ri.data(), ri.size() * 8);
-        std::memcpy(oc, rc.data(), rc.size() * 8);
-        *ids = oi;
-        *counts = oc;
-        *nrows = ri.size();
+        out_rows(rows, ids, counts, nrows);
     });
 }
 
 // The per-key operations work shard by shard: documents — hence object ids — are disjoint across shards, so the union over
-// shards is a concatenation, ordered afterwards the way the single-GPU call orders it.
+// shards is a concatenation, ordered afterwards the way the single-GPU call orders it.  The shards work concurrently.
 namespace {
+void shards_or_rows(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, bool ranked, int64_t lo, int64_t hi,
+                    uint64_t limit, std::vector<std::pair<int64_t, int64_t>>& rows) {
+    std::shared_lock<std::shared_mutex> st(h->state);
+    const int G = std::max(h->used, 1);
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> part(G);
+    parallel_shards(G, [&](int i) {
+        int64_t *pi = nullptr, *pc = nullptr;
+        size_t n = 0;
+        // (every shard's own top `limit` rows contain its share of the global top `limit`)
+        check_shard(h, i, ranked ? cdb_query_ranked(h->shard[i], blob, offsets, nkw, lo, hi, limit, &pi, &pc, &n)
+                                 : cdb_query_or(h->shard[i], blob, offsets, nkw, &pi, &pc, &n));
+        part[i].reserve(n);
+        for (size_t r = 0; r < n; ++r) part[i].emplace_back(pi[r], pc[r]);
+        cdb_free(pi);
+        cdb_free(pc);
+    });
+    for (int i = 0; i < G; ++i) rows.insert(rows.end(), part[i].begin(), part[i].end());
+    if (h->used > 1) {
+        if (ranked) {
+            std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
+            if (limit && rows.size() > limit) rows.resize(limit);
+        } else {
+            std::sort(rows.begin(), rows.end());
+        }
+    }
+}
 int shards_or_impl(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, bool ranked, int64_t lo, int64_t hi,
                    uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows) {
     if (!h || !ids || !counts || !nrows || (nkw && !offsets)) return CDB_E_INVALID;
@@ -676,38 +987,8 @@ int shards_or_impl(cdb_shards* h, const char* blob, const uint64_t* offsets, uin
     *nrows = 0;
     return guarded_on(h, [&] {
         std::vector<std::pair<int64_t, int64_t>> rows;
-        for (int i = 0; i < std::max(h->used, 1); ++i) {
-            int64_t *pi = nullptr, *pc = nullptr;
-            size_t n = 0;
-            // (every shard's own top `limit` rows contain its share of the global top `limit`)
-            check_shard(h, i, ranked ? cdb_query_ranked(h->shard[i], blob, offsets, nkw, lo, hi, limit, &pi, &pc, &n)
-                                     : cdb_query_or(h->shard[i], blob, offsets, nkw, &pi, &pc, &n));
-            for (size_t r = 0; r < n; ++r) rows.emplace_back(pi[r], pc[r]);
-            cdb_free(pi);
-            cdb_free(pc);
-        }
-        if (h->used > 1) {
-            if (ranked) {
-                std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.second != b.second ? a.second > b.second : a.first < b.first; });
-                if (limit && rows.size() > limit) rows.resize(limit);
-            } else {
-                std::sort(rows.begin(), rows.end());
-            }
-        }
-        int64_t* oi = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
-        int64_t* oc = (int64_t*)std::malloc(std::max<size_t>(rows.size(), 1) * 8);
-        if (!oi || !oc) {
-            std::free(oi);
-            std::free(oc);
-            throw std::bad_alloc();
-        }
-        for (size_t r = 0; r < rows.size(); ++r) {
-            oi[r] = rows[r].first;
-            oc[r] = rows[r].second;
-        }
-        *ids = oi;
-        *counts = oc;
-        *nrows = rows.size();
+        shards_or_rows(h, blob, offsets, nkw, ranked, lo, hi, limit, rows);
+        out_rows(rows, ids, counts, nrows);
     });
 }
 }  // namespace
@@ -722,21 +1003,71 @@ int cdb_shards_query_ranked(cdb_shards* h, const char* blob, const uint64_t* off
     return shards_or_impl(h, blob, offsets, nkw, true, corr_lo, corr_hi, limit, ids, counts, nrows);
 }
 
+// AND across keys (interface.cpp:114-146) when string keys are sharded columns.  Different columns are cut at different
+// documents (the cut balances bytes), so the intersection cannot be taken shard by shard: every sharded key is resolved
+// with its OR over its own shards (rows ascending by id), then all row lists meet in ONE device merge — the same
+// and_merge_on_device as cdb_query_and — on the first shard of the first sharded key.
+int cdb_shards_query_and(const cdb_shards_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi, uint64_t limit,
+                         int64_t** ids, int64_t** counts, size_t* nrows) {
+    if (!keys || nkeys < 1 || !ids || !counts || !nrows) return CDB_E_INVALID;
+    *ids = nullptr;
+    *counts = nullptr;
+    *nrows = 0;
+    cdb_shards* lead = nullptr;
+    for (int k = 0; k < nkeys; ++k)
+        if (keys[k].shards && !lead) lead = keys[k].shards;
+    if (!lead) return CDB_E_INVALID;
+    return guarded_on(lead, [&] {
+        std::vector<std::vector<int64_t>> hi(nkeys), hc(nkeys);
+        std::vector<cdb_key_query> flat(nkeys);
+        for (int k = 0; k < nkeys; ++k) {
+            const cdb_shards_key_query& q = keys[k];
+            std::memset(&flat[k], 0, sizeof(cdb_key_query));
+            if (q.shards) {
+                if (q.nkw == 0) throw Error("The constraint list cannot be empty");  // interface.cpp:75-77
+                if (!q.offsets) throw Error("cdb_shards_query_and: keyword offsets missing");
+                for (uint64_t j = 0; j < q.nkw; ++j)
+                    if (q.offsets[j + 1] <= q.offsets[j]) throw Error("Empty keywords are not allowed");
+                std::vector<std::pair<int64_t, int64_t>> rows;
+                shards_or_rows(q.shards, q.blob, q.offsets, q.nkw, false, 0, 0, 0, rows);
+                hi[k].reserve(rows.size());
+                hc[k].reserve(rows.size());
+                for (auto& r : rows) {
+                    hi[k].push_back(r.first);
+                    hc[k].push_back(r.second);
+                }
+                flat[k].ids = hi[k].data();
+                flat[k].counts = hc[k].data();
+                flat[k].nrows = hi[k].size();
+            } else {
+                if (q.nrows && (!q.ids || !q.counts)) throw Error("cdb_shards_query_and: row list missing");
+                flat[k].ids = q.ids;
+                flat[k].counts = q.counts;
+                flat[k].nrows = q.nrows;
+            }
+        }
+        std::shared_lock<std::shared_mutex> st(lead->state);
+        cdb_index* dev = lead->shard[0];
+        check_handle(dev, query_and_with_lead(dev, flat.data(), nkeys, ranked, corr_lo, corr_hi, limit, ids, counts, nrows));
+    });
+}
+
 int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out) {
     if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     const int rc = guarded_on(h, [&] {
+        std::shared_lock<std::shared_mutex> st(h->state);
         std::vector<cdb_spans> parts(std::max(h->used, 1));
+        for (auto& x : parts) std::memset(&x, 0, sizeof(cdb_spans));
         struct Cleanup {
             std::vector<cdb_spans>& p;
             ~Cleanup() { for (auto& x : p) cdb_spans_free(&x); }
         } cleanup{parts};
+        parallel_shards((int)parts.size(), [&](int i) { check_shard(h, i, cdb_query_spans(h->shard[i], blob, offsets, nkw, &parts[i])); });
         uint64_t nd = 0, ns = 0;
-        for (size_t i = 0; i < parts.size(); ++i) {  // shard order = ascending document index
-            std::memset(&parts[i], 0, sizeof(cdb_spans));
-            check_shard(h, (int)i, cdb_query_spans(h->shard[i], blob, offsets, nkw, &parts[i]));
-            nd += parts[i].ndocs;
-            ns += parts[i].nspans;
+        for (const cdb_spans& p : parts) {  // shard order = ascending document index
+            nd += p.ndocs;
+            ns += p.nspans;
         }
         out->ndocs = nd;
         out->nspans = ns;
@@ -763,64 +1094,152 @@ int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offs
     return rc;
 }
 
-int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+namespace {
+// Host merge of the shards' CSR answers (the consumer of the C ABI is the host: SURVEY §8e — every GPU hands over its own
+// slice, nothing is replicated on the devices).  Every shard answers the whole batch through its own host entry point
+// (patterns up and rows down over its own PCIe link, concurrently); the rows of a pattern are then the shards' rows in
+// shard order.  The interleave runs over pattern ranges on several host threads.
+void shards_batch_host(cdb_shards* h, int G, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out, cdb_hits* hits) {
+    std::vector<cdb_result> part(G);
+    std::vector<cdb_hits> hpart(G);
+    for (int i = 0; i < G; ++i) {
+        std::memset(&part[i], 0, sizeof(cdb_result));
+        std::memset(&hpart[i], 0, sizeof(cdb_hits));
+    }
+    struct Cleanup {
+        std::vector<cdb_result>& p;
+        std::vector<cdb_hits>& q;
+        ~Cleanup() {
+            for (auto& x : p) cdb_result_free(&x);
+            for (auto& x : q) cdb_hits_free(&x);
+        }
+    } cleanup{part, hpart};
+    parallel_shards(G, [&](int i) {
+        check_shard(h, i, hits ? cdb_query_batch_offsets(h->shard[i], blob, offsets, npat, &part[i], &hpart[i])
+                               : cdb_query_batch(h->shard[i], blob, offsets, npat, &part[i]));
+    });
+    uint64_t nrows = 0, nhits = 0;
+    for (int i = 0; i < G; ++i) {
+        nrows += part[i].nrows;
+        nhits += part[i].nhits;
+    }
+    out->npat = npat;
+    out->nrows = nrows;
+    out->nhits = nhits;
+    out->row_ptr = (uint64_t*)host_alloc((npat + 1) * 8);
+    out->ids = (int64_t*)host_alloc(nrows * 8);
+    out->counts = (int64_t*)host_alloc(nrows * 8);
+    if (hits) {
+        hits->hit_ptr = (uint64_t*)host_alloc((nrows + 1) * 8);
+        hits->offsets = (uint64_t*)host_alloc(nhits * 8);
+    }
+    // first row (and first hit) of every pattern range = the rows (hits) the shards hold in front of it
+    const int T = std::max(G, 4);
+    parallel_ranges(npat, T, [&](int, uint64_t j0, uint64_t j1) {
+        uint64_t row = 0, hit = 0;
+        for (int i = 0; i < G; ++i) {
+            row += part[i].row_ptr[j0];
+            if (hits) hit += hpart[i].hit_ptr[part[i].row_ptr[j0]];
+        }
+        for (uint64_t j = j0; j < j1; ++j) {
+            out->row_ptr[j] = row;
+            for (int i = 0; i < G; ++i) {
+                const uint64_t a = part[i].row_ptr[j], b = part[i].row_ptr[j + 1];
+                if (a == b) continue;
+                std::memcpy(out->ids + row, part[i].ids + a, (b - a) * 8);
+                std::memcpy(out->counts + row, part[i].counts + a, (b - a) * 8);
+                if (hits) {
+                    const uint64_t ha = hpart[i].hit_ptr[a], hb = hpart[i].hit_ptr[b];
+                    for (uint64_t r = a; r < b; ++r) hits->hit_ptr[row + (r - a)] = hit + (hpart[i].hit_ptr[r] - ha);
+                    std::memcpy(hits->offsets + hit, hpart[i].offsets + ha, (hb - ha) * 8);
+                    hit += hb - ha;
+                }
+                row += b - a;
+            }
+        }
+    });
+    out->row_ptr[npat] = nrows;
+    if (hits) hits->hit_ptr[nrows] = nhits;
+}
+
+// ... or merged on the devices (option device_merge: the RCCL all-gatherv path, for consumers that keep the rows in HBM;
+// every shard ends up holding the merged CSR, shard 0 hands it to the host)
+void shards_batch_device(cdb_shards* h, int G, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+    const uint64_t base = npat ? offsets[0] : 0, nbytes = npat ? offsets[npat] - base : 0;
+    std::vector<uint64_t> rel(npat + 1);
+    for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
+    std::vector<cdb_device_result> local(G), merged(G);
+    // every shard stays locked from its query to the end of the merge (the merge reads the shard's result
+    // buffers, which a concurrent query on that shard would overwrite); ascending shard order
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (int i = 0; i < G; ++i) locks.emplace_back(h->shard[i]->ix.mu);
+    parallel_shards(G, [&](int i) {
+        Index& ix = h->shard[i]->ix;
+        CDB_HIP(hipSetDevice(ix.device));
+        StreamScope ss(ix.stream);
+        hipStream_t s = ix.stream;
+        ix.q_pat.ensure(nbytes + 16);
+        ix.q_offs.ensure((npat + 1) * 8);
+        if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
+        CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
+        const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
+        local[i] = cdb_device_result{npat, r.nrows, r.nhits, ix.q_rowptr.as<uint64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>()};
+    });
+    uint64_t hits = 0;
+    for (int i = 0; i < G; ++i) hits += local[i].nhits;
+    // the collective merge is a phase of its own: a shard that failed above never leaves the others waiting
+    parallel_shards(G, [&](int i) { merge_core(*h->ranks[i], local[i], merged[i]); });
+    Index& ix0 = h->shard[0]->ix;
+    CDB_HIP(hipSetDevice(ix0.device));
+    hipStream_t s = ix0.stream;
+    const cdb_device_result& m = merged[0];
+    out->npat = npat;
+    out->nrows = m.nrows;
+    out->nhits = hits;
+    out->row_ptr = (uint64_t*)host_alloc((npat + 1) * 8);
+    out->ids = (int64_t*)host_alloc(m.nrows * 8);
+    out->counts = (int64_t*)host_alloc(m.nrows * 8);
+    CDB_HIP(hipMemcpyAsync(out->row_ptr, m.d_row_ptr, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (m.nrows) {
+        CDB_HIP(hipMemcpyAsync(out->ids, m.d_ids, m.nrows * 8, hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipMemcpyAsync(out->counts, m.d_counts, m.nrows * 8, hipMemcpyDeviceToHost, s));
+    }
+    CDB_HIP(hipStreamSynchronize(s));
+}
+
+int shards_batch_impl(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out, cdb_hits* hits) {
     if (!h || !out || (npat && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
+    if (hits) std::memset(hits, 0, sizeof(*hits));
     const int rc = guarded_on(h, [&] {
         for (uint64_t j = 0; j < npat; ++j)
             if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
-        std::lock_guard<std::mutex> g(h->mu);
+        std::shared_lock<std::shared_mutex> st(h->state);
         const int G = std::max(h->used, 1);
         if (G == 1) {
-            check_shard(h, 0, cdb_query_batch(h->shard[0], blob, offsets, npat, out));
+            check_shard(h, 0, hits ? cdb_query_batch_offsets(h->shard[0], blob, offsets, npat, out, hits)
+                                   : cdb_query_batch(h->shard[0], blob, offsets, npat, out));
             return;
         }
-        const uint64_t base = npat ? offsets[0] : 0, nbytes = npat ? offsets[npat] - base : 0;
-        std::vector<uint64_t> rel(npat + 1);
-        for (uint64_t j = 0; j <= npat; ++j) rel[j] = npat ? offsets[j] - base : 0;
-        std::vector<cdb_device_result> local(G), merged(G);
-        uint64_t hits = 0;
-        // every shard: patterns up (the host broadcasts over each GPU's own PCIe link) and the batched query ...
-        parallel_shards(G, [&](int i) {
-            Index& ix = h->shard[i]->ix;
-            std::lock_guard<std::mutex> lk(ix.mu);
-            if (std::getenv("CDB_DEBUG_SHARDS")) std::fprintf(stderr, "[shards] query: shard %d of %d handle %p device %d\n", i, G, (void*)h->shard[i], ix.device);
-            CDB_HIP(hipSetDevice(ix.device));
-            StreamScope ss(ix.stream);
-            hipStream_t s = ix.stream;
-            ix.q_pat.ensure(nbytes + 16);
-            ix.q_offs.ensure((npat + 1) * 8);
-            if (nbytes) CDB_HIP(hipMemcpyAsync(ix.q_pat.p, blob + base, nbytes, hipMemcpyHostToDevice, s));
-            CDB_HIP(hipMemcpyAsync(ix.q_offs.p, rel.data(), (npat + 1) * 8, hipMemcpyHostToDevice, s));
-            const DeviceCsr r = query_batch_on_device(ix, ix.q_pat.as<uint8_t>(), ix.q_offs.as<uint64_t>(), npat);
-            local[i] = cdb_device_result{npat, r.nrows, r.nhits, ix.q_rowptr.as<uint64_t>(), ix.q_ids.as<int64_t>(), ix.q_counts.as<int64_t>()};
-        });
-        for (int i = 0; i < G; ++i) hits += local[i].nhits;
-        // ... then the collective merge (a phase of its own: a shard that failed above never leaves the others waiting)
-        parallel_shards(G, [&](int i) {
-            std::lock_guard<std::mutex> lk(h->shard[i]->ix.mu);
-            merge_core(*h->ranks[i], local[i], merged[i]);
-        });
-        // the merged CSR is identical on every shard's device: rank 0 hands it to the host
-        Index& ix0 = h->shard[0]->ix;
-        CDB_HIP(hipSetDevice(ix0.device));
-        hipStream_t s = ix0.stream;
-        const cdb_device_result& m = merged[0];
-        out->npat = npat;
-        out->nrows = m.nrows;
-        out->nhits = hits;
-        out->row_ptr = (uint64_t*)host_alloc((npat + 1) * 8);
-        out->ids = (int64_t*)host_alloc(m.nrows * 8);
-        out->counts = (int64_t*)host_alloc(m.nrows * 8);
-        CDB_HIP(hipMemcpyAsync(out->row_ptr, m.d_row_ptr, (npat + 1) * 8, hipMemcpyDeviceToHost, s));
-        if (m.nrows) {
-            CDB_HIP(hipMemcpyAsync(out->ids, m.d_ids, m.nrows * 8, hipMemcpyDeviceToHost, s));
-            CDB_HIP(hipMemcpyAsync(out->counts, m.d_counts, m.nrows * 8, hipMemcpyDeviceToHost, s));
-        }
-        CDB_HIP(hipStreamSynchronize(s));
+        if (h->device_merge && !hits) shards_batch_device(h, G, blob, offsets, npat, out);
+        else shards_batch_host(h, G, blob, offsets, npat, out, hits);
     });
-    if (rc != CDB_OK) cdb_result_free(out);
+    if (rc != CDB_OK) {
+        cdb_result_free(out);
+        if (hits) cdb_hits_free(hits);
+    }
     return rc;
+}
+}  // namespace
+
+int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out) {
+    return shards_batch_impl(h, blob, offsets, npat, out, nullptr);
+}
+
+int cdb_shards_query_batch_offsets(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
+                                   cdb_hits* hits) {
+    if (!hits) return CDB_E_INVALID;
+    return shards_batch_impl(h, blob, offsets, npat, out, hits);
 }
 
 }  // extern "C"

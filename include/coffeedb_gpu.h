@@ -98,6 +98,13 @@ int cdb_load(cdb_index* h, const char* path);
  * suffix array on the GPU.  Errors reuse the reference's messages (index.cpp:196,199). */
 int cdb_build(cdb_index* h);
 
+/* Build straight from the caller's host column, without the staging copy cdb_add_bulk makes — string_index itself
+ * holds non-owning string_views into the caller's strings (src/index.h:58, database.cpp:262-264).  ids[ndocs],
+ * doc_start[ndocs + 1] (offsets into blob, non-decreasing; blob[doc_start[0] .. doc_start[ndocs]) is the column).
+ * Replaces whatever cdb_add* staged.  The text travels through a chunked pinned upload (~50 GB/s); afterwards the
+ * handle holds device copies only (a later cdb_add fetches the column back first). */
+int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
+
 /* Same build, but over text that already resides in device memory (HBM-resident timing in bench.py,
  * multi-GPU shards).  d_text must stay valid for the lifetime of the index (the reference's
  * string_view contract, database.cpp:262-264); doc_start/ids are host arrays and are copied. */
@@ -241,6 +248,30 @@ int cdb_shards_query_or(cdb_shards* h, const char* blob, const uint64_t* offsets
 int cdb_shards_query_ranked(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, int64_t corr_lo, int64_t corr_hi,
                             uint64_t limit, int64_t** ids, int64_t** counts, size_t* nrows);
 int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, cdb_spans* out);
+/* cdb_query_batch_offsets over all shards (occurrence offsets are relative to their document, so they need no re-basing) */
+int cdb_shards_query_batch_offsets(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out,
+                                   cdb_hits* hits);
+/* AND across keys (interface.cpp:114-146) with sharded string keys: a key is a sharded column + its keyword list, or a
+ * row list resolved elsewhere (shards = NULL), exactly like cdb_key_query.  Different columns are cut at different
+ * documents, so every sharded key is first resolved with its own OR over its shards; the row lists then meet in one device
+ * merge (on the first shard of the first sharded key).  Same result rules as cdb_query_and. */
+typedef struct cdb_shards_key_query {
+    cdb_shards* shards;      /* sharded string key, or NULL */
+    const char* blob;
+    const uint64_t* offsets;
+    uint64_t nkw;
+    const int64_t* ids;      /* shards == NULL: host rows */
+    const int64_t* counts;
+    size_t nrows;
+} cdb_shards_key_query;
+int cdb_shards_query_and(const cdb_shards_key_query* keys, int nkeys, int ranked, int64_t corr_lo, int64_t corr_hi, uint64_t limit,
+                         int64_t** ids, int64_t** counts, size_t* nrows);
+/* raw-file ingest into the sharded column (cdb_add_raw_dir, database.cpp:170-275) and persistence (cdb_save / cdb_load per
+ * shard: `path` holds the shard count and document bounds, `path.<i>` shard i's file).  Loading replaces the column;
+ * a failed load leaves the serving shards untouched. */
+int cdb_shards_add_raw_dir(cdb_shards* h, const char* dir, const char* key, uint64_t* records, uint64_t* added);
+int cdb_shards_save(cdb_shards* h, const char* path);
+int cdb_shards_load(cdb_shards* h, const char* path);
 /* introspection: shards in use after build, the handle of shard i (per-shard parity: its suffix array is that of its
  * documents alone), its first document, and how the shards exchange ("rccl" / "device copies" / "none") */
 int cdb_shards_count(const cdb_shards* h);
@@ -258,6 +289,19 @@ int cdb_comm_create(cdb_comm** out, const void* id128, int rank, int world, int 
 void cdb_comm_destroy(cdb_comm* c);
 const char* cdb_comm_last_error(const cdb_comm* c);
 int cdb_comm_merge(cdb_comm* c, const cdb_device_result* local, cdb_device_result* merged);
+/* Counts-only merge for consumers that keep (or download) their own slice — SURVEY §8e: when the consumer is not on the
+ * GPU "each GPU D2H's its slice".  Collective; exchanges nothing but the per-pattern row counts (npat x u32 per rank).
+ * Every rank learns the merged row_ptr and, per pattern, where ITS rows start in the merged row stream:
+ * merged rows [d_row_base[j], d_row_base[j] + local count of j) are this rank's rows of pattern j, in order.  No rank holds
+ * another rank's rows (the full all-gatherv of C4 — 10^7 patterns x 8 shards — would put ~10^9 rows on every GPU). */
+typedef struct cdb_shard_slice {
+    uint64_t npat, nrows_total, nrows_local;
+    const uint64_t* d_row_ptr;   /* npat + 1, merged, identical on every rank; device memory owned by the communicator */
+    const uint64_t* d_row_base;  /* npat, this rank's first merged row of every pattern */
+} cdb_shard_slice;
+int cdb_comm_merge_counts(cdb_comm* c, const cdb_device_result* local, cdb_shard_slice* out);
+int cdb_comm_world(const cdb_comm* c);
+const char* cdb_comm_transport(const cdb_comm* c);
 
 /* ---- introspection (parity tests; mirrors the private members src/index.h:56-60) -------------- */
 uint64_t cdb_size(const cdb_index* h);  /* number of suffixes = text bytes */
