@@ -49,7 +49,35 @@ WORKLOADS = {
     "c3shard": dict(kind="ascii", docs=1 << 23, doclen=1024, npat=100_000, mmin=4, mmax=16),
     # configs[4] per GPU: 16 GiB UTF-8 (8 of these = 128 GiB), 10 M patterns, $correlation ranking
     "c4shard": dict(kind="utf8", bytes=16 << 30, npat=10_000_000, mmin=4, mmax=16, ranked=True),
+    # configs[3] / configs[4] as BASELINE.json words them — a FIXED corpus split across the ranks (--scaling strong):
+    # 32 GiB ASCII over 4 GPUs, 128 GiB UTF-8 over 8 GPUs with 10 M patterns and $correlation ranking
+    "c3": dict(kind="ascii", docs=1 << 25, doclen=1024, npat=100_000, mmin=4, mmax=16, total=True),
+    "c4": dict(kind="utf8", bytes=128 << 30, npat=10_000_000, mmin=4, mmax=16, ranked=True, total=True),
 }
+MAX_SHARD_BYTES = 16 << 30  # the largest corpus one MI355X builds (8-byte entries: 128 GiB of suffix array + scratch)
+
+
+def per_rank_cfg(cfg, world, scaling):
+    """This rank's share.  weak: the workload as written, per GPU.  strong: a fixed total cut into `world` doc-aligned
+    shards; a share that does not fit one GPU is clamped (and says so: the run is then not the whole corpus)."""
+    if scaling != "strong":
+        return dict(cfg), None
+    c = dict(cfg)
+    note = None
+    if c["kind"] == "utf8":
+        share = c["bytes"] // world
+        if share > MAX_SHARD_BYTES:
+            note = f"clamped: {share / 2**30:.0f} GiB per GPU does not fit, {MAX_SHARD_BYTES / 2**30:.0f} GiB built"
+            share = MAX_SHARD_BYTES
+        c["bytes"] = share
+    else:
+        docs = c["docs"] // world
+        if docs * c["doclen"] > MAX_SHARD_BYTES:
+            note = f"clamped: {docs * c['doclen'] / 2**30:.0f} GiB per GPU does not fit, {MAX_SHARD_BYTES / 2**30:.0f} GiB built"
+            docs = MAX_SHARD_BYTES // c["doclen"]
+        c["docs"] = docs
+    return c, note
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -141,12 +169,13 @@ def query_roofline(torch, r, npat, n, width, query_s, device):
                                        "latency-bound (dependent probes), so this is reported, not priced against HBM peak"}
 
 
-def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None):
+def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None, merge_mode="counts",
+               dist=None, world=1):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
-    if make_merger is not None and cfg["npat"] > 1_000_000:
-        # N > 1: every rank ends up holding the merged rows of ALL shards; 10^7 patterns x N shards would be ~10^9 rows
-        # per rank — the batch is cut to 10^6 patterns for the sharded run (the single-GPU block runs the full 10^7)
+    if make_merger is not None and merge_mode == "full" and cfg["npat"] > 1_000_000:
+        # full all-gatherv merge: every rank ends up holding the merged rows of ALL shards; 10^7 patterns x N shards would
+        # be ~10^9 rows per rank — the batch is cut to 10^6 patterns (the counts-only merge runs the whole batch)
         cfg = dict(cfg, npat=1_000_000)
     t_gen = time.perf_counter()
     text, ds, n = make_corpus(torch, W, cfg, rank, device)
@@ -202,7 +231,16 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
                 mres = merger.merge(r, cfg["npat"])
                 mms.append((time.perf_counter() - t) * 1e3)
             out["merge_ms"] = [round(x, 3) for x in mms[1:]]
-            out["merged_rows"] = int(getattr(mres, "nrows", 0)) if not isinstance(mres, tuple) else int(mres[1].numel())
+            out["merge"] = merger.note
+            if hasattr(mres, "nrows_total"):
+                out["merged_rows"] = int(mres.nrows_total)
+            else:
+                out["merged_rows"] = int(getattr(mres, "nrows", 0)) if not isinstance(mres, tuple) else int(mres[0][-1].item())
+            if dist is not None and world > 1:  # rows every rank contributes (its slice of the merged CSR)
+                mine = torch.tensor([int(r.nrows)], dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                out["rows_per_rank"] = [int(x.item()) for x in allr]
             merger.close()
         out["query_ms"] = [round(x, 3) for x in qms[1:]]
         out["query_patterns_per_s"] = round(cfg["npat"] / (min(qms[1:]) * 1e-3), 1)
@@ -216,9 +254,25 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
             ho = d_offs[: nkw + 1].cpu().numpy().astype(np.uint64)
             kws_blob, kws_offs = hb, ho
             t = time.perf_counter()
-            rows = g.query_ranked_arrays(kws_blob, kws_offs, 1, 1 << 62, 1000)
-            out["ranked"] = {"keywords": nkw, "limit": 1000, "rows": rows, "ms": round((time.perf_counter() - t) * 1e3, 2),
+            rids, rcnt = g.query_ranked_arrays(kws_blob, kws_offs, 1, 1 << 62, 1000, rows=True)
+            out["ranked"] = {"keywords": nkw, "limit": 1000, "rows": len(rids), "ms": round((time.perf_counter() - t) * 1e3, 2),
                              "note": "cdb_query_ranked: host keyword list in, top rows out (PCIe-inclusive)"}
+            if dist is not None and world > 1:
+                # global $correlation ranking over the shards (object ids are disjoint: every shard's own top `limit` rows
+                # hold its share of the global top `limit`): gather the shard lists, rank once more
+                t = time.perf_counter()
+                pad = torch.full((2, 1000), -1, dtype=torch.int64)
+                pad[0, :len(rids)] = torch.from_numpy(rids)
+                pad[1, :len(rcnt)] = torch.from_numpy(rcnt)
+                pad = pad.to(device if dist.get_backend() == "nccl" else "cpu")
+                allp = [torch.empty_like(pad) for _ in range(world)]
+                dist.all_gather(allp, pad)
+                cat = torch.cat(allp, 1).cpu().numpy()
+                keep = cat[1] >= 0
+                order = np.lexsort((cat[0][keep], -cat[1][keep]))[:1000]
+                out["ranked"]["global"] = {"rows": int(len(order)), "top_count": int(cat[1][keep][order[0]]) if len(order) else 0,
+                                           "ms": round((time.perf_counter() - t) * 1e3, 2),
+                                           "note": "per-shard top lists all-gathered and ranked (descending count, ties ascending id)"}
         v = g.verify()
         out["verify"] = {"invalid_entries": int(v["invalid_entries"]), "inversions": int(v["inversions"]),
                          "tie_violations": int(v["tie_violations"]), "entry_sum_ok": bool(v["entry_sum"] == v["expected_entry_sum"])}
@@ -347,6 +401,12 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only)")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the RCCL merge of the N > 1 step with a one-rank communicator (testing the plumbing on one GPU)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload per GPU (default; what the driver's --gpus N runs measure).  strong: a FIXED corpus "
+                         "(--workload c3 = 32 GiB, c4 = 128 GiB) generated shard-wise on the devices and split across the ranks")
+    ap.add_argument("--merge", default="counts", choices=["counts", "full"],
+                    help="N > 1: counts = all-gather of the per-pattern row counts only, every rank keeps its own rows "
+                         "(cdb_comm_merge_counts; host / rank-local consumers); full = all-gatherv of all rows to every rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -373,7 +433,9 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    cfg = WORKLOADS[args.workload]
+    cfg, clamp_note = per_rank_cfg(WORKLOADS[args.workload], world, args.scaling)
+    if cfg.get("total") and args.scaling != "strong":
+        raise SystemExit(f"--workload {args.workload} is a fixed-size corpus: run it with --scaling strong")
     text, doc_start, n = make_corpus(torch, W, cfg, rank, device)
     ndocs = len(doc_start) - 1
     npat, mmin, mmax = cfg["npat"], cfg["mmin"], cfg["mmax"]
@@ -424,7 +486,7 @@ def main():
 
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
-    merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device) if (world > 1 or args.force_merge) else None
+    merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device, mode=args.merge) if (world > 1 or args.force_merge) else None
 
     def step():
         # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
@@ -489,13 +551,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64" if g.sa_width == 8 else "u32",  # suffix-array entries and sort keys of this configuration (text is u8)
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: " + describe(cfg, n, ndocs) + " per GPU; step = SA build + batched query"
-                            + (" + RCCL merge of the shards' match lists" if world > 1 else ""),
+                            + (" + RCCL merge of the shards' match lists" if world > 1 else "")
+                            + (f"; fixed corpus of {world * n / 2**30:.0f} GiB split into {world} doc-aligned shards" if args.scaling == "strong" else "")
+                            + (f" ({clamp_note})" if clamp_note else ""),
                 "docs_per_gpu": ndocs, "bytes_per_gpu": n, "patterns": npat,
             },
             "commit": git_head(),
@@ -560,14 +624,15 @@ def main():
         blocks = {}
         for name in [x for x in extra.split(",") if x]:
             try:
-                mk = (lambda gi: shard.ShardMerger(capi, gi, dist, rank, world, coll_device, device)) if world > 1 else None
+                mk = (lambda gi: shard.ShardMerger(capi, gi, dist, rank, world, coll_device, device, mode=args.merge)) if world > 1 else None
 
                 def agree(ok):
                     t_ = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
                     dist.all_reduce(t_, op=dist.ReduceOp.MIN)
                     return bool(t_.item())
 
-                res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk, agree=agree if world > 1 else None)
+                res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk, agree=agree if world > 1 else None,
+                                 merge_mode=args.merge, dist=dist if world > 1 else None, world=world)
             except Exception as e:  # noqa: BLE001
                 res = {"workload": name, "error": repr(e)[:300]}
             if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N

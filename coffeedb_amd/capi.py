@@ -294,16 +294,20 @@ class GpuStringIndex:
         self._lib.cdb_free(cnt)
         return out
 
-    def query_ranked_arrays(self, blob, offsets, lo=1, hi=(1 << 62), limit=0):
-        """cdb_query_ranked over an already packed keyword list (bench: 10^5 keywords); returns the number of rows."""
+    def query_ranked_arrays(self, blob, offsets, lo=1, hi=(1 << 62), limit=0, rows=False):
+        """cdb_query_ranked over an already packed keyword list (bench: 10^5 keywords); returns the number of rows
+        (rows=True: the (ids, counts) arrays)."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         ids, cnt, n = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_size_t(0)
         self._check(self._lib.cdb_query_ranked(self._h, _ptr(blob), _ptr(offsets), len(offsets) - 1, int(lo), int(hi), int(limit),
                                                C.byref(ids), C.byref(cnt), C.byref(n)))
+        out = int(n.value)
+        if rows:
+            out = (np.array(ids[:n.value], dtype=np.int64), np.array(cnt[:n.value], dtype=np.int64))
         self._lib.cdb_free(ids)
         self._lib.cdb_free(cnt)
-        return int(n.value)
+        return out
 
     def query_spans(self, keywords):
         """{object id: [(begin, end_inclusive), ...]} — merged highlight spans (database.cpp:58-76)."""

@@ -72,6 +72,21 @@ def merge_shard_results(torch, dist, row_ptr, ids, counts, world):
     return g_row_ptr, out[0], out[1]
 
 
+def merge_shard_counts(torch, dist, row_ptr, world, rank):
+    """Counts-only merge (the consumer is not on the GPU — every shard keeps its own slice): all-gather of
+    the per-pattern row counts only.  Returns (global_row_ptr int64[npat+1], row_base int64[npat]): this rank's rows of
+    pattern j are the merged rows [row_base[j], row_base[j] + local count of j).  The torch restatement of
+    cdb_comm_merge_counts (shards.hip), used by the gloo test mode."""
+    cnt = (row_ptr[1:] - row_ptr[:-1]).contiguous()
+    cnt_list = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnt_list, cnt)
+    all_cnt = torch.stack(cnt_list)                      # [world, npat]
+    g_row_ptr = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=row_ptr.device)
+    torch.cumsum(all_cnt.sum(0), 0, out=g_row_ptr[1:])
+    base = g_row_ptr[:-1] + all_cnt[:rank].sum(0)
+    return g_row_ptr, base
+
+
 class _DevArr:
     def __init__(self, ptr, n, typestr):
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
@@ -82,9 +97,10 @@ class ShardMerger:
     library's own (cdb_comm_* of the C ABI: all-gather of the row counts, all-gatherv of the rows, HIP placement kernel);
     `--backend gloo --share-gpu` (a one-GPU box, testing only) goes through torch.distributed instead."""
 
-    def __init__(self, capi, index, dist, rank, world, coll_device, device):
+    def __init__(self, capi, index, dist, rank, world, coll_device, device, mode="counts"):
         import torch
         self.torch, self.dist, self.index, self.world, self.device, self.coll_device = torch, dist, index, world, device, coll_device
+        self.rank, self.mode = rank, mode   # counts: cdb_comm_merge_counts (every rank keeps its slice); full: all-gatherv
         self.comm = None
         self.note = "torch.distributed all-gathers (gloo test mode)"
         if coll_device == device and hasattr(capi, "ShardComm"):
@@ -107,14 +123,19 @@ class ShardMerger:
                     self.comm = None
                     self.note = "torch.distributed all-gathers (cdb_comm_create failed on another rank)"
             if self.comm is not None:
-                self.note = "cdb_comm_merge (RCCL all-gather + grouped broadcasts + placement kernel)"
+                self.note = ("cdb_comm_merge_counts (RCCL all-gather of the row counts; every rank keeps its own rows and learns "
+                             "where they sit in the merged CSR)" if mode == "counts" else
+                             "cdb_comm_merge (RCCL all-gather + grouped broadcasts + placement kernel)")
+                self.note += f"; {self.comm.world} RCCL ranks, transport {self.comm.transport}"
 
     def merge(self, r, npat):
         if self.comm is not None:
-            return self.comm.merge(r)
+            return self.comm.merge_counts(r) if self.mode == "counts" else self.comm.merge(r)
         torch = self.torch
         nrows = int(r.nrows)
         row_ptr = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=self.device)
+        if self.mode == "counts":
+            return merge_shard_counts(torch, self.dist, row_ptr.to(self.coll_device), self.world, self.rank)
         if nrows:
             ids = torch.as_tensor(_DevArr(r.d_ids, nrows, "<i8"), device=self.device)
             cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=self.device)

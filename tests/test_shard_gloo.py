@@ -46,6 +46,12 @@ def _worker(rank, world, port, q):
         frp, fi, fc, _ = full.query_batch(pb, po)
         ok = (np.array_equal(g_rp.numpy(), frp.astype(np.int64)) and np.array_equal(g_ids.numpy(), fi)
               and np.array_equal(g_cnt.numpy(), fc))
+        # counts-only merge: merged row_ptr + where this rank's own rows sit in the merged row stream
+        c_rp, base = shard.merge_shard_counts(torch, dist, torch.from_numpy(rp.astype(np.int64)), world, rank)
+        ok = ok and np.array_equal(c_rp.numpy(), frp.astype(np.int64))
+        for j in range(len(po) - 1):
+            k = int(rp[j + 1] - rp[j])
+            ok = ok and np.array_equal(fi[int(base[j]):int(base[j]) + k], ri[int(rp[j]):int(rp[j + 1])])
         q.put((rank, bool(ok), int(g_rp[-1])))
     finally:
         dist.destroy_process_group()
