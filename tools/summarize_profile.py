@@ -26,12 +26,17 @@ def find(sub, pat):
 def family(name):
     """rocprof kernel name -> the library profiler's name for the same instantiation."""
     m = re.search(r"rs_onesweep_kernel<(unsigned int|unsigned long), (unsigned int|unsigned long|cdb::NoVal), "
-                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|unsigned short|cdb::NoVal)>", name)
+                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|unsigned short|unsigned int|cdb::NoVal)"
+                  r"(?:, cdb::(NoSeg|SegArgs|SegFinalArgs))?>", name)
     if m:
         k = {"unsigned int": "k32", "unsigned long": "k64"}[m.group(1)]
         v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(2)]
         tile = int(m.group(3)) * int(m.group(4))
-        aux = {"unsigned char": "_w8", "unsigned short": "_w16", "cdb::NoVal": ""}[m.group(6)]
+        aux = {"unsigned char": "_w8", "unsigned short": "_w16", "unsigned int": "_w32", "cdb::NoVal": ""}[m.group(6)]
+        if m.group(7) == "SegFinalArgs":
+            return f"rs_seg_final{aux}_t{tile}"
+        if m.group(7) == "SegArgs":
+            return f"rs_seg_{k}{v}{aux}_t{tile}"
         if m.group(5) == "TextGen":
             return f"rs_onesweep_textgen{'_split' if aux else ''}_t{tile}"
         return f"rs_onesweep_{k}{v}{aux}_t{tile}"
@@ -41,7 +46,7 @@ def family(name):
 
 stats = find("trace", "*kernel_stats.csv")
 if stats:
-    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 3 --warmup 1 --no-cpu-baseline) ==")
+    print("== rocprofv3 --kernel-trace --stats ==")
     for r in list(csv.DictReader(open(stats)))[:12]:
         print(f"{family(r['Name']):34s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={r['Percentage']}")
