@@ -14,4 +14,7 @@ for D in $SRC/*/; do
   [ -n "$S" ] && cp $S profiles/${TAG}_${W}_kernel_stats.csv
 done
 [ -f $SRC/c1/traffic.json ] && cp $SRC/c1/traffic.json profiles/traffic_latest.json
+for W in utf8_4g c2 c4shard c3shard; do
+  [ -f $SRC/$W/traffic.json ] && cp $SRC/$W/traffic.json profiles/traffic_latest_$W.json
+done
 ls profiles | grep "^${TAG}_"
