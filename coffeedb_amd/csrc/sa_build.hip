@@ -1903,6 +1903,9 @@ void build_typed(Index& ix, bool big) {
                 at += h_first[border[k]];
             }
             st.root_folded = 1;
+            bool lo_class = false;
+            for (int b = 0; b < 128; ++b) lo_class |= h_map[b] != 0;
+            if (lo_class) st.compat_rotations += 1;  // (what the root rotation would have counted: both classes present)
         }
         // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
         // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort

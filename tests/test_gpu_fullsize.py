@@ -185,6 +185,42 @@ def test_c2_full_size_zipf_one_million_patterns_with_offsets():
         assert np.array_equal(rc[a:b], want_cnt.cpu().numpy()), (j, bytes(kw))
         got_off = off[int(hp[a]):int(hp[b])]
         assert np.array_equal(got_off, (pos % dl).cpu().numpy().astype(np.uint64)), (j, bytes(kw))   # (doc, offset) ascending
+    del rp, ri, rc, hp, off
+
+    # ---- the short-pattern tail of SURVEY §8(d)'s C2 (m from 2): keywords of 2..5 bytes match 10^4 .. 4 x 10^8 suffixes
+    # each on this text — the regime where the reference switches to its 17-bit radix (index.cpp:288-315) and where the
+    # batch is resolved in chunks of patterns under the hit budget (2^31 hits of sort scratch).  Results stay in HBM
+    # (3 x 10^9 hits with offsets are ~50 GB); rows and offsets of sampled keywords are checked by brute-force scans.
+    nshort = 200
+    s_blob, s_offs, s_bytes = W.sample_patterns_torch(text, d_ds, nshort, 2, 5, seed=5, miss_byte=0x7F)
+    torch.cuda.synchronize()
+    g.set_option("query_hit_budget", 1 << 30)                                            # several chunks at this size
+    r, hx = g.query_batch_offsets_device(s_blob.data_ptr(), s_offs.data_ptr(), nshort, s_bytes)
+
+    def dev(ptr, cnt):
+        class A:
+            __cuda_array_interface__ = {"shape": (int(cnt),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(A(), device="cuda")
+    nrows, nhits = int(r.nrows), int(r.nhits)
+    assert nhits > 1 << 30 and nrows > 100_000_000, (nhits, nrows)                       # far beyond one chunk
+    rp_d, rc_d, ri_d = dev(r.d_row_ptr, nshort + 1), dev(r.d_counts, nrows), dev(r.d_ids, nrows)
+    hp_d, off_d = dev(hx.d_hit_ptr, nrows + 1), dev(hx.d_offsets, nhits)
+    assert int(rp_d[0]) == 0 and int(rp_d[-1]) == nrows and int(hp_d[-1]) == nhits
+    assert int(rc_d.sum()) == nhits and bool((rc_d > 0).all())
+    assert bool((hp_d[1:] - hp_d[:-1] == rc_d).all())                                    # a row owns `count` offsets
+    srows = (rp_d[1:] - rp_d[:-1]).cpu().numpy()
+    so = s_offs.cpu().numpy()
+    sb = s_blob[:s_bytes].cpu().numpy()
+    for j in [int(np.argmax(srows)), int(np.argmax(np.diff(so))), 17]:
+        kw = sb[int(so[j]):int(so[j + 1])]
+        pos = _scan_occurrences(torch, text, torch.from_numpy(kw.copy()).cuda())
+        pos = pos[(pos % dl) + len(kw) <= dl]
+        want_docs, want_cnt = torch.unique(pos // dl, return_counts=True)
+        a, b = int(rp_d[j]), int(rp_d[j + 1])
+        assert b - a == want_docs.numel(), (j, bytes(kw), b - a, want_docs.numel())
+        assert bool(((ri_d[a:b] - 1) // 2 == want_docs).all()) and bool((rc_d[a:b] == want_cnt).all()), (j, bytes(kw))
+        assert bool((off_d[int(hp_d[a]):int(hp_d[b])] == pos % dl).all()), (j, bytes(kw))
+        del pos, want_docs, want_cnt
     g.close()
     capi.load_library().cdb_release_cached_memory()
 
