@@ -679,6 +679,15 @@ def main():
                                                   "p90": round(float(c_us[(len(c_us) * 9) // 10]), 2),
                                                   "note": "the same calls timed inside the library (cdb_debug_query_latency): what a C++ caller "
                                                           "such as database.cpp:392 sees; median over 32 calls per keyword"}
+            # the same with the opt-in resident workgroup (resident_query = 1: no launch per query, host-mapped mailbox)
+            g.set_option("resident_query", 1)
+            for kw in kws[:8]:
+                g.query(kw)
+            r_us = np.sort(g.query_latency_us(kws, reps=32))
+            g.set_option("resident_query", 0)
+            out["single_query_us"]["resident"] = {"median": round(float(r_us[len(r_us) // 2]), 2), "p10": round(float(r_us[len(r_us) // 10]), 2),
+                                                  "p90": round(float(r_us[(len(r_us) * 9) // 10]), 2),
+                                                  "note": "option resident_query = 1, timed inside the library like c_caller"}
         except Exception as e:  # noqa: BLE001
             out["single_query_us"] = {"error": repr(e)[:200]}
     extra = args.configs

@@ -150,6 +150,7 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
 
 // back to "never built" (queries answer {}): a failed build or load must not leave new parameters over an old array
 void reset_unbuilt(Index& ix) {
+    query_resident_stop(ix);  // (the resident query workgroup reads the arrays released below)
     (void)hipStreamSynchronize(ix.stream);
     ix.d_sa.release();
     ix.drop_keys();
@@ -281,7 +282,10 @@ void cdb_destroy(cdb_index* h) {
     if (!h) return;
     (void)hipSetDevice(h->ix.device);
     hipStream_t s = h->ix.stream;
+    query_resident_stop(h->ix);
     if (s) (void)hipStreamSynchronize(s);
+    if (h->ix.res_stream) (void)hipStreamDestroy(h->ix.res_stream);
+    if (h->ix.h_res) (void)hipHostFree(h->ix.h_res);
     if (h->ix.h_single) (void)hipHostFree(h->ix.h_single);
     h->ix.stream = nullptr;
     delete h;  // (device blocks go back to the cache untagged: the stream is idle)
@@ -1288,6 +1292,11 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "hybrid_passes")) ix.hybrid_passes = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
     else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
+    else if (!std::strcmp(name, "resident_query")) {
+        std::lock_guard<std::mutex> g(ix.mu);
+        if (!value) query_resident_stop(ix);
+        ix.resident_query = value != 0;
+    }
     else if (!std::strcmp(name, "bucket_group_limit")) ix.bucket_group_limit = (uint64_t)value;
     else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
         ix.query_hit_budget = value > 0 ? std::min<uint64_t>((uint64_t)value, 1ull << 31) : 1;

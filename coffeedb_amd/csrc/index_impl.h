@@ -47,6 +47,17 @@ struct QueryStats {
     uint64_t nhits = 0, nrows = 0;
 };
 
+// kept sort keys for the lone-keyword kernels (query.hip): suffixes starting with the keyword's first min(m, nsym) symbols
+// are exactly those with key in [klo, khi] (coded on the host); decisive = the keyword has at most nsym symbols
+struct SingleKeys {
+    const uint64_t* keys64 = nullptr;
+    const uint32_t* keys32 = nullptr;
+    const void* keylow = nullptr;
+    int low_bits = 0, low_bytes = 0, nsym = 0;
+    bool decisive = false;
+    uint64_t klo = 0, khi = 0;
+};
+
 struct Index {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -62,6 +73,14 @@ struct Index {
     bool use_single_query = true; // a lone cdb_query is answered by one wavefront in one launch (query.hip)
     void* h_single = nullptr;     // host-mapped result block of that kernel (+ its device address)
     void* d_single = nullptr;
+    // resident_query: one workgroup stays on the device and answers lone keywords from a host-mapped mailbox (query.hip)
+    bool resident_query = false;
+    void* h_res = nullptr;        // the mailbox (+ its device address)
+    void* d_res = nullptr;
+    hipStream_t res_stream = nullptr;
+    bool res_running = false;
+    uint32_t res_seq = 0;         // requests posted so far
+    SingleKeys res_keys;          // the key arrays the running workgroup was started with
     bool use_fast_search = true;  // pivot-table / galloping search on sorted arrays (query.hip)
 
     // ---- host staging (cdb_add)
@@ -189,6 +208,7 @@ enum class SingleLaunch { NotApplicable, Absent, Launched };
 SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len);
 bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
 void query_single_empty(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows);
+void query_resident_stop(Index& ix);  // the resident workgroup leaves (before the arrays it reads are replaced or freed)
 // highlight spans of all documents matching any pattern: ids -> ix.q_ids, span_ptr -> ix.q_rowptr, span begins ->
 // ix.q_keys0, inclusive span ends -> ix.q_keys1
 struct SpanResult {

@@ -1119,16 +1119,6 @@ struct SingleKw {
     uint32_t len;
     uint8_t bytes[124];
 };
-// kept sort keys for the lone-keyword kernel: suffixes starting with the keyword's first min(m, nsym) symbols are
-// exactly those with key in [klo, khi] (coded on the host); decisive = the keyword has at most nsym symbols
-struct SingleKeys {
-    const uint64_t* keys64 = nullptr;
-    const uint32_t* keys32 = nullptr;
-    const void* keylow = nullptr;
-    int low_bits = 0, low_bytes = 0, nsym = 0;
-    bool decisive = false;
-    uint64_t klo = 0, khi = 0;
-};
 constexpr uint32_t SINGLE_MAX_HITS = 4096;
 struct SingleOut {
     uint64_t nrows;  // written LAST by the kernel; ~0 = still pending, ~0 - 1 = not answered here (more than SINGLE_MAX_HITS hits)
@@ -1137,24 +1127,22 @@ struct SingleOut {
     int64_t counts[SINGLE_MAX_HITS];
 };
 
+// The answer to one keyword (k[0 .. m) in LDS) by one workgroup of 256 threads; every thread enters and leaves together
+// (the resident kernel below calls it once per request).  `done` = the word that announces the rows (written last).
 template <typename V>
-__global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
-                                                      const uint8_t* __restrict__ text,
-                                                      const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
-                                                      const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out,
-                                                      bool sorted, SingleKeys sk) {
-    __shared__ uint8_t s_kw[128];
+__device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64_t n, const uint8_t* __restrict__ text,
+                                                const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                const int64_t* __restrict__ ids, const uint8_t* k, uint64_t m,
+                                                SingleOut* __restrict__ out, bool sorted, const SingleKeys& sk) {
     __shared__ int64_t s_left;
     __shared__ uint64_t s_hits;
+    __shared__ int s_inwin;          // the entries of the hits are already in s_win (fetched with the last probe window)
+    __shared__ uint64_t s_win[64];
     __shared__ uint32_t s_doc[SINGLE_MAX_HITS];
     __shared__ int64_t s_rid[SINGLE_MAX_HITS];    // rows are assembled in LDS and leave for the host-mapped block
     __shared__ uint32_t s_rcnt[SINGLE_MAX_HITS];  // with consecutive lanes on consecutive slots
     __shared__ uint32_t s_wcnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t m = kw.len;
-    if (tid < 128) s_kw[tid] = tid < 124 ? kw.bytes[tid] : (uint8_t)0;
-    __syncthreads();
-    const uint8_t* k = s_kw;
     if (wave == 0) {  // ---- the search is the first wavefront's business
     // three-way compare of the keyword with the suffix at slot M: <0 keyword smaller, 0 keyword is a prefix of
     // the suffix or equal on the common part
@@ -1166,6 +1154,12 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
                 key = sk.keys64[M];
             } else {
                 const uint64_t hpart = sk.keys32[M];
+                // (the low digits are fetched beside the high part, not after it: one round trip instead of two for the
+                //  lanes that need them — the wavefront waits for its slowest lane)
+                uint64_t lowv = 0;
+                if (sk.keylow)
+                    lowv = sk.low_bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(sk.keylow)[M]
+                                             : (uint64_t)static_cast<const uint16_t*>(sk.keylow)[M];
                 if (sk.keylow) {
                     const uint64_t a = sk.klo >> sk.low_bits, b2 = sk.khi >> sk.low_bits;
                     if (hpart < a || hpart > b2 || (hpart > a && hpart < b2)) {
@@ -1175,8 +1169,7 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
                         if (hpart > b2) { le = true; pref = false; return; }
                         if (sk.decisive) { le = true; pref = true; return; }
                     } else {
-                        key = (hpart << sk.low_bits) | (sk.low_bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(sk.keylow)[M]
-                                                                          : (uint64_t)static_cast<const uint16_t*>(sk.keylow)[M]);
+                        key = (hpart << sk.low_bits) | lowv;
                     }
                 } else {
                     key = hpart;
@@ -1223,6 +1216,7 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
             const int64_t rgt = L + 1;
             s_left = lft;
             s_hits = rgt > lft ? (uint64_t)(rgt - lft) : 0ull;
+            s_inwin = 0;
         }
     } else {
     // ---- lower bound (index.cpp:260-274): smallest M in [0, n-1] with keyword <= suffix(M), else n-1
@@ -1240,17 +1234,36 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
             if (f > 0) L = shfl64(M, f - 1) + 1;
         }
     }
+    bool in_window = false;  // the whole hit range lies inside the last probe window: no further round trips
+    int64_t right_w = 0;
     {
         const int64_t M = L + lane;
         bool le = true, pf = false;
-        if (M < R) probe(M, le, pf);  // (slot R itself is the saturated answer)
+        const bool probed = M < R;
+        V ew = 0;
+        if (probed) {
+            ew = sa[M];       // (fetched beside the probe: if the hits end inside this window they are already here)
+            probe(M, le, pf);  // (slot R itself is the saturated answer)
+        }
         const uint64_t b = __ballot(le);
-        L += __ffsll((unsigned long long)b) - 1;
+        const int f = __ffsll((unsigned long long)b) - 1;
+        // first probed slot at or behind the lower bound that is no match
+        const uint64_t nomatch = __ballot(probed && !pf) & ~((1ull << f) - 1ull);
+        if (nomatch != 0) {
+            in_window = true;
+            right_w = L + (__ffsll((unsigned long long)nomatch) - 1);
+            const uint32_t lo = __shfl((uint32_t)ew, (lane + f) & 63);
+            const uint32_t hi = sizeof(V) == 8 ? __shfl((uint32_t)((uint64_t)ew >> 32), (lane + f) & 63) : 0u;
+            s_win[lane] = ((uint64_t)hi << 32) | lo;  // entries of slots left, left + 1, ... (lanes behind the window: junk)
+        }
+        L += f;
     }
     const int64_t left = L;
     // ---- prefix upper bound (index.cpp:275-287): the hits are [left, right)
     int64_t right = left;
-    {
+    if (in_window) {
+        right = right_w;
+    } else {
         bool le, pf = false;
         const int64_t M = left + lane;
         if (M < (int64_t)n) probe(M, le, pf);
@@ -1282,25 +1295,25 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
     if (lane == 0) {
         s_left = left;
         s_hits = (uint64_t)(right - left);
+        s_inwin = in_window ? 1 : 0;
     }
     }  // sorted
     }  // wave 0
     __syncthreads();
     const int64_t left = s_left;
     const uint64_t hits = s_hits;
+    const uint32_t h = (uint32_t)hits;
     if (hits > SINGLE_MAX_HITS) {
         if (tid == 0) {
             out->hits = hits;
             __hip_atomic_store(&out->nrows, ~0ull - 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // "not answered here"
         }
-        return;
-    }
-    const uint32_t h = (uint32_t)hits;
-    if (h <= 64) {
+    } else if (h <= 64) {
         // ---- rows (index.cpp:288-322) of a short hit list: sorted and run-length encoded in registers
-        if (wave != 0) return;
+        if (wave == 0) {
         uint32_t v = 0xFFFFFFFFu;
-        if ((uint32_t)lane < h) v = (uint32_t)((uint64_t)sa[(uint64_t)left + lane] & mask);  // (doc indices fit 32 bits: index.cpp:199)
+        if ((uint32_t)lane < h)  // (doc indices fit 32 bits: index.cpp:199)
+            v = s_inwin ? (uint32_t)(s_win[lane] & mask) : (uint32_t)((uint64_t)sa[(uint64_t)left + lane] & mask);
 #pragma unroll
         for (int kk = 2; kk <= 64; kk <<= 1) {
 #pragma unroll
@@ -1327,8 +1340,8 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
             out->hits = hits;
             __hip_atomic_store(&out->nrows, (uint64_t)__popcll(heads), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        return;
-    }
+        }  // wave 0
+    } else {
     // ---- up to SINGLE_MAX_HITS hits: bitonic sort of the document indices in LDS by the whole workgroup, heads
     // counted per thread chunk, rows written in order
     uint32_t cap = 128;
@@ -1389,6 +1402,89 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
         out->hits = hits;
         __hip_atomic_store(&out->nrows, (uint64_t)total_rows, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    }
+    __syncthreads();  // (the LDS state is free for the next request)
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
+                                                      const uint8_t* __restrict__ text,
+                                                      const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                      const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out,
+                                                      bool sorted, SingleKeys sk) {
+    __shared__ uint8_t s_kw[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) s_kw[tid] = tid < 124 ? kw.bytes[tid] : (uint8_t)0;
+    __syncthreads();
+    q_single_answer<V>(sa, n, text, doc_start, bits, mask, ids, s_kw, (uint64_t)kw.len, out, sorted, sk);
+}
+
+// ---- the same answer from a RESIDENT workgroup (option resident_query) ----------------------------------------------
+// A launch costs ~5 us before the first instruction runs, and a kernel that runs once starts cold (instruction fetch,
+// wave start-up): more than the search itself.  With resident_query = 1 one workgroup stays on the device and polls a
+// host-mapped mailbox; the host posts the keyword there and polls the answer block like before.  The request is a
+// handful of 8-byte words that each carry 7 payload bytes and a 1-byte sequence tag: every word is read atomically, so
+// a snapshot whose tags all equal the expected sequence number is consistent — one PCIe round trip per poll, no flag
+// word to read first.  The workgroup leaves by itself after ~3 ms without a request (so device-wide synchronisations —
+// hipFree, hipDeviceSynchronize of anybody in the process — are held up by at most that) and announces it in `exited`,
+// written LAST; the host relaunches it with the next request.  Builds, loads and destroy stop it first (query_resident_stop).
+constexpr int RES_WORDS = 21;       // 147 payload bytes: len u32, decisive u8, pad, klo u64, khi u64, keyword <= 120 bytes
+constexpr uint32_t RES_IDLE_POLLS = 2500;
+struct ResidentBox {
+    uint64_t w[RES_WORDS];          // host -> device: request words, (payload 56 bits | tag << 56)
+    uint64_t stop;                  // host -> device: leave now
+    uint64_t pad0[64 - RES_WORDS - 1];
+    uint64_t exited;                // device -> host: nonzero = the workgroup has left (nothing is written after it)
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void q_resident_kernel(const V* __restrict__ sa, uint64_t n, const uint8_t* __restrict__ text,
+                                                        const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
+                                                        const int64_t* __restrict__ ids, ResidentBox* __restrict__ box,
+                                                        SingleOut* __restrict__ out, bool sorted, SingleKeys sk, uint32_t seq0) {
+    __shared__ __attribute__((aligned(8))) uint8_t s_req[RES_WORDS * 8];
+    __shared__ int s_state;  // 0 = request in s_req, 1 = leave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t seq = seq0;  // last request answered
+    for (;;) {
+        if (wave == 0) {  // ---- the first wavefront polls the mailbox: one 8-byte load per lane and poll
+            uint32_t idle = 0;
+            for (;;) {
+                const uint32_t want = (seq + 1u) & 0xFFu;
+                uint64_t v = (uint64_t)want << 56;
+                if (lane < RES_WORDS) v = __hip_atomic_load(&box->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else if (lane == RES_WORDS) v = __hip_atomic_load(&box->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? ~0ull : v;
+                const bool stop = __any(lane == RES_WORDS && v == ~0ull);
+                const bool fresh = __all(lane >= RES_WORDS || (uint32_t)(v >> 56) == want);
+                if (fresh) {
+                    if (lane < RES_WORDS) {
+#pragma unroll
+                        for (int b = 0; b < 7; ++b) s_req[lane * 7 + b] = (uint8_t)(v >> (8 * b));
+                    }
+                    if (lane == 0) s_state = 0;
+                    break;
+                }
+                if (stop || ++idle > RES_IDLE_POLLS) {
+                    if (lane == 0) s_state = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_state == 1) break;
+        seq += 1;
+        const uint32_t len = *reinterpret_cast<const uint32_t*>(s_req);
+        const uint64_t klo = *reinterpret_cast<const uint64_t*>(s_req + 8), khi = *reinterpret_cast<const uint64_t*>(s_req + 16);
+        SingleKeys k2 = sk;
+        k2.decisive = s_req[4] != 0;
+        k2.klo = klo;
+        k2.khi = khi;
+        q_single_answer<V>(sa, n, text, doc_start, bits, mask, ids, s_req + 24, (uint64_t)len, out, sorted, k2);
+    }
+    if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&box->exited, (uint64_t)seq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // true = answered (rows in freshly malloc'd *ids_out / *counts_out); false = take the batched path
@@ -1406,6 +1502,40 @@ void single_empty_rows(Index& ix, int64_t** ids_out, int64_t** counts_out, size_
     ix.qstats.nhits = ix.qstats.nrows = 0;
 }
 }  // namespace
+
+// starts the resident workgroup unless it is running (ix.mu held); seq0 = the last request already answered
+void query_resident_ensure(Index& ix, const SingleKeys& sk) {
+    ResidentBox* box = static_cast<ResidentBox*>(ix.h_res);
+    if (ix.res_running && __atomic_load_n(&box->exited, __ATOMIC_ACQUIRE) == 0) return;
+    if (ix.res_running) CDB_HIP(hipStreamSynchronize(ix.res_stream));  // (it has announced its exit: this returns at once)
+    __atomic_store_n(&box->exited, 0ull, __ATOMIC_RELAXED);
+    __atomic_store_n(&box->stop, 0ull, __ATOMIC_RELEASE);
+    SingleKeys base = sk;
+    base.decisive = false;
+    base.klo = base.khi = 0;
+    ix.res_keys = base;
+    const uint32_t seq0 = ix.res_seq - 1u;
+    SingleOut* out = static_cast<SingleOut*>(ix.d_single);
+    if (ix.width == 8)
+        hipLaunchKernelGGL((q_resident_kernel<uint64_t>), dim3(1), dim3(256), 0, ix.res_stream, (const uint64_t*)ix.d_sa.as<uint64_t>(),
+                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), static_cast<ResidentBox*>(ix.d_res), out, ix.sa_sorted, base, seq0);
+    else
+        hipLaunchKernelGGL((q_resident_kernel<uint32_t>), dim3(1), dim3(256), 0, ix.res_stream, (const uint32_t*)ix.d_sa.as<uint32_t>(),
+                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
+                           (const int64_t*)ix.d_ids.as<int64_t>(), static_cast<ResidentBox*>(ix.d_res), out, ix.sa_sorted, base, seq0);
+    CDB_HIP(hipGetLastError());
+    ix.res_running = true;
+}
+
+// the resident workgroup reads the index arrays: it leaves before they are replaced or freed (builds, loads, destroy)
+void query_resident_stop(Index& ix) {
+    if (!ix.res_running || !ix.h_res) return;
+    ResidentBox* box = static_cast<ResidentBox*>(ix.h_res);
+    __atomic_store_n(&box->stop, 1ull, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(ix.res_stream);
+    ix.res_running = false;
+}
 
 // The lone-keyword path in two halves, so that a caller holding several indexes (shards.hip: one per GPU) can have all
 // their kernels in flight before it waits for the first answer.
@@ -1445,6 +1575,32 @@ SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
         sk.khi = sk.klo + (kpw - 1);
     }
     out->nrows = ~0ull;
+    if (ix.resident_query) {
+        // ---- post the request to the resident workgroup (started now if it is not there)
+        if (!ix.res_stream) CDB_HIP(hipStreamCreateWithFlags(&ix.res_stream, hipStreamNonBlocking));
+        if (!ix.h_res) {
+            CDB_HIP(hipHostMalloc(&ix.h_res, sizeof(ResidentBox), hipHostMallocMapped));
+            std::memset(ix.h_res, 0, sizeof(ResidentBox));
+            CDB_HIP(hipHostGetDevicePointer(&ix.d_res, ix.h_res, 0));
+        }
+        ResidentBox* box = static_cast<ResidentBox*>(ix.h_res);
+        uint8_t pay[RES_WORDS * 7] = {0};
+        const uint32_t l32 = (uint32_t)len;
+        std::memcpy(pay, &l32, 4);
+        pay[4] = sk.decisive ? 1 : 0;
+        std::memcpy(pay + 8, &sk.klo, 8);
+        std::memcpy(pay + 16, &sk.khi, 8);
+        std::memcpy(pay + 24, kw, len);
+        const uint32_t seq = ++ix.res_seq;
+        for (int i = 0; i < RES_WORDS; ++i) {
+            uint64_t wv = (uint64_t)(seq & 0xFFu) << 56;
+            for (int b = 0; b < 7; ++b) wv |= (uint64_t)pay[i * 7 + b] << (8 * b);
+            __atomic_store_n(&box->w[i], wv, __ATOMIC_RELAXED);
+        }
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        query_resident_ensure(ix, sk);
+        return SingleLaunch::Launched;
+    }
     if (ix.width == 8)
         hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
                            ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
@@ -1465,7 +1621,23 @@ bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, si
     // instead of paying for hipStreamSynchronize's wake-up (~10 us of the ~20 us a call used to cost).  The stream
     // keeps its order for whatever is launched next; a kernel that never answers (device error) is left to the
     // ordinary synchronisation after ~2 ms.
-    {
+    if (ix.resident_query && ix.res_running) {
+        ResidentBox* box = static_cast<ResidentBox*>(ix.h_res);
+        volatile uint64_t* flag = &out->nrows;
+        uint64_t v = ~0ull;
+        for (uint64_t spin = 0; spin < (1ull << 28); ++spin) {
+            v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+            if (v != ~0ull) break;
+            if ((spin & 63) == 63 && __atomic_load_n(&box->exited, __ATOMIC_ACQUIRE) != 0) {
+                // the workgroup left (idle timeout) without seeing this request: start a new one, which finds it posted
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ~0ull) continue;  // (answered just before it left)
+                ix.res_running = false;
+                query_resident_ensure(ix, ix.res_keys);
+            }
+            __builtin_ia32_pause();
+        }
+        if (v == ~0ull) throw Error("HIP error: the resident query kernel did not answer");
+    } else {
         volatile uint64_t* flag = &out->nrows;
         uint64_t v = ~0ull;
         for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
@@ -1478,7 +1650,7 @@ bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, si
     if (out->nrows >= ~0ull - 1) {
         if (out->nrows == ~0ull) throw Error("HIP error: the single-keyword kernel did not answer");
         if (getenv("CDB_DEBUG_SINGLE")) std::fprintf(stderr, "[single] handed over: hits=%llu\n", (unsigned long long)out->hits);
-        CDB_HIP(hipStreamSynchronize(s));
+        if (!ix.resident_query) CDB_HIP(hipStreamSynchronize(s));
         return false;
     }
     *nrows = (size_t)out->nrows;

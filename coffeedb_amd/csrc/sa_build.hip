@@ -2435,6 +2435,7 @@ void build_typed(Index& ix, bool big) {
 
 void build_suffix_array(Index& ix) {
     const double t0 = now_ms();
+    query_resident_stop(ix);  // (a resident query workgroup reads the arrays this build replaces)
     struct GroupScope {  // the build's sorts may use the XCD-aware tile order: a starved pass is redone below
         RadixWorkspace& ws;
         explicit GroupScope(RadixWorkspace& w) : ws(w) { ws.allow_group = true; }

