@@ -1278,6 +1278,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;
     else if (!std::strcmp(name, "fold_root")) ix.fold_root = value != 0;
+    else if (!std::strcmp(name, "fold_depth1")) ix.fold_depth1 = value != 0;
     else if (!std::strcmp(name, "search_lanes")) ix.search_lanes = (value == 1 || value == 8) ? (int)value : 0;
     else if (!std::strcmp(name, "digit_bits")) ix.digit_bits = (int)value;
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;

@@ -139,6 +139,7 @@ struct Index {
     int initial_passes = 0;
     int sort_variant = 0;
     int search_lanes = 0;      // lanes per keyword in the fast batched search: 0 = by batch size, 1 or 8
+    bool fold_depth1 = true;     // ... and (segmented sort) the two byte blocks of big first-symbol buckets swapped by the last pass
     bool fold_root = true;       // bucket-wise build under reference_compat: bucket order = the reference's root child order
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)

@@ -194,7 +194,17 @@ struct NoSeg {};
 struct SegInfo {
     unsigned long long begin, end;  // element range of the segment inside the group's record buffers
     uint32_t tile_begin, pad;       // its first tile
+    // final pass only: the sorted segment [0, a) [a, b) [b, len) is written as [0, a) [b, len) [a, b) — the reference's child
+    // order inside a radix node (end of document, bytes 0x80..0xFF, bytes 0x00..0x7F; index.h:66-73).  a = b = 0: as sorted
+    unsigned long long rot_a, rot_b;
 };
+// where slot r of a segment goes under that block swap
+__device__ __forceinline__ unsigned long long rs_seg_rotated(const SegInfo& si, unsigned long long slot) {
+    if (si.rot_b == 0) return slot;
+    const unsigned long long r = slot - si.begin, len = si.end - si.begin;
+    if (r < si.rot_a) return slot;
+    return r < si.rot_b ? slot + (len - si.rot_b) : slot - (si.rot_b - si.rot_a);
+}
 struct SegArgs {
     const uint32_t* tile_seg = nullptr;  // [tiles] segment of every tile
     const SegInfo* segs = nullptr;
@@ -336,10 +346,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     uint64_t tile0 = 0;     // first tile of the look-back chain this tile belongs to
     uint64_t seg_n = n;     // end of the element range the tile may read
     uint32_t sg = 0;
+    SegInfo si = {};
     if constexpr (SEG) {
         if (tile >= (uint64_t)seg.tiles) return;  // (the grid is rounded up to whole tile groups)
         sg = seg.tile_seg[tile];
-        const SegInfo si = seg.segs[sg];
+        si = seg.segs[sg];
         tile0 = si.tile_begin;
         base = si.begin + (tile - tile0) * TILE;
         seg_n = si.end;
@@ -809,7 +820,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                     const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
                                                       : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
-                    if (!(seg.abl & 1)) seg.flags[s_gbase[dd] + i] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
+                    if (!(seg.abl & 1))
+                        seg.flags[rs_seg_rotated(si, s_gbase[dd] + i)] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
                     continue;
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             const uint32_t i = j * NT + tid;
             if constexpr (FINAL) {
                 if (i < valid && !(seg.abl & 2))
-                    seg.eout[s_gbase[dig[j]] + i] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
+                    seg.eout[rs_seg_rotated(si, s_gbase[dig[j]] + i)] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
             } else {
                 if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
             }
@@ -860,7 +872,8 @@ static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEd
     if (t >= tiles) return;
     const SegEdge e = edges[(size_t)t * 256 + d];
     if (!e.cnt) return;
-    const uint32_t t0 = segs[tile_seg[t]].tile_begin;
+    const SegInfo si = segs[tile_seg[t]];
+    const uint32_t t0 = si.tile_begin;
     if (t == t0) return;
     // largest t' in [t0, t) whose run starts in front of this one (runs of tiles without the digit share its start)
     uint32_t lo = t0, hi = t;  // invariant: answer (if any) in [lo, hi)
@@ -886,8 +899,8 @@ static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEd
         if (clear) atomicAnd(w, ~(clear << sh));
         if (set) atomicOr(w, set << sh);
     };
-    patch(e.pos, 1u, exhausted ? 0u : 2u);       // first of this run: not a head
-    patch(e.pos - 1, 0u, exhausted ? 0u : 2u);   // last of the run in front: not a tail
+    patch(rs_seg_rotated(si, e.pos), 1u, exhausted ? 0u : 2u);       // first of this run: not a head
+    patch(rs_seg_rotated(si, e.pos - 1), 0u, exhausted ? 0u : 2u);   // last of the run in front: not a tail
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -72,6 +72,62 @@ __global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __rest
     if (s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
+// Reference order, one level below the root (bucket-wise build): how the suffixes of every first byte split by what
+// FOLLOWS that byte — a byte below 0x80, a byte from 0x80, or the end of the document.  Inside a first-symbol bucket that
+// the reference treats as a radix node its children come [end][0x80..0xFF][0x00..0x7F] (index.h:66-73); with these counts
+// the last pass of the segmented sort writes the two byte blocks swapped straight away (no rotation afterwards).
+// pair[b][c] = positions p with text[p] = b and text[p + 1] in class c (0: < 0x80 or p + 1 = n, 1: >= 0x80), document
+// ends ignored; sa_docend_class_kernel counts, per last byte of a document, what has to move from those to "end".
+__global__ __launch_bounds__(256) void sa_pairclass_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                           unsigned long long* __restrict__ pair /*[256][2]*/) {
+    __shared__ uint32_t s[512];
+    s[threadIdx.x] = 0;
+    s[256 + threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t words = n / 16;
+    const uint4* t4 = reinterpret_cast<const uint4*>(text);
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += stride) {
+        const uint4 v = t4[w];
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t nxt = w * 16 + 16 < n ? (uint32_t)text[w * 16 + 16] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t follow = q < 3 ? x[q + 1] & 0xFFu : nxt;  // the byte behind this dword
+            atomicAdd(&s[2 * (x[q] & 0xFF) + ((x[q] >> 15) & 1u)], 1u);
+            atomicAdd(&s[2 * ((x[q] >> 8) & 0xFF) + ((x[q] >> 23) & 1u)], 1u);
+            atomicAdd(&s[2 * ((x[q] >> 16) & 0xFF) + (x[q] >> 31)], 1u);
+            atomicAdd(&s[2 * (x[q] >> 24) + (follow >> 7)], 1u);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) {
+        const uint64_t p = words * 16 + threadIdx.x;
+        atomicAdd(&s[2 * text[p] + (p + 1 < n ? (uint32_t)(text[p + 1] >> 7) : 0u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256)
+        if (s[i]) atomicAdd(&pair[i], (unsigned long long)s[i]);
+}
+// corr[b][c] (c = 0, 1): documents whose last byte is b and that are followed by a byte of class c (to be taken off
+// pair[b][c]); corr[b][2]: documents whose last byte is b (their last suffix ends behind its first symbol)
+__global__ __launch_bounds__(256) void sa_docend_class_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_start,
+                                                              uint64_t ndocs, uint64_t n, unsigned long long* __restrict__ corr /*[256][3]*/) {
+    __shared__ uint32_t s[768];
+    for (int i = threadIdx.x; i < 768; i += 256) s[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < ndocs; d += stride) {
+        const uint64_t b0 = doc_start[d], e = doc_start[d + 1];
+        if (e == b0) continue;
+        const uint32_t last = text[e - 1];
+        atomicAdd(&s[3 * last + 2], 1u);
+        atomicAdd(&s[3 * last + (e < n ? (uint32_t)(text[e] >> 7) : 0u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += 256)
+        if (s[i]) atomicAdd(&corr[i], (unsigned long long)s[i]);
+}
+
 // Digit histograms of the initial sort without reading any key: with one symbol per digit, the digit of
 // pass p is the symbol k = nsym-1-p positions into the suffix, so its histogram is the symbol histogram
 // of the text minus the symbols sitting at offsets < k of their document, and the "end" code counts the
@@ -1578,6 +1634,11 @@ void build_typed(Index& ix, bool big) {
 
     // ---- 2 + 3. keys + entries, initial sort
     DevBuf sorted_keys, sa_buf, flags;
+    struct Depth1Fold {
+        uint64_t nend = 0, nlow = 0, nhigh = 0;
+        bool fold = false, done = false;  // done: the segmented sort really wrote the bucket with its blocks swapped
+    };
+    std::vector<Depth1Fold> depth1;          // ... per bucket: how its suffixes split by the class of their second symbol
     std::vector<CompatBucket> folded_roots;  // bucket-wise build in the reference's root order: the first-symbol buckets
     SortStats ss;
     const bool fused = big || (ix.fuse_keygen && (dense || dbits == symbits) && nsym <= HC_MAXSYM &&
@@ -1906,6 +1967,37 @@ void build_typed(Index& ix, bool big) {
             bool lo_class = false;
             for (int b = 0; b < 128; ++b) lo_class |= h_map[b] != 0;
             if (lo_class) st.compat_rotations += 1;  // (what the root rotation would have counted: both classes present)
+            // one level down: first-symbol buckets that are radix nodes of the reference (more than chuck suffixes) and
+            // hold children on both sides of 0x80 — their blocks are swapped by the segmented sort's last pass
+            if (ix.fold_depth1) {
+                DevBuf d_cls;
+                d_cls.alloc((512 + 768) * sizeof(uint64_t));
+                CDB_HIP(hipMemsetAsync(d_cls.p, 0, (512 + 768) * sizeof(uint64_t), s));
+                int t = ix.prof.begin(s);
+                hipLaunchKernelGGL(sa_pairclass_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(n, 256 * 16 * 4), 2048))),
+                                   dim3(256), 0, s, text, n, d_cls.as<unsigned long long>());
+                hipLaunchKernelGGL(sa_docend_class_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))),
+                                   dim3(256), 0, s, text, doc_start, D, n, d_cls.as<unsigned long long>() + 512);
+                ix.prof.end(t, "sa_pairclass", n + D * 18, s);
+                std::vector<uint64_t> cls(512 + 768);
+                CDB_HIP(hipMemcpyAsync(cls.data(), d_cls.p, cls.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                CDB_HIP(hipStreamSynchronize(s));
+                const uint64_t chuck1 = std::max<uint64_t>(4096, n / 256);
+                depth1.assign((size_t)sigma, Depth1Fold{});
+                for (int b = 0; b < 256; ++b) {
+                    if (!h_map[b]) continue;
+                    const uint64_t* pr = &cls[2 * b];
+                    const uint64_t* co = &cls[512 + 3 * b];
+                    Depth1Fold f;
+                    f.nend = co[2];
+                    f.nlow = pr[0] - co[0];
+                    f.nhigh = pr[1] - co[1];
+                    f.fold = h_counts[b] > chuck1 && f.nlow && f.nhigh && f.nend + f.nlow + f.nhigh == h_counts[b];
+                    int slot = 0;
+                    while (border[slot] != (int)h_map[b]) ++slot;
+                    depth1[slot] = f;
+                }
+            }
         }
         // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
         // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort
@@ -1994,7 +2086,13 @@ void build_typed(Index& ix, bool big) {
                         g.elems = bstart[b1] - bstart[b0];
                         uint32_t tiles = 0;
                         for (uint32_t b = b0; b < b1; ++b) {
-                            h_segs[b] = SegInfo{(unsigned long long)(bstart[b] - g.gstart), (unsigned long long)(bstart[b + 1] - g.gstart), tiles, 0u};
+                            h_segs[b] = SegInfo{(unsigned long long)(bstart[b] - g.gstart), (unsigned long long)(bstart[b + 1] - g.gstart), tiles, 0u, 0ull, 0ull};
+                            if (!depth1.empty() && depth1[b].fold) {  // [end][low][high] is written as [end][high][low]
+                                h_segs[b].rot_a = depth1[b].nend;
+                                h_segs[b].rot_b = depth1[b].nend + depth1[b].nlow;
+                                depth1[b].done = true;
+                                st.compat_rotations += 1;
+                            }
                             tiles += (uint32_t)ceil_div(bstart[b + 1] - bstart[b], (uint64_t)RS_SEG_TILE);
                         }
                         g.tiles = tiles;
@@ -2422,6 +2520,22 @@ void build_typed(Index& ix, bool big) {
         std::memcpy(ix.h_symmap_q, h_map, sizeof(h_map));
     }
     if (ix.reference_compat && high_bytes) {
+        // buckets whose two byte blocks were swapped by the sort enter the walk as their two blocks (each sorted by the
+        // second symbol and with all children on one side of 0x80: no rotation there, their big children are walked)
+        if (!folded_roots.empty() && !depth1.empty()) {
+            std::vector<CompatBucket> nodes;
+            for (size_t b = 0; b < folded_roots.size(); ++b) {
+                const CompatBucket r = folded_roots[b];
+                if (depth1[b].done) {
+                    const unsigned long long hs = r.lo + depth1[b].nend, ls = hs + depth1[b].nhigh;
+                    nodes.push_back(CompatBucket{hs, ls});
+                    nodes.push_back(CompatBucket{ls, r.hi});  // (the suffixes that end behind the first symbol stay in front)
+                } else {
+                    nodes.push_back(r);
+                }
+            }
+            folded_roots.swap(nodes);
+        }
         const std::vector<CompatBucket>* roots = folded_roots.empty() ? nullptr : &folded_roots;
         if (!apply_reference_order_oop<V>(ix, sa_buf, roots)) {
             apply_reference_order<V>(ix, sa, roots);  // in place when no second array fits

@@ -256,6 +256,24 @@ def test_segmented_bucket_sort_groups_across_tiles(G, plain_order):
                 assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0
 
 
+def test_reference_order_folded_into_the_bucket_wise_build(G):
+    # text with bytes >= 0x80 through the segmented bucket-wise build: the partition pass lays the first-symbol buckets
+    # out in the reference's root order, the last pass writes the two byte blocks of every bucket that is a radix node of
+    # the reference swapped, deeper radix nodes are rotated afterwards — bit parity with the oracle (index.h:66-73
+    # signed children inside radix nodes, unsigned leaves), with each fold switched off in turn
+    ds = _wide_entry_docs(40000, 4, 70000)
+    n = int(ds[-1])
+    for seed, syms in ((5, [0x41, 0x42, 0xC3, 0xA9]), (6, [0x10, 0x7F, 0x80, 0xF0, 0x41]), (7, [0xC3, 0xA9, 0xE2]), (8, list(range(0x60, 0xA0)))):
+        blob = _few_symbols(n, seed, syms)
+        pats = W.sample_patterns(blob, ds, 150, 1, 7, seed=3, miss_frac=0.1, miss_byte=0x5A)
+        for opts in (dict(), dict(fold_depth1=0), dict(fold_root=0), dict(bucket_group_limit=60000), dict(segmented_sort=0)):
+            g, o = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, **opts)
+            assert g.sa_width == 8 and g.stat("bucketed") == 1
+            r = g.verify_reference()
+            assert r["violations"] == 0 and r["tie_violations"] == 0, (syms, opts, r)
+            assert g.verify()["inversions"] == g.stat("compat_rotations"), (syms, opts)
+
+
 def test_test_string_shape_property(G):
     # test/test-string.py shape (a-z, 3-char keywords) scaled to 300 x 5000, brute-force oracle
     from oracle import brute_count
