@@ -16,14 +16,14 @@ LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
 _LIB = None
 
 EXPORTS = [
-    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_view", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
+    "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_view", "cdb_build_views", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule", "cdb_debug_query_latency",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
-    "cdb_shards_transport", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
+    "cdb_shards_transport", "cdb_shards_build_views", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
     "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge", "cdb_comm_merge_counts",
     "cdb_comm_world", "cdb_comm_transport",
 ]
@@ -177,6 +177,8 @@ def load_library():
     lib.cdb_comm_transport.argtypes = [vp]
     lib.cdb_comm_transport.restype = cp
     lib.cdb_build_view.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_build_views.argtypes = [vp, vp, vp, vp, u64]
+    lib.cdb_shards_build_views.argtypes = [vp, vp, vp, vp, u64]
     lib.cdb_shards_query_batch_offsets.argtypes = [vp, vp, vp, u64, C.POINTER(CdbResult), C.POINTER(CdbHits)]
     lib.cdb_shards_query_and.argtypes = [C.POINTER(CdbKeyQuery), C.c_int, C.c_int, i64, i64, u64, C.POINTER(C.POINTER(i64)),
                                          C.POINTER(C.POINTER(i64)), C.POINTER(C.c_size_t)]
@@ -234,6 +236,13 @@ class GpuStringIndex:
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
         assert len(doc_start) == len(ids) + 1
         self._check(self._lib.cdb_build_view(self._h, _ptr(ids), _ptr(blob) if len(blob) else None, _ptr(doc_start), len(ids)))
+
+    def build_views(self, ids, docs):
+        """cdb_build_views: documents as separate bytes objects (string_index's views), gathered by the library."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        ptrs = (C.c_char_p * len(docs))(*docs)
+        lens = np.array([len(d) for d in docs], dtype=np.uint64)
+        self._check(self._lib.cdb_build_views(self._h, _ptr(ids), C.cast(ptrs, C.c_void_p), _ptr(lens), len(docs)))
 
     def add_raw_record(self, key: bytes, record: bytes):
         self._check(self._lib.cdb_add_raw_record(self._h, key, record, len(record)))
@@ -490,6 +499,12 @@ class GpuShards:
 
     def build(self):
         self._check(self._lib.cdb_shards_build(self._h))
+
+    def build_views(self, ids, docs):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        ptrs = (C.c_char_p * len(docs))(*docs)
+        lens = np.array([len(d) for d in docs], dtype=np.uint64)
+        self._check(self._lib.cdb_shards_build_views(self._h, _ptr(ids), C.cast(ptrs, C.c_void_p), _ptr(lens), len(docs)))
 
     count = property(lambda s: s._lib.cdb_shards_count(s._h))
     transport = property(lambda s: s._lib.cdb_shards_transport(s._h).decode())

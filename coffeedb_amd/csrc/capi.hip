@@ -148,6 +148,68 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
     if (!failure.empty()) throw Error(failure);
 }
 
+// The same for a column that is NOT contiguous on the host: document d is the lens[d] bytes at ptrs[d] — string_index's own
+// state (index.h:58: non-owning string_views into database.cpp's strings).  The gather into the pinned chunks IS the
+// staging copy (there is no other one); doc_start = the running sum of lens.
+void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start, uint64_t ndocs, size_t bytes, hipStream_t s,
+                  int device) {
+    constexpr size_t CHUNK = 16u << 20;
+    const int T = bytes >= 4 * CHUNK ? 4 : 1;
+    const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+    std::string failure;
+    std::mutex fmu;
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+        void* pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        try {
+            CDB_HIP(hipSetDevice(device));
+            for (int k = 0; k < 2; ++k) {
+                pin[k] = HostPool::get().alloc(CHUNK);
+                if (!pin[k]) throw Error("HIP error: no pinned staging memory");
+                CDB_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+            }
+            int k = 0;
+            bool used[2] = {false, false};
+            for (size_t c = t; c < nchunks; c += T, k ^= 1) {
+                const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
+                if (used[k]) CDB_HIP(hipEventSynchronize(ev[k]));  // the DMA out of this block has finished
+                // documents overlapping [off, off + len): the first one is the last d with doc_start[d] <= off
+                uint64_t d = std::upper_bound(doc_start, doc_start + ndocs + 1, (uint64_t)off) - doc_start - 1;
+                size_t at = 0;
+                while (at < len) {
+                    const uint64_t ds = doc_start[d], de = doc_start[d + 1];
+                    const uint64_t from = std::max<uint64_t>(ds, off + at), to = std::min<uint64_t>(de, off + len);
+                    if (to > from) {
+                        std::memcpy(static_cast<char*>(pin[k]) + at, ptrs[d] + (from - ds), to - from);
+                        at += to - from;
+                    }
+                    ++d;
+                }
+                CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, s));
+                CDB_HIP(hipEventRecord(ev[k], s));
+                used[k] = true;
+            }
+            for (int q = 0; q < 2; ++q)
+                if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> g(fmu);
+            if (failure.empty()) failure = e.what();
+        }
+        for (int q = 0; q < 2; ++q) {
+            if (ev[q]) (void)hipEventDestroy(ev[q]);
+            if (pin[q]) (void)HostPool::get().release(pin[q]);
+        }
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    if (!failure.empty()) throw Error(failure);
+}
+
 // back to "never built" (queries answer {}): a failed build or load must not leave new parameters over an old array
 void reset_unbuilt(Index& ix) {
     query_resident_stop(ix);  // (the resident query workgroup reads the arrays released below)
@@ -699,6 +761,54 @@ int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uin
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
             const double tu = wall_ms();
             if (n) upload_pageable(text.p, blob + first, n, ix.stream, ix.device);
+            upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
+            committed = true;
+            reset_unbuilt(ix);
+            ix.host_upload_ms = wall_ms() - tu;
+            commit_layout(ix, L);
+            ix.ids.swap(hid);
+            ix.doc_start.swap(hstart);
+            ix.host_tables_valid = true;
+            std::string().swap(ix.host_text);
+            ix.host_text_valid = false;  // the column lives on the device (and with the caller)
+            ix.d_text_owned = std::move(text);
+            ix.d_text = ix.d_text_owned.as<uint8_t>();
+            ix.text_padded = true;
+            ix.d_doc_start = std::move(d_start);
+            ix.d_ids = std::move(d_ids);
+            build_suffix_array(ix);
+        } catch (...) {
+            if (committed) reset_unbuilt(ix);
+            else (void)hipStreamSynchronize(ix.stream);
+            throw;
+        }
+    });
+}
+
+/* cdb_build_views: the same for documents that are separate strings on the host (ptrs[d], lens[d]) — exactly what
+ * string_index::add collects (index.cpp:174-177: ids.push_back(id); data.push_back(view)).  The shim's build() is this call. */
+int cdb_build_views(cdb_index* h, const int64_t* ids, const char* const* ptrs, const uint64_t* lens, uint64_t ndocs) {
+    if (!h || (ndocs && (!ids || !ptrs || !lens))) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        DeviceScope dscope(ix);
+        std::vector<int64_t> hid(ids, ids + ndocs);
+        std::vector<uint64_t> hstart(ndocs + 1);
+        hstart[0] = 0;
+        for (uint64_t d = 0; d < ndocs; ++d) {
+            if (lens[d] && !ptrs[d]) throw Error("cdb_build_views: null document");
+            hstart[d + 1] = hstart[d] + lens[d];
+        }
+        const Layout L = layout_of(hstart, ndocs);  // (throws the reference's capacity errors: nothing changed yet)
+        const uint64_t n = L.size;
+        bool committed = false;
+        try {
+            DevBuf text, d_start, d_ids;
+            text.alloc(n + TEXT_PAD);
+            CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
+            const double tu = wall_ms();
+            if (n) upload_views(text.p, ptrs, hstart.data(), ndocs, n, ix.stream, ix.device);
             upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
             committed = true;
             reset_unbuilt(ix);

@@ -832,6 +832,43 @@ int cdb_shards_build(cdb_shards* h) {
     });
 }
 
+// The same from the caller's own strings (string_index's views): nothing is staged in the handle, every shard gathers its
+// documents straight into its pinned upload chunks.  A later cdb_shards_add fetches the column back from the shards.
+int cdb_shards_build_views(cdb_shards* h, const int64_t* ids, const char* const* ptrs, const uint64_t* lens, uint64_t ndocs) {
+    if (!h || (ndocs && (!ids || !ptrs || !lens))) return CDB_E_INVALID;
+    return guarded_on(h, [&] {
+        std::lock_guard<std::mutex> sg(h->staging_mu);
+        std::vector<uint64_t> ds(ndocs + 1, 0);
+        for (uint64_t d = 0; d < ndocs; ++d) ds[d + 1] = ds[d] + lens[d];
+        const int G = (int)h->devices.size();
+        const uint64_t total = ds[ndocs];
+        int used = h->use_all ? G : (int)std::min<uint64_t>((uint64_t)G, std::max<uint64_t>(1, ceil_div(total, h->max_shard_bytes)));
+        used = std::max(1, std::min<int>(used, (int)std::max<uint64_t>(ndocs, 1)));
+        std::vector<uint64_t> b = shard_bounds(ds, used);
+        std::vector<cdb_index*> fresh = fresh_handles(h);
+        std::vector<std::unique_ptr<MergeRank>> ranks;
+        std::shared_ptr<Transport> tr;
+        try {
+            parallel_shards(used, [&](int i) {
+                const uint64_t d0 = b[i], d1 = b[i + 1];
+                check_handle(fresh[i], cdb_build_views(fresh[i], ids + d0, ptrs + d0, lens + d0, d1 - d0));
+            });
+            make_merge(h->devices, fresh, used, ranks, tr);
+        } catch (...) {
+            ranks.clear();
+            tr.reset();
+            for (cdb_index* p : fresh) cdb_destroy(p);
+            throw;
+        }
+        std::unique_lock<std::shared_mutex> st(h->state);
+        install(h, fresh, used, b, ranks, tr);
+        h->ids.clear();
+        h->doc_start.assign(1, 0);
+        std::string().swap(h->text);
+        h->staging_valid = false;  // (the column lives on the devices and with the caller)
+    });
+}
+
 // f4 over shards: `path` holds the shard count and document bounds, `path.<i>` shard i's own file (cdb_save)
 namespace {
 constexpr uint64_t SHARDS_MAGIC = 0x3130485344424443ull;  // "CDBDSH01"

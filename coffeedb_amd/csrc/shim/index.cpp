@@ -115,23 +115,22 @@ string_index::~string_index() {
     cdb_shards_destroy(shards);
 }
 
+// index.cpp:174-177: like the reference, add() only remembers the id and a VIEW of the caller's string (database.cpp keeps
+// the strings alive in its `data` map, database.cpp:262-264); build() hands the views to the library, which gathers them
+// straight into its pinned upload chunks — no staging copy of the column on the host.
 void string_index::add(int64_t id, std::string_view value) {
-    if (shards) {
-        const int rc = cdb_shards_add(shards, id, value.data(), value.size());
-        if (rc != CDB_OK) rethrow(shards, rc);
-        return;
-    }
-    const int rc = cdb_add(handle, id, value.data(), value.size());
-    if (rc != CDB_OK) rethrow(handle, rc);
+    ids.push_back(id);
+    ptrs.push_back(value.data());
+    lens.push_back(value.size());
 }
 
 void string_index::build() {
     if (shards) {
-        const int rc = cdb_shards_build(shards);
+        const int rc = cdb_shards_build_views(shards, ids.data(), ptrs.data(), lens.data(), ids.size());
         if (rc != CDB_OK) rethrow(shards, rc);
         return;
     }
-    const int rc = cdb_build(handle);
+    const int rc = cdb_build_views(handle, ids.data(), ptrs.data(), lens.data(), ids.size());
     if (rc != CDB_OK) rethrow(handle, rc);
 }
 

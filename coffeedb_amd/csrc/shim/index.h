@@ -69,8 +69,8 @@ public:
     static constexpr int8_t number = 3;
     string_index();
     ~string_index() override;
-    // index.cpp:174-177.  The bytes are copied (the GPU build uploads them); the caller's string may
-    // be released afterwards, which is weaker than what the reference requires of database.cpp.
+    // index.cpp:174-177.  As in the reference the index keeps a VIEW: the caller's string must stay valid until
+    // build() has returned (the reference needs it for the index's whole life; here the text lives on the GPU afterwards).
     void add(int64_t id, std::string_view value);
     // index.cpp:178-236: suffix-array construction, now on the GPU.  Throws std::runtime_error with
     // the reference's messages for the capacity limits (index.cpp:196,199).
@@ -96,6 +96,9 @@ public:
         const std::vector<std::string>& keywords) const;
 
 private:
+    std::vector<int64_t> ids;        // index.h:58-59: ids and (non-owning) views of the documents, in add() order
+    std::vector<const char*> ptrs;
+    std::vector<uint64_t> lens;
     cdb_index* handle = nullptr;   // one GPU
     cdb_shards* shards = nullptr;  // several GPUs (environment COFFEEDB_GPUS; the library shards a column only when it
                                    // exceeds one GPU's share)

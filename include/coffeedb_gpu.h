@@ -104,6 +104,9 @@ int cdb_build(cdb_index* h);
  * Replaces whatever cdb_add* staged.  The text travels through a chunked pinned upload (~50 GB/s); afterwards the
  * handle holds device copies only (a later cdb_add fetches the column back first). */
 int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
+/* The same for documents that are separate strings: document d = lens[d] bytes at ptrs[d] — what string_index::add
+ * collects (index.cpp:174-177) and what the shim's build() passes.  The strings must stay valid during the call only. */
+int cdb_build_views(cdb_index* h, const int64_t* ids, const char* const* ptrs, const uint64_t* lens, uint64_t ndocs);
 
 /* Same build, but over text that already resides in device memory (HBM-resident timing in bench.py,
  * multi-GPU shards).  d_text must stay valid for the lifetime of the index (the reference's
@@ -239,6 +242,8 @@ int cdb_shards_add(cdb_shards* h, int64_t id, const char* value, size_t len);   
 int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs);
 int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value);
 int cdb_shards_build(cdb_shards* h);                                                           /* index.cpp:178-236 */
+/* build straight from the caller's separate strings (cdb_build_views per shard; replaces whatever cdb_shards_add* staged) */
+int cdb_shards_build_views(cdb_shards* h, const int64_t* ids, const char* const* ptrs, const uint64_t* lens, uint64_t ndocs);
 int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** ids, int64_t** counts, size_t* nrows);
 int cdb_shards_query_batch(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t npat, cdb_result* out);
 /* cdb_query_or / cdb_query_ranked / cdb_query_spans over all shards (object ids are disjoint across shards: the shard

@@ -800,6 +800,44 @@ def test_single_keyword_wavefront_path(G):
             assert g2.query(kw) == o2.query(kw), kw
 
 
+def test_build_from_views_of_the_callers_column(G):
+    # cdb_build_view (one contiguous host column) and cdb_build_views (separate strings: what string_index::add collects,
+    # index.cpp:174-177) build the same index as add + build, without a staging copy inside the handle; a later add
+    # fetches the column back from the device first
+    blob, ds = W.ragged_corpus(6000, 300, seed=44, lo=0x61, hi=0x68, empty_every=17)
+    ids = np.arange(6000, dtype=np.int64) * 7 - 9
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 300, 1, 9, seed=5)
+    want = o.query_batch(pb, po)
+    docs = [bytes(blob[int(ds[d]):int(ds[d + 1])]) for d in range(6000)]
+    for how in ("view", "views", "view_slice"):
+        g = G()
+        if how == "view":
+            g.build_view(ids, blob, ds)
+        elif how == "views":
+            g.build_views(ids, docs)
+        else:                                          # a slice of a larger column: offsets need not start at 0
+            g.build_view(ids[100:], blob, ds[100:])
+            g.build_view(ids, blob, ds)                # ... and a rebuild replaces it
+        assert np.array_equal(g.sa(), o.sa()) and (g.size, g.bits, g.mask) == (o.size, o.bits, o.mask)
+        got = g.query_batch(pb, po)
+        assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3]))
+        g.add(123456, b"abcabcabcxyz")                  # the staged column comes back from the device
+        g.build()
+        assert g.query(b"abcxyz") == [(123456, 1)] and g.size == o.size + 12
+    # 80 MiB through the multi-threaded gather (chunks of 16 MiB cut documents anywhere)
+    big, bds = W.ragged_corpus(40000, 4200, seed=45, lo=0x20, hi=0x7E)
+    bids = np.arange(40000, dtype=np.int64)
+    g1, g2 = G(), G()
+    g1.build_view(bids, big, bds)
+    g2.build_views(bids, [bytes(big[int(bds[d]):int(bds[d + 1])]) for d in range(40000)])
+    assert np.array_equal(g1.sa(), g2.sa())
+    v = g2.verify()
+    assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
+    with pytest.raises(RuntimeError, match="non-decreasing"):
+        G().build_view(ids[:2], blob, np.array([5, 3, 9], dtype=np.uint64))
+
+
 def test_resident_query_workgroup(G):
     # option resident_query: lone keywords are answered by a workgroup that STAYS on the device and polls a host-mapped
     # mailbox (no launch per query).  Same answers as the launched kernel and the oracle for every kind of keyword; it

@@ -145,7 +145,17 @@ def test_sharded_and_persistence_raw_ingest(tmp_path):
     one.build()
     for kw in (b"ab", b"dcb", b"a"):
         assert sr.query(kw) == one.query(kw)
-    for x in (sr, one, sa, sb, one_a, one_b):
+    # build straight from the caller's separate strings (the shim's string_index::build over several GPUs)
+    sv = capi.GpuShards([0, 0, 0])
+    sv.set_option("use_all_devices", 1)
+    sv.build_views(ids, [bytes(blob_a[int(ds_a[d]):int(ds_a[d + 1])]) for d in range(nd)])
+    assert sv.count == 3 and [sv.first_doc(i) for i in range(4)] == [sa.first_doc(i) for i in range(4)]
+    g3 = sv.query_batch(pb, po)
+    assert g1[3] == g3[3] and all(np.array_equal(a, b) for a, b in zip(g1[:3], g3[:3]))
+    sv.add(31337, b"abcdabcdabcd")                               # (the column comes back from the shards)
+    sv.build()
+    assert sv.query(b"abcdabcdabcd") == [(31337, 1)]
+    for x in (sr, one, sa, sb, one_a, one_b, sv):
         x.close()
 
 
