@@ -59,6 +59,8 @@ public:
     void* alloc(size_t bytes, int device, size_t& actual) {
         const size_t gran = bytes >= (8u << 20) ? (2u << 20) : 256;
         const size_t need = (bytes + gran - 1) / gran * gran;
+        Block busy{};
+        bool have_busy = false;
         {
             std::lock_guard<std::mutex> g(mu_);
             int best = -1, best_busy = -1;
@@ -81,11 +83,6 @@ public:
                     best_busy = i;
                 }
             }
-            if (best < 0 && best_busy >= 0) {  // waiting for the other stream beats a fresh hipMalloc
-                Block& b = free_[best_busy];
-                if (hipEventSynchronize(b.ev) != hipSuccess) (void)hipGetLastError();
-                best = best_busy;
-            }
             if (best >= 0) {
                 Block b = free_[best];
                 free_.erase(free_.begin() + best);
@@ -94,6 +91,23 @@ public:
                 actual = b.bytes;
                 return b.p;
             }
+            if (best_busy >= 0) {  // waiting for the other stream beats a fresh hipMalloc ...
+                busy = free_[best_busy];
+                free_.erase(free_.begin() + best_busy);
+                cached_ -= busy.bytes;
+                have_busy = true;
+            }
+        }
+        if (have_busy) {
+            // ... but NOT under the pool's lock: every allocation and release of every handle — the queries of
+            // the index still serving included — would stall behind a multi-second build on the other stream
+            if (hipEventSynchronize(busy.ev) != hipSuccess) (void)hipGetLastError();
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                put_event(busy.device, busy.ev);
+            }
+            actual = busy.bytes;
+            return busy.p;
         }
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, need);

@@ -2141,7 +2141,8 @@ void build_typed(Index& ix, bool big) {
                                            d_items2.as<BucketItem>());
                         ix.prof.end(t, "sa_gather_plan", (uint64_t)g.cells * 24 + (g.elems / BR_ITEM) * sizeof(BucketItem), s);
                         t = ix.prof.begin(s);
-                        hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(256 * 8), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
+                        static const unsigned gather_wgs = getenv("CDB_GATHER_WGS") ? (unsigned)std::atoi(getenv("CDB_GATHER_WGS")) : 256u * 8u;
+                        hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(gather_wgs), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
                                            g.b0, kb[0].as<uint32_t>(), wb[0].as<W>(), eb[0].as<uint32_t>(), d_bh2.as<unsigned long long>(),
@@ -2609,6 +2610,8 @@ void build_suffix_array(Index& ix) {
             const bool was_atomic = rs_atomic_rank_ok(ix.stream);
             if (was_atomic && !ix.debug_fail_self_check) rs_atomic_rank_disable(ix.device);  // (the test hook leaves the device alone)
             ix.self_check_fallbacks += 1;
+            ix.d_sa.release();  // (the failed array and its keys go first: the rebuild needs their memory on large corpora)
+            ix.drop_keys();
             try {
                 run();
                 CDB_HIP(hipStreamSynchronize(ix.stream));
