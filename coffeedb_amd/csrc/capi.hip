@@ -318,8 +318,6 @@ int cdb_create(cdb_index** out, int device) {
     cdb_index* h = new (std::nothrow) cdb_index();
     if (!h) return CDB_E_DEVICE;
     h->ix.device = device;
-    if (const char* e = std::getenv("CDB_HYBRID")) h->ix.hybrid = std::atoi(e);
-    if (const char* e = std::getenv("CDB_HYBRID_PASSES")) h->ix.hybrid_passes = std::atoi(e);  // test hook: default of the "hybrid" option
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->ix.stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return CDB_E_DEVICE;
@@ -1399,8 +1397,6 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
-    else if (!std::strcmp(name, "hybrid")) ix.hybrid = (int)value;
-    else if (!std::strcmp(name, "hybrid_passes")) ix.hybrid_passes = (int)value;
     else if (!std::strcmp(name, "narrow_keys")) ix.narrow_keys = value != 0;
     else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
     else if (!std::strcmp(name, "resident_query")) {
@@ -1430,7 +1426,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"root_folded", (double)b.root_folded}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"hybrid", (double)b.hybrid}, {"hybrid_largest_bucket", (double)b.hybrid_largest_bucket}, {"hybrid_estimate", (double)b.hybrid_estimate}, {"hybrid_retries", (double)b.hybrid_retries}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"root_folded", (double)b.root_folded}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

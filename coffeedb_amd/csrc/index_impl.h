@@ -30,11 +30,6 @@ struct BuildStats {
     int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
     int root_folded = 0;         // ... first-symbol buckets laid out in the reference's root order (bytes >= 0x80 first)
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
-    int hybrid = 0;              // hybrid initial sort: global passes before the LDS bucket sort (0 = plain LSD sort,
-                                 // -1 = tried, a bucket did not fit, redone by the plain sort)
-    uint64_t hybrid_largest_bucket = 0;
-    uint64_t hybrid_estimate = 0;  // fullest bucket predicted from the key sample
-    int hybrid_retries = 0;        // plans that failed on a bucket larger than a workgroup's capacity
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
     uint64_t final_depth = 0;    // symbols compared when the last group was resolved
@@ -157,9 +152,6 @@ struct Index {
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)
     int digit_bits = 0;
     bool narrow_keys = true;      // 32-bit sort keys (+ a byte for the dropped low digit) when the key width allows
-    int hybrid = 0;               // hybrid initial sort (bucket_sort.h; experimental, measured slower than the plain LSD
-                                  // sort — DESIGN.md §4.5): 0 = off, 1 = from 2^27 suffixes, 2 = whenever the key layout allows
-    int hybrid_passes = 0;        // hybrid sort: 0 = fewest global passes that fit, 1..3 = exactly that many
     int key_coding = 0;           // initial sort keys: 0 = dense when that saves a pass, 1 = bit-aligned symbols, 2 = dense
     uint64_t query_hit_budget = 1ull << 31;  // hits resolved per chunk of a batch (16 B of scratch each)
 

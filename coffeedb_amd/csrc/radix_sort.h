@@ -156,35 +156,8 @@ struct TextGen {
     bool padded = false;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
     bool first_only = false;  // entries-only partition by the first symbol: the key is just that symbol's digit
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
-    // hybrid sort (bucket_sort.h): the key K is re-coded as (b = K / hyb_w, r = K % hyb_w): the low `low_bits` bits
-    // of b travel in the auxiliary digits, the rest of b sits above the hyb_rbits bits of r in the 32-bit key, so
-    // the global passes partition by b and every bucket is finished in LDS.  hyb_w = 0: plain keys.
-    uint64_t hyb_w = 0, hyb_magic = 0;  // hyb_magic = floor(2^64 / hyb_w)
-    int hyb_rbits = 0;
 };
 constexpr int RS_GEN_LOOK = 64;
-
-// (b, r) coding of a dense key for the hybrid sort: ((b >> lead) << (rbits + lead)) | (r << lead) | (b & (2^lead - 1))
-__device__ __forceinline__ uint64_t rs_hyb_key(uint64_t kk, uint64_t w, uint64_t magic, int rbits, int lead_bits) {
-    uint64_t q = __umul64hi(kk, magic);  // floor(kk / w) or one less (kk < 2^64: the error of magic is below 1)
-    uint64_t r = kk - q * w;
-    if (r >= w) {
-        r -= w;
-        q += 1;
-    }
-    return ((q >> lead_bits) << (rbits + lead_bits)) | (r << lead_bits) | (q & ((1ull << lead_bits) - 1ull));
-}
-
-// Optional by-product of the LAST global pass of a hybrid sort: where every bucket b starts in the output
-// (atomic minimum over the tiles that hold elements of b; empty buckets are filled in afterwards).  A tile's run of
-// one digit is ordered by the lower digits of b (the input is, and the pass is stable), so bucket starts are the
-// places where b changes between neighbours of the sorted tile.
-struct BStartArgs {
-    void* table = nullptr;  // u32[NB + 1] (wide = 0) or u64[NB + 1]
-    int wide = 0;
-    int rbits = 0;          // b = ((key >> rbits) << lead_bits) | (aux & (2^lead_bits - 1))
-    int lead_bits = 0;
-};
 
 // Segmented passes (the bucket-wise build of corpora >= 2^32, sa_build.hip): ONE launch sorts every first-symbol
 // bucket ("segment") of a bucket group on its own — a tile belongs to exactly one segment (tile_seg), takes its digit
@@ -289,8 +262,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const V* __restrict__ vin, V* __restrict__ vout, uint64_t n,
     int shift, uint32_t dmask, const unsigned long long* __restrict__ digit_start, uint64_t* __restrict__ status,
     uint32_t* __restrict__ ticket, uint32_t epoch, uint32_t* __restrict__ err, Gen gen = Gen(),
-    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr, int aux_shift = -1, BStartArgs bs = BStartArgs(),
-    Seg seg = Seg()) {
+    const W* __restrict__ win = nullptr, W* __restrict__ wout = nullptr, int aux_shift = -1, Seg seg = Seg()) {
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool SEG = !std::is_same<Seg, NoSeg>::value;
     constexpr bool FINAL = std::is_same<Seg, SegFinalArgs>::value;
@@ -462,7 +434,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         const uint64_t cin = q + (uint32_t)nsym <= dend_l ? (uint64_t)s_text[q + nsym - 1] : 0ull;
                         kk = (kk - (uint64_t)s_text[q - 1] * top) * gen.base + cin;
                     }
-                    const uint64_t kx = gen.hyb_w ? rs_hyb_key(kk, gen.hyb_w, gen.hyb_magic, gen.hyb_rbits, gen.low_bits) : kk;
+                    const uint64_t kx = kk;
                     kt[swz(q)] = (uint32_t)(kx >> gen.low_bits);
                     if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx & ((1ull << gen.low_bits) - 1ull));
                     ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
@@ -510,7 +482,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 }
                 uint64_t kk = gen.first_only ? ((uint64_t)s_text[li] << shift)
                                              : rs_pack_key(s_words, li, nsym, gen.base, dend_l - li);
-                if (gen.hyb_w) kk = rs_hyb_key(kk, gen.hyb_w, gen.hyb_magic, gen.hyb_rbits, gen.low_bits);
                 if constexpr (HAS_W) {
                     aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
                     key[j] = (K)(kk >> gen.low_bits);
@@ -826,22 +797,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
                 if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
-                if constexpr (HAS_W && sizeof(K) == 4) {
-                    if (bs.table) {  // (uniform) hybrid sort: first slot of every bucket that starts in this tile
-                        const uint32_t lm = (1u << bs.lead_bits) - 1u;
-                        const uint32_t b = (((uint32_t)k >> bs.rbits) << bs.lead_bits) | ((uint32_t)s_aux[i] & lm);
-                        bool first = i == 0;
-                        if (!first) {
-                            const uint32_t pb = (((uint32_t)s_keys[i - 1] >> bs.rbits) << bs.lead_bits) | ((uint32_t)s_aux[i - 1] & lm);
-                            first = pb != b;
-                        }
-                        if (first) {
-                            const uint64_t at = s_gbase[dd] + i;
-                            if (bs.wide) atomicMin(static_cast<unsigned long long*>(bs.table) + b, (unsigned long long)at);
-                            else atomicMin(static_cast<unsigned int*>(bs.table) + b, (unsigned int)at);
-                        }
-                    }
-                }
             }
         }
         __syncthreads();
@@ -1067,7 +1022,7 @@ template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                    int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
                    const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr, int lead_in = 0,
-                   const BStartArgs* bstart = nullptr, const unsigned long long* d_hist_in = nullptr) {
+                   const unsigned long long* d_hist_in = nullptr) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
@@ -1133,7 +1088,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
             bool trivial = false;
             for (int d = 0; d < 256; ++d)
                 if (h_hist[(size_t)p * 256 + d] == n) trivial = true;
-            if (trivial && (mat || p + 1 < npass) && !(GEN && LEAD > 0 && p == 0) && !bstart) {
+            if (trivial && (mat || p + 1 < npass) && !(GEN && LEAD > 0 && p == 0)) {
                 if (stats) stats->passes_skipped++;
                 continue;
             }
@@ -1159,7 +1114,6 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
         const uint32_t dmask = p == npass - 1 && kpass ? last_mask : ((1u << dbits) - 1u);
         const int shift = begin_bit + dbits * (p - LEAD);  // (unused by the leading passes of a split sort)
         const int aux_shift = p < LEAD ? dbits * p : -1;
-        const BStartArgs bsa = (bstart && ri + 1 == k) ? *bstart : BStartArgs();  // bucket starts come from the last pass
         int t = prof.begin(s);
         if (!materialised) {
             if constexpr (GEN) {
@@ -1171,7 +1125,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                 hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, Gen, W>), dim3(grid_tiles), dim3(Cfg::NT), 0, s,
                                    (const K*)nullptr, kb[cur ^ 1], (const V*)nullptr, vout_p, n, shift, dmask,
                                    (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
-                                   Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift, bsa);
+                                   Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, wb[cur ^ 1], aux_shift);
             }
             prof.end(t, (std::string("rs_onesweep_textgen") + (HAS_W ? "_split" : "") + "_t" + std::to_string(TILE)).c_str(),
                      n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0)), s);
@@ -1181,7 +1135,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                (const K*)kb[cur], kb[cur ^ 1], (const V*)vin_p, vout_p, n, shift, dmask,
                                (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
                                Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e,
-                               ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift, bsa);
+                               ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift);
             prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) : "") + "_t" + std::to_string(TILE)).c_str(),
                      2 * n * pair_bytes, s);
         }
@@ -1224,8 +1178,7 @@ int radix_sort(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, 
         if (!atomrank && (variant == 31 || variant == 36 || variant == 32)) variant -= variant == 32 ? 31 : 10;
 #define CDB_RS(...)                                                                                                      \
     return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, stats, dbits, h_hist_in, \
-                                                    (const NoGen*)nullptr, (NoVal*)nullptr, (NoVal*)nullptr, 0,           \
-                                                    (const BStartArgs*)nullptr, d_hist_in)
+                                                    (const NoGen*)nullptr, (NoVal*)nullptr, (NoVal*)nullptr, 0, d_hist_in)
 #define CDB_RS_GEN(...)                                                                                               \
     if (gen)                                                                                                          \
         return radix_sort_cfg<K, V, RsCfg<__VA_ARGS__>, TextGen>(s, ws, prof, k0, k1, v0, v1, n, begin_bit, end_bit, \
@@ -1280,8 +1233,8 @@ inline void radix_check_error(hipStream_t s, RadixWorkspace& ws) {
 template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
                      W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
-                     const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const BStartArgs* bstart = nullptr,
-                     const unsigned long long* d_hist = nullptr, int lead_digits = -1) {
+                     const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const unsigned long long* d_hist = nullptr,
+                     int lead_digits = -1) {
     // lead_digits: sort digits in the auxiliary array of materialised records (default: every byte of W); the bytes
     // above them are carried along untouched (the bucket-wise build keeps bits 32..39 of its entries there)
     const int lead_in = lead_digits >= 0 ? lead_digits : (int)sizeof(W);
@@ -1299,11 +1252,11 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
         if (gen)                                                                                                       \
             return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n,          \
                                                                                key_begin, hi_bits, stats, dbits,        \
-                                                                               h_hist, gen, w0, w1, 0, bstart);         \
+                                                                               h_hist, gen, w0, w1, 0);                 \
     }                                                                                                                  \
     return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin, hi_bits, \
                                                                      stats, dbits, h_hist, (const NoGen*)nullptr, w0, w1, \
-                                                                     lead_in, bstart, d_hist)
+                                                                     lead_in, d_hist)
     switch (variant) {
         default:
         case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);
@@ -1403,7 +1356,7 @@ void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uin
     hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, W, SEGT>), dim3(grid), dim3(1024), 0, s,            \
                        (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], m, shift, dmask, dstart, \
                        ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift,     \
-                       BStartArgs(), SEGV)
+                       SEGV)
         if (p == npass - 1) {
             if (grouped) CDB_SEG_LAUNCH(CfgG, SegFinalArgs, fin);
             else CDB_SEG_LAUNCH(CfgP, SegFinalArgs, fin);

@@ -35,7 +35,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "bucket_sort.h"
 #include "index_impl.h"
 #include "scan.h"
 
@@ -207,21 +206,6 @@ __global__ __launch_bounds__(256) void sa_sample_count_kernel(const uint64_t* __
     if (threadIdx.x >= 1 && threadIdx.x < 32 && s_eq[threadIdx.x]) atomicAdd(&eq[threadIdx.x], (unsigned long long)s_eq[threadIdx.x]);
 }
 
-// Hybrid sort: how evenly would the buckets b = K / w be filled?  The sorted sample is binned into groups of
-// 2^gshift neighbouring buckets (single buckets hold too few sample keys for a count to mean anything).
-__global__ __launch_bounds__(256) void sa_sample_buckets_kernel(const uint64_t* __restrict__ keys, uint64_t S, int symbits, int kmax,
-                                                                int nsym, uint32_t kbase, uint64_t w, uint64_t magic, int gshift,
-                                                                unsigned int* __restrict__ groups) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= S) return;
-    const uint64_t x = keys[i];
-    uint64_t K = 0;
-    for (int k = 0; k < nsym; ++k) K = K * kbase + ((x >> ((kmax - 1 - k) * symbits)) & ((1ull << symbits) - 1ull));
-    uint64_t b = __umul64hi(K, magic);
-    if (K - b * w >= w) b += 1;
-    atomicAdd(&groups[b >> gshift], 1u);
-}
-
 // ---------------------------------------------------------------------------------------------
 // 2. key generation
 // ---------------------------------------------------------------------------------------------
@@ -291,8 +275,7 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                                                          const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                          uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
                                                          int nsym, int npass, bool padded,
-                                                         unsigned long long* __restrict__ hist, uint64_t hyb_w,
-                                                         uint64_t hyb_magic) {
+                                                         unsigned long long* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) uint8_t s_code[KH_TILE + KG_LOOK];
     __shared__ uint16_t s_map[256];
     __shared__ uint64_t s_drange[2];
@@ -356,11 +339,7 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                     const uint64_t cin = p + (uint64_t)nsym <= dend ? (uint64_t)s_code[li + nsym - 1] : 0ull;
                     key = (key - (uint64_t)s_code[li - 1] * top) * kbase + cin;
                 }
-                uint64_t dk = key;
-                if (hyb_w) {  // hybrid sort: the passes run over the digits of the bucket number b = key / w
-                    dk = __umul64hi(key, hyb_magic);
-                    if (key - dk * hyb_w >= hyb_w) dk += 1;
-                }
+                const uint64_t dk = key;
                 for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(dk >> (8 * q)) & 0xFFu], 1u);
             }
         }
@@ -385,8 +364,7 @@ template <int P>
 __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restrict__ text,
                                                           const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                           uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
-                                                          int npass, bool padded, unsigned long long* __restrict__ hist,
-                                                          uint64_t hyb_w, uint64_t hyb_magic) {
+                                                          int npass, bool padded, unsigned long long* __restrict__ hist) {
     constexpr int NSYM = 3 * P;
     constexpr int NG = KH3_PER + 3 * (P - 1);  // G values a thread needs
     static_assert(NG + 2 <= 48, "window of three 16-byte reads");
@@ -400,11 +378,6 @@ __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restr
     const uint32_t W = kbase * kbase * kbase;
     const uint64_t tiles = (n + KH_TILE - 1) / KH_TILE;
     auto count = [&](uint64_t key) {
-        if (hyb_w) {  // hybrid sort: the passes run over the digits of the bucket number b = key / w
-            uint64_t b = __umul64hi(key, hyb_magic);
-            if (key - b * hyb_w >= hyb_w) b += 1;
-            key = b;
-        }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (q < npass) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
@@ -1516,17 +1489,12 @@ void build_typed(Index& ix, bool big) {
     // too optimistic for correlated text such as multi-byte UTF-8.)  Small corpora use the order-0 model.
     int nsym;
     const int kmax = std::min(64 / symbits, 16);
-    DevBuf sample_sorted;  // the sorted key sample (kept for the hybrid sort's bucket-size estimate)
-    uint64_t sample_n = 0;
-    int sample_kmax = 0;
     if (ix.initial_passes > 0) {
         const int passes = std::min(ix.initial_passes, 8);
         nsym = std::min((8 * passes) / symbits, 64 / symbits);
     } else if (n >= (1ull << 24)) {
         const uint64_t S = n >= (1ull << 32) ? 1ull << 22 : 1ull << 21;  // S^2 / 2 sample pairs must resolve 1 / (64 n)
         DevBuf sk0, sk1, d_eq;
-        sample_n = S;
-        sample_kmax = kmax;
         sk0.alloc(S * 8);
         sk1.alloc(S * 8);
         d_eq.alloc(32 * 8);
@@ -1540,7 +1508,6 @@ void build_typed(Index& ix, bool big) {
         uint64_t h_eq[32];
         CDB_HIP(hipMemcpyAsync(h_eq, d_eq.p, sizeof(h_eq), hipMemcpyDeviceToHost, s));
         CDB_HIP(hipStreamSynchronize(s));
-        sample_sorted = std::move(ssel ? sk1 : sk0);
         const double pairs = (double)S * (double)S / 2.0;
         if (getenv("CDB_DEBUG_SAMPLE")) {
             for (int k = 1; k <= kmax; ++k) std::fprintf(stderr, "[sample] k=%d adjacent-equal=%llu\n", k, (unsigned long long)h_eq[k]);
@@ -1598,13 +1565,6 @@ void build_typed(Index& ix, bool big) {
     int key_bits = nsym * symbits;
     uint32_t kbase = 1u << symbits;
     bool dense = false;
-    // The hybrid sort (bucket_sort.h: a few global passes by bucket = key / w, the rest of the key sorted in LDS)
-    // needs no whole-symbol digits at all, so it always takes the dense coding.  hybrid: 0 = off, 1 = corpora of
-    // 2^27 suffixes and more (where the passes dominate), 2 = whenever the key layout allows (tests).
-    const bool want_hybrid = ix.hybrid != 0 && !big && sizeof(V) == 4 && ix.narrow_keys && ix.fuse_keygen && ix.digit_bits == 0 &&
-                             ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255 && nsym <= HC_MAXSYM &&
-                             (n >= (1ull << 27) || ix.hybrid >= 2) &&
-                             rs_variant_has_gen(ix.sort_variant);
     if (!big && ix.digit_bits == 0 && ix.initial_passes == 0 && ix.key_coding != 1 && sigma < 255) {
         const unsigned __int128 B = (unsigned)sigma + 1u;
         auto bits_of = [&](int k) {  // bits of B^k - 1; 999 when beyond 56 bits
@@ -1617,7 +1577,7 @@ void build_typed(Index& ix, bool big) {
         };
         const int bd = bits_of(nsym);
         const int passes_dense = (int)ceil_div(bd, 8), passes_aligned = (int)ceil_div(key_bits, dbits);
-        if (bd <= 56 && (passes_dense < passes_aligned || ix.key_coding == 2 || want_hybrid)) {
+        if (bd <= 56 && (passes_dense < passes_aligned || ix.key_coding == 2)) {
             dense = true;
             while (nsym < HC_MAXSYM && bits_of(nsym + 1) <= 8 * passes_dense) ++nsym;  // symbols that ride along for free
             key_bits = bits_of(nsym);
@@ -1645,8 +1605,8 @@ void build_typed(Index& ix, bool big) {
                                rs_variant_has_gen(ix.sort_variant));
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
-    // digit histograms of the keys (hyb_w = 0) or of the hybrid sort's bucket numbers, counted in one sweep over the text
-    auto key_histograms = [&](int npass, uint64_t hyb_w, uint64_t hyb_magic) {
+    // digit histograms of the dense keys, counted in one sweep over the text
+    auto key_histograms = [&](int npass) {
         DevBuf d_kh;
         d_kh.alloc((size_t)npass * 256 * sizeof(uint64_t));
         CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
@@ -1655,8 +1615,7 @@ void build_typed(Index& ix, bool big) {
         const bool by3 = ix.keyhist3 && nsym % 3 == 0 && nsym >= 6 && nsym <= 15;
 #define CDB_KH3(PARTS)                                                                                              \
     hipLaunchKernelGGL((sa_keyhist3_kernel<PARTS>), dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n, \
-                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>(), \
-                       hyb_w, hyb_magic)
+                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>())
         if (by3 && nsym == 6) CDB_KH3(2);
         else if (by3 && nsym == 9) CDB_KH3(3);
         else if (by3 && nsym == 12) CDB_KH3(4);
@@ -1664,75 +1623,15 @@ void build_typed(Index& ix, bool big) {
         else
             hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
                                (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
-                               d_kh.as<unsigned long long>(), hyb_w, hyb_magic);
+                               d_kh.as<unsigned long long>());
 #undef CDB_KH3
         ix.prof.end(t, "sa_keyhist", n, s);
         h_hist.assign((size_t)npass * 256, 0);
         CDB_HIP(hipMemcpyAsync(h_hist.data(), d_kh.p, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         CDB_HIP(hipStreamSynchronize(s));
     };
-    // Hybrid plan: G global passes over the digits of b = K / w, then every bucket is finished in LDS.  G is the
-    // smallest number of passes that makes the expected bucket (n / buckets; the keys of real text are close enough
-    // to uniform in key space for that, and a bucket that does not fit sends the build down the plain path) fit a
-    // workgroup; the record must still fit (u32 key, entry, u8 / u16).
-    // Candidates: G = 1, 2, 3 global passes, tried in that order (fewest passes first).  A plan is viable when the
-    // record still fits (u32 key, entry, u8 / u16) and the AVERAGE bucket leaves room for skew (0.7 of a workgroup's
-    // capacity: the keys of even "uniform" text are not uniform in key space — C1's fullest bucket holds 1.33 x the
-    // average).  Gross skew shows in the key sample already and rules a plan out up front; what the sample cannot
-    // see is caught by the bucket sort itself (a bucket that does not fit), and the next plan — more, smaller
-    // buckets — or finally the plain LSD sort takes over.
-    std::vector<HybridPlan> plans;
-    if (want_hybrid && fused && dense && key_bits <= 56) {
-        unsigned __int128 space = 1;
-        for (int i = 0; i < nsym; ++i) space *= kbase;
-        const int cap = n >= (1ull << 22) ? BS_CAP_BIG : BS_CAP_SMALL;
-        for (int G = 1; G <= 3; ++G) {
-            if (ix.hybrid_passes && G != ix.hybrid_passes) continue;  // (option: only this many global passes)
-            const unsigned __int128 nbmax = (unsigned __int128)1 << (8 * G);
-            const uint64_t w = (uint64_t)std::max<unsigned __int128>((space + nbmax - 1) / nbmax, 1);
-            const uint64_t nb = (uint64_t)((space + w - 1) / w);
-            const int rbits = bit_width64(w - 1);
-            if (w == 1) break;  // (nothing left to sort inside a bucket: the plain sort is as good)
-            if ((double)n / (double)nb > 0.7 * cap) continue;
-            if (rbits > 24) continue;  // (the bucket sort packs a round's key into 25 bits beside a 15-bit index)
-            int lead = 0;
-            if (rbits + 8 * (G - 1) <= 32) lead = 1;
-            else if (G >= 2 && rbits + 8 * (G - 2) <= 32) lead = 2;
-            if (!lead) continue;
-            HybridPlan p;
-            p.ok = true;
-            p.G = G;
-            p.lead = lead;
-            p.rbits = rbits;
-            p.w = w;
-            p.magic = ~0ull / w;  // floor(2^64 / w), or one less for a power of two: the quotient is corrected either way
-            p.nb = nb;
-            p.cap = cap;
-            if (sample_sorted.p && G < 3) {  // fullest group of buckets in the sample, with 20 % for what happens inside a group
-                const int gshift = std::max(0, bit_width64(nb - 1) - 10);
-                const uint64_t ngroups = (nb >> gshift) + 1;
-                DevBuf d_groups;
-                d_groups.alloc(ngroups * sizeof(uint32_t));
-                CDB_HIP(hipMemsetAsync(d_groups.p, 0, ngroups * sizeof(uint32_t), s));
-                hipLaunchKernelGGL(sa_sample_buckets_kernel, dim3((unsigned)ceil_div(sample_n, 256)), dim3(256), 0, s,
-                                   (const uint64_t*)sample_sorted.as<uint64_t>(), sample_n, symbits, sample_kmax, nsym, kbase, w, p.magic,
-                                   gshift, d_groups.as<unsigned int>());
-                std::vector<uint32_t> hg(ngroups);
-                CDB_HIP(hipMemcpyAsync(hg.data(), d_groups.p, ngroups * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                CDB_HIP(hipStreamSynchronize(s));
-                const double est = (double)*std::max_element(hg.begin(), hg.end()) / (double)(1ull << gshift) * ((double)n / (double)sample_n) * 1.2;
-                st.hybrid_estimate = (uint64_t)est;
-                if (est > 0.95 * cap) continue;
-            }
-            plans.push_back(p);
-            if (plans.size() == 2) break;
-        }
-    }
-    sample_sorted.release();
-    HybridPlan plan = plans.empty() ? HybridPlan() : plans[0];
     if (fused && dense) {
-        if (plan.ok) key_histograms(plan.G, plan.w, plan.magic);
-        else key_histograms((int)ceil_div(key_bits, 8), 0, 0);
+        key_histograms((int)ceil_div(key_bits, 8));
     } else if (fused && !big) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
@@ -1788,8 +1687,6 @@ void build_typed(Index& ix, bool big) {
     DevBuf sorted_k32, sorted_low;
     const int low_bits = layout == SPLIT ? dbits : (layout == SPLIT2 ? 2 * dbits : 0);
     const int low_bytes = layout == SPLIT ? 1 : (layout == SPLIT2 ? 2 : 0);
-    int hyb_low_bits = low_bits;  // low digits of the KEPT keys (the hybrid sort always keeps them split)
-    bool flags_done = false;  // the hybrid sort writes the group flags itself
     if (!big && layout != WIDE) {
         if constexpr (sizeof(V) == 4) {
             DevBuf k32[2], vals[2], low[2];
@@ -1797,72 +1694,16 @@ void build_typed(Index& ix, bool big) {
             k32[1].alloc(n * sizeof(uint32_t));
             vals[0].alloc(n * sizeof(V));
             vals[1].alloc(n * sizeof(V));
-            int low_alloc = low_bytes;
-            for (const HybridPlan& hp : plans) low_alloc = std::max(low_alloc, hp.lead);
-            if (low_alloc) {
-                low[0].alloc(n * low_alloc);
-                low[1].alloc(n * low_alloc);
+            if (low_bytes) {
+                low[0].alloc(n * low_bytes);
+                low[1].alloc(n * low_bytes);
             }
             st.alloc_ms += now_ms() - ta;
             if (getenv("CDB_DEBUG_BUFS"))
                 std::fprintf(stderr, "[bufs] k32 %p %p vals %p %p low %p %p flags %p\n", k32[0].p, k32[1].p, vals[0].p, vals[1].p, low[0].p,
                              low[1].p, flags.p);
             int sel = 0;
-            for (size_t attempt = 0; attempt < plans.size() && !flags_done; ++attempt) {
-                // ---- hybrid: G global passes by bucket, buckets finished in LDS (bucket_sort.h)
-                plan = plans[attempt];
-                if (attempt > 0) key_histograms(plan.G, plan.w, plan.magic);
-                DevBuf bstart;
-                bstart.alloc((plan.nb + 1) * sizeof(uint32_t));
-                CDB_HIP(hipMemsetAsync(bstart.p, 0xFF, (plan.nb + 1) * sizeof(uint32_t), s));
-                BStartArgs bsa;
-                bsa.table = bstart.p;
-                bsa.wide = 0;
-                bsa.rbits = plan.rbits;
-                bsa.lead_bits = 8 * plan.lead;
-                TextGen hgen = gen;
-                hgen.low_bits = 8 * plan.lead;
-                hgen.hyb_w = plan.w;
-                hgen.hyb_magic = plan.magic;
-                hgen.hyb_rbits = plan.rbits;
-                const int hi_bits = plan.rbits + 8 * (plan.G - plan.lead);
-                uint64_t largest = 0;
-                bool ok;
-                if (plan.lead == 1) {
-                    sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
-                                                       vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n, hi_bits, &ss,
-                                                       ix.sort_variant, 8, h_hist.data(), &hgen, plan.rbits, &bsa);
-                    ok = bucket_sort_finish<V, uint8_t, uint32_t, uint8_t>(
-                        s, ix.prof, ix.scan_partials, k32[sel].as<uint32_t>(), vals[sel].as<V>(), low[sel].as<uint8_t>(),
-                        bstart.as<uint32_t>(), plan, n, kbase, kmagic, 8, flags.as<uint8_t>(),
-                        ix.keep_keys ? low[sel].as<uint8_t>() : (uint8_t*)nullptr, &largest);
-                } else {
-                    sel = radix_sort_split<V, uint16_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
-                                                        vals[1].as<V>(), low[0].as<uint16_t>(), low[1].as<uint16_t>(), n, hi_bits, &ss,
-                                                        ix.sort_variant, 8, h_hist.data(), &hgen, plan.rbits, &bsa);
-                    ok = bucket_sort_finish<V, uint16_t, uint32_t, uint16_t>(
-                        s, ix.prof, ix.scan_partials, k32[sel].as<uint32_t>(), vals[sel].as<V>(), low[sel].as<uint16_t>(),
-                        bstart.as<uint32_t>(), plan, n, kbase, kmagic, 16, flags.as<uint8_t>(),
-                        ix.keep_keys ? low[sel].as<uint16_t>() : (uint16_t*)nullptr, &largest);
-                }
-                st.hybrid = ok ? plan.G : -1;
-                st.hybrid_largest_bucket = largest;
-                if (ok) {
-                    flags_done = true;
-                    layout = plan.lead == 1 ? SPLIT : SPLIT2;  // (the layout of the kept keys)
-                    st.key_layout = (int)layout;
-                } else {
-                    // a bucket larger than a workgroup's capacity (skewed key distribution): the next plan (more, smaller
-                    // buckets) or, after the last one, the plain LSD sort redoes the work
-                    plan.ok = false;
-                    st.hybrid_retries++;
-                }
-            }
-            if (!plans.empty() && !flags_done) key_histograms((int)ceil_div(key_bits, 8), 0, 0);
-            const int low_bits_h = flags_done ? 8 * plan.lead : low_bits;
-            if (flags_done) {
-                sorted_low = std::move(low[sel]);
-            } else if (layout == SPLIT) {
+            if (layout == SPLIT) {
                 gen.low_bits = low_bits;
                 sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
                                                    vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n,
@@ -1878,7 +1719,6 @@ void build_typed(Index& ix, bool big) {
                 sel = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
                                               vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
             }
-            hyb_low_bits = low_bits_h;
             CDB_HIP(hipStreamSynchronize(s));
             sorted_k32 = std::move(k32[sel]);
             sa_buf = std::move(vals[sel]);
@@ -2243,7 +2083,7 @@ void build_typed(Index& ix, bool big) {
                         if constexpr (HAS_W)
                             r = radix_sort_split<V, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), eb, ET.as<V>(), lb, lowt.as<W>(), cnt,
                                                        bbits - blow, &ss, ix.sort_variant, 8, (const uint64_t*)nullptr,
-                                                       (const TextGen*)nullptr, 0, (const BStartArgs*)nullptr, hb);
+                                                       (const TextGen*)nullptr, 0, hb);
                         else
                             r = radix_sort<K, V>(s, ix.rws, ix.prof, kb, k32t.as<K>(), eb, ET.as<V>(), cnt, 0, bbits, &ss,
                                                  ix.sort_variant, 8, (const uint64_t*)nullptr, (const TextGen*)nullptr, hb);
@@ -2298,8 +2138,7 @@ void build_typed(Index& ix, bool big) {
                             ix.rws.value_spare = nullptr;
                             r = radix_sort_split<uint32_t, W>(s, ix.rws, ix.prof, kb, k32t.as<uint32_t>(), vb, elot.as<uint32_t>(), lb,
                                                               lowt.as<W>(), cnt, bbits - blow, &ss, ix.sort_variant, 8,
-                                                              (const uint64_t*)nullptr, (const TextGen*)nullptr, 0,
-                                                              (const BStartArgs*)nullptr, hb, lowb);
+                                                              (const uint64_t*)nullptr, (const TextGen*)nullptr, 0, hb, lowb);
                             vr = ix.rws.value_result;
                         }
                         const W* ls = r ? lowt.as<W>() : lb;
@@ -2360,7 +2199,7 @@ void build_typed(Index& ix, bool big) {
         sa_buf = std::move(E);
     }
     bool tile_sums_ready = false;  // the flag kernel has left the raw tile sums of the first compaction in scan_partials
-    if (!big && !flags_done) {  // (the bucket-wise and the hybrid sort write the flags themselves)
+    if (!big) {  // (the bucket-wise sort writes the flags itself)
         int t = ix.prof.begin(s);
         if (layout == WIDE)
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
@@ -2393,8 +2232,8 @@ void build_typed(Index& ix, bool big) {
         ix.d_keys = std::move(sorted_keys);
         ix.d_keys32 = std::move(sorted_k32);
         ix.d_keylow = std::move(sorted_low);
-        ix.key_low_bits = flags_done ? hyb_low_bits : low_bits;
-        ix.key_low_bytes = flags_done ? hyb_low_bits / 8 : low_bytes;
+        ix.key_low_bits = low_bits;
+        ix.key_low_bytes = low_bytes;
         ix.key_nsym = nsym;
         ix.key_base = kbase;
     } else {

@@ -59,9 +59,8 @@ def test_fuzz_parity(seed):
     if rng.random() < 0.2: opts["fast_search"] = 0
     if rng.random() < 0.2: opts["wave_rows"] = 0
     rng2 = np.random.default_rng(50_000 + seed)   # (its own stream: the draws above keep their seeds' meaning)
-    if rng2.random() < 0.35:                       # the experimental hybrid initial sort, any number of global passes
-        opts["hybrid"] = 2
-        if rng2.random() < 0.6: opts["hybrid_passes"] = int(rng2.integers(1, 4))
+    if rng2.random() < 0.35:                       # the lone-keyword path through the resident workgroup
+        opts["resident_query"] = 1
     o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
     g = capi.GpuStringIndex()
     for k, v in opts.items():

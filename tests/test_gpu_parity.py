@@ -1123,21 +1123,6 @@ def test_reference_order_verifier_agrees_with_oracle_parity(G):
             assert v["mixed_pairs"] == 0
 
 
-def test_hybrid_sort_option_matches_oracle(G):
-    # the experimental hybrid initial sort (bucket_sort.h: global passes by bucket = key / w, buckets finished in LDS by a
-    # counting pass + wavefront sorts) must give the same suffix array as the plain LSD sort; a skewed corpus makes a
-    # bucket overflow and exercises the fall-back chain
-    cases = [W.ascii_corpus(3000, 200, seed=5), W.ragged_corpus(4000, 150, seed=9, empty_every=7),
-             W.zipf_corpus(1500, 256, seed=2), W.utf8_corpus(300, 120, seed=4),
-             (np.full(60000, 0x61, dtype=np.uint8), W.uniform_docs(300, 200))]
-    took = 0
-    for blob, ds in cases:
-        pats = W.sample_patterns(blob, ds, 200, 1, 8, seed=3)
-        g, _ = _check_parity(G, blob, ds, patterns=pats, hybrid=2)
-        took += g.stat("hybrid") > 0
-    assert took >= 2
-
-
 def test_bulk_raw_directory_ingest(G, tmp_path):
     # f3: a raw/ directory in the reference's on-disk layout (database.cpp:334-378: one file per object, named by its
     # id) loaded in one call; same index as adding the values one by one; malformed files fail the call atomically
