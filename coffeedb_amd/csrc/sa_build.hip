@@ -1118,6 +1118,25 @@ struct HeadIn {  // group start (+1) of compacted entry j, 0 for non-heads  -> m
     const I* U;
     __device__ __forceinline__ uint64_t operator()(uint64_t j) const { return nh[j] ? (uint64_t)U[j] + 1 : 0ull; }
 };
+// Prefix doubling compares RANKS, and a rank is a slot number of the array: it orders suffixes correctly only while the
+// array's slot order is the plain unsigned order.  When the bucket-wise build lays blocks out in the reference's order
+// (first-symbol buckets by signed byte, the two byte blocks of radix-node buckets swapped) a rank is taken through the
+// inverse of that block permutation first: slot -> where the slot would sit in unsigned order.  nseg = 0: identity.
+struct SlotOrder {
+    const unsigned long long* a_start = nullptr;  // [nseg] block starts in the array, ascending
+    const unsigned long long* u_start = nullptr;  // [nseg] where each block starts in unsigned order
+    uint32_t nseg = 0;
+    __device__ __forceinline__ uint64_t operator()(uint64_t slot) const {
+        if (nseg == 0) return slot;
+        uint32_t lo = 0, hi = nseg - 1;  // last block with a_start <= slot
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo + 1) / 2;
+            if (a_start[mid] <= slot) lo = mid; else hi = mid - 1;
+        }
+        return slot - a_start[lo] + u_start[lo];
+    }
+};
+
 template <typename V, typename I, typename R>
 struct UpdateOut {
     const V* sval;
@@ -1131,10 +1150,11 @@ struct UpdateOut {
     uint8_t* flags;
     R* rank;
     unsigned long long* still_open;
+    SlotOrder order;
     __device__ __forceinline__ void operator()(uint64_t j, uint64_t, uint64_t incl) const {
         uint64_t q;
         sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
-        rank[q] = (R)incl;
+        rank[q] = (R)(order(incl - 1) + 1);  // (incl = the group's first slot + 1)
     }
 };
 
@@ -1150,10 +1170,11 @@ struct IsaOut {
     int bits;
     uint64_t mask;
     R* rank;
+    SlotOrder order;
     __device__ __forceinline__ void operator()(uint64_t i, uint64_t, uint64_t incl) const {
         const V v = sa[i];
         const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
-        rank[doc_start[d] + d + off] = (R)incl;
+        rank[doc_start[d] + d + off] = (R)(order(incl - 1) + 1);
     }
 };
 
@@ -2245,6 +2266,47 @@ void build_typed(Index& ix, bool big) {
     V* sa = sa_buf.as<V>();
 
     // ---- 4. refinement rounds
+    // slot order of the array as the bucket-wise build laid it out -> plain unsigned order (ranks of prefix doubling)
+    DevBuf d_order;
+    SlotOrder order;
+    if (!folded_roots.empty()) {
+        struct Blk { unsigned long long a, len; int code, cls; };  // cls: 0 = end of document, 1 = bytes < 0x80, 2 = bytes >= 0x80
+        std::vector<Blk> blks;
+        std::vector<int> code_of_root;  // first-symbol code of every root bucket, in array order
+        {
+            for (int b = 128; b < 256; ++b) if (h_map[b]) code_of_root.push_back(h_map[b]);
+            for (int b = 0; b < 128; ++b) if (h_map[b]) code_of_root.push_back(h_map[b]);
+        }
+        for (size_t b = 0; b < folded_roots.size(); ++b) {
+            const CompatBucket r = folded_roots[b];
+            if (!depth1.empty() && depth1[b].done) {  // written as [end][high][low]
+                blks.push_back(Blk{r.lo, depth1[b].nend, code_of_root[b], 0});
+                blks.push_back(Blk{r.lo + depth1[b].nend, depth1[b].nhigh, code_of_root[b], 2});
+                blks.push_back(Blk{r.lo + depth1[b].nend + depth1[b].nhigh, depth1[b].nlow, code_of_root[b], 1});
+            } else {
+                blks.push_back(Blk{r.lo, r.hi - r.lo, code_of_root[b], 0});
+            }
+        }
+        // unsigned order: by first-symbol code, inside a bucket [end][low][high]
+        std::vector<size_t> by_u(blks.size());
+        for (size_t i = 0; i < by_u.size(); ++i) by_u[i] = i;
+        std::sort(by_u.begin(), by_u.end(), [&](size_t x, size_t y) {
+            return blks[x].code != blks[y].code ? blks[x].code < blks[y].code : blks[x].cls < blks[y].cls;
+        });
+        std::vector<unsigned long long> tab(2 * blks.size());
+        unsigned long long at = 0;
+        for (size_t i : by_u) {
+            tab[blks.size() + i] = at;
+            at += blks[i].len;
+        }
+        for (size_t i = 0; i < blks.size(); ++i) tab[i] = blks[i].a;
+        d_order.alloc(tab.size() * sizeof(unsigned long long));
+        CDB_HIP(hipMemcpyAsync(d_order.p, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        order.a_start = d_order.as<unsigned long long>();
+        order.u_start = d_order.as<unsigned long long>() + blks.size();
+        order.nseg = (uint32_t)blks.size();
+    }
     DevBuf U, skey[2], sval[2], nh, rank;
     uint64_t h = (uint64_t)nsym;
     bool isa = false;
@@ -2283,7 +2345,7 @@ void build_typed(Index& ix, bool big) {
                 CDB_HIP(hipMemsetAsync(rank.p, 0, (n + D + 1) * sizeof(R), s));
                 AllHeadIn ain{flags.as<uint8_t>()};
                 (void)scan_totals<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0);
-                IsaOut<V, R> iout{sa, doc_start, (int)ix.bits, ix.mask, rank.as<R>()};
+                IsaOut<V, R> iout{sa, doc_start, (int)ix.bits, ix.mask, rank.as<R>(), order};
                 int t = ix.prof.begin(s);
                 scan_apply<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0, iout);
                 ix.prof.end(t, "sa_isa_init", n * (1 + sizeof(V) + sizeof(R)), s);
@@ -2331,7 +2393,7 @@ void build_typed(Index& ix, bool big) {
                 HeadIn<I> hin{nh.as<uint8_t>(), U.as<I>()};
                 (void)scan_totals<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0);
                 UpdateOut<V, I, R> uo{sval[rs].as<V>(), U.as<I>(), nh.as<uint8_t>(), m, doc_start, (int)ix.bits,
-                                      ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>(), d_open.as<unsigned long long>()};
+                                      ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>(), d_open.as<unsigned long long>(), order};
                 scan_apply<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0, uo);
                 st.dbl_rounds++;
             } else {

@@ -81,3 +81,59 @@ def test_fuzz_parity(seed):
     for kw in kws[:6]:   # a lone keyword takes the one-wavefront kernel (<= 4096 hits) or hands over to the batch path
         assert g.query(kw) == o.query(kw), (seed, opts, kw)
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_SEG_N", "16"))))
+def test_fuzz_segmented_bucket_wise_parity(seed):
+    """The >= 2^32 code path with 8-byte entries (packed records, segmented passes, entries + flags from the last pass,
+    reference order folded into the sort) on seeded corpora small enough for the oracle: tens of thousands of tiny
+    documents and one long one make bits + offset bits exceed 32; alphabets from 2 symbols to all 256 byte values."""
+    from coffeedb_amd import capi
+    from oracle import OracleIndex
+    rng = np.random.default_rng(7000 + seed)
+    nd = int(rng.integers(33000, 60000))
+    lens = rng.integers(0, 6, size=nd).astype(np.uint64)
+    lens[int(rng.integers(0, nd))] = int(rng.integers(66000, 120000))
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(ds[-1])
+    kind = int(rng.integers(0, 5))
+    if kind == 0:      # a handful of symbols on both sides of 0x80: radix nodes several levels deep
+        syms = sorted(set(int(x) for x in rng.choice([0x00, 0x10, 0x41, 0x42, 0x7F, 0x80, 0xA9, 0xC3, 0xE2, 0xFF], size=int(rng.integers(2, 6)))))
+        blob = np.asarray(syms, dtype=np.uint8)[W.random_bytes(n, int(rng.integers(1 << 30)), 0, len(syms) - 1)]
+    elif kind == 1:    # any byte range
+        lo = int(rng.integers(0, 200)); hi = int(min(255, lo + rng.integers(1, 200)))
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), lo, hi)
+    elif kind == 2:    # skewed
+        blob = W.zipf_corpus(1, n, seed=int(rng.integers(1 << 30)))[0][:n]
+    elif kind == 3:    # all 256 byte values
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), 0, 255)
+    else:              # repeats: equal suffixes from different documents, groups that never resolve
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), 0x61, 0x63)
+        half = n // 3
+        blob[half:2 * half] = blob[:half]
+    ids = rng.permutation(nd).astype(np.int64) * 2 + 9
+    opts = {"force_big_path": 1}
+    if rng.random() < 0.5: opts["bucket_group_limit"] = int(rng.integers(1, 80000))
+    if rng.random() < 0.25: opts["segmented_sort"] = 0
+    if rng.random() < 0.25: opts["fold_root"] = 0
+    if rng.random() < 0.25: opts["fold_depth1"] = 0
+    if rng.random() < 0.3: opts["plain_tile_order"] = 1
+    if rng.random() < 0.3: opts["force_doubling"] = 1
+    if rng.random() < 0.2: opts["reference_compat"] = 0
+    if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
+    g = capi.GpuStringIndex()
+    for k, v in opts.items():
+        g.set_option(k, v)
+    g.add_bulk(ids, blob, ds)
+    g.build()
+    assert g.sa_width == 8 and g.stat("bucketed") == 1, opts
+    if opts.get("reference_compat", 1):
+        o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
+        assert np.array_equal(g.sa(), o.sa()), (seed, kind, opts)
+        pb, po = W.sample_patterns(blob, ds, 120, 1, 9, seed=seed, miss_frac=0.1, miss_byte=int(blob[0]) ^ 0x55)
+        got, want = g.query_batch(pb, po), o.query_batch(pb, po)
+        assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])), (seed, kind, opts)
+    else:              # plain unsigned order: a sorted permutation (the oracle restates the reference's order)
+        v = g.verify()
+        assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"], (seed, kind, opts)
+    g.close()
