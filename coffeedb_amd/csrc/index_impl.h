@@ -29,6 +29,7 @@ struct BuildStats {
     int bucket_low_digits = 0;   // ... low digits (bytes) carried beside the 32-bit bucket key
     int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
     int root_folded = 0;         // ... first-symbol buckets laid out in the reference's root order (bytes >= 0x80 first)
+    int flags_in_last_pass = 0;  // single sort: group flags written by the last radix pass (no flag kernel)
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -134,6 +135,7 @@ struct Index {
     int initial_passes = 0;
     int sort_variant = 0;
     int search_lanes = 0;      // lanes per keyword in the fast batched search: 0 = by batch size, 1 or 8
+    bool flags_in_last_pass = true;  // builds below 2^32: the last radix pass writes the group flags (0 = the flag kernel)
     bool fold_depth1 = true;     // ... and (segmented sort) the two byte blocks of big first-symbol buckets swapped by the last pass
     bool fold_root = true;       // bucket-wise build under reference_compat: bucket order = the reference's root child order
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags

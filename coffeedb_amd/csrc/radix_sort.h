@@ -205,6 +205,20 @@ struct SegFinalArgs : SegArgs {
     int abl = 0;                // timing experiments only (WRONG results): 1 = no flag stores, 2 = no entry stores, 4 = no neighbour compares
 };
 
+// The last pass of an ordinary (single-segment) sort of split records can do the same and still write its records (the
+// kept search keys): the suffix-array build below 2^32 then needs no flag kernel (5-6 B read + 1 B written per suffix).
+// tile_sums (optional): per scan tile of `sums_tile` flags {unresolved entries, unresolved group heads} as pairs of u64 —
+// what the first compaction of the refinement wants; counted here (unresolved entries are rare), corrected by the edge fix.
+struct SegFinalKeepArgs : SegArgs {
+    uint8_t* flags = nullptr;
+    SegEdge* edges = nullptr;
+    int low_bits = 0;
+    uint32_t kbase = 2;
+    unsigned long long kmagic = 0;
+    unsigned long long* tile_sums = nullptr;
+    uint32_t sums_tile = 1;
+};
+
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
 // in byte i): Horner over the first nsym (<= 16) codes in base `base`, first symbol most significant; codes
 // at or behind the end of the document (rem symbols left) count as 0.  Four codes at a time are combined
@@ -266,6 +280,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool SEG = !std::is_same<Seg, NoSeg>::value;
     constexpr bool FINAL = std::is_same<Seg, SegFinalArgs>::value;
+    constexpr bool KEEP = std::is_same<Seg, SegFinalKeepArgs>::value;  // flags + edge records beside the ordinary record write-out
+    constexpr bool FLAGS = FINAL || KEEP;
     static_assert(!SEG || (!GEN && Cfg::REUSE && !Cfg::DMA), "segmented passes: materialised records, shared staging");
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     SegInfo si = {};
     if constexpr (SEG) {
         if (tile >= (uint64_t)seg.tiles) return;  // (the grid is rounded up to whole tile groups)
-        sg = seg.tile_seg[tile];
+        sg = seg.tile_seg ? seg.tile_seg[tile] : 0u;  // (no map: one segment)
         si = seg.segs[sg];
         tile0 = si.tile_begin;
         base = si.begin + (tile - tile0) * TILE;
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         s_gbase[d] = (Cfg::ABL & 2) ? base : dstart + excl - (uint64_t)tstart;
     }
     __syncthreads();
-    if constexpr (FINAL) {
+    if constexpr (FLAGS) {
         if (tid < 256) {  // edge record of this tile's run of digit d (the sorted keys sit in LDS until the next barrier)
             SegEdge e;
             e.first = e.last = 0;
@@ -779,21 +795,38 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const K k = s_keys[i];
                 const uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
                 dig[j] = (uint8_t)dd;
-                if constexpr (FINAL) {
+                if constexpr (FLAGS) {
                     // group flags from the neighbours in the sorted tile (equal keys have equal digits, so the ends of
                     // a digit run come out as head / tail: provisional there, settled by rs_seg_edge_fix_kernel)
-                    const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
-                    const uint64_t kc = ((uint64_t)k << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i : 0] & lmask);
+                    // (32-bit compares; the "key ends inside the document" test — a 64-bit division by the alphabet size —
+                    //  only for the rare element that has an equal neighbour: the pass stays memory-bound)
+                    const uint32_t lmask = seg.low_bits >= 32 ? 0xFFFFFFFFu : (1u << seg.low_bits) - 1u;
+                    const uint32_t ac = (uint32_t)s_aux[HAS_W ? i : 0] & lmask;
                     bool head = true, tail = true;
-                    if (!(seg.abl & 4)) {
-                    if (i > 0) head = (((uint64_t)s_keys[i - 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i - 1 : 0] & lmask)) != kc;
-                    if (i + 1 < valid) tail = (((uint64_t)s_keys[i + 1] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? i + 1 : 0] & lmask)) != kc;
+                    bool cmp = true;
+                    if constexpr (FINAL) cmp = !(seg.abl & 4);
+                    if (cmp) {
+                        if (i > 0) head = s_keys[i - 1] != k || ((uint32_t)s_aux[HAS_W ? i - 1 : 0] & lmask) != ac;
+                        if (i + 1 < valid) tail = s_keys[i + 1] != k || ((uint32_t)s_aux[HAS_W ? i + 1 : 0] & lmask) != ac;
                     }
-                    const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
-                                                      : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
-                    if (!(seg.abl & 1))
-                        seg.flags[rs_seg_rotated(si, s_gbase[dd] + i)] = (uint8_t)((head ? 1 : 0) | ((!(head && tail) && !exhausted) ? 2 : 0));
-                    continue;
+                    uint32_t f = head ? 1u : 0u;
+                    if (!(head && tail)) {
+                        const uint64_t kc = ((uint64_t)k << seg.low_bits) | (uint64_t)ac;
+                        const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
+                                                          : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
+                        if (!exhausted) f |= 2u;
+                    }
+                    if constexpr (FINAL) {
+                        if (!(seg.abl & 1)) seg.flags[rs_seg_rotated(si, s_gbase[dd] + i)] = (uint8_t)f;
+                        continue;
+                    } else {
+                        const uint64_t slot = s_gbase[dd] + i;
+                        seg.flags[slot] = (uint8_t)f;
+                        if ((f & 2u) && seg.tile_sums) {  // (rare: a fraction of a percent of the suffixes stays unresolved)
+                            atomicAdd(seg.tile_sums + 2 * (slot / seg.sums_tile), 1ull);
+                            if (f & 1u) atomicAdd(seg.tile_sums + 2 * (slot / seg.sums_tile) + 1, 1ull);
+                        }
+                    }
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
                 if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
@@ -822,12 +855,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 // and both elements belong to an unresolved group unless the key ends inside the document.
 static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEdge* __restrict__ edges, const uint32_t* __restrict__ tile_seg,
                                                                      const SegInfo* __restrict__ segs, uint32_t tiles,
-                                                                     uint8_t* __restrict__ flags, uint32_t kbase, unsigned long long kmagic) {
+                                                                     uint8_t* __restrict__ flags, uint32_t kbase, unsigned long long kmagic,
+                                                                     unsigned long long* __restrict__ tile_sums = nullptr,
+                                                                     uint32_t sums_tile = 1) {
     const uint32_t t = blockIdx.x, d = threadIdx.x;
     if (t >= tiles) return;
     const SegEdge e = edges[(size_t)t * 256 + d];
     if (!e.cnt) return;
-    const SegInfo si = segs[tile_seg[t]];
+    const SegInfo si = segs[tile_seg ? tile_seg[t] : 0u];
     const uint32_t t0 = si.tile_begin;
     if (t == t0) return;
     // largest t' in [t0, t) whose run starts in front of this one (runs of tiles without the digit share its start)
@@ -845,17 +880,35 @@ static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEd
     const SegEdge pe = edges[(size_t)lo * 256 + d];
     if (pe.last != e.first) return;
     const bool exhausted = kmagic ? (e.first - __umul64hi(e.first, kmagic) * kbase) == 0 : (e.first & (uint64_t)(kbase - 1u)) == 0;
-    auto patch = [&](unsigned long long slot, uint32_t clear, uint32_t set) {
+    // one atomic per change; the old value each one returns says exactly what that change did to the tile sums
+    auto change = [&](unsigned long long slot, uint32_t clear, uint32_t set) {
         // (the word that holds the byte: `flags` points at the group's first flag, which need not be 4-byte aligned;
         //  the flag array itself is a 256-byte-aligned device block, so the word lies inside it)
         const uintptr_t a = reinterpret_cast<uintptr_t>(flags + slot);
         unsigned int* w = reinterpret_cast<unsigned int*>(a & ~(uintptr_t)3);
         const uint32_t sh = 8u * (uint32_t)(a & 3u);
-        if (clear) atomicAnd(w, ~(clear << sh));
-        if (set) atomicOr(w, set << sh);
+        uint32_t before, after;
+        if (clear) {
+            before = (atomicAnd(w, ~(clear << sh)) >> sh) & 0xFFu;
+            after = before & ~clear;
+        } else {
+            before = (atomicOr(w, set << sh) >> sh) & 0xFFu;
+            after = before | set;
+        }
+        if (tile_sums && before != after) {
+            const long long da = (long long)((after >> 1) & 1u) - (long long)((before >> 1) & 1u);
+            const long long db = (long long)((after >> 1) & after & 1u) - (long long)((before >> 1) & before & 1u);
+            unsigned long long* ts = tile_sums + 2 * (slot / sums_tile);
+            if (da) atomicAdd(ts, (unsigned long long)da);
+            if (db) atomicAdd(ts + 1, (unsigned long long)db);
+        }
     };
-    patch(rs_seg_rotated(si, e.pos), 1u, exhausted ? 0u : 2u);       // first of this run: not a head
-    patch(rs_seg_rotated(si, e.pos - 1), 0u, exhausted ? 0u : 2u);   // last of the run in front: not a tail
+    const unsigned long long sb = rs_seg_rotated(si, e.pos), sa_ = rs_seg_rotated(si, e.pos - 1);
+    change(sb, 1u, 0u);                    // first of this run: not a head
+    if (!exhausted) {
+        change(sb, 0u, 2u);                // ... and part of an unresolved group, like
+        change(sa_, 0u, 2u);               // the last of the run in front: not a tail
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -954,6 +1007,9 @@ struct RadixWorkspace {
     // value_result says where the values ended up (0 = v0, 1 = v1)
     void* value_spare = nullptr;
     int value_result = 0;
+    DevBuf seg1;               // one SegInfo: the whole array as a single segment (flags written by the last pass)
+    SegInfo h_seg1 = {};
+    bool keep_applied = false;  // the last pass of the previous sort wrote the group flags (SegFinalKeepArgs)
     uint32_t epoch = 0;
     uint64_t min_tile = 0;
     // XCD-aware tile order (RS_GROUP) is used only where the caller can redo the sort after a starved pass: the
@@ -989,7 +1045,7 @@ struct RadixWorkspace {
     uint32_t* ticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + (e & 255u); }
     uint32_t* xticket_ptr(uint32_t e) { return tickets.as<uint32_t>() + 260 + (e & 255u) * 8; }
     uint32_t* err_ptr() { return tickets.as<uint32_t>() + 256; }
-    void release() { hist.release(); status.release(); tickets.release(); tile_doc.release(); epoch = 0; }
+    void release() { hist.release(); status.release(); tickets.release(); tile_doc.release(); seg1.release(); epoch = 0; }
 };
 
 template <typename K, typename V> inline const char* rs_kernel_name();
@@ -1022,7 +1078,7 @@ template <typename K, typename V, typename Cfg, typename Gen = NoGen, typename W
 int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* k1, V* v0, V* v1, uint64_t n,
                    int begin_bit, int end_bit, SortStats* stats, int dbits, const uint64_t* h_hist_in = nullptr,
                    const Gen* gen = nullptr, W* w0 = nullptr, W* w1 = nullptr, int lead_in = 0,
-                   const unsigned long long* d_hist_in = nullptr) {
+                   const unsigned long long* d_hist_in = nullptr, const SegFinalKeepArgs* keep = nullptr) {
     constexpr int IPT = Cfg::IPT;
     constexpr int TILE = Cfg::NT * IPT;
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
@@ -1045,6 +1101,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
     const int last_bits = kpass ? nbits - dbits * (kpass - 1) : dbits;
     const uint32_t last_mask = (1u << last_bits) - 1u;
     ws.prepare(n, TILE, s);
+    ws.keep_applied = false;
 
     unsigned long long* d_hist = ws.hist.as<unsigned long long>();
     unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
@@ -1131,13 +1188,39 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                      n * (1 + (kb[cur ^ 1] ? sizeof(K) : 0) + (HAS_V ? sizeof(V) : 0) + (HAS_W ? sizeof(W) : 0)), s);
             materialised = true;
         } else {
+            // the last pass can write the group flags beside its records (16 Ki-tile one-atomic configurations, split records)
+            constexpr bool CAN_KEEP = HAS_W && HAS_V && sizeof(K) == 4 && sizeof(V) == 4 && Cfg::NT == 1024 && Cfg::ATOMRANK && Cfg::REUSE && !Cfg::DMA;
+            bool kept = false;
+            if constexpr (CAN_KEEP) {
+                if (keep && ri + 1 == k) {
+                    ws.h_seg1 = SegInfo{0ull, (unsigned long long)n, 0u, 0u, 0ull, 0ull};
+                    ws.seg1.ensure(sizeof(SegInfo));
+                    CDB_HIP(hipMemcpyAsync(ws.seg1.p, &ws.h_seg1, sizeof(SegInfo), hipMemcpyHostToDevice, s));
+                    SegFinalKeepArgs ka = *keep;
+                    ka.tile_seg = nullptr;
+                    ka.segs = ws.seg1.as<SegInfo>();
+                    ka.tiles = tiles;
+                    ka.start_stride = 0;
+                    hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W, SegFinalKeepArgs>), dim3(grid_tiles), dim3(Cfg::NT), 0, s,
+                                       (const K*)kb[cur], kb[cur ^ 1], (const V*)vin_p, vout_p, n, shift, dmask,
+                                       (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
+                                       Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e, ws.err_ptr(), NoGen(),
+                                       (const W*)wb[cur], wb[cur ^ 1], aux_shift, ka);
+                    hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(tiles), dim3(256), 0, s, (const SegEdge*)ka.edges, (const uint32_t*)nullptr,
+                                       (const SegInfo*)ws.seg1.as<SegInfo>(), tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile);
+                    kept = true;
+                    ws.keep_applied = true;
+                }
+            }
+            if (!kept)
             hipLaunchKernelGGL((rs_onesweep_kernel<K, V, Cfg, NoGen, W>), dim3(grid_tiles), dim3(Cfg::NT), 0, s,
                                (const K*)kb[cur], kb[cur ^ 1], (const V*)vin_p, vout_p, n, shift, dmask,
                                (const unsigned long long*)(d_start + p * 256), ws.status.as<uint64_t>(),
                                Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e,
                                ws.err_ptr(), NoGen(), (const W*)wb[cur], wb[cur ^ 1], aux_shift);
-            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) : "") + "_t" + std::to_string(TILE)).c_str(),
-                     2 * n * pair_bytes, s);
+            prof.end(t, (std::string(rs_kernel_name<K, V>()) + (HAS_W ? (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) : "") +
+                         (kept ? "_flags" : "") + "_t" + std::to_string(TILE)).c_str(),
+                     2 * n * pair_bytes + (kept ? n : 0), s);
         }
         cur ^= 1;
         if (stats) stats->passes_run++;
@@ -1234,7 +1317,7 @@ template <typename V, typename W>
 int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k0, uint32_t* k1, V* v0, V* v1,
                      W* w0, W* w1, uint64_t n, int hi_bits, SortStats* stats, int variant, int dbits,
                      const uint64_t* h_hist, const TextGen* gen, int key_begin = 0, const unsigned long long* d_hist = nullptr,
-                     int lead_digits = -1) {
+                     int lead_digits = -1, const SegFinalKeepArgs* keep = nullptr) {
     // lead_digits: sort digits in the auxiliary array of materialised records (default: every byte of W); the bytes
     // above them are carried along untouched (the bucket-wise build keeps bits 32..39 of its entries there)
     const int lead_in = lead_digits >= 0 ? lead_digits : (int)sizeof(W);
@@ -1252,11 +1335,11 @@ int radix_sort_split(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t
         if (gen)                                                                                                       \
             return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, TextGen, W>(s, ws, prof, k0, k1, v0, v1, n,          \
                                                                                key_begin, hi_bits, stats, dbits,        \
-                                                                               h_hist, gen, w0, w1, 0);                 \
+                                                                               h_hist, gen, w0, w1, 0, nullptr, keep);  \
     }                                                                                                                  \
     return radix_sort_cfg<uint32_t, V, RsCfg<__VA_ARGS__>, NoGen, W>(s, ws, prof, k0, k1, v0, v1, n, key_begin, hi_bits, \
                                                                      stats, dbits, h_hist, (const NoGen*)nullptr, w0, w1, \
-                                                                     lead_in, d_hist)
+                                                                     lead_in, d_hist, keep)
     switch (variant) {
         default:
         case 21: CDB_RS_SPLIT(IPT_BIG, true, true, 1024, false, 1, 0, 4);

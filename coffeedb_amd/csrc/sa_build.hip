@@ -1706,6 +1706,7 @@ void build_typed(Index& ix, bool big) {
     }
     st.key_layout = (int)layout;
     DevBuf sorted_k32, sorted_low;
+    bool flags_by_sort = false;  // the sort's last pass wrote the group flags and the tile sums of the first compaction
     const int low_bits = layout == SPLIT ? dbits : (layout == SPLIT2 ? 2 * dbits : 0);
     const int low_bytes = layout == SPLIT ? 1 : (layout == SPLIT2 ? 2 : 0);
     if (!big && layout != WIDE) {
@@ -1724,18 +1725,42 @@ void build_typed(Index& ix, bool big) {
                 std::fprintf(stderr, "[bufs] k32 %p %p vals %p %p low %p %p flags %p\n", k32[0].p, k32[1].p, vals[0].p, vals[1].p, low[0].p,
                              low[1].p, flags.p);
             int sel = 0;
+            // The last pass writes the group flags itself (radix_sort.h: SegFinalKeepArgs) where its kernel configuration
+            // can (16 Ki tiles, one-atomic ranking): the flag kernel — 5-6 B read per suffix — is then not needed, and the
+            // per-tile counts of unresolved entries for the first compaction are counted on the way.
+            SegFinalKeepArgs keep;
+            DevBuf edges;
+            const bool want_keep = ix.flags_in_last_pass && dbits == 8 &&
+                                   (n >= (1ull << 23) || ix.sort_variant == 31 || ix.sort_variant == 33);  // (16 Ki-tile configurations)
+            if (want_keep) {
+                const uint64_t nbt = ceil_div(n, (uint64_t)SC_TILE);
+                ix.scan_partials.ensure(scan_partials_slots(nbt) * sizeof(U2));
+                CDB_HIP(hipMemsetAsync(ix.scan_partials.p, 0, nbt * sizeof(U2), s));
+                edges.alloc(ceil_div(n, (uint64_t)RS_SEG_TILE) * 256 * sizeof(SegEdge));
+                keep.flags = flags.as<uint8_t>();
+                keep.edges = edges.as<SegEdge>();
+                keep.low_bits = low_bits;
+                keep.kbase = kbase;
+                keep.kmagic = kmagic;
+                keep.tile_sums = ix.scan_partials.as<unsigned long long>();
+                keep.sums_tile = SC_TILE;
+            }
             if (layout == SPLIT) {
                 gen.low_bits = low_bits;
                 sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
                                                    vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n,
-                                                   key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+                                                   key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen, 0, nullptr, -1,
+                                                   want_keep ? &keep : nullptr);
                 sorted_low = std::move(low[sel]);
+                flags_by_sort = ix.rws.keep_applied;
             } else if (layout == SPLIT2) {
                 gen.low_bits = low_bits;
                 sel = radix_sort_split<V, uint16_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
                                                     vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint16_t>(), low[1].as<uint16_t>(),
-                                                    n, key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
+                                                    n, key_bits - low_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen, 0, nullptr, -1,
+                                                    want_keep ? &keep : nullptr);
                 sorted_low = std::move(low[sel]);
+                flags_by_sort = ix.rws.keep_applied;
             } else {
                 sel = radix_sort<uint32_t, V>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<V>(),
                                               vals[1].as<V>(), n, 0, key_bits, &ss, ix.sort_variant, dbits, h_hist.data(), &gen);
@@ -2219,8 +2244,9 @@ void build_typed(Index& ix, bool big) {
         st.bucketed = 1;
         sa_buf = std::move(E);
     }
-    bool tile_sums_ready = false;  // the flag kernel has left the raw tile sums of the first compaction in scan_partials
-    if (!big) {  // (the bucket-wise sort writes the flags itself)
+    bool tile_sums_ready = flags_by_sort;  // the raw tile sums of the first compaction are in scan_partials already
+    st.flags_in_last_pass = flags_by_sort ? 1 : 0;
+    if (!big && !flags_by_sort) {  // (the bucket-wise sort writes the flags itself)
         int t = ix.prof.begin(s);
         if (layout == WIDE)
             hipLaunchKernelGGL(sa_initflags_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s,
@@ -2430,8 +2456,11 @@ void build_typed(Index& ix, bool big) {
                 const CompatBucket r = folded_roots[b];
                 if (depth1[b].done) {
                     const unsigned long long hs = r.lo + depth1[b].nend, ls = hs + depth1[b].nhigh;
+                    // (every slot must belong to some entry of the list: the out-of-place form of the walk COPIES the
+                    //  array range by range — the fuzz-sized test caught the block of one-symbol suffixes missing here)
+                    if (depth1[b].nend) nodes.push_back(CompatBucket{r.lo, hs});
                     nodes.push_back(CompatBucket{hs, ls});
-                    nodes.push_back(CompatBucket{ls, r.hi});  // (the suffixes that end behind the first symbol stay in front)
+                    nodes.push_back(CompatBucket{ls, r.hi});
                 } else {
                     nodes.push_back(r);
                 }

@@ -49,6 +49,7 @@ def test_c1_full_size_properties():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.bits, g.sa_width) == (nd * dl, 21, 4)      # 21 + 11 bits = 32 -> u32 edge (Q4)
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
@@ -89,6 +90,7 @@ def test_beyond_4gib_on_one_gpu():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.sa_width, g.bits) == (n, 8, 16) and g.stat("bucketed") == 1   # 16 + 18 bits -> u64 entries
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
@@ -157,6 +159,7 @@ def test_c2_full_size_zipf_one_million_patterns_with_offsets():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1       # 24 + 11 bits -> u64 entries
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
@@ -246,6 +249,7 @@ def test_utf8_4gib_reference_order_and_true_order():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)                                              # reference_compat = 1 (default)
     assert g.size == n and g.sa_width == 8 and g.stat("compat_rotations") >= 1
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
     assert v["inversions"] == g.stat("compat_rotations")        # not globally sorted: one inversion per rotated node
@@ -262,6 +266,7 @@ def test_utf8_4gib_reference_order_and_true_order():
     g = capi.GpuStringIndex()
     g.set_option("reference_compat", 0)
     g.build_device(text.data_ptr(), ds, ids)
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
@@ -299,6 +304,7 @@ def test_c4_shard_16gib_utf8_ten_million_patterns():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)
     assert g.size == n and g.sa_width == 8 and g.stat("bucketed") == 1
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
     r = g.verify_reference()
@@ -411,6 +417,7 @@ def test_c3_shard_8gib_ascii():
     g = capi.GpuStringIndex()
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]

@@ -67,6 +67,7 @@ def test_fuzz_parity(seed):
         g.set_option(k, v)
     g.add_bulk(ids, blob, ds)
     g.build()   # (no configuration is refused any more: the bucket-wise path takes all 256 byte values too)
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0, opts   # (a fallback would mask a wrong array)
     assert (g.size, g.bits, g.mask, g.sa_width) == (o.size, o.bits, o.mask, o.sa_width), (seed, opts)
     assert np.array_equal(g.sa(), o.sa()), (seed, opts)
     npat = int(rng.integers(1, 400))
@@ -127,6 +128,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     g.add_bulk(ids, blob, ds)
     g.build()
     assert g.sa_width == 8 and g.stat("bucketed") == 1, opts
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0, (seed, kind, opts)   # (a fallback would mask a wrong array)
     if opts.get("reference_compat", 1):
         o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
         assert np.array_equal(g.sa(), o.sa()), (seed, kind, opts)
