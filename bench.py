@@ -188,12 +188,11 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
     d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, cfg["npat"], cfg["mmin"], cfg["mmax"], seed=99,
                                                      miss_byte=miss, utf8=cfg["kind"] == "utf8")
     torch.cuda.synchronize()
-    # torch hands its cached blocks back to the driver only where the build needs the room (16 GiB shards): VRAM that a
-    # process has just released is scrubbed by the driver when it is allocated again (53 ms per GiB against 7.5 ms per GiB for
-    # untouched VRAM, tools/experiments/alloc_cost.hip), which is what made first_build_ms seconds long in round 2
-    recycled = n >= (12 << 30)
-    if recycled:
-        torch.cuda.empty_cache()
+    # (by now this process has released VRAM — the main run's tensors and block cache — so the first build of a configuration
+    #  is served recycled pages, which the driver scrubs when they are allocated again: 53 ms per GiB against 7.5 ms per GiB for
+    #  untouched VRAM, tools/experiments/alloc_cost.hip.  A process that builds on untouched VRAM — server.cpp:44's start-up
+    #  build — pays 1.1 x a warm build: tools/big_one.py)
+    torch.cuda.empty_cache()
     t_gen = time.perf_counter() - t_gen
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
@@ -211,7 +210,7 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         out["dtype"] = "u64" if g.sa_width == 8 else "u32"
         out["build_ms"] = [round(x, 2) for x in bms[1:]]
         out["first_build_ms_incl_allocation"] = round(bms[0], 1)
-        out["first_build_vram"] = "recycled (released by torch just before: scrubbed by the driver)" if recycled else "untouched by this process"
+        out["first_build_vram"] = "recycled: released by this process just before, scrubbed by the driver on re-allocation (untouched VRAM: ~1.1 x a warm build, DESIGN.md §5)"
         out["sa_build_GiB_per_s"] = round(n / 2**30 / (min(bms[1:]) * 1e-3), 3)
         out["build_stats"] = build_stats(g)
         out["roofline"] = dominant(prof_build)
