@@ -41,3 +41,16 @@ def test_shim_string_index_spread_over_shards():
     env = dict(os.environ, COFFEEDB_GPUS="0,0", COFFEEDB_SHARD_ALL="1")
     out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_shim_string_index_with_the_resident_query_workgroup():
+    # COFFEEDB_RESIDENT_QUERY=1: the same walk with lone query() calls answered by the resident workgroup (one GPU, and
+    # two shards with a workgroup each)
+    exe = os.path.join(CPP, "test_index_shim")
+    if not os.path.exists(exe):
+        exe = _build()
+    for extra in ({}, {"COFFEEDB_GPUS": "0,0", "COFFEEDB_SHARD_ALL": "1"}):
+        env = dict(os.environ, COFFEEDB_RESIDENT_QUERY="1", **extra)
+        out = subprocess.run([exe, "all"], capture_output=True, text=True, timeout=120, env=env)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
