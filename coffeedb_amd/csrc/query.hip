@@ -1430,6 +1430,8 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
 // written LAST; the host relaunches it with the next request.  Builds, loads and destroy stop it first (query_resident_stop).
 constexpr int RES_WORDS = 21;       // 147 payload bytes: len u32, decisive u8, pad, klo u64, khi u64, keyword <= 120 bytes
 constexpr uint32_t RES_IDLE_POLLS = 2500;
+constexpr uint32_t RES_MAX_SERVED = 4096;  // it also leaves after this many answers (~30 ms of back-to-back queries): a
+                                           // device-wide synchronisation elsewhere in the process is never starved by traffic
 struct ResidentBox {
     uint64_t w[RES_WORDS];          // host -> device: request words, (payload 56 bits | tag << 56)
     uint64_t stop;                  // host -> device: leave now
@@ -1480,6 +1482,7 @@ __global__ __launch_bounds__(256) void q_resident_kernel(const V* __restrict__ s
         k2.klo = klo;
         k2.khi = khi;
         q_single_answer<V>(sa, n, text, doc_start, bits, mask, ids, s_req + 24, (uint64_t)len, out, sorted, k2);
+        if (seq - seq0 >= RES_MAX_SERVED) break;  // (uniform; the host starts the next one with its next request)
     }
     if (tid == 0) {
         __threadfence_system();
