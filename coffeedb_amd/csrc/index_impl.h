@@ -30,6 +30,7 @@ struct BuildStats {
     int bucket_groups = 0;       // ... bucket groups whose records were gathered in one text-ordered sweep
     int root_folded = 0;         // ... first-symbol buckets laid out in the reference's root order (bytes >= 0x80 first)
     int flags_in_last_pass = 0;  // single sort: group flags written by the last radix pass (no flag kernel)
+    int msd_first = 0;           // single sort: top digit first, then (u32, u32) records sorted bucket by bucket (radix_sort_msd)
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -124,6 +125,7 @@ struct Index {
 
     // ---- scratch kept across calls
     RadixWorkspace rws;
+    MsdWorkspace msd_ws;  // segments / per-bucket digit tables of the MSD-first initial sort
     DevBuf scan_partials;
     uint64_t q_spec_cap = 0;  // > 0: hits the next batch's buffers are sized for without asking (query.hip)
     DevBuf q_spec;
@@ -133,6 +135,7 @@ struct Index {
     bool reference_compat = true;   // bit-parity with the reference also for bytes >= 0x80
     bool force_doubling = false;
     int initial_passes = 0;
+    int key_symbols = 0;       // test hook: symbols in the initial sort key (0 = chosen from the text)
     int sort_variant = 0;
     int search_lanes = 0;      // lanes per keyword in the fast batched search: 0 = by batch size, 1 or 8
     bool flags_in_last_pass = true;  // builds below 2^32: the last radix pass writes the group flags (0 = the flag kernel)
@@ -141,6 +144,8 @@ struct Index {
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
+    bool msd_first = true;    // keys of 33..40 bits below 2^32 suffixes: top digit first, then every bucket on its own with
+                              // (u32, u32) records (radix_sort_msd); 0 = LSD split sort with the low digit as a travelling byte
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)

@@ -155,6 +155,9 @@ struct TextGen {
                        // as a separate byte per element; the remaining passes see key >> low_bits (32-bit keys)
     bool padded = false;  // text buffer has >= RS_GEN_LOOK + 16 readable bytes behind n
     bool first_only = false;  // entries-only partition by the first symbol: the key is just that symbol's digit
+    int msd_shift = 0;  // > 0 (split records, MSD-first sort): the generated pass sorts on the key's TOP digit, key >> msd_shift,
+                        // which is then implied by the bucket an element sits in — the records are (u32 key, entry) with no
+                        // auxiliary byte at all, and the remaining passes sort every bucket on its own (radix_sort_msd)
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
@@ -166,7 +169,7 @@ constexpr int RS_GEN_LOOK = 64;
 struct NoSeg {};
 struct SegInfo {
     unsigned long long begin, end;  // element range of the segment inside the group's record buffers
-    uint32_t tile_begin, pad;       // its first tile
+    uint32_t tile_begin, top;       // its first tile; MSD-first sort: the top digit every key of the segment shares
     // final pass only: the sorted segment [0, a) [a, b) [b, len) is written as [0, a) [b, len) [a, b) — the reference's child
     // order inside a radix node (end of document, bytes 0x80..0xFF, bytes 0x00..0x7F; index.h:66-73).  a = b = 0: as sorted
     unsigned long long rot_a, rot_b;
@@ -217,6 +220,10 @@ struct SegFinalKeepArgs : SegArgs {
     unsigned long long kmagic = 0;
     unsigned long long* tile_sums = nullptr;
     uint32_t sums_tile = 1;
+    // MSD-first sort (radix_sort_msd): the records have no auxiliary array (win == nullptr), the full key of an element is
+    // (segment's top digit << msd_shift) | k32, and the pass writes the kept search keys in the layout of the LSD split sort —
+    // (u32)(full >> 8) and the low byte — so that everything downstream of the sort is the same
+    int msd_shift = 0;
 };
 
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     uint64_t seg_n = n;     // end of the element range the tile may read
     uint32_t sg = 0;
     SegInfo si = {};
+    uint64_t ktop = 0;  // MSD-first final pass: the segment's top digit, in place above the 32 key bits
     if constexpr (SEG) {
         if (tile >= (uint64_t)seg.tiles) return;  // (the grid is rounded up to whole tile groups)
         sg = seg.tile_seg ? seg.tile_seg[tile] : 0u;  // (no map: one segment)
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         tile0 = si.tile_begin;
         base = si.begin + (tile - tile0) * TILE;
         seg_n = si.end;
+        if constexpr (KEEP) ktop = seg.msd_shift ? (uint64_t)si.top << seg.msd_shift : 0ull;
     } else if constexpr (Cfg::GROUP > 0) {
         if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
     }
@@ -451,8 +460,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         kk = (kk - (uint64_t)s_text[q - 1] * top) * gen.base + cin;
                     }
                     const uint64_t kx = kk;
-                    kt[swz(q)] = (uint32_t)(kx >> gen.low_bits);
-                    if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx & ((1ull << gen.low_bits) - 1ull));
+                    if (gen.msd_shift) {  // (uniform)
+                        kt[swz(q)] = (uint32_t)kx;
+                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx >> gen.msd_shift);
+                    } else {
+                        kt[swz(q)] = (uint32_t)(kx >> gen.low_bits);
+                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx & ((1ull << gen.low_bits) - 1ull));
+                    }
                     ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                 }
             }
@@ -499,8 +513,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 uint64_t kk = gen.first_only ? ((uint64_t)s_text[li] << shift)
                                              : rs_pack_key(s_words, li, nsym, gen.base, dend_l - li);
                 if constexpr (HAS_W) {
-                    aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
-                    key[j] = (K)(kk >> gen.low_bits);
+                    if (gen.msd_shift) {  // (uniform)
+                        aux[j] = (WS)(kk >> gen.msd_shift);
+                        key[j] = (K)kk;
+                    } else {
+                        aux[j] = (WS)(kk & ((1ull << gen.low_bits) - 1ull));
+                        key[j] = (K)(kk >> gen.low_bits);
+                    }
                 } else {
                     key[j] = (K)kk;
                 }
@@ -555,10 +574,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         if constexpr (HAS_W) {
+            if (!KEEP || win) {
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const uint32_t li = wbase + j * 64;
-                aux[j] = li < valid ? rs_load<NTM>(win + base + li) : WS(0);
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t li = wbase + j * 64;
+                    aux[j] = li < valid ? rs_load<NTM>(win + base + li) : WS(0);
+                }
             }
         }
     } else {
@@ -572,10 +593,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             key[j] = rs_load<NTM>(kin + base + (li < valid ? li : lastv));
         }
         if constexpr (HAS_W && Cfg::LOAD == 1) {
+            if (!KEEP || win) {  // (uniform; the final pass of an MSD-first sort has no auxiliary input)
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const uint32_t li = wbase + j * 64;
-                aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t li = wbase + j * 64;
+                    aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+                }
             }
         }
         if constexpr (EARLYV) {
@@ -586,10 +609,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         if constexpr (HAS_W && Cfg::LOAD != 1) {
+            if (!KEEP || win) {
 #pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const uint32_t li = wbase + j * 64;
-                aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t li = wbase + j * 64;
+                    aux[j] = rs_load<NTM>(win + base + (li < valid ? li : lastv));
+                }
             }
         }
 #pragma unroll
@@ -765,8 +790,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (real) {
                 const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
                 const uint32_t a = tstart, b = tstart + (uint32_t)real - 1u;
-                e.first = ((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask);
-                e.last = ((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask);
+                e.first = ktop | ((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask);
+                e.last = ktop | ((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask);
             }
             seg.edges[tile * 256 + d] = e;
         }
@@ -811,7 +836,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                     uint32_t f = head ? 1u : 0u;
                     if (!(head && tail)) {
-                        const uint64_t kc = ((uint64_t)k << seg.low_bits) | (uint64_t)ac;
+                        const uint64_t kc = ktop | ((uint64_t)k << seg.low_bits) | (uint64_t)ac;
                         const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
                                                           : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
                         if (!exhausted) f |= 2u;
@@ -828,8 +853,18 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         }
                     }
                 }
+                if constexpr (KEEP) {
+                    if (seg.msd_shift) {  // (uniform) kept search keys in the layout of the LSD split sort: full key >> 8, low byte
+                        const uint64_t kf = ktop | (uint64_t)k;
+                        rs_store<NTM>(kout + s_gbase[dd] + i, (K)(kf >> 8));
+                        if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)(kf & 0xFFu));
+                        continue;
+                    }
+                }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
-                if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
+                if constexpr (HAS_W) {
+                    if (!GEN || wout) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
+                }
             }
         }
         __syncthreads();
@@ -1457,6 +1492,199 @@ void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uin
     hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(tiles), dim3(256), 0, s, (const SegEdge*)fin.edges, d_tile_seg, d_segs, tiles,
                        fin.flags, fin.kbase, fin.kmagic);
     prof.end(t, "rs_seg_edge_fix", (uint64_t)tiles * 256 * sizeof(SegEdge), s);
+    CDB_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// MSD-first sort of generated split records (suffix-array builds below 2^32 whose key is 33..40 bits wide)
+// ---------------------------------------------------------------------------------------------
+// The LSD split sort drops the digit its generated pass sorts on into a byte that then travels through every other
+// pass (the group flags at the end need the whole key): 9 bytes per record and pass, scattered over the whole array.
+// Here the generated pass sorts on the TOP digit instead (key >> 32): an element's bucket then implies that digit, the
+// records are (u32 key, u32 entry) = 8 bytes, and the remaining four passes sort every bucket on its own — one
+// segmented launch per pass, the scatter of a tile stays inside its bucket (tools/experiments/seg_bench.hip: 3.6 ms per
+// pass of 2^30 records against 4.45 ms for the 9-byte records of the LSD form).  The price: the digit histograms of the
+// buckets cannot come from the text sweep (bucket x pass x digit counters do not fit the LDS), they are counted from
+// the partitioned keys (rs_seg_hist_kernel: 4 B read per record).
+constexpr int RS_MSD_HIST_TILES = 32;  // consecutive tiles per workgroup of the histogram sweep
+
+// hist[g][p][d] (the [nseg][8][256] layout of rs_seg_digit_start_kernel): 8-bit digits p < NPASS of the keys of segment g
+template <int NPASS>
+__global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tile_seg,
+                                                           const SegInfo* __restrict__ segs, uint32_t tiles,
+                                                           unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t sh[NPASS][256];
+    const int tid = threadIdx.x;
+    const uint32_t t0 = blockIdx.x * RS_MSD_HIST_TILES;
+    const uint32_t t1 = t0 + RS_MSD_HIST_TILES < tiles ? t0 + RS_MSD_HIST_TILES : tiles;
+    uint32_t cur = ~0u;
+    auto flush = [&]() {
+        __syncthreads();
+        if (cur != ~0u)
+            for (int i = tid; i < NPASS * 256; i += 1024)
+                if ((&sh[0][0])[i]) atomicAdd(&hist[((size_t)cur * 8 + i / 256) * 256 + i % 256], (unsigned long long)(&sh[0][0])[i]);
+        for (int i = tid; i < NPASS * 256; i += 1024) (&sh[0][0])[i] = 0;
+        __syncthreads();
+    };
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t g = tile_seg[t];
+        if (g != cur) {  // (uniform)
+            flush();
+            cur = g;
+        }
+        const SegInfo si = segs[g];
+        const uint64_t base = si.begin + (uint64_t)(t - si.tile_begin) * RS_SEG_TILE;
+        const uint32_t valid = (uint32_t)((si.end - base) < (uint64_t)RS_SEG_TILE ? (si.end - base) : (uint64_t)RS_SEG_TILE);
+        uint32_t k[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // 16 keys per thread, four 16-byte loads (segments start on 256-byte boundaries or not: plain loads)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
+                k[q] = li < valid ? keys[base + li] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
+                if (li < valid) {
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) atomicAdd(&sh[p][(k[q] >> (8 * p)) & 0xFFu], 1u);
+                }
+            }
+        }
+    }
+    flush();
+}
+
+struct MsdWorkspace {
+    DevBuf segs, tile_seg, hist, starts;
+    void release() { segs.release(); tile_seg.release(); hist.release(); starts.release(); }
+};
+
+// Sorts the records the generator produces (key = up to 32 + 8 bits, msd_shift = 32) — see above.  h_top[256] = counts of
+// the top digit (host).  Result: entries in v1, kept search keys (u32)(key >> 8) in k1 and key & 0xFF in wout, the group
+// flags / edge fixes / tile sums of `keep` written by the last pass.  k0 / v0 are scratch.
+inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, Profiler& prof, uint32_t* k0, uint32_t* k1,
+                           uint32_t* v0, uint32_t* v1, uint8_t* wout, uint64_t n, const uint64_t* h_top, const TextGen& gen_in,
+                           const SegFinalKeepArgs& keep_in, SortStats* stats) {
+    if (!rs_atomic_rank_ok(s)) throw Error("radix_sort_msd: needs the one-atomic ranking (internal)");
+    constexpr int TILE = RS_SEG_TILE;
+    constexpr int KPASS = 4;
+    using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+    using CfgP = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true>;
+    const bool grouped = ws.allow_group && !ws.plain_order;
+    // segments = the non-empty buckets of the top digit
+    std::vector<SegInfo> h_segs;
+    uint32_t seg_tiles = 0;
+    {
+        uint64_t at = 0;
+        for (int d = 0; d < 256; ++d) {
+            if (!h_top[d]) continue;
+            h_segs.push_back(SegInfo{(unsigned long long)at, (unsigned long long)(at + h_top[d]), seg_tiles, (uint32_t)d, 0ull, 0ull});
+            seg_tiles += (uint32_t)ceil_div(h_top[d], (uint64_t)TILE);
+            at += h_top[d];
+        }
+        if (at != n) throw Error("radix_sort_msd: top-digit histogram does not add up (internal)");
+    }
+    const uint32_t nseg = (uint32_t)h_segs.size();
+    const uint32_t gen_tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
+    ws.prepare((uint64_t)seg_tiles * TILE, TILE, s);
+    ws.keep_applied = false;
+    unsigned long long* d_hist = ws.hist.as<unsigned long long>();
+    unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
+    mw.segs.ensure(nseg * sizeof(SegInfo));
+    mw.tile_seg.ensure((size_t)seg_tiles * sizeof(uint32_t));
+    mw.hist.ensure((size_t)nseg * 8 * 256 * sizeof(uint64_t));
+    mw.starts.ensure((size_t)nseg * 8 * 256 * sizeof(uint64_t));
+    CDB_HIP(hipMemcpyAsync(d_hist, h_top, 256 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    CDB_HIP(hipMemcpyAsync(mw.segs.p, h_segs.data(), nseg * sizeof(SegInfo), hipMemcpyHostToDevice, s));
+    CDB_HIP(hipStreamSynchronize(s));  // (pageable host memory)
+    hipLaunchKernelGGL(rs_digit_start_kernel, dim3(1), dim3(256), 0, s, d_hist, d_start);
+    hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(seg_tiles, 256u)), dim3(256), 0, s, mw.segs.as<SegInfo>(), nseg,
+                       seg_tiles, mw.tile_seg.as<uint32_t>());
+    CDB_HIP(hipMemsetAsync(mw.hist.p, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
+    // ---- generated pass: partition by the top digit, records (u32 key, entry)
+    {
+        TextGen g2 = gen_in;
+        g2.msd_shift = 32;
+        g2.low_bits = 0;
+        ws.tile_doc.ensure(((size_t)gen_tiles + 1) * sizeof(uint64_t));
+        hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)gen_tiles + 1, 256)), dim3(256), 0, s, g2.doc_start, g2.ndocs,
+                           n, (uint64_t)TILE, (uint64_t)gen_tiles, ws.tile_doc.as<uint64_t>());
+        g2.tile_doc = ws.tile_doc.as<uint64_t>();
+        const uint32_t e = ws.next_epoch(s);
+        const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles;
+        int t = prof.begin(s);
+        if (grouped)
+            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                               ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+        else
+            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                               ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+        prof.end(t, "rs_onesweep_textgen_msd_t16384", n * 9, s);
+        if (stats) stats->passes_run++;
+    }
+    // ---- digit histograms of every bucket's four passes
+    {
+        int t = prof.begin(s);
+        hipLaunchKernelGGL((rs_seg_hist_kernel<KPASS>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s,
+                           (const uint32_t*)k1, (const uint32_t*)mw.tile_seg.as<uint32_t>(), (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles,
+                           mw.hist.as<unsigned long long>());
+        prof.end(t, "rs_seg_hist", n * 4, s);
+        hipLaunchKernelGGL(rs_seg_digit_start_kernel, dim3(nseg), dim3(256), 0, s, (const unsigned long long*)mw.hist.as<unsigned long long>(),
+                           (const SegInfo*)mw.segs.as<SegInfo>(), KPASS, mw.starts.as<unsigned long long>());
+    }
+    // ---- the buckets' LSD passes, one segmented launch each; the last one writes flags + kept keys
+    SegArgs sa;
+    sa.tile_seg = mw.tile_seg.as<uint32_t>();
+    sa.segs = mw.segs.as<SegInfo>();
+    sa.tiles = seg_tiles;
+    sa.start_stride = 8 * 256;
+    SegFinalKeepArgs ka = keep_in;
+    static_cast<SegArgs&>(ka) = sa;
+    ka.low_bits = 0;
+    ka.msd_shift = 32;
+    const uint32_t grid = grouped ? (uint32_t)(ceil_div(seg_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : seg_tiles;
+    uint32_t* kb[2] = {k0, k1};
+    uint32_t* vb[2] = {v0, v1};
+    int cur = 1;
+    for (int p = 0; p < KPASS; ++p) {
+        const uint32_t e = ws.next_epoch(s);
+        const unsigned long long* dstart = mw.starts.as<unsigned long long>() + (size_t)p * 256;
+        uint32_t* tk = grouped ? ws.xticket_ptr(e) : ws.ticket_ptr(e);
+        int t = prof.begin(s);
+        if (p + 1 < KPASS) {
+#define CDB_MSD_LAUNCH(CFG)                                                                                                          \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, NoVal, SegArgs>), dim3(grid), dim3(1024), 0, s,          \
+                       (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], n, 8 * p, 0xFFu, dstart,        \
+                       ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const NoVal*)nullptr, (NoVal*)nullptr, -1, sa)
+            if (grouped) CDB_MSD_LAUNCH(CfgG);
+            else CDB_MSD_LAUNCH(CfgP);
+#undef CDB_MSD_LAUNCH
+            prof.end(t, "rs_seg_k32_v32_t16384", 2 * n * 8, s);
+        } else {
+#define CDB_MSD_FINAL(CFG)                                                                                                           \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, uint8_t, SegFinalKeepArgs>), dim3(grid), dim3(1024), 0, s, \
+                       (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], n, 8 * p, 0xFFu, dstart,        \
+                       ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const uint8_t*)nullptr, wout, -1, ka)
+            if (grouped) CDB_MSD_FINAL(CfgG);
+            else CDB_MSD_FINAL(CfgP);
+#undef CDB_MSD_FINAL
+            prof.end(t, "rs_seg_k32_v32_flags_t16384", n * (8 + 9 + 1), s);
+        }
+        cur ^= 1;
+        if (stats) stats->passes_run++;
+    }
+    // (cur == 1: four passes from buffers 1 end in buffers 1)
+    {
+        int t = prof.begin(s);
+        hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(seg_tiles), dim3(256), 0, s, (const SegEdge*)ka.edges, (const uint32_t*)mw.tile_seg.as<uint32_t>(),
+                           (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile);
+        prof.end(t, "rs_seg_edge_fix", (uint64_t)seg_tiles * 256 * sizeof(SegEdge), s);
+    }
+    ws.keep_applied = true;
     CDB_HIP(hipGetLastError());
 }
 

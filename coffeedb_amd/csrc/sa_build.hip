@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                                                          const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                          uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
                                                          int nsym, int npass, bool padded,
-                                                         unsigned long long* __restrict__ hist) {
+                                                         unsigned long long* __restrict__ hist, uint32_t digit_mask) {
+    // digit_mask: bit q set = digit q is counted (the MSD-first sort only needs the top digit)
     __shared__ __attribute__((aligned(16))) uint8_t s_code[KH_TILE + KG_LOOK];
     __shared__ uint16_t s_map[256];
     __shared__ uint64_t s_drange[2];
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256) void sa_keyhist_kernel(const uint8_t* __restri
                     key = (key - (uint64_t)s_code[li - 1] * top) * kbase + cin;
                 }
                 const uint64_t dk = key;
-                for (int q = 0; q < npass; ++q) atomicAdd(&s_hist[q][(uint32_t)(dk >> (8 * q)) & 0xFFu], 1u);
+                for (int q = 0; q < npass; ++q)
+                    if ((digit_mask >> q) & 1u) atomicAdd(&s_hist[q][(uint32_t)(dk >> (8 * q)) & 0xFFu], 1u);
             }
         }
     }
@@ -364,7 +366,8 @@ template <int P>
 __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restrict__ text,
                                                           const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                           uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
-                                                          int npass, bool padded, unsigned long long* __restrict__ hist) {
+                                                          int npass, bool padded, unsigned long long* __restrict__ hist,
+                                                          uint32_t digit_mask) {
     constexpr int NSYM = 3 * P;
     constexpr int NG = KH3_PER + 3 * (P - 1);  // G values a thread needs
     static_assert(NG + 2 <= 48, "window of three 16-byte reads");
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void sa_keyhist3_kernel(const uint8_t* __restr
     auto count = [&](uint64_t key) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (q < npass) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
+            if (q < npass && ((digit_mask >> q) & 1u)) atomicAdd(&s_hist[q][(uint32_t)(key >> (8 * q)) & 0xFFu], 1u);
     };
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint64_t p0 = tile * KH_TILE;
@@ -1549,6 +1552,7 @@ void build_typed(Index& ix, bool big) {
         const double need = pc < 0.999 ? std::log(64.0 * (double)n) / -std::log(pc) : 1e9;
         nsym = (int)std::min<double>(std::ceil(need), 64.0);
     }
+    if (ix.key_symbols > 0 && ix.initial_passes == 0) nsym = ix.key_symbols;
     nsym = std::min(std::max(nsym, 1), std::min(64 / symbits, 32));
     // digit width of the initial sort: whole symbols per digit when that costs no extra pass — the
     // digit then takes at most alphabet+1 values, which lengthens the per-digit runs of a tile
@@ -1627,7 +1631,7 @@ void build_typed(Index& ix, bool big) {
     st.fused_keygen = fused ? 1 : 0;
     std::vector<uint64_t> h_hist;  // [nsym][256] digit histograms of the LSD passes (fused path)
     // digit histograms of the dense keys, counted in one sweep over the text
-    auto key_histograms = [&](int npass) {
+    auto key_histograms = [&](int npass, uint32_t digit_mask) {
         DevBuf d_kh;
         d_kh.alloc((size_t)npass * 256 * sizeof(uint64_t));
         CDB_HIP(hipMemsetAsync(d_kh.p, 0, (size_t)npass * 256 * sizeof(uint64_t), s));
@@ -1636,7 +1640,7 @@ void build_typed(Index& ix, bool big) {
         const bool by3 = ix.keyhist3 && nsym % 3 == 0 && nsym >= 6 && nsym <= 15;
 #define CDB_KH3(PARTS)                                                                                              \
     hipLaunchKernelGGL((sa_keyhist3_kernel<PARTS>), dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n, \
-                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>())
+                       (const uint16_t*)d_symmap.as<uint16_t>(), kbase, npass, ix.text_padded, d_kh.as<unsigned long long>(), digit_mask)
         if (by3 && nsym == 6) CDB_KH3(2);
         else if (by3 && nsym == 9) CDB_KH3(3);
         else if (by3 && nsym == 12) CDB_KH3(4);
@@ -1644,15 +1648,22 @@ void build_typed(Index& ix, bool big) {
         else
             hipLaunchKernelGGL(sa_keyhist_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, doc_start, D, n,
                                (const uint16_t*)d_symmap.as<uint16_t>(), kbase, nsym, npass, ix.text_padded,
-                               d_kh.as<unsigned long long>());
+                               d_kh.as<unsigned long long>(), digit_mask);
 #undef CDB_KH3
         ix.prof.end(t, "sa_keyhist", n, s);
         h_hist.assign((size_t)npass * 256, 0);
         CDB_HIP(hipMemcpyAsync(h_hist.data(), d_kh.p, h_hist.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         CDB_HIP(hipStreamSynchronize(s));
     };
+    // MSD-first form of the split sort (radix_sort.h: radix_sort_msd): dense keys of 33..40 bits, 16 Ki-key tiles with the
+    // one-atomic ranking, flags written by the last pass.  Only the TOP digit's histogram comes from the text sweep.
+    const bool use_msd = fused && dense && !big && sizeof(V) == 4 && ix.narrow_keys && ix.msd_first && ix.flags_in_last_pass &&
+                         dbits == 8 && key_bits > 32 && key_bits <= 40 && rs_atomic_rank_ok(s) &&
+                         ((ix.sort_variant == 0 && n >= (1ull << 23)) || ix.sort_variant == 31 || ix.sort_variant == 33);
+    st.msd_first = use_msd ? 1 : 0;
     if (fused && dense) {
-        key_histograms((int)ceil_div(key_bits, 8));
+        const int npass = (int)ceil_div(key_bits, 8);
+        key_histograms(npass, use_msd ? 1u << (npass - 1) : 0xFFFFFFFFu);
     } else if (fused && !big) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
@@ -1717,7 +1728,7 @@ void build_typed(Index& ix, bool big) {
             vals[0].alloc(n * sizeof(V));
             vals[1].alloc(n * sizeof(V));
             if (low_bytes) {
-                low[0].alloc(n * low_bytes);
+                if (!use_msd) low[0].alloc(n * low_bytes);  // (the MSD-first sort has no travelling byte: only its last pass writes one)
                 low[1].alloc(n * low_bytes);
             }
             st.alloc_ms += now_ms() - ta;
@@ -1736,7 +1747,7 @@ void build_typed(Index& ix, bool big) {
                 const uint64_t nbt = ceil_div(n, (uint64_t)SC_TILE);
                 ix.scan_partials.ensure(scan_partials_slots(nbt) * sizeof(U2));
                 CDB_HIP(hipMemsetAsync(ix.scan_partials.p, 0, nbt * sizeof(U2), s));
-                edges.alloc(ceil_div(n, (uint64_t)RS_SEG_TILE) * 256 * sizeof(SegEdge));
+                edges.alloc((ceil_div(n, (uint64_t)RS_SEG_TILE) + 256) * 256 * sizeof(SegEdge));  // (MSD-first: one ragged tile per bucket)
                 keep.flags = flags.as<uint8_t>();
                 keep.edges = edges.as<SegEdge>();
                 keep.low_bits = low_bits;
@@ -1745,7 +1756,15 @@ void build_typed(Index& ix, bool big) {
                 keep.tile_sums = ix.scan_partials.as<unsigned long long>();
                 keep.sums_tile = SC_TILE;
             }
-            if (layout == SPLIT) {
+            if (layout == SPLIT && use_msd && want_keep) {
+                // the final pass writes the kept keys in the split layout (u32 = key >> 8, low byte), entries and flags
+                radix_sort_msd(s, ix.rws, ix.msd_ws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<uint32_t>(),
+                               vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_hist.data() + (size_t)((int)ceil_div(key_bits, 8) - 1) * 256,
+                               gen, keep, &ss);
+                sel = 1;
+                sorted_low = std::move(low[1]);
+                flags_by_sort = ix.rws.keep_applied;
+            } else if (layout == SPLIT) {
                 gen.low_bits = low_bits;
                 sel = radix_sort_split<V, uint8_t>(s, ix.rws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(),
                                                    vals[0].as<V>(), vals[1].as<V>(), low[0].as<uint8_t>(), low[1].as<uint8_t>(), n,

@@ -827,6 +827,36 @@ def test_group_flags_written_by_the_last_radix_pass(G, variant):
             assert g.stat("rounds") == g0.stat("rounds")
 
 
+@pytest.mark.parametrize("variant", [31, 33])
+def test_msd_first_split_sort(G, variant):
+    # keys of 33..40 bits below 2^32 suffixes: the generated pass sorts on the TOP digit, the records are (u32 key, entry)
+    # without a travelling low byte, and every bucket of that digit is then sorted on its own by segmented passes whose last
+    # one writes flags, entries and the kept search keys in the split layout (radix_sort.h: radix_sort_msd).  Forced onto
+    # small inputs through the 16 Ki-tile configurations; same array and rows as the oracle and as the LSD split sort.
+    # (blob, doc starts, key symbols forced through the test hook: small corpora would pick narrower keys)
+    cases = [W.ascii_corpus(2000, 256, seed=4) + (6,),                                # C0-like: 96^6 < 2^40
+             W.ascii_corpus(5000, 100, seed=11, lo=0x30, hi=0x7A) + (6,),             # 75 symbols: 76^6 < 2^38
+             W.ragged_corpus(40000, 12, seed=5, lo=0x21, hi=0x7E, empty_every=7) + (6,),  # document ends inside most keys
+             W.ascii_corpus(1500, 300, seed=12, lo=0x90, hi=0xEF) + (6,),             # bytes >= 0x80: reference order on top
+             W.ascii_corpus(300, 1500, seed=13, lo=0x61, hi=0x64) + (15,)]            # 4 symbols: 5^15 < 2^35, deep ties
+    base, _ = W.ascii_corpus(1, 1100, seed=9)
+    cases.append((np.concatenate([base] * 40), (np.arange(41) * 1100).astype(np.uint64), 6))  # equal keys across tile seams
+    seen = 0
+    for blob, ds, ksym in cases:
+        pats = W.sample_patterns(blob, ds, 300, 1, 10, seed=8, miss_frac=0.1, miss_byte=0x7F)
+        for fd in (0, 1):
+            g, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=variant, force_doubling=fd, key_coding=2, key_symbols=ksym)
+            g0, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=variant, force_doubling=fd, key_coding=2, key_symbols=ksym,
+                                  msd_first=0)
+            assert g0.stat("msd_first") == 0
+            if g0.stat("key_layout") == 2:                                            # split records with one low digit
+                assert g.stat("msd_first") == 1 and g.stat("flags_in_last_pass") == 1
+                seen += 1
+            assert g.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial")
+            assert g.stat("rounds") == g0.stat("rounds")
+    assert seen >= 8
+
+
 def test_build_from_views_of_the_callers_column(G):
     # cdb_build_view (one contiguous host column) and cdb_build_views (separate strings: what string_index::add collects,
     # index.cpp:174-177) build the same index as add + build, without a staging copy inside the handle; a later add
