@@ -1385,6 +1385,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "keyhist3")) ix.keyhist3 = value != 0;
     else if (!std::strcmp(name, "key_symbols")) ix.key_symbols = (int)value;
     else if (!std::strcmp(name, "msd_first")) ix.msd_first = value != 0;
+    else if (!std::strcmp(name, "msd_pair")) ix.msd_pair = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;
     else if (!std::strcmp(name, "fold_root")) ix.fold_root = value != 0;

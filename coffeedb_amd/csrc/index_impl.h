@@ -146,6 +146,7 @@ struct Index {
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
     bool msd_first = true;    // keys of 33..40 bits below 2^32 suffixes: top digit first, then every bucket on its own with
                               // (u32, u32) records (radix_sort_msd); 0 = LSD split sort with the low digit as a travelling byte
+    bool msd_pair = true;     // ... 6-symbol keys: top digit from the first two symbols (pair count of the text, 32-bit part arithmetic)
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)

@@ -158,9 +158,29 @@ struct TextGen {
     int msd_shift = 0;  // > 0 (split records, MSD-first sort): the generated pass sorts on the key's TOP digit, key >> msd_shift,
                         // which is then implied by the bucket an element sits in — the records are (u32 key, entry) with no
                         // auxiliary byte at all, and the remaining passes sort every bucket on its own (radix_sort_msd)
+    // MSD-first sort, pair form (6-symbol keys): top digit = (first two symbols as a number A) / span, i.e. key / M with
+    // M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count of the text instead of
+    // a sweep that evaluates every key.  The generated pass then works in 32-bit part arithmetic (G = three symbols as a
+    // number, key = G(p) base^3 + G(p + 3)): no rolling 64-bit key.  rs_div24: floor(x / d) for x < 2^24 from (mul, sh).
+    bool msd_pair = false;
+    uint32_t msd_span_mul = 0, msd_span_sh = 0;  // / span
+    uint32_t msd_mlo = 0;                        // M mod 2^32
+    uint32_t div_b_mul = 0, div_b_sh = 0;        // / base
+    uint32_t div_b2_mul = 0, div_b2_sh = 0;      // / base^2
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
+
+// floor(x / d) for x < 2^24 as one multiply-high: with L = ceil(log2 d) and m = ceil(2^(24+L) / d) (< 2^25, error
+// m d - 2^(24+L) < d <= 2^L, so x < 2^24 keeps the quotient exact), mul = m << 7 and sh = L + 7
+struct RsDiv24 { uint32_t mul, sh; };
+inline RsDiv24 rs_div24_make(uint32_t d) {
+    uint32_t L = 0;
+    while ((1ull << L) < d) ++L;
+    const uint64_t m = ((1ull << (24 + L)) + d - 1) / d;
+    return RsDiv24{(uint32_t)(m << 7), L + 7};
+}
+__device__ __forceinline__ uint32_t rs_div24(uint32_t x, uint32_t mul, uint32_t sh) { return __umulhi(x << 8, mul) >> sh; }
 
 // Segmented passes (the bucket-wise build of corpora >= 2^32, sa_build.hip): ONE launch sorts every first-symbol
 // bucket ("segment") of a bucket group on its own — a tile belongs to exactly one segment (tile_seg), takes its digit
@@ -223,7 +243,7 @@ struct SegFinalKeepArgs : SegArgs {
     // MSD-first sort (radix_sort_msd): the records have no auxiliary array (win == nullptr), the full key of an element is
     // (segment's top digit << msd_shift) | k32, and the pass writes the kept search keys in the layout of the LSD split sort —
     // (u32)(full >> 8) and the low byte — so that everything downstream of the sort is the same
-    int msd_shift = 0;
+    unsigned long long msd_m = 0;  // full key = top * msd_m + k32 (0: not an MSD-first sort)
 };
 
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         tile0 = si.tile_begin;
         base = si.begin + (tile - tile0) * TILE;
         seg_n = si.end;
-        if constexpr (KEEP) ktop = seg.msd_shift ? (uint64_t)si.top << seg.msd_shift : 0ull;
+        if constexpr (KEEP) ktop = (uint64_t)si.top * seg.msd_m;
     } else if constexpr (Cfg::GROUP > 0) {
         if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
     }
@@ -430,6 +450,64 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             for (int q = 1; q < nsym; ++q) top *= gen.base;
             uint32_t ent[IPT];
             uint64_t kk = 0;
+            if (HAS_W && gen.msd_pair) {  // (uniform) MSD-first sort, pair form: 6-symbol keys in 32-bit part arithmetic
+                const uint32_t B = gen.base, W3 = B * B * B;
+                uint32_t cw[6];  // codes of the thread's 16 positions + 5 of look-ahead (+ 3 unused)
+                {
+                    const uint4 ca = *reinterpret_cast<const uint4*>(s_text + q0);
+                    const uint2 cb = *reinterpret_cast<const uint2*>(s_text + q0 + 16);
+                    cw[0] = ca.x; cw[1] = ca.y; cw[2] = ca.z; cw[3] = ca.w; cw[4] = cb.x; cw[5] = cb.y;
+                }
+                auto code = [&](int t) -> uint32_t { return (cw[t >> 2] >> (8 * (t & 3))) & 0xFFu; };
+                uint32_t A[IPT + 3], G[IPT + 3];  // A(t) = first two symbols at q0 + t as a number, G(t) = first three
+#pragma unroll
+                for (int t = 0; t < IPT + 3; ++t) {
+                    A[t] = __umul24(code(t), B) + code(t + 1);
+                    G[t] = __umul24(A[t], B) + code(t + 2);
+                }
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t q = q0 + j;
+                    ent[j] = 0;
+                    if (q < valid) {
+                        if (j == 0 || q >= dend_l) {
+                            const uint64_t p = base + q;
+                            uint64_t ds, de;
+                            if (docs_in_lds) {
+                                d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
+                                ds = s_docs[d - dlo];
+                                de = s_docs[d - dlo + 1];
+                            } else {
+                                d = rs_doc_upper(gen.doc_start, d, dhi, p);
+                                ds = gen.doc_start[d];
+                                de = gen.doc_start[d + 1];
+                            }
+                            const uint64_t rel = de - base;
+                            dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
+                            ebase = d - (ds << gen.bits);
+                        }
+                        uint32_t g0 = G[j], g3 = G[j + 3], a = A[j];
+                        const uint32_t rem = dend_l - q;  // symbols left in the document (>= 1)
+                        if (rem < 6u) {  // (rare) the symbols behind the document end count as 0: truncate the parts
+                            if (rem <= 3u) {
+                                g3 = 0;
+                                if (rem < 3u) {
+                                    const bool one = rem == 1u;
+                                    g0 = rs_div24(g0, one ? gen.div_b2_mul : gen.div_b_mul, one ? gen.div_b2_sh : gen.div_b_sh) * (one ? B * B : B);
+                                }
+                            } else {
+                                const bool four = rem == 4u;
+                                g3 = rs_div24(g3, four ? gen.div_b2_mul : gen.div_b_mul, four ? gen.div_b2_sh : gen.div_b_sh) * (four ? B * B : B);
+                            }
+                            a = rs_div24(g0, gen.div_b_mul, gen.div_b_sh);
+                        }
+                        const uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
+                        kt[swz(q)] = g0 * W3 + g3 - top * gen.msd_mlo;  // key - top * M (< 2^32: exact modulo 2^32)
+                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)top;
+                        ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const uint32_t q = q0 + j;
@@ -469,6 +547,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                     ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                 }
+            }
             }
             __syncthreads();
 #pragma unroll
@@ -790,8 +869,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (real) {
                 const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
                 const uint32_t a = tstart, b = tstart + (uint32_t)real - 1u;
-                e.first = ktop | ((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask);
-                e.last = ktop | ((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask);
+                e.first = ktop + (((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask));
+                e.last = ktop + (((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask));
             }
             seg.edges[tile * 256 + d] = e;
         }
@@ -836,7 +915,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                     uint32_t f = head ? 1u : 0u;
                     if (!(head && tail)) {
-                        const uint64_t kc = ktop | ((uint64_t)k << seg.low_bits) | (uint64_t)ac;
+                        const uint64_t kc = ktop + (((uint64_t)k << seg.low_bits) | (uint64_t)ac);
                         const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
                                                           : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
                         if (!exhausted) f |= 2u;
@@ -854,8 +933,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                 }
                 if constexpr (KEEP) {
-                    if (seg.msd_shift) {  // (uniform) kept search keys in the layout of the LSD split sort: full key >> 8, low byte
-                        const uint64_t kf = ktop | (uint64_t)k;
+                    if (seg.msd_m) {  // (uniform) kept search keys in the layout of the LSD split sort: full key >> 8, low byte
+                        const uint64_t kf = ktop + (uint64_t)k;
                         rs_store<NTM>(kout + s_gbase[dd] + i, (K)(kf >> 8));
                         if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)(kf & 0xFFu));
                         continue;
@@ -1566,7 +1645,9 @@ struct MsdWorkspace {
 // flags / edge fixes / tile sums of `keep` written by the last pass.  k0 / v0 are scratch.
 inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, Profiler& prof, uint32_t* k0, uint32_t* k1,
                            uint32_t* v0, uint32_t* v1, uint8_t* wout, uint64_t n, const uint64_t* h_top, const TextGen& gen_in,
-                           const SegFinalKeepArgs& keep_in, SortStats* stats) {
+                           unsigned long long msd_m, const SegFinalKeepArgs& keep_in, SortStats* stats) {
+    // gen_in says how the generated pass splits a key into (top digit, u32 rest): msd_shift = 32 (msd_m = 2^32) or the pair
+    // form (msd_m = span * base^4); the last pass puts the full key together again as top * msd_m + rest
     if (!rs_atomic_rank_ok(s)) throw Error("radix_sort_msd: needs the one-atomic ranking (internal)");
     constexpr int TILE = RS_SEG_TILE;
     constexpr int KPASS = 4;
@@ -1606,7 +1687,6 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
     // ---- generated pass: partition by the top digit, records (u32 key, entry)
     {
         TextGen g2 = gen_in;
-        g2.msd_shift = 32;
         g2.low_bits = 0;
         ws.tile_doc.ensure(((size_t)gen_tiles + 1) * sizeof(uint64_t));
         hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)gen_tiles + 1, 256)), dim3(256), 0, s, g2.doc_start, g2.ndocs,
@@ -1645,7 +1725,7 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
     SegFinalKeepArgs ka = keep_in;
     static_cast<SegArgs&>(ka) = sa;
     ka.low_bits = 0;
-    ka.msd_shift = 32;
+    ka.msd_m = msd_m;
     const uint32_t grid = grouped ? (uint32_t)(ceil_div(seg_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : seg_tiles;
     uint32_t* kb[2] = {k0, k1};
     uint32_t* vb[2] = {v0, v1};

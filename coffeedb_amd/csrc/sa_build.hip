@@ -71,6 +71,60 @@ __global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __rest
     if (s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
+// MSD-first initial sort, pair form (radix_sort.h: TextGen::msd_pair): how often every pair of symbol CODES (c0, c1) starts
+// a suffix, as the number c0 * base + c1 — c1 = 0 where the document ends behind c0.  The sweep ignores document ends (and
+// counts nothing for the last byte of the text); sa_docend_pair_kernel moves the last position of every document from the
+// pair it was counted under to (c0, 0).  cnt[base^2], wrapping 64-bit adds.
+__global__ __launch_bounds__(1024) void sa_paircode_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ symmap,
+                                                           uint32_t kbase, unsigned long long* __restrict__ cnt) {
+    extern __shared__ uint32_t s_pair[];  // [kbase * kbase]
+    __shared__ uint16_t s_map[256];
+    const uint32_t np = kbase * kbase;
+    for (uint32_t i = threadIdx.x; i < np; i += 1024) s_pair[i] = 0;
+    if (threadIdx.x < 256) s_map[threadIdx.x] = symmap[threadIdx.x];
+    __syncthreads();
+    const uint64_t words = n / 16;
+    const uint4* t4 = reinterpret_cast<const uint4*>(text);
+    const uint64_t stride = (uint64_t)gridDim.x * 1024;
+    for (uint64_t w = (uint64_t)blockIdx.x * 1024 + threadIdx.x; w < words; w += stride) {
+        const uint4 v = t4[w];
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        const bool has_next = w * 16 + 16 < n;
+        const uint32_t nxt = has_next ? (uint32_t)s_map[text[w * 16 + 16]] : 0u;
+        uint32_t c[17];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c[4 * q] = s_map[x[q] & 0xFF];
+            c[4 * q + 1] = s_map[(x[q] >> 8) & 0xFF];
+            c[4 * q + 2] = s_map[(x[q] >> 16) & 0xFF];
+            c[4 * q + 3] = s_map[x[q] >> 24];
+        }
+        c[16] = nxt;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) atomicAdd(&s_pair[__umul24(c[q], kbase) + c[q + 1]], 1u);
+        if (has_next) atomicAdd(&s_pair[__umul24(c[15], kbase) + c[16]], 1u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) {
+        const uint64_t p = words * 16 + threadIdx.x;
+        if (p + 1 < n) atomicAdd(&s_pair[__umul24((uint32_t)s_map[text[p]], kbase) + (uint32_t)s_map[text[p + 1]]], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < np; i += 1024)
+        if (s_pair[i]) atomicAdd(&cnt[i], (unsigned long long)s_pair[i]);
+}
+__global__ __launch_bounds__(256) void sa_docend_pair_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_start,
+                                                             uint64_t ndocs, uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
+                                                             unsigned long long* __restrict__ cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < ndocs; d += stride) {
+        const uint64_t b0 = doc_start[d], e = doc_start[d + 1];
+        if (e == b0) continue;
+        const uint32_t c0 = symmap[text[e - 1]];
+        atomicAdd(&cnt[c0 * kbase], 1ull);
+        if (e < n) atomicAdd(&cnt[c0 * kbase + (uint32_t)symmap[text[e]]], ~0ull);  // (- 1)
+    }
+}
+
 // Reference order, one level below the root (bucket-wise build): how the suffixes of every first byte split by what
 // FOLLOWS that byte — a byte below 0x80, a byte from 0x80, or the end of the document.  Inside a first-symbol bucket that
 // the reference treats as a radix node its children come [end][0x80..0xFF][0x00..0x7F] (index.h:66-73); with these counts
@@ -1661,9 +1715,38 @@ void build_typed(Index& ix, bool big) {
                          dbits == 8 && key_bits > 32 && key_bits <= 40 && rs_atomic_rank_ok(s) &&
                          ((ix.sort_variant == 0 && n >= (1ull << 23)) || ix.sort_variant == 31 || ix.sort_variant == 33);
     st.msd_first = use_msd ? 1 : 0;
-    if (fused && dense) {
+    // pair form: 6-symbol keys whose top digit is a function of the first two symbols (TextGen::msd_pair); otherwise the
+    // top digit is key >> 32, counted by the key sweep
+    unsigned long long msd_m = 1ull << 32;
+    uint32_t msd_span = 0;
+    std::vector<uint64_t> h_top;
+    if (use_msd && ix.msd_pair && nsym == 6 && kbase <= 128) {
+        const uint64_t P4 = (uint64_t)kbase * kbase * kbase * kbase;  // (< 2^28)
+        msd_span = (uint32_t)std::min<uint64_t>((1ull << 32) / P4, (uint64_t)kbase * kbase);
+        if (ceil_div((uint64_t)kbase * kbase, (uint64_t)msd_span) > 256) msd_span = 0;
+    }
+    if (msd_span) {
+        msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
+        const uint32_t np = kbase * kbase;
+        DevBuf d_pc;
+        d_pc.alloc((size_t)np * sizeof(uint64_t));
+        CDB_HIP(hipMemsetAsync(d_pc.p, 0, (size_t)np * sizeof(uint64_t), s));
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_paircode_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(n, 1024 * 16 * 4), 512))), dim3(1024),
+                           np * sizeof(uint32_t), s, text, n, (const uint16_t*)d_symmap.as<uint16_t>(), kbase, d_pc.as<unsigned long long>());
+        hipLaunchKernelGGL(sa_docend_pair_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))), dim3(256), 0, s,
+                           text, doc_start, D, n, (const uint16_t*)d_symmap.as<uint16_t>(), kbase, d_pc.as<unsigned long long>());
+        ix.prof.end(t, "sa_paircode", n + D * 18, s);
+        std::vector<uint64_t> pc(np);
+        CDB_HIP(hipMemcpyAsync(pc.data(), d_pc.p, (size_t)np * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        h_top.assign(256, 0);
+        for (uint32_t a = 0; a < np; ++a) h_top[a / msd_span] += pc[a];
+        st.msd_first = 2;
+    } else if (fused && dense) {
         const int npass = (int)ceil_div(key_bits, 8);
         key_histograms(npass, use_msd ? 1u << (npass - 1) : 0xFFFFFFFFu);
+        if (use_msd) h_top.assign(h_hist.begin() + (size_t)(npass - 1) * 256, h_hist.begin() + (size_t)npass * 256);
     } else if (fused && !big) {
         // per-pass digit histograms from the byte counts + document-head corrections (no key is read)
         DevBuf d_corr;
@@ -1758,9 +1841,18 @@ void build_typed(Index& ix, bool big) {
             }
             if (layout == SPLIT && use_msd && want_keep) {
                 // the final pass writes the kept keys in the split layout (u32 = key >> 8, low byte), entries and flags
+                if (msd_span) {
+                    gen.msd_pair = true;
+                    const RsDiv24 ds = rs_div24_make(msd_span), db = rs_div24_make(kbase), db2 = rs_div24_make(kbase * kbase);
+                    gen.msd_span_mul = ds.mul; gen.msd_span_sh = ds.sh;
+                    gen.div_b_mul = db.mul; gen.div_b_sh = db.sh;
+                    gen.div_b2_mul = db2.mul; gen.div_b2_sh = db2.sh;
+                    gen.msd_mlo = (uint32_t)msd_m;
+                } else {
+                    gen.msd_shift = 32;
+                }
                 radix_sort_msd(s, ix.rws, ix.msd_ws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<uint32_t>(),
-                               vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_hist.data() + (size_t)((int)ceil_div(key_bits, 8) - 1) * 256,
-                               gen, keep, &ss);
+                               vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_top.data(), gen, msd_m, keep, &ss);
                 sel = 1;
                 sorted_low = std::move(low[1]);
                 flags_by_sort = ix.rws.keep_applied;

@@ -850,7 +850,12 @@ def test_msd_first_split_sort(G, variant):
                                   msd_first=0)
             assert g0.stat("msd_first") == 0
             if g0.stat("key_layout") == 2:                                            # split records with one low digit
-                assert g.stat("msd_first") == 1 and g.stat("flags_in_last_pass") == 1
+                # 6-symbol keys take the pair form (top digit from the first two symbols, 32-bit part arithmetic in the
+                # generated pass), the others key >> 32; msd_pair = 0 forces the latter
+                assert g.stat("msd_first") == (2 if ksym == 6 else 1) and g.stat("flags_in_last_pass") == 1
+                g1, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=variant, force_doubling=fd, key_coding=2, key_symbols=ksym,
+                                      msd_pair=0)
+                assert g1.stat("msd_first") == 1 and g1.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial")
                 seen += 1
             assert g.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial")
             assert g.stat("rounds") == g0.stat("rounds")
