@@ -170,6 +170,11 @@ struct TextGen {
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 constexpr int RS_GEN_LOOK = 64;
+// timing-only ablations of the generated pass (tools/experiments/gen_bench.hip; WRONG results): 1 = no key arithmetic,
+// 2 = no transposition through LDS, 4 = no text staging
+#ifndef RS_GEN_ABL
+#define RS_GEN_ABL 0
+#endif
 
 // floor(x / d) for x < 2^24 as one multiply-high: with L = ceil(log2 d) and m = ceil(2^(24+L) / d) (< 2^25, error
 // m d - 2^(24+L) < d <= 2^L, so x < 2^24 keeps the quotient exact), mul = m << 7 and sh = L + 7
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         // bytes -> symbol codes on their way into LDS: one table lookup per text byte instead of one per
         // (suffix, symbol)
         for (uint32_t i = tid * 16; i < (uint32_t)TILE + RS_GEN_LOOK; i += NT * 16) {
+            if (RS_GEN_ABL & 4) break;
             const uint64_t g = base + i;
             uint32_t x[4];
             if (gen.padded ? (g < n + RS_GEN_LOOK) : (g + 16 <= n)) {
@@ -501,8 +507,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                             }
                             a = rs_div24(g0, gen.div_b_mul, gen.div_b_sh);
                         }
-                        const uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
-                        kt[swz(q)] = g0 * W3 + g3 - top * gen.msd_mlo;  // key - top * M (< 2^32: exact modulo 2^32)
+                        uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
+                        uint32_t kp = g0 * W3 + g3 - top * gen.msd_mlo;  // key - top * M (< 2^32: exact modulo 2^32)
+                        if (RS_GEN_ABL & 1) { top = q & 127u; kp = q * 2654435761u; }
+                        kt[swz(q)] = kp;
                         if constexpr (HAS_W) s_aux[swz(q)] = (WS)top;
                         ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                     }
@@ -557,6 +565,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 if constexpr (HAS_W) aux[j] = li < valid ? s_aux[swz(li)] : WS(0);
             }
             __syncthreads();
+            if (RS_GEN_ABL & 2) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) val[j] = (VS)ent[j];
+            } else {
 #pragma unroll
             for (int j = 0; j < IPT; ++j) kt[swz(q0 + j)] = ent[j];
             __syncthreads();
@@ -564,6 +576,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             for (int j = 0; j < IPT; ++j) {
                 const uint32_t li = wbase + j * 64;
                 val[j] = li < valid ? (VS)kt[swz(li)] : VS(0);
+            }
             }
         } else {
 #pragma unroll

@@ -115,14 +115,20 @@ __global__ __launch_bounds__(1024) void sa_paircode_kernel(const uint8_t* __rest
 __global__ __launch_bounds__(256) void sa_docend_pair_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_start,
                                                              uint64_t ndocs, uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
                                                              unsigned long long* __restrict__ cnt) {
+    __shared__ uint32_t s_end[257];  // documents by the code of their last symbol (few hot counters: not straight to memory)
+    for (int i = threadIdx.x; i < 257; i += 256) s_end[i] = 0;
+    __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < ndocs; d += stride) {
         const uint64_t b0 = doc_start[d], e = doc_start[d + 1];
         if (e == b0) continue;
         const uint32_t c0 = symmap[text[e - 1]];
-        atomicAdd(&cnt[c0 * kbase], 1ull);
+        atomicAdd(&s_end[c0], 1u);
         if (e < n) atomicAdd(&cnt[c0 * kbase + (uint32_t)symmap[text[e]]], ~0ull);  // (- 1)
     }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < kbase; c += 256)
+        if (s_end[c]) atomicAdd(&cnt[c * kbase], (unsigned long long)s_end[c]);
 }
 
 // Reference order, one level below the root (bucket-wise build): how the suffixes of every first byte split by what
