@@ -162,6 +162,13 @@ struct TextGen {
     // M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count of the text instead of
     // a sweep that evaluates every key.  The generated pass then works in 32-bit part arithmetic (G = three symbols as a
     // number, key = G(p) base^3 + G(p + 3)): no rolling 64-bit key.  rs_div24: floor(x / d) for x < 2^24 from (mul, sh).
+    // Bucket-wise build, fused form (sa_build.hip): the generated pass writes the bucket RECORDS itself instead of partitioning
+    // the entries for a later gather — sort digit = bucket slot of the suffix's first symbol (slotmap[code]), key = the
+    // nsym - 1 symbols behind it as a dense number (k32 = key >> rec_low_bits), W = its low digits | entry bits 32.. above
+    // them, value = entry bits 0..31.  16 Ki-key tiles only (thread-consecutive rolling keys).
+    bool rec_mode = false;
+    const uint8_t* slotmap = nullptr;  // [257] symbol code -> bucket slot
+    int rec_low_bits = 0;
     bool msd_pair = false;
     uint32_t msd_span_mul = 0, msd_span_sh = 0;  // / span
     uint32_t msd_mlo = 0;                        // M mod 2^32
@@ -339,7 +346,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     constexpr uint32_t GEN_TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
     constexpr uint32_t GEN_DOCS = 1024;
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char s_gen[BLK ? GEN_TEXTB + 512 + GEN_DOCS * 8 : 16];
+    constexpr uint32_t GEN_SLOTS = 320;  // code -> bucket slot (records mode), behind the document table
+    __shared__ __attribute__((aligned(16))) unsigned char s_gen[BLK ? GEN_TEXTB + 512 + GEN_DOCS * 8 + GEN_SLOTS : 16];
     __shared__ WS s_aux[HAS_W ? TILE : 1];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_whist[NW][256];
@@ -385,6 +393,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     K key[IPT];
     VS val[EARLYV ? IPT : 1];
     WS aux[HAS_W ? IPT : 1] = {};
+    uint32_t gdig[BLK ? IPT / 4 : 1] = {};  // records mode of the generated pass: the elements' sort digits, four per register
+    bool recs = false;
+    if constexpr (BLK) recs = gen.rec_mode;
     auto digit_of = [&](K k, WS a) -> uint32_t {
         if constexpr (HAS_W) {
             if (aux_shift >= 0) return ((uint32_t)a >> aux_shift) & dmask;
@@ -409,6 +420,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         if (docs_in_lds)
             for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
         for (int i = tid; i < 256; i += NT) s_map[i] = gen.symmap[i];
+        if constexpr (BLK) {
+            if (recs && tid < 257) (gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8)[tid] = gen.slotmap[tid];
+        }
         __syncthreads();
         // bytes -> symbol codes on their way into LDS: one table lookup per text byte instead of one per
         // (suffix, symbol)
@@ -515,6 +529,46 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                     }
                 }
+            } else if (HAS_W && recs) {  // (uniform) bucket records: key = the nsym - 1 symbols BEHIND the first one, 40-bit entries
+                const int ns1 = nsym - 1;
+                uint64_t top1 = 1;  // weight of the symbol that leaves the (shifted) window
+                for (int q = 1; q < ns1; ++q) top1 *= gen.base;
+                const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t q = q0 + j;
+                    ent[j] = 0;
+                    if (q < valid) {
+                        bool fresh = j == 0;
+                        if (j == 0 || q >= dend_l) {
+                            const uint64_t p = base + q;
+                            uint64_t ds, de;
+                            if (docs_in_lds) {
+                                d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
+                                ds = s_docs[d - dlo];
+                                de = s_docs[d - dlo + 1];
+                            } else {
+                                d = rs_doc_upper(gen.doc_start, d, dhi, p);
+                                ds = gen.doc_start[d];
+                                de = gen.doc_start[d + 1];
+                            }
+                            const uint64_t rel = de - base;
+                            dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
+                            ebase = d - (ds << gen.bits);
+                            fresh = true;
+                        }
+                        if (fresh) {
+                            kk = rs_pack_key(s_words, q + 1u, ns1, gen.base, dend_l - q - 1u);
+                        } else {
+                            const uint64_t cin = q + (uint32_t)nsym - 1u < dend_l ? (uint64_t)s_text[q + nsym - 1] : 0ull;
+                            kk = (kk - (uint64_t)s_text[q] * top1) * gen.base + cin;
+                        }
+                        const uint64_t e64 = ((base + q) << gen.bits) + ebase;
+                        kt[swz(q)] = (uint32_t)(kk >> gen.rec_low_bits);
+                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)((kk & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+                        ent[j] = (uint32_t)e64;
+                    }
+                }
             } else {
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
@@ -577,6 +631,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const uint32_t li = wbase + j * 64;
                 val[j] = li < valid ? (VS)kt[swz(li)] : VS(0);
             }
+            }
+            if (recs) {  // sort digits of the thread's (lane-striped) elements: bucket slot of the first symbol
+                const uint8_t* s_slot = gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t li = wbase + j * 64;
+                    gdig[j >> 2] |= (uint32_t)s_slot[s_text[li < valid ? li : 0u]] << (8 * (j & 3));
+                }
             }
         } else {
 #pragma unroll
@@ -722,7 +784,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
-            const uint32_t d = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
+            uint32_t d = digit_of(key[j], aux[HAS_W ? j : 0]);
+            if constexpr (BLK) d = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : d;
+            d = li < valid ? d : 255u;
             rank[j] = atomicAdd(&s_whist[wave][d], 1u);
         }
     } else {
@@ -731,7 +795,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         const uint32_t li = wbase + j * 64;
         // out-of-range slots take digit 255: they have the largest indices of the tile, so they end
         // up behind every real element and are simply not written out.
-        const uint32_t d = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
+        uint32_t d = digit_of(key[j], aux[HAS_W ? j : 0]);
+        if constexpr (BLK) d = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : d;
+        d = li < valid ? d : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -802,11 +868,16 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
-        const uint32_t dd = li < valid ? digit_of(key[j], aux[HAS_W ? j : 0]) : 255u;
+        uint32_t dd = digit_of(key[j], aux[HAS_W ? j : 0]);
+        if constexpr (BLK) dd = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : dd;
+        dd = li < valid ? dd : 255u;
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
         if constexpr (HAS_W) s_aux[pos] = aux[j];
+        if constexpr (BLK) {
+            if (recs) s_gen[pos] = (unsigned char)dd;  // (the text codes are dead: their LDS carries the digits to the write-out)
+        }
     }
     if constexpr (HAS_V && !REUSE) {
 #pragma unroll
@@ -910,7 +981,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             dig[j] = 0;
             if (i < valid) {
                 const K k = s_keys[i];
-                const uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
+                uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
+                if constexpr (BLK) dd = recs ? (uint32_t)s_gen[i] : dd;
                 dig[j] = (uint8_t)dd;
                 if constexpr (FLAGS) {
                     // group flags from the neighbours in the sorted tile (equal keys have equal digits, so the ends of
@@ -1600,12 +1672,13 @@ void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uin
 // the partitioned keys (rs_seg_hist_kernel: 4 B read per record).
 constexpr int RS_MSD_HIST_TILES = 32;  // consecutive tiles per workgroup of the histogram sweep
 
-// hist[g][p][d] (the [nseg][8][256] layout of rs_seg_digit_start_kernel): 8-bit digits p < NPASS of the keys of segment g
-template <int NPASS>
-__global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tile_seg,
-                                                           const SegInfo* __restrict__ segs, uint32_t tiles,
-                                                           unsigned long long* __restrict__ hist) {
-    __shared__ uint32_t sh[NPASS][256];
+// hist[g][p][d] (the [nseg][8][256] layout of rs_seg_digit_start_kernel) from the materialised records of every segment:
+// digit p < lead is byte p of the auxiliary word, digit lead + q byte q of the key (the order the segmented passes sort in)
+template <typename W>
+__global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __restrict__ keys, const W* __restrict__ aux, int lead, int npass,
+                                                           const uint32_t* __restrict__ tile_seg, const SegInfo* __restrict__ segs,
+                                                           uint32_t tiles, unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t sh[8][256];
     const int tid = threadIdx.x;
     const uint32_t t0 = blockIdx.x * RS_MSD_HIST_TILES;
     const uint32_t t1 = t0 + RS_MSD_HIST_TILES < tiles ? t0 + RS_MSD_HIST_TILES : tiles;
@@ -1613,9 +1686,9 @@ __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __res
     auto flush = [&]() {
         __syncthreads();
         if (cur != ~0u)
-            for (int i = tid; i < NPASS * 256; i += 1024)
+            for (int i = tid; i < npass * 256; i += 1024)
                 if ((&sh[0][0])[i]) atomicAdd(&hist[((size_t)cur * 8 + i / 256) * 256 + i % 256], (unsigned long long)(&sh[0][0])[i]);
-        for (int i = tid; i < NPASS * 256; i += 1024) (&sh[0][0])[i] = 0;
+        for (int i = tid; i < npass * 256; i += 1024) (&sh[0][0])[i] = 0;
         __syncthreads();
     };
     for (uint32_t t = t0; t < t1; ++t) {
@@ -1627,20 +1700,26 @@ __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __res
         const SegInfo si = segs[g];
         const uint64_t base = si.begin + (uint64_t)(t - si.tile_begin) * RS_SEG_TILE;
         const uint32_t valid = (uint32_t)((si.end - base) < (uint64_t)RS_SEG_TILE ? (si.end - base) : (uint64_t)RS_SEG_TILE);
-        uint32_t k[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // 16 keys per thread, four 16-byte loads (segments start on 256-byte boundaries or not: plain loads)
+        for (int r = 0; r < 4; ++r) {  // 16 records per thread, four loads in flight
+            uint32_t k[4], a[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
                 k[q] = li < valid ? keys[base + li] : 0u;
+                a[q] = (li < valid && lead > 0) ? (uint32_t)aux[base + li] : 0u;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
                 if (li < valid) {
 #pragma unroll
-                    for (int p = 0; p < NPASS; ++p) atomicAdd(&sh[p][(k[q] >> (8 * p)) & 0xFFu], 1u);
+                    for (int p = 0; p < 8; ++p) {
+                        if (p < npass) {
+                            const uint32_t dg = p < lead ? (a[q] >> (8 * p)) & 0xFFu : (k[q] >> (8 * (p - lead))) & 0xFFu;
+                            atomicAdd(&sh[p][dg], 1u);
+                        }
+                    }
                 }
             }
         }
@@ -1722,9 +1801,9 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
     // ---- digit histograms of every bucket's four passes
     {
         int t = prof.begin(s);
-        hipLaunchKernelGGL((rs_seg_hist_kernel<KPASS>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s,
-                           (const uint32_t*)k1, (const uint32_t*)mw.tile_seg.as<uint32_t>(), (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles,
-                           mw.hist.as<unsigned long long>());
+        hipLaunchKernelGGL((rs_seg_hist_kernel<uint8_t>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s,
+                           (const uint32_t*)k1, (const uint8_t*)nullptr, 0, KPASS, (const uint32_t*)mw.tile_seg.as<uint32_t>(),
+                           (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles, mw.hist.as<unsigned long long>());
         prof.end(t, "rs_seg_hist", n * 4, s);
         hipLaunchKernelGGL(rs_seg_digit_start_kernel, dim3(nseg), dim3(256), 0, s, (const unsigned long long*)mw.hist.as<unsigned long long>(),
                            (const SegInfo*)mw.segs.as<SegInfo>(), KPASS, mw.starts.as<unsigned long long>());
@@ -1778,6 +1857,54 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
         prof.end(t, "rs_seg_edge_fix", (uint64_t)seg_tiles * 256 * sizeof(SegEdge), s);
     }
     ws.keep_applied = true;
+    CDB_HIP(hipGetLastError());
+}
+
+// Bucket-wise build (>= 2^32 suffixes), fused form: ONE generated pass writes the packed bucket records (TextGen::rec_mode)
+// of every first-symbol bucket into buffers (k, v, w) — the entries are never partitioned on their own and no gather
+// re-reads the text in bucket order — and a sweep over the records counts the digit histograms of every bucket's passes
+// (d_hist_out: [nseg][8][256], zeroed here).  h_first[256]: suffixes per bucket slot.  radix_sort_segmented follows.
+template <typename W>
+void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const uint64_t* h_first,
+                       const TextGen& gen_in, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles, int lead,
+                       int npass, unsigned long long* d_hist_out, SortStats* stats) {
+    static_assert(sizeof(W) <= 2, "the generated pass keeps text, records and auxiliary words of a 16 Ki tile in the LDS: u8 / u16 only");
+    if (!rs_atomic_rank_ok(s)) throw Error("radix_gen_records: needs the one-atomic ranking (internal)");
+    constexpr int TILE = RS_SEG_TILE;
+    using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+    using CfgP = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true>;
+    const bool grouped = ws.allow_group && !ws.plain_order;
+    const uint32_t gen_tiles = (uint32_t)ceil_div(n, (uint64_t)TILE);
+    ws.prepare((uint64_t)std::max(gen_tiles, seg_tiles) * TILE, TILE, s);
+    unsigned long long* d_hist = ws.hist.as<unsigned long long>();
+    unsigned long long* d_start = d_hist + RS_MAX_PASSES * 256;
+    CDB_HIP(hipMemcpyAsync(d_hist, h_first, 256 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    CDB_HIP(hipStreamSynchronize(s));  // (pageable host memory)
+    hipLaunchKernelGGL(rs_digit_start_kernel, dim3(1), dim3(256), 0, s, d_hist, d_start);
+    CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
+    TextGen g2 = gen_in;
+    g2.rec_mode = true;
+    ws.tile_doc.ensure(((size_t)gen_tiles + 1) * sizeof(uint64_t));
+    hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)gen_tiles + 1, 256)), dim3(256), 0, s, g2.doc_start, g2.ndocs, n,
+                       (uint64_t)TILE, (uint64_t)gen_tiles, ws.tile_doc.as<uint64_t>());
+    g2.tile_doc = ws.tile_doc.as<uint64_t>();
+    const uint32_t e = ws.next_epoch(s);
+    const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles;
+    int t = prof.begin(s);
+    if (grouped)
+        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGen, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
+                           (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                           ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, w, -1);
+    else
+        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGen, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
+                           (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                           ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, w, -1);
+    prof.end(t, (std::string("rs_onesweep_textgen_records") + (sizeof(W) == 1 ? "_w8" : "_w16") + "_t16384").c_str(), n * (1 + 8 + sizeof(W)), s);
+    if (stats) stats->passes_run++;
+    t = prof.begin(s);
+    hipLaunchKernelGGL((rs_seg_hist_kernel<W>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s, (const uint32_t*)k,
+                       (const W*)w, lead, npass, d_tile_seg, d_segs, seg_tiles, d_hist_out);
+    prof.end(t, "rs_seg_hist", n * (4 + (lead > 0 ? sizeof(W) : 0)), s);
     CDB_HIP(hipGetLastError());
 }
 

@@ -1937,9 +1937,11 @@ void build_typed(Index& ix, bool big) {
         }
         std::vector<uint64_t> first_by_code(258, 0), first_digit(256, 0);
         uint16_t h_map_first[256];
+        uint8_t h_slotmap[260] = {0};  // symbol code -> bucket slot (the fused records pass)
         {
             int slot_of_code[258] = {0};
             for (int k = 0; k < sigma; ++k) slot_of_code[border[k]] = k;
+            for (int c = 1; c <= sigma; ++c) h_slotmap[c] = (uint8_t)slot_of_code[c];
             for (int b = 0; b < 256; ++b) {
                 h_map_first[b] = h_map[b] ? (uint16_t)slot_of_code[h_map[b]] : (uint16_t)0;
                 if (h_map[b]) {
@@ -1953,13 +1955,60 @@ void build_typed(Index& ix, bool big) {
         d_symmap_first.alloc(256 * sizeof(uint16_t));
         CDB_HIP(hipMemcpyAsync(d_symmap_first.p, h_map_first, sizeof(h_map_first), hipMemcpyHostToDevice, s));
         CDB_HIP(hipStreamSynchronize(s));  // (h_map_first is a stack array)
-        gen.first_only = true;
-        gen.symmap = d_symmap_first.as<uint16_t>();
-        const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
-        (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
-                                      &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
         uint64_t maxb = 0;
         for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
+        // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
+        // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort
+        // path when it fits 32 bits + one or two low digits: (u32, entry, u8 / u16) instead of (u64, entry).
+        const uint32_t bbase = (uint32_t)sigma + 1u;
+        int bbits = 0;  // bits of bbase^(nsym-1) - 1; 999 beyond 56 bits
+        {
+            unsigned __int128 v = 1;
+            for (int i = 0; i + 1 < nsym && bbits != 999; ++i) {
+                v *= bbase;
+                if (v > ((unsigned __int128)1 << 56)) bbits = 999;
+            }
+            if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
+        }
+        // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
+        //  symbols, the grouped gather and no separate histogram pass)
+        // packed entries (sa_bucket_records_packed_kernel): 8-byte entries below 2^40 travel as u32 + one byte on top of the
+        // low digits; up to three low digits then keep every key of <= 56 bits in (u32, u32, u8 / u16 / u32) records
+        const bool packed = sizeof(V) == 8 && ix.pack_entries && (int)ix.bits + ix.off_bits <= 40 && ix.narrow_keys && nsym > 1 &&
+                            bbits <= 56;
+        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : (bbits <= 56 ? (packed ? 24 : 0) : -1)));
+        const bool bwide = !packed && bbits > 48 && bbits <= 56;
+        // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
+        //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
+        const bool brecords = ix.narrow_keys && blow >= 0 && nsym > 1;  // (codes up to 256 are u16 in the record kernel)
+        // FUSED form: when the records of ALL buckets fit the memory at once (one bucket group) and their auxiliary word is a
+        // u8 / u16 (the tile of the generated pass holds text, records and auxiliary words in the LDS), the generated pass
+        // writes the records itself (radix_sort.h: radix_gen_records) — the entries are never partitioned on their own, no
+        // gather walks the text bucket by bucket (4 GiB of UTF-8: 22 ms partition + 32 ms gather -> one 24 ms pass + a 7 ms
+        // histogram sweep of the records).
+        bool fuse_rec = false;
+        // (the tile stages symbol CODES as bytes: alphabets of all 256 byte values — codes up to 256 — keep the gather)
+        if (brecords && packed && blow <= 8 && sigma <= 255 && ix.segmented_sort && ix.fuse_records && sizeof(V) == 8 && rs_atomic_rank_ok(s) &&
+            (ix.bucket_group_limit == 0 || ix.bucket_group_limit >= n)) {
+            size_t fre = 0, tot = 0;
+            CDB_HIP(hipMemGetInfo(&fre, &tot));
+            const double avail = (double)fre + (double)DevPool::get().cached_bytes();
+            const int recb0 = 4 + (blow == 0 ? 1 : 2) + 4;
+            fuse_rec = avail * 0.85 / (2.0 * recb0 + 1.0) >= (double)n;
+        }
+        st.fused_records = fuse_rec ? 1 : 0;
+        DevBuf d_slotmap;
+        if (fuse_rec) {
+            d_slotmap.alloc(260);
+            CDB_HIP(hipMemcpyAsync(d_slotmap.p, h_slotmap, 260, hipMemcpyHostToDevice, s));
+            CDB_HIP(hipStreamSynchronize(s));  // (h_slotmap is a stack array)
+        } else {
+            gen.first_only = true;
+            gen.symmap = d_symmap_first.as<uint16_t>();
+            const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
+            (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
+                                          &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
+        }
         if (root_folded) {
             uint64_t at = 0;
             for (int k = 0; k < sigma; ++k) {
@@ -2002,30 +2051,6 @@ void build_typed(Index& ix, bool big) {
                 }
             }
         }
-        // Bucket records.  Inside a bucket the first symbol is constant, so the sort key is the remaining
-        // nsym - 1 symbols — as a dense base-(alphabet + 1) number, split like the records of the single-sort
-        // path when it fits 32 bits + one or two low digits: (u32, entry, u8 / u16) instead of (u64, entry).
-        const uint32_t bbase = (uint32_t)sigma + 1u;
-        int bbits = 0;  // bits of bbase^(nsym-1) - 1; 999 beyond 56 bits
-        {
-            unsigned __int128 v = 1;
-            for (int i = 0; i + 1 < nsym && bbits != 999; ++i) {
-                v *= bbase;
-                if (v > ((unsigned __int128)1 << 56)) bbits = 999;
-            }
-            if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
-        }
-        // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
-        //  symbols, the grouped gather and no separate histogram pass)
-        // packed entries (sa_bucket_records_packed_kernel): 8-byte entries below 2^40 travel as u32 + one byte on top of the
-        // low digits; up to three low digits then keep every key of <= 56 bits in (u32, u32, u8 / u16 / u32) records
-        const bool packed = sizeof(V) == 8 && ix.pack_entries && (int)ix.bits + ix.off_bits <= 40 && ix.narrow_keys && nsym > 1 &&
-                            bbits <= 56;
-        const int blow = bbits <= 32 ? 0 : (bbits <= 40 ? 8 : (bbits <= 48 ? 16 : (bbits <= 56 ? (packed ? 24 : 0) : -1)));
-        const bool bwide = !packed && bbits > 48 && bbits <= 56;
-        // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
-        //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
-        const bool brecords = ix.narrow_keys && blow >= 0 && nsym > 1;  // (codes up to 256 are u16 in the record kernel)
         st.bucket_low_digits = brecords && blow > 0 ? blow / 8 : 0;
         st.key_layout = brecords ? (packed ? 5 : (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3)))) : 0;
         if (brecords) {
@@ -2043,8 +2068,9 @@ void build_typed(Index& ix, bool big) {
             const uint32_t nch = (uint32_t)ceil_div(n, chunk);
             DevBuf d_bstart, d_bounds;
             d_bstart.alloc((nb + 1) * 8);
-            d_bounds.alloc((size_t)nb * (nch + 1) * 8);
+            d_bounds.alloc(fuse_rec ? 8 : (size_t)nb * (nch + 1) * 8);
             CDB_HIP(hipMemcpyAsync(d_bstart.p, bstart.data(), (nb + 1) * 8, hipMemcpyHostToDevice, s));
+            if (!fuse_rec)
             hipLaunchKernelGGL((sa_bucket_bounds_kernel<V>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
                                (const V*)E.as<V>(), (const unsigned long long*)d_bstart.as<unsigned long long>(), nb, nch, chunk,
                                doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
@@ -2066,7 +2092,9 @@ void build_typed(Index& ix, bool big) {
                     if (ix.bucket_group_limit) cap = std::max<uint64_t>(std::min<uint64_t>(cap, ix.bucket_group_limit), maxb);
                     seg_cap = std::min<uint64_t>(cap, n);
                 }
+                if (fuse_rec) seg_cap = n;  // (decided with the same bound before the entries were NOT partitioned)
             }
+            if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
             auto run_segmented = [&](auto wtag) {
                 using W = decltype(wtag);
                 if constexpr (sizeof(V) == 8) {
@@ -2135,6 +2163,19 @@ void build_typed(Index& ix, bool big) {
                         const uint32_t gb = g.b1 - g.b0;
                         uint32_t* list_len = lists.as<uint32_t>() + gi * 16;
                         uint32_t* tickets = list_len + 8;
+                        if (fuse_rec) {
+                            if constexpr (sizeof(W) <= 2) {
+                                hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
+                                                   (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
+                                TextGen rg{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, bbase, nsym, 0, ix.text_padded};
+                                rg.slotmap = d_slotmap.as<uint8_t>();
+                                rg.rec_low_bits = blow;
+                                radix_gen_records<W>(s, ix.rws, ix.prof, kb[0].as<uint32_t>(), eb[0].as<uint32_t>(), wb[0].as<W>(), n,
+                                                     first_digit.data(), rg, (const uint32_t*)tile_seg.as<uint32_t>(),
+                                                     (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
+                                                     d_bh2.as<unsigned long long>(), &ss);
+                            }
+                        } else {
                         CDB_HIP(hipMemsetAsync(d_bh2.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
                         int t = ix.prof.begin(s);
                         hipLaunchKernelGGL(sa_gather_plan_kernel, dim3(8), dim3(1024), 0, s, bnd, nch, g.b0, gb, g.plan, cell_off.as<uint32_t>(),
@@ -2154,6 +2195,7 @@ void build_typed(Index& ix, bool big) {
                         st.gather_items += g.elems / BR_ITEM;
                         hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
                                            (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
+                        }
                         SegFinalArgs fin;
                         fin.eout = E.as<uint64_t>() + g.gstart;
                         fin.flags = flags.as<uint8_t>() + g.gstart;

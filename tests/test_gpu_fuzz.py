@@ -116,6 +116,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     opts = {"force_big_path": 1}
     if rng.random() < 0.5: opts["bucket_group_limit"] = int(rng.integers(1, 80000))
     if rng.random() < 0.25: opts["segmented_sort"] = 0
+    if rng.random() < 0.3: opts["fuse_records"] = 0      # (records by partition + gather although they all fit at once)
     if rng.random() < 0.25: opts["fold_root"] = 0
     if rng.random() < 0.25: opts["fold_depth1"] = 0
     if rng.random() < 0.3: opts["plain_tile_order"] = 1

@@ -234,6 +234,13 @@ def test_bucket_sorts_with_packed_entries(G, pack):
             g, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, **opts)
             assert g.sa_width == 8 and g.stat("bucketed") == 1 and g.stat("segmented") == int(pack == 1)
             layouts.add((int(g.stat("key_layout")), int(g.stat("bucket_low_digits"))))
+            # one bucket group, u8 / u16 auxiliary words: the generated pass writes the records itself (no partition of the
+            # entries, no gather); fuse_records = 0 is the partition + gather form of the same sort
+            fused = pack == 1 and group_limit == 0 and g.stat("bucket_low_digits") <= 1 and g.stat("alphabet") <= 255
+            assert g.stat("fused_records") == int(fused)
+            if fused:
+                g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, fuse_records=0, **opts)
+                assert g2.stat("fused_records") == 0 and g2.stat("unresolved_after_initial") == g.stat("unresolved_after_initial")
     assert (5 in {l for l, _ in layouts}) == bool(pack), layouts
     assert not pack or {d for _, d in layouts} == {0, 1, 2, 3}, layouts   # u8 / u16 / u32 auxiliary arrays
 
@@ -270,7 +277,7 @@ def test_reference_order_folded_into_the_bucket_wise_build(G):
     for seed, syms in ((5, [0x41, 0x42, 0xC3, 0xA9]), (6, [0x10, 0x7F, 0x80, 0xF0, 0x41]), (7, [0xC3, 0xA9, 0xE2]), (8, list(range(0x60, 0xA0)))):
         blob = _few_symbols(n, seed, syms)
         pats = W.sample_patterns(blob, ds, 150, 1, 7, seed=3, miss_frac=0.1, miss_byte=0x5A)
-        for opts in (dict(), dict(fold_depth1=0), dict(fold_root=0), dict(bucket_group_limit=60000), dict(segmented_sort=0)):
+        for opts in (dict(), dict(fold_depth1=0), dict(fold_root=0), dict(bucket_group_limit=60000), dict(segmented_sort=0), dict(fuse_records=0)):
             g, o = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, **opts)
             assert g.sa_width == 8 and g.stat("bucketed") == 1
             r = g.verify_reference()
