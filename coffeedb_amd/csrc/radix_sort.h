@@ -348,7 +348,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
     constexpr uint32_t GEN_SLOTS = 320;  // code -> bucket slot (records mode), behind the document table
     __shared__ __attribute__((aligned(16))) unsigned char s_gen[BLK ? GEN_TEXTB + 512 + GEN_DOCS * 8 + GEN_SLOTS : 16];
-    __shared__ WS s_aux[HAS_W ? TILE : 1];
+    // W32G: a generated pass with 4-byte auxiliary words (bucket records with two or three low digits) has no room for them
+    // beside text + records: they cross the tile through the staging buffer in a phase of their own, like keys and values
+    constexpr bool W32G = GEN && HAS_W && sizeof(WS) == 4;
+    __shared__ WS s_aux[(HAS_W && !W32G) ? TILE : 1];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint32_t s_tstart[256];
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             uint64_t top = 1;  // weight of the symbol that leaves the window
             for (int q = 1; q < nsym; ++q) top *= gen.base;
             uint32_t ent[IPT];
+            uint32_t auxc[W32G ? IPT : 1] = {};  // (W32G) the auxiliary words of the thread's consecutive positions
             uint64_t kk = 0;
             if (HAS_W && gen.msd_pair) {  // (uniform) MSD-first sort, pair form: 6-symbol keys in 32-bit part arithmetic
                 const uint32_t B = gen.base, W3 = B * B * B;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         uint32_t kp = g0 * W3 + g3 - top * gen.msd_mlo;  // key - top * M (< 2^32: exact modulo 2^32)
                         if (RS_GEN_ABL & 1) { top = q & 127u; kp = q * 2654435761u; }
                         kt[swz(q)] = kp;
-                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)top;
+                        if constexpr (HAS_W && !W32G) s_aux[swz(q)] = (WS)top;
                         ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                     }
                 }
@@ -565,7 +569,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         }
                         const uint64_t e64 = ((base + q) << gen.bits) + ebase;
                         kt[swz(q)] = (uint32_t)(kk >> gen.rec_low_bits);
-                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)((kk & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+                        if constexpr (W32G) auxc[j] = (uint32_t)((kk & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+                        else if constexpr (HAS_W) s_aux[swz(q)] = (WS)((kk & lmask) | ((e64 >> 32) << gen.rec_low_bits));
                         ent[j] = (uint32_t)e64;
                     }
                 }
@@ -602,10 +607,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     const uint64_t kx = kk;
                     if (gen.msd_shift) {  // (uniform)
                         kt[swz(q)] = (uint32_t)kx;
-                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx >> gen.msd_shift);
+                        if constexpr (HAS_W && !W32G) s_aux[swz(q)] = (WS)(kx >> gen.msd_shift);
                     } else {
                         kt[swz(q)] = (uint32_t)(kx >> gen.low_bits);
-                        if constexpr (HAS_W) s_aux[swz(q)] = (WS)(kx & ((1ull << gen.low_bits) - 1ull));
+                        if constexpr (HAS_W && !W32G) s_aux[swz(q)] = (WS)(kx & ((1ull << gen.low_bits) - 1ull));
                     }
                     ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                 }
@@ -616,9 +621,20 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             for (int j = 0; j < IPT; ++j) {
                 const uint32_t li = wbase + j * 64;
                 key[j] = li < valid ? (K)kt[swz(li)] : (K)~(K)0;
-                if constexpr (HAS_W) aux[j] = li < valid ? s_aux[swz(li)] : WS(0);
+                if constexpr (HAS_W && !W32G) aux[j] = li < valid ? s_aux[swz(li)] : WS(0);
             }
             __syncthreads();
+            if constexpr (W32G) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) kt[swz(q0 + j)] = auxc[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t li = wbase + j * 64;
+                    aux[j] = li < valid ? (WS)kt[swz(li)] : WS(0);
+                }
+                __syncthreads();
+            }
             if (RS_GEN_ABL & 2) {
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) val[j] = (VS)ent[j];
@@ -874,7 +890,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
-        if constexpr (HAS_W) s_aux[pos] = aux[j];
+        if constexpr (HAS_W && !W32G) s_aux[pos] = aux[j];
         if constexpr (BLK) {
             if (recs) s_gen[pos] = (unsigned char)dd;  // (the text codes are dead: their LDS carries the digits to the write-out)
         }
@@ -1026,12 +1042,23 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
-                if constexpr (HAS_W) {
+                if constexpr (HAS_W && !W32G) {
                     if (!GEN || wout) rs_store<NTM>(wout + s_gbase[dd] + i, (W)s_aux[i]);
                 }
             }
         }
         __syncthreads();
+        if constexpr (W32G) {  // the auxiliary words' own phase through the staging buffer
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) s_vals[rank[j]] = (VS)aux[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t i = j * NT + tid;
+                if (i < valid) rs_store<NTM>(wout + s_gbase[dig[j]] + i, (W)s_vals[i]);
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < IPT; ++j) s_vals[rank[j]] = val[j];
         __syncthreads();
@@ -1868,7 +1895,6 @@ template <typename W>
 void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const uint64_t* h_first,
                        const TextGen& gen_in, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles, int lead,
                        int npass, unsigned long long* d_hist_out, SortStats* stats) {
-    static_assert(sizeof(W) <= 2, "the generated pass keeps text, records and auxiliary words of a 16 Ki tile in the LDS: u8 / u16 only");
     if (!rs_atomic_rank_ok(s)) throw Error("radix_gen_records: needs the one-atomic ranking (internal)");
     constexpr int TILE = RS_SEG_TILE;
     using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
@@ -1899,7 +1925,8 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
         hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGen, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
                            (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                            ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, w, -1);
-    prof.end(t, (std::string("rs_onesweep_textgen_records") + (sizeof(W) == 1 ? "_w8" : "_w16") + "_t16384").c_str(), n * (1 + 8 + sizeof(W)), s);
+    prof.end(t, (std::string("rs_onesweep_textgen_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t16384").c_str(),
+             n * (1 + 8 + sizeof(W)), s);
     if (stats) stats->passes_run++;
     t = prof.begin(s);
     hipLaunchKernelGGL((rs_seg_hist_kernel<W>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s, (const uint32_t*)k,

@@ -1915,9 +1915,7 @@ void build_typed(Index& ix, bool big) {
         // inside the tile — and every bucket then gathers its keys from the text (its entries are still in
         // text order, so the gather walks the text front to back), LSD-sorts (key, entry) on the remaining
         // symbols and writes its group flags.  Peak = 8 n (entries) + 24 x the largest bucket.
-        DevBuf E, KT[2], ET;
-        E.alloc(n * sizeof(V));
-        st.alloc_ms += now_ms() - ta;
+        DevBuf E, KT[2], ET;  // (E: allocated below, once it is known whether the entries are partitioned at all)
         const int top_shift = (nsym - 1) * symbits;
         // Every position starts a suffix, and a suffix is never empty: the first symbol is never "end of document", so
         // the partition digit is code - 1 (0 .. alphabet - 1: 8 bits even for all 256 byte values, where the codes
@@ -1981,21 +1979,23 @@ void build_typed(Index& ix, bool big) {
         // (a one-symbol key leaves nothing behind the bucket symbol: its "ends inside the key" test would look at an
         //  empty remainder, so that corner keeps the plain (u64 key, entry) records)
         const bool brecords = ix.narrow_keys && blow >= 0 && nsym > 1;  // (codes up to 256 are u16 in the record kernel)
-        // FUSED form: when the records of ALL buckets fit the memory at once (one bucket group) and their auxiliary word is a
-        // u8 / u16 (the tile of the generated pass holds text, records and auxiliary words in the LDS), the generated pass
-        // writes the records itself (radix_sort.h: radix_gen_records) — the entries are never partitioned on their own, no
-        // gather walks the text bucket by bucket (4 GiB of UTF-8: 22 ms partition + 32 ms gather -> one 24 ms pass + a 7 ms
-        // histogram sweep of the records).
+        // FUSED form: when the records of ALL buckets fit the memory at once (one bucket group), the generated pass writes the
+        // records itself (radix_sort.h: radix_gen_records) — the entries are never partitioned on their own, no gather walks
+        // the text bucket by bucket (4 GiB of UTF-8: 22 ms partition + 32 ms gather -> one 28 ms pass + a 6 ms histogram
+        // sweep of the records), and the finished entries land in the record buffer the last pass does not read.
         bool fuse_rec = false;
         // (the tile stages symbol CODES as bytes: alphabets of all 256 byte values — codes up to 256 — keep the gather)
-        if (brecords && packed && blow <= 8 && sigma <= 255 && ix.segmented_sort && ix.fuse_records && sizeof(V) == 8 && rs_atomic_rank_ok(s) &&
+        if (brecords && packed && sigma <= 255 && ix.segmented_sort && ix.fuse_records && sizeof(V) == 8 && rs_atomic_rank_ok(s) &&
             (ix.bucket_group_limit == 0 || ix.bucket_group_limit >= n)) {
             size_t fre = 0, tot = 0;
             CDB_HIP(hipMemGetInfo(&fre, &tot));
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
-            const int recb0 = 4 + (blow == 0 ? 1 : 2) + 4;
+            const int recb0 = 4 + (blow == 0 ? 1 : (blow == 8 ? 2 : 4)) + 4;
+            // (no separate entry array: the last pass writes the finished entries over the record buffer it does not read)
             fuse_rec = avail * 0.85 / (2.0 * recb0 + 1.0) >= (double)n;
         }
+        if (!fuse_rec) E.alloc(n * sizeof(V));
+        st.alloc_ms += now_ms() - ta;
         st.fused_records = fuse_rec ? 1 : 0;
         DevBuf d_slotmap;
         if (fuse_rec) {
@@ -2141,9 +2141,22 @@ void build_typed(Index& ix, bool big) {
                     uint64_t max_elems = 0;
                     for (const Group& g : groups) max_elems = std::max(max_elems, g.elems);
                     DevBuf kb[2], eb[2], wb[2], edges, d_starts, d_segs, tile_seg, cell_off, lists, d_items2, d_bh2;
+                    uint32_t *kbp[2], *ebp[2];
+                    // fused form: key and entry halves of a record buffer are ONE block, so that the last pass can write the
+                    // finished 8-byte entries over the buffer it does not read (the passes ping-pong: pass p reads buffer p & 1)
+                    // — that block then IS the suffix array, and no separate 8 n bytes are ever allocated
+                    const int dead = bpass & 1;
                     for (int q = 0; q < 2; ++q) {
-                        kb[q].alloc(max_elems * sizeof(uint32_t));
-                        eb[q].alloc(max_elems * sizeof(uint32_t));
+                        if (fuse_rec) {
+                            kb[q].alloc(max_elems * 2 * sizeof(uint32_t));
+                            kbp[q] = kb[q].as<uint32_t>();
+                            ebp[q] = kbp[q] + max_elems;
+                        } else {
+                            kb[q].alloc(max_elems * sizeof(uint32_t));
+                            eb[q].alloc(max_elems * sizeof(uint32_t));
+                            kbp[q] = kb[q].as<uint32_t>();
+                            ebp[q] = eb[q].as<uint32_t>();
+                        }
                         wb[q].alloc(max_elems * sizeof(W));
                     }
                     edges.alloc((size_t)max_tiles * 256 * sizeof(SegEdge));
@@ -2164,13 +2177,13 @@ void build_typed(Index& ix, bool big) {
                         uint32_t* list_len = lists.as<uint32_t>() + gi * 16;
                         uint32_t* tickets = list_len + 8;
                         if (fuse_rec) {
-                            if constexpr (sizeof(W) <= 2) {
+                            {
                                 hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
                                                    (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
                                 TextGen rg{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, bbase, nsym, 0, ix.text_padded};
                                 rg.slotmap = d_slotmap.as<uint8_t>();
                                 rg.rec_low_bits = blow;
-                                radix_gen_records<W>(s, ix.rws, ix.prof, kb[0].as<uint32_t>(), eb[0].as<uint32_t>(), wb[0].as<W>(), n,
+                                radix_gen_records<W>(s, ix.rws, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n,
                                                      first_digit.data(), rg, (const uint32_t*)tile_seg.as<uint32_t>(),
                                                      (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
                                                      d_bh2.as<unsigned long long>(), &ss);
@@ -2189,7 +2202,7 @@ void build_typed(Index& ix, bool big) {
                         hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(gather_wgs), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
-                                           g.b0, kb[0].as<uint32_t>(), wb[0].as<W>(), eb[0].as<uint32_t>(), d_bh2.as<unsigned long long>(),
+                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>(),
                                            getenv("CDB_GATHER_ABL") ? std::atoi(getenv("CDB_GATHER_ABL")) : 0);
                         ix.prof.end(t, "sa_bucket_records", g.elems * ((uint64_t)nsym + recb + sizeof(V)), s);
                         st.gather_items += g.elems / BR_ITEM;
@@ -2197,7 +2210,7 @@ void build_typed(Index& ix, bool big) {
                                            (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
                         }
                         SegFinalArgs fin;
-                        fin.eout = E.as<uint64_t>() + g.gstart;
+                        fin.eout = (fuse_rec ? kb[dead].as<uint64_t>() : E.as<uint64_t>()) + g.gstart;
                         fin.flags = flags.as<uint8_t>() + g.gstart;
                         fin.edges = edges.as<SegEdge>();
                         fin.hi_shift = blow;
@@ -2205,14 +2218,14 @@ void build_typed(Index& ix, bool big) {
                         fin.kbase = bbase;
                         fin.kmagic = bmagic;
                         if (const char* ab = getenv("CDB_SEG_ABL")) fin.abl = std::atoi(ab);
-                        radix_sort_segmented<W>(s, ix.rws, ix.prof, kb[0].as<uint32_t>(), kb[1].as<uint32_t>(), eb[0].as<uint32_t>(),
-                                                eb[1].as<uint32_t>(), wb[0].as<W>(), wb[1].as<W>(), g.elems,
+                        radix_sort_segmented<W>(s, ix.rws, ix.prof, kbp[0], kbp[1], ebp[0], ebp[1], wb[0].as<W>(), wb[1].as<W>(), g.elems,
                                                 (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), (const uint32_t*)tile_seg.as<uint32_t>(), gb,
                                                 g.tiles, (const unsigned long long*)d_bh2.as<unsigned long long>(),
                                                 d_starts.as<unsigned long long>(), bbits - blow, lowb, fin, &ss);
                         st.bucket_groups++;
                     }
                     CDB_HIP(hipStreamSynchronize(s));  // (h_segs and the group scratch go out of scope)
+                    if (fuse_rec) E = std::move(kb[dead]);
                     st.segmented = 1;
                 }
             };

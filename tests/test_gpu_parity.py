@@ -236,7 +236,7 @@ def test_bucket_sorts_with_packed_entries(G, pack):
             layouts.add((int(g.stat("key_layout")), int(g.stat("bucket_low_digits"))))
             # one bucket group, u8 / u16 auxiliary words: the generated pass writes the records itself (no partition of the
             # entries, no gather); fuse_records = 0 is the partition + gather form of the same sort
-            fused = pack == 1 and group_limit == 0 and g.stat("bucket_low_digits") <= 1 and g.stat("alphabet") <= 255
+            fused = pack == 1 and group_limit == 0 and g.stat("alphabet") <= 255
             assert g.stat("fused_records") == int(fused)
             if fused:
                 g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, fuse_records=0, **opts)
