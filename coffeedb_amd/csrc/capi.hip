@@ -1386,6 +1386,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "key_symbols")) ix.key_symbols = (int)value;
     else if (!std::strcmp(name, "msd_first")) ix.msd_first = value != 0;
     else if (!std::strcmp(name, "msd_pair")) ix.msd_pair = value != 0;
+    else if (!std::strcmp(name, "key_directory")) { ix.key_directory = value != 0; ix.h_keydir.clear(); ix.keydir_tried = false; }
     else if (!std::strcmp(name, "fuse_records")) ix.fuse_records = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;
@@ -1431,7 +1432,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

@@ -54,6 +54,10 @@ struct SingleKeys {
     int low_bits = 0, low_bytes = 0, nsym = 0;
     bool decisive = false;
     uint64_t klo = 0, khi = 0;
+    // slots the lower bound can lie in, from the host-side key directory (query.hip: query_keydir_ensure): every slot in
+    // front of lo0 holds a key below klo, slot hi0 (if it exists) a key above khi
+    bool ranged = false;
+    uint64_t lo0 = 0, hi0 = 0;
 };
 
 struct Index {
@@ -120,7 +124,17 @@ struct Index {
         key_nsym = 0;
         key_low_bits = 0;
         key_low_bytes = 0;
+        h_keydir.clear();
+        h_keydir.shrink_to_fit();
+        keydir_tried = false;
     }
+    // Host-side key directory of the lone-keyword path: h_keydir[c] = first slot whose kept key is >= c << keydir_shift
+    // (2^keydir_bits + 1 entries), built once per index at its first lone keyword.  The 64-ary search then starts from the
+    // few dozen slots between two directory entries instead of the whole array: 1-2 rounds of dependent loads instead of 5-6.
+    std::vector<uint32_t> h_keydir;
+    int keydir_shift = 0, keydir_bits = 0;
+    bool keydir_tried = false;
+    bool key_directory = true;  // option: 0 = every lone keyword searches the whole array
     DevBuf d_pivots;                  // top levels of the lower-bound search tree (query.hip), built lazily
     int pivot_levels = 0;
 

@@ -1220,7 +1220,12 @@ __device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64
         }
     } else {
     // ---- lower bound (index.cpp:260-274): smallest M in [0, n-1] with keyword <= suffix(M), else n-1
+    // (with a key directory: every slot in front of lo0 holds a smaller key, slot hi0 a larger one — same answer)
     int64_t L = 0, R = (int64_t)n - 1;
+    if (sk.ranged) {
+        L = (int64_t)sk.lo0;
+        R = (int64_t)sk.hi0 < R ? (int64_t)sk.hi0 : R;
+    }
     while (R - L >= 64) {
         const int64_t M = L + ((R - L) / 65) * (lane + 1) + (((R - L) % 65) * (lane + 1)) / 65;
         bool le, pf;
@@ -1428,7 +1433,8 @@ __global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa,
 // word to read first.  The workgroup leaves by itself after ~3 ms without a request (so device-wide synchronisations —
 // hipFree, hipDeviceSynchronize of anybody in the process — are held up by at most that) and announces it in `exited`,
 // written LAST; the host relaunches it with the next request.  Builds, loads and destroy stop it first (query_resident_stop).
-constexpr int RES_WORDS = 21;       // 147 payload bytes: len u32, decisive u8, pad, klo u64, khi u64, keyword <= 120 bytes
+constexpr int RES_WORDS = 22;       // 154 payload bytes: len u32, decisive u8, ranged u8, pad, klo u64, khi u64, lo0 u32, hi0 u32,
+                                    // keyword <= 120 bytes
 constexpr uint32_t RES_IDLE_POLLS = 2500;
 constexpr uint32_t RES_MAX_SERVED = 4096;  // it also leaves after this many answers (~30 ms of back-to-back queries): a
                                            // device-wide synchronisation elsewhere in the process is never starved by traffic
@@ -1481,7 +1487,10 @@ __global__ __launch_bounds__(256) void q_resident_kernel(const V* __restrict__ s
         k2.decisive = s_req[4] != 0;
         k2.klo = klo;
         k2.khi = khi;
-        q_single_answer<V>(sa, n, text, doc_start, bits, mask, ids, s_req + 24, (uint64_t)len, out, sorted, k2);
+        k2.ranged = s_req[5] != 0;
+        k2.lo0 = *reinterpret_cast<const uint32_t*>(s_req + 24);
+        k2.hi0 = *reinterpret_cast<const uint32_t*>(s_req + 28);
+        q_single_answer<V>(sa, n, text, doc_start, bits, mask, ids, s_req + 32, (uint64_t)len, out, sorted, k2);
         if (seq - seq0 >= RES_MAX_SERVED) break;  // (uniform; the host starts the next one with its next request)
     }
     if (tid == 0) {
@@ -1540,6 +1549,61 @@ void query_resident_stop(Index& ix) {
     ix.res_running = false;
 }
 
+// Host-side key directory (index_impl.h: h_keydir): one bisection per cell over the kept keys, once per index.
+__global__ __launch_bounds__(256) void q_keydir_kernel(SingleKeys sk, uint64_t n, int shift, uint32_t cells, uint32_t* __restrict__ dir) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > cells) return;
+    if (i == cells) {
+        dir[i] = (uint32_t)n;
+        return;
+    }
+    const uint64_t T = i << shift;
+    uint64_t lo = 0, hi = n;  // first slot in [0, n] whose key is >= T
+    while (lo < hi) {
+        const uint64_t M = lo + (hi - lo) / 2;
+        uint64_t key;
+        if (sk.keys64) {
+            key = sk.keys64[M];
+        } else {
+            key = sk.keys32[M];
+            if (sk.keylow)
+                key = (key << sk.low_bits) | (sk.low_bytes == 1 ? (uint64_t)static_cast<const uint8_t*>(sk.keylow)[M]
+                                                                : (uint64_t)static_cast<const uint16_t*>(sk.keylow)[M]);
+        }
+        if (key >= T) hi = M; else lo = M + 1;
+    }
+    dir[i] = (uint32_t)lo;
+}
+
+// builds the directory at the index's first lone keyword (ix.mu held; sk = the kept keys of the index)
+void query_keydir_ensure(Index& ix, const SingleKeys& sk) {
+    if (ix.keydir_tried || !ix.key_directory) return;
+    ix.keydir_tried = true;
+    const uint64_t n = ix.size;
+    if (!ix.sa_sorted || n < (1ull << 16) || n >= 0xFFFFFFFFull || !sk.nsym) return;
+    unsigned __int128 mx = 1;  // keys are numbers below key_base^key_nsym
+    for (int q = 0; q < ix.key_nsym; ++q) {
+        mx *= (unsigned)ix.key_base;
+        if (mx > ((unsigned __int128)1 << 63)) return;
+    }
+    const int kb = bit_width64((uint64_t)(mx - 1));
+    int lg = 0;
+    while ((2ull << lg) <= n) ++lg;
+    const int bits = std::min(std::min(24, kb), std::max(8, lg - 6));  // ~64 slots per cell, at most 2^24 cells (64 MiB)
+    const uint32_t cells = 1u << bits;
+    DevBuf d_dir;
+    d_dir.alloc(((size_t)cells + 1) * sizeof(uint32_t));
+    hipStream_t s = ix.stream;
+    hipLaunchKernelGGL(q_keydir_kernel, dim3((unsigned)ceil_div((uint64_t)cells + 1, 256)), dim3(256), 0, s, sk, n, kb - bits, cells,
+                       d_dir.as<uint32_t>());
+    std::vector<uint32_t> dir((size_t)cells + 1);
+    CDB_HIP(hipMemcpyAsync(dir.data(), d_dir.p, dir.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+    ix.h_keydir = std::move(dir);
+    ix.keydir_shift = kb - bits;
+    ix.keydir_bits = bits;
+}
+
 // The lone-keyword path in two halves, so that a caller holding several indexes (shards.hip: one per GPU) can have all
 // their kernels in flight before it waits for the first answer.
 SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
@@ -1576,6 +1640,14 @@ SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
         sk.decisive = len <= (size_t)ix.key_nsym;
         sk.klo = kwc * kpw;
         sk.khi = sk.klo + (kpw - 1);
+        query_keydir_ensure(ix, sk);
+        if (!ix.h_keydir.empty()) {
+            const uint64_t cells = 1ull << ix.keydir_bits;
+            const uint64_t c_lo = sk.klo >> ix.keydir_shift, c_hi = sk.khi >> ix.keydir_shift;
+            sk.ranged = true;
+            sk.lo0 = ix.h_keydir[std::min<uint64_t>(c_lo, cells)];
+            sk.hi0 = ix.h_keydir[std::min<uint64_t>(c_hi + 1, cells)];
+        }
     }
     out->nrows = ~0ull;
     if (ix.resident_query) {
@@ -1591,9 +1663,13 @@ SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
         const uint32_t l32 = (uint32_t)len;
         std::memcpy(pay, &l32, 4);
         pay[4] = sk.decisive ? 1 : 0;
+        pay[5] = sk.ranged ? 1 : 0;
         std::memcpy(pay + 8, &sk.klo, 8);
         std::memcpy(pay + 16, &sk.khi, 8);
-        std::memcpy(pay + 24, kw, len);
+        const uint32_t lo32 = (uint32_t)sk.lo0, hi32 = (uint32_t)sk.hi0;
+        std::memcpy(pay + 24, &lo32, 4);
+        std::memcpy(pay + 28, &hi32, 4);
+        std::memcpy(pay + 32, kw, len);
         const uint32_t seq = ++ix.res_seq;
         for (int i = 0; i < RES_WORDS; ++i) {
             uint64_t wv = (uint64_t)(seq & 0xFFu) << 56;

@@ -777,6 +777,8 @@ def test_single_keyword_wavefront_path(G):
     o = _oracle(blob, ds, ids)
     g = _gpu(G, blob, ds, ids)
     g0 = _gpu(G, blob, ds, ids, single_query=0)
+    gn = _gpu(G, blob, ds, ids, key_directory=0)      # every lone keyword searches the whole array
+    gr = _gpu(G, blob, ds, ids, resident_query=1)     # the resident workgroup takes the directory's range through its mailbox
     rng = np.random.default_rng(3)
     kws = [bytes(blob[:1]), b"zz", b"a", bytes(blob[10:13]), bytes(blob[-5:]), bytes(blob[:300]), bytes(blob[:200]) + b"x",
            bytes(blob[7:7 + 121]), bytes(blob[7:7 + 120]), b"\x01", b"\xff"]
@@ -793,6 +795,11 @@ def test_single_keyword_wavefront_path(G):
         want = o.query(kw)
         assert g.query(kw) == want, kw
         assert g0.query(kw) == want, kw
+        assert gn.query(kw) == want, kw
+        assert gr.query(kw) == want, kw
+    # the host-side key directory (first slot of every 2^-k th of the key space, built at the first lone keyword) narrows
+    # the 64-ary search to the slots between two of its entries
+    assert g.stat("key_directory_cells") >= 1024 and gr.stat("key_directory_cells") >= 1024 and gn.stat("key_directory_cells") == 0
     # first and last suffix, every document at once
     srt = sorted(bytes(blob[int(ds[d]):int(ds[d + 1])]) for d in range(50))
     for kw in (srt[0], srt[-1], srt[0][:2], srt[-1][:2]):
