@@ -63,7 +63,11 @@ int main(int argc, char** argv) {
     unsigned long long* d_out;
     CDB_HIP(hipMalloc(&d_out, 4 * 8));
     if (!rs_atomic_rank_ok(s)) std::printf("one-atomic ranking self-test FAILED on this device\n");
+#ifdef SEG_NOREUSE   // keys and values both staged at once (128 KB): one write-out phase instead of two
+    using CfgG = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+#else
     using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+#endif
     Profiler prof;
     prof.enabled = true;
     // (a) one sort over everything
