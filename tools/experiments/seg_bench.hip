@@ -63,7 +63,9 @@ int main(int argc, char** argv) {
     unsigned long long* d_out;
     CDB_HIP(hipMalloc(&d_out, 4 * 8));
     if (!rs_atomic_rank_ok(s)) std::printf("one-atomic ranking self-test FAILED on this device\n");
-#ifdef SEG_NOREUSE   // keys and values both staged at once (128 KB): one write-out phase instead of two
+#ifdef SEG_IPT       // other tile sizes (keys and values share the staging buffer)
+    using CfgG = RsCfg<SEG_IPT, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+#elif defined(SEG_NOREUSE)   // keys and values both staged at once (128 KB): one write-out phase instead of two
     using CfgG = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
 #else
     using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
@@ -99,7 +101,7 @@ int main(int argc, char** argv) {
         for (uint32_t g = 0; g < nseg; ++g) {
             const uint64_t b = n * g / nseg, e = n * (g + 1) / nseg;
             h_segs[g] = SegInfo{b, e, tiles, 0u, 0ull, 0ull};
-            tiles += (uint32_t)ceil_div(e - b, (uint64_t)RS_SEG_TILE);
+            tiles += (uint32_t)ceil_div(e - b, (uint64_t)(CfgG::NT * CfgG::IPT));
         }
         SegInfo* d_segs;
         uint32_t* d_tile_seg;
@@ -111,7 +113,7 @@ int main(int argc, char** argv) {
         CDB_HIP(hipMemcpy(d_segs, h_segs.data(), nseg * sizeof(SegInfo), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(tiles, 256u)), dim3(256), 0, s, d_segs, nseg, tiles, d_tile_seg);
         RadixWorkspace ws;
-        ws.prepare((uint64_t)tiles * RS_SEG_TILE, RS_SEG_TILE, s);
+        ws.prepare((uint64_t)tiles * (CfgG::NT * CfgG::IPT), CfgG::NT * CfgG::IPT, s);
         SegArgs sa;
         sa.tile_seg = d_tile_seg;
         sa.segs = d_segs;
