@@ -165,8 +165,7 @@ struct TextGen {
     // Bucket-wise build, fused form (sa_build.hip): the generated pass writes the bucket RECORDS itself instead of partitioning
     // the entries for a later gather — sort digit = bucket slot of the suffix's first symbol (slotmap[code]), key = the
     // nsym - 1 symbols behind it as a dense number (k32 = key >> rec_low_bits), W = its low digits | entry bits 32.. above
-    // them, value = entry bits 0..31.  16 Ki-key tiles only (thread-consecutive rolling keys).
-    bool rec_mode = false;
+    // them, value = entry bits 0..31.  16 Ki-key tiles only (thread-consecutive rolling keys); kernels of type TextGenRec.
     const uint8_t* slotmap = nullptr;  // [257] symbol code -> bucket slot
     int rec_low_bits = 0;
     bool msd_pair = false;
@@ -176,12 +175,18 @@ struct TextGen {
     uint32_t div_b2_mul = 0, div_b2_sh = 0;      // / base^2
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
+// The generator's FORM is part of the kernel's type: the 16 Ki-tile pass is ~15 k instructions of straight-line code per
+// form (everything is unrolled 16 x), and a kernel that carries all three runs 4 % slower than one that carries its own
+// (tools/experiments/gen_bench.hip, -DRS_GEN_MODES: 5.55 vs 5.31 ms).  TextGen itself = the rolling-key form.
+struct TextGenPair : TextGen {};  // MSD-first sort, pair form (msd_pair)
+struct TextGenRec : TextGen {};   // bucket records (rec_mode)
 constexpr int RS_GEN_LOOK = 64;
 // timing-only ablations of the generated pass (tools/experiments/gen_bench.hip; WRONG results): 1 = no key arithmetic,
 // 2 = no transposition through LDS, 4 = no text staging
 #ifndef RS_GEN_ABL
 #define RS_GEN_ABL 0
 #endif
+
 
 // floor(x / d) for x < 2^24 as one multiply-high: with L = ceil(log2 d) and m = ceil(2^(24+L) / d) (< 2^25, error
 // m d - 2^(24+L) < d <= 2^L, so x < 2^24 keeps the quotient exact), mul = m << 7 and sh = L + 7
@@ -397,9 +402,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     K key[IPT];
     VS val[EARLYV ? IPT : 1];
     WS aux[HAS_W ? IPT : 1] = {};
-    uint32_t gdig[BLK ? IPT / 4 : 1] = {};  // records mode of the generated pass: the elements' sort digits, four per register
-    bool recs = false;
-    if constexpr (BLK) recs = gen.rec_mode;
+    uint32_t gdig[std::is_same<Gen, TextGenRec>::value ? IPT / 4 : 1] = {};  // records generator: the elements' sort digits, four per register
+    constexpr bool GM_PAIR = std::is_same<Gen, TextGenPair>::value;
+    constexpr bool GM_REC = std::is_same<Gen, TextGenRec>::value;
+    static_assert(!(GM_PAIR || GM_REC) || (BLK && HAS_W), "pair / records generators: 16 Ki tiles with an auxiliary word");
+    constexpr bool recs = GM_REC;
     auto digit_of = [&](K k, WS a) -> uint32_t {
         if constexpr (HAS_W) {
             if (aux_shift >= 0) return ((uint32_t)a >> aux_shift) & dmask;
@@ -424,8 +431,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         if (docs_in_lds)
             for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
         for (int i = tid; i < 256; i += NT) s_map[i] = gen.symmap[i];
-        if constexpr (BLK) {
-            if (recs && tid < 257) (gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8)[tid] = gen.slotmap[tid];
+        if constexpr (recs) {
+            if (tid < 257) (gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8)[tid] = gen.slotmap[tid];
         }
         __syncthreads();
         // bytes -> symbol codes on their way into LDS: one table lookup per text byte instead of one per
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             uint32_t ent[IPT];
             uint32_t auxc[W32G ? IPT : 1] = {};  // (W32G) the auxiliary words of the thread's consecutive positions
             uint64_t kk = 0;
-            if (HAS_W && gen.msd_pair) {  // (uniform) MSD-first sort, pair form: 6-symbol keys in 32-bit part arithmetic
+            if constexpr (GM_PAIR) {  // MSD-first sort, pair form: 6-symbol keys in 32-bit part arithmetic
                 const uint32_t B = gen.base, W3 = B * B * B;
                 uint32_t cw[6];  // codes of the thread's 16 positions + 5 of look-ahead (+ 3 unused)
                 {
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
                     }
                 }
-            } else if (HAS_W && recs) {  // (uniform) bucket records: key = the nsym - 1 symbols BEHIND the first one, 40-bit entries
+            } else if constexpr (GM_REC) {  // bucket records: key = the nsym - 1 symbols BEHIND the first one, 40-bit entries
                 const int ns1 = nsym - 1;
                 uint64_t top1 = 1;  // weight of the symbol that leaves the (shifted) window
                 for (int q = 1; q < ns1; ++q) top1 *= gen.base;
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 val[j] = li < valid ? (VS)kt[swz(li)] : VS(0);
             }
             }
-            if (recs) {  // sort digits of the thread's (lane-striped) elements: bucket slot of the first symbol
+            if constexpr (recs) {  // sort digits of the thread's (lane-striped) elements: bucket slot of the first symbol
                 const uint8_t* s_slot = gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8;
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         for (int j = 0; j < IPT; ++j) {
             const uint32_t li = wbase + j * 64;
             uint32_t d = digit_of(key[j], aux[HAS_W ? j : 0]);
-            if constexpr (BLK) d = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : d;
+            if constexpr (recs) d = (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu;
             d = li < valid ? d : 255u;
             rank[j] = atomicAdd(&s_whist[wave][d], 1u);
         }
@@ -813,7 +820,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         // out-of-range slots take digit 255: they have the largest indices of the tile, so they end
         // up behind every real element and are simply not written out.
         uint32_t d = digit_of(key[j], aux[HAS_W ? j : 0]);
-        if constexpr (BLK) d = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : d;
+        if constexpr (recs) d = (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu;
         d = li < valid ? d : 255u;
         uint64_t m = ~0ull;
 #pragma unroll
@@ -886,15 +893,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     for (int j = 0; j < IPT; ++j) {
         const uint32_t li = wbase + j * 64;
         uint32_t dd = digit_of(key[j], aux[HAS_W ? j : 0]);
-        if constexpr (BLK) dd = recs ? (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu : dd;
+        if constexpr (recs) dd = (gdig[j >> 2] >> (8 * (j & 3))) & 0xFFu;
         dd = li < valid ? dd : 255u;
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
         if constexpr (HAS_W && !W32G) s_aux[pos] = aux[j];
-        if constexpr (BLK) {
-            if (recs) s_gen[pos] = (unsigned char)dd;  // (the text codes are dead: their LDS carries the digits to the write-out)
-        }
+        if constexpr (recs) s_gen[pos] = (unsigned char)dd;  // (the text codes are dead: their LDS carries the digits to the write-out)
     }
     if constexpr (HAS_V && !REUSE) {
 #pragma unroll
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (i < valid) {
                 const K k = s_keys[i];
                 uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
-                if constexpr (BLK) dd = recs ? (uint32_t)s_gen[i] : dd;
+                if constexpr (recs) dd = (uint32_t)s_gen[i];
                 dig[j] = (uint8_t)dd;
                 if constexpr (FLAGS) {
                     // group flags from the neighbours in the sorted tile (equal keys have equal digits, so the ends of
@@ -1815,14 +1820,20 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
         const uint32_t e = ws.next_epoch(s);
         const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles;
         int t = prof.begin(s);
-        if (grouped)
-            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
-                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
-                               ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
-        else
-            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
-                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
-                               ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+#define CDB_MSD_GEN(CFG, GENT, GENV, TICKET)                                                                                              \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, GENT, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, \
+                       k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(), TICKET, \
+                       e, ws.err_ptr(), GENV, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0)
+        if (g2.msd_pair) {  // (the generator's form is part of the kernel's type)
+            TextGenPair gp;
+            static_cast<TextGen&>(gp) = g2;
+            if (grouped) CDB_MSD_GEN(CfgG, TextGenPair, gp, ws.xticket_ptr(e));
+            else CDB_MSD_GEN(CfgP, TextGenPair, gp, ws.ticket_ptr(e));
+        } else {
+            if (grouped) CDB_MSD_GEN(CfgG, TextGen, g2, ws.xticket_ptr(e));
+            else CDB_MSD_GEN(CfgP, TextGen, g2, ws.ticket_ptr(e));
+        }
+#undef CDB_MSD_GEN
         prof.end(t, "rs_onesweep_textgen_msd_t16384", n * 9, s);
         if (stats) stats->passes_run++;
     }
@@ -1913,8 +1924,8 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
     CDB_HIP(hipStreamSynchronize(s));  // (pageable host memory)
     hipLaunchKernelGGL(rs_digit_start_kernel, dim3(1), dim3(256), 0, s, d_hist, d_start);
     CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
-    TextGen g2 = gen_in;
-    g2.rec_mode = true;
+    TextGenRec g2;
+    static_cast<TextGen&>(g2) = gen_in;
     ws.tile_doc.ensure(((size_t)gen_tiles + 1) * sizeof(uint64_t));
     hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)gen_tiles + 1, 256)), dim3(256), 0, s, g2.doc_start, g2.ndocs, n,
                        (uint64_t)TILE, (uint64_t)gen_tiles, ws.tile_doc.as<uint64_t>());
@@ -1923,11 +1934,11 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
     const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles;
     int t = prof.begin(s);
     if (grouped)
-        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGen, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
+        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGenRec, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
                            (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                            ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, w, -1);
     else
-        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGen, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
+        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGenRec, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
                            (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                            ws.ticket_ptr(e), e, ws.err_ptr(), g2, (const W*)nullptr, w, -1);
     prof.end(t, (std::string("rs_onesweep_textgen_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t16384").c_str(),

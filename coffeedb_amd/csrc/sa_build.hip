@@ -1994,6 +1994,25 @@ void build_typed(Index& ix, bool big) {
             // (no separate entry array: the last pass writes the finished entries over the record buffer it does not read)
             fuse_rec = avail * 0.85 / (2.0 * recb0 + 1.0) >= (double)n;
         }
+        // (allocate the record buffers NOW: if the device cannot provide them after all — fragmentation, other handles —
+        //  nothing has happened yet and the build takes partition + gather instead of failing)
+        DevBuf fr_kv[2], fr_w[2];
+        if (fuse_rec) {
+            const size_t auxb0 = blow == 0 ? 1 : (blow == 8 ? 2 : 4);
+            try {
+                for (int q = 0; q < 2; ++q) {
+                    fr_kv[q].alloc(n * 2 * sizeof(uint32_t));
+                    fr_w[q].alloc(n * auxb0);
+                }
+            } catch (const std::exception&) {
+                for (int q = 0; q < 2; ++q) {
+                    fr_kv[q].release();
+                    fr_w[q].release();
+                }
+                (void)hipGetLastError();
+                fuse_rec = false;
+            }
+        }
         if (!fuse_rec) E.alloc(n * sizeof(V));
         st.alloc_ms += now_ms() - ta;
         st.fused_records = fuse_rec ? 1 : 0;
@@ -2148,9 +2167,11 @@ void build_typed(Index& ix, bool big) {
                     const int dead = bpass & 1;
                     for (int q = 0; q < 2; ++q) {
                         if (fuse_rec) {
-                            kb[q].alloc(max_elems * 2 * sizeof(uint32_t));
+                            kb[q] = std::move(fr_kv[q]);  // (allocated when the fused form was chosen: max_elems = n)
                             kbp[q] = kb[q].as<uint32_t>();
                             ebp[q] = kbp[q] + max_elems;
+                            wb[q] = std::move(fr_w[q]);
+                            continue;
                         } else {
                             kb[q].alloc(max_elems * sizeof(uint32_t));
                             eb[q].alloc(max_elems * sizeof(uint32_t));

@@ -155,7 +155,18 @@ int main(int argc, char** argv) {
                 hipEvent_t a, b;
                 CDB_HIP(hipEventCreate(&a)); CDB_HIP(hipEventCreate(&b));
                 CDB_HIP(hipEventRecord(a, s));
-                if (abl)
+                if (pair) {
+                    TextGenPair gp;
+                    static_cast<TextGen&>(gp) = g2;
+                    if (abl)
+                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGenPair, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                                           k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
+                                           ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+                    else
+                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGenPair, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                                           k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
+                                           ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+                } else if (abl)
                     hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
                                        k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
                                        ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
