@@ -263,6 +263,10 @@ struct SegFinalKeepArgs : SegArgs {
     unsigned long long msd_m = 0;  // full key = top * msd_m + k32 (0: not an MSD-first sort)
 };
 
+// ... as a type of its own for the last pass of an MSD-first sort (no auxiliary input, full key = top * msd_m + k32): the
+// auxiliary loads, their LDS traffic and the byte compares of the LSD form are not compiled into it
+struct SegFinalKeepMsdArgs : SegFinalKeepArgs {};
+
 // Key of the suffix at tile-local position li from symbol CODES staged in LDS (dword view, code of position i
 // in byte i): Horner over the first nsym (<= 16) codes in base `base`, first symbol most significant; codes
 // at or behind the end of the document (rem symbols left) count as 0.  Four codes at a time are combined
@@ -324,14 +328,15 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     constexpr bool GEN = !std::is_same<Gen, NoGen>::value;
     constexpr bool SEG = !std::is_same<Seg, NoSeg>::value;
     constexpr bool FINAL = std::is_same<Seg, SegFinalArgs>::value;
-    constexpr bool KEEP = std::is_same<Seg, SegFinalKeepArgs>::value;  // flags + edge records beside the ordinary record write-out
+    constexpr bool KEEPM = std::is_same<Seg, SegFinalKeepMsdArgs>::value;  // ... of an MSD-first sort (no auxiliary input)
+    constexpr bool KEEP = std::is_same<Seg, SegFinalKeepArgs>::value || KEEPM;  // flags + edge records beside the ordinary record write-out
     constexpr bool FLAGS = FINAL || KEEP;
     static_assert(!SEG || (!GEN && !Cfg::DMA), "segmented passes: materialised records");
-    static_assert(!FLAGS || Cfg::REUSE, "flag-writing passes: shared staging");
+    static_assert(!FLAGS || Cfg::REUSE || KEEPM, "flag-writing passes: shared staging (the MSD-first last pass also runs with keys and values staged at once)");
     constexpr bool HAS_V = !std::is_same<V, NoVal>::value;
     constexpr bool HAS_W = !std::is_same<W, NoVal>::value;
     using WS = typename std::conditional<HAS_W, W, uint8_t>::type;
-    static_assert(!HAS_W || (Cfg::REUSE && HAS_V && !Cfg::DMA), "the auxiliary byte needs the shared-staging configuration");
+    static_assert(!HAS_W || KEEPM || (Cfg::REUSE && HAS_V && !Cfg::DMA), "the auxiliary byte needs the shared-staging configuration");
     constexpr int IPT = Cfg::IPT;
     constexpr bool REUSE = Cfg::REUSE && HAS_V;
     constexpr bool EARLYV = (Cfg::EARLYV || REUSE) && HAS_V;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // W32G: a generated pass with 4-byte auxiliary words (bucket records with two or three low digits) has no room for them
     // beside text + records: they cross the tile through the staging buffer in a phase of their own, like keys and values
     constexpr bool W32G = GEN && HAS_W && sizeof(WS) == 4;
-    __shared__ WS s_aux[(HAS_W && !W32G) ? TILE : 1];
+    __shared__ WS s_aux[(HAS_W && !W32G && !KEEPM) ? TILE : 1];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint32_t s_tstart[256];
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         tile0 = si.tile_begin;
         base = si.begin + (tile - tile0) * TILE;
         seg_n = si.end;
-        if constexpr (KEEP) ktop = (uint64_t)si.top * seg.msd_m;
+        if constexpr (KEEPM) ktop = (uint64_t)si.top * seg.msd_m;
     } else if constexpr (Cfg::GROUP > 0) {
         if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
     }
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         if constexpr (HAS_W) {
-            if (!KEEP || win) {
+            if constexpr (!KEEPM) {
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
                     const uint32_t li = wbase + j * 64;
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             key[j] = rs_load<NTM>(kin + base + (li < valid ? li : lastv));
         }
         if constexpr (HAS_W && Cfg::LOAD == 1) {
-            if (!KEEP || win) {  // (uniform; the final pass of an MSD-first sort has no auxiliary input)
+            if constexpr (!KEEPM) {  // (the final pass of an MSD-first sort has no auxiliary input)
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
                     const uint32_t li = wbase + j * 64;
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         if constexpr (HAS_W && Cfg::LOAD != 1) {
-            if (!KEEP || win) {
+            if constexpr (!KEEPM) {
 #pragma unroll
                 for (int j = 0; j < IPT; ++j) {
                     const uint32_t li = wbase + j * 64;
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         const uint32_t pos = s_tstart[dd] + s_whist[wave][dd] + rank[j];
         rank[j] = pos;
         s_keys[pos] = key[j];
-        if constexpr (HAS_W && !W32G) s_aux[pos] = aux[j];
+        if constexpr (HAS_W && !W32G && !KEEPM) s_aux[pos] = aux[j];
         if constexpr (recs) s_gen[pos] = (unsigned char)dd;  // (the text codes are dead: their LDS carries the digits to the write-out)
     }
     if constexpr (HAS_V && !REUSE) {
@@ -975,8 +980,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (real) {
                 const uint64_t lmask = (1ull << seg.low_bits) - 1ull;
                 const uint32_t a = tstart, b = tstart + (uint32_t)real - 1u;
-                e.first = ktop + (((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask));
-                e.last = ktop + (((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask));
+                if constexpr (KEEPM) {
+                    e.first = ktop + (uint64_t)s_keys[a];
+                    e.last = ktop + (uint64_t)s_keys[b];
+                } else {
+                    e.first = ((uint64_t)s_keys[a] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? a : 0] & lmask);
+                    e.last = ((uint64_t)s_keys[b] << seg.low_bits) | ((uint64_t)s_aux[HAS_W ? b : 0] & lmask);
+                }
             }
             seg.edges[tile * 256 + d] = e;
         }
@@ -991,6 +1001,29 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                 const K k = s_keys[i];
                 const uint32_t dd = (uint32_t)(k >> shift) & dmask;
                 const uint64_t dst = s_gbase[dd] + i;
+                if constexpr (KEEPM) {
+                    // last pass of an MSD-first sort with keys and values staged at once: flags, kept search keys (full key >> 8 and
+                    // its low byte) and entries in ONE write-out phase — the logic of the shared-staging branch below
+                    bool head = true, tail = true;
+                    if (i > 0) head = s_keys[i - 1] != k;
+                    if (i + 1 < valid) tail = s_keys[i + 1] != k;
+                    const uint64_t kf = ktop + (uint64_t)k;
+                    uint32_t f = head ? 1u : 0u;
+                    if (!(head && tail)) {
+                        const bool exhausted = seg.kmagic ? (kf - __umul64hi(kf, seg.kmagic) * seg.kbase) == 0
+                                                          : (kf & (uint64_t)(seg.kbase - 1u)) == 0;
+                        if (!exhausted) f |= 2u;
+                    }
+                    seg.flags[dst] = (uint8_t)f;
+                    if ((f & 2u) && seg.tile_sums) {
+                        atomicAdd(seg.tile_sums + 2 * (dst / seg.sums_tile), 1ull);
+                        if (f & 1u) atomicAdd(seg.tile_sums + 2 * (dst / seg.sums_tile) + 1, 1ull);
+                    }
+                    rs_store<NTM>(kout + dst, (K)(kf >> 8));
+                    if constexpr (HAS_W) rs_store<NTM>(wout + dst, (W)(kf & 0xFFu));
+                    rs_store<NTM>(vout + dst, (V)s_vals[i]);
+                    continue;
+                }
                 if (!GEN || kout) rs_store<NTM>(kout + dst, k);  // generated pass: kout may be null (entries only)
                 if constexpr (HAS_V) rs_store<NTM>(vout + dst, (V)s_vals[i]);
             }
@@ -1003,7 +1036,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             dig[j] = 0;
             if (i < valid) {
                 const K k = s_keys[i];
-                uint32_t dd = digit_of(k, s_aux[HAS_W ? i : 0]);
+                uint32_t dd;
+                if constexpr (KEEPM) dd = (uint32_t)(k >> shift) & dmask;  // (no auxiliary word: the digit is a key digit)
+                else dd = digit_of(k, s_aux[HAS_W ? i : 0]);
                 if constexpr (recs) dd = (uint32_t)s_gen[i];
                 dig[j] = (uint8_t)dd;
                 if constexpr (FLAGS) {
@@ -1012,17 +1047,21 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     // (32-bit compares; the "key ends inside the document" test — a 64-bit division by the alphabet size —
                     //  only for the rare element that has an equal neighbour: the pass stays memory-bound)
                     const uint32_t lmask = seg.low_bits >= 32 ? 0xFFFFFFFFu : (1u << seg.low_bits) - 1u;
-                    const uint32_t ac = (uint32_t)s_aux[HAS_W ? i : 0] & lmask;
+                    uint32_t ac = 0;
+                    if constexpr (!KEEPM) ac = (uint32_t)s_aux[HAS_W ? i : 0] & lmask;
                     bool head = true, tail = true;
                     bool cmp = true;
                     if constexpr (FINAL) cmp = !(seg.abl & 4);
-                    if (cmp) {
+                    if constexpr (KEEPM) {
+                        if (i > 0) head = s_keys[i - 1] != k;
+                        if (i + 1 < valid) tail = s_keys[i + 1] != k;
+                    } else if (cmp) {
                         if (i > 0) head = s_keys[i - 1] != k || ((uint32_t)s_aux[HAS_W ? i - 1 : 0] & lmask) != ac;
                         if (i + 1 < valid) tail = s_keys[i + 1] != k || ((uint32_t)s_aux[HAS_W ? i + 1 : 0] & lmask) != ac;
                     }
                     uint32_t f = head ? 1u : 0u;
                     if (!(head && tail)) {
-                        const uint64_t kc = ktop + (((uint64_t)k << seg.low_bits) | (uint64_t)ac);
+                        const uint64_t kc = KEEPM ? ktop + (uint64_t)k : (((uint64_t)k << seg.low_bits) | (uint64_t)ac);
                         const bool exhausted = seg.kmagic ? (kc - __umul64hi(kc, seg.kmagic) * seg.kbase) == 0
                                                           : (kc & (uint64_t)(seg.kbase - 1u)) == 0;
                         if (!exhausted) f |= 2u;
@@ -1039,13 +1078,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         }
                     }
                 }
-                if constexpr (KEEP) {
-                    if (seg.msd_m) {  // (uniform) kept search keys in the layout of the LSD split sort: full key >> 8, low byte
-                        const uint64_t kf = ktop + (uint64_t)k;
-                        rs_store<NTM>(kout + s_gbase[dd] + i, (K)(kf >> 8));
-                        if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)(kf & 0xFFu));
-                        continue;
-                    }
+                if constexpr (KEEPM) {  // kept search keys in the layout of the LSD split sort: full key >> 8, low byte
+                    const uint64_t kf = ktop + (uint64_t)k;
+                    rs_store<NTM>(kout + s_gbase[dd] + i, (K)(kf >> 8));
+                    if constexpr (HAS_W) rs_store<NTM>(wout + s_gbase[dd] + i, (W)(kf & 0xFFu));
+                    continue;
                 }
                 if (!GEN || kout) rs_store<NTM>(kout + s_gbase[dd] + i, k);
                 if constexpr (HAS_W && !W32G) {
@@ -1853,7 +1890,8 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
     sa.segs = mw.segs.as<SegInfo>();
     sa.tiles = seg_tiles;
     sa.start_stride = 8 * 256;
-    SegFinalKeepArgs ka = keep_in;
+    SegFinalKeepMsdArgs ka;
+    static_cast<SegFinalKeepArgs&>(ka) = keep_in;
     static_cast<SegArgs&>(ka) = sa;
     ka.low_bits = 0;
     ka.msd_m = msd_m;
@@ -1866,26 +1904,26 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
         const unsigned long long* dstart = mw.starts.as<unsigned long long>() + (size_t)p * 256;
         uint32_t* tk = grouped ? ws.xticket_ptr(e) : ws.ticket_ptr(e);
         int t = prof.begin(s);
+        // (records of 8 bytes: keys AND values of a 16 Ki tile fit the staging buffer at once — one write-out phase instead
+        //  of two, 3.45 instead of 3.62 ms per pass in tools/experiments/seg_bench.hip)
+        using CfgG2 = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+        using CfgP2 = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true>;
         if (p + 1 < KPASS) {
 #define CDB_MSD_LAUNCH(CFG)                                                                                                          \
     hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, NoVal, SegArgs>), dim3(grid), dim3(1024), 0, s,          \
                        (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], n, 8 * p, 0xFFu, dstart,        \
                        ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const NoVal*)nullptr, (NoVal*)nullptr, -1, sa)
-            // (records of 8 bytes: keys AND values of a 16 Ki tile fit the staging buffer at once — one write-out phase instead
-            //  of two, 3.45 instead of 3.62 ms per pass in tools/experiments/seg_bench.hip)
-            using CfgG2 = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
-            using CfgP2 = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true>;
             if (grouped) CDB_MSD_LAUNCH(CfgG2);
             else CDB_MSD_LAUNCH(CfgP2);
 #undef CDB_MSD_LAUNCH
             prof.end(t, "rs_seg_k32_v32_t16384", 2 * n * 8, s);
         } else {
 #define CDB_MSD_FINAL(CFG)                                                                                                           \
-    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, uint8_t, SegFinalKeepArgs>), dim3(grid), dim3(1024), 0, s, \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, NoGen, uint8_t, SegFinalKeepMsdArgs>), dim3(grid), dim3(1024), 0, s, \
                        (const uint32_t*)kb[cur], kb[cur ^ 1], (const uint32_t*)vb[cur], vb[cur ^ 1], n, 8 * p, 0xFFu, dstart,        \
                        ws.status.as<uint64_t>(), tk, e, ws.err_ptr(), NoGen(), (const uint8_t*)nullptr, wout, -1, ka)
-            if (grouped) CDB_MSD_FINAL(CfgG);
-            else CDB_MSD_FINAL(CfgP);
+            if (grouped) CDB_MSD_FINAL(CfgG2);
+            else CDB_MSD_FINAL(CfgP2);
 #undef CDB_MSD_FINAL
             prof.end(t, "rs_seg_k32_v32_flags_t16384", n * (8 + 9 + 1), s);
         }

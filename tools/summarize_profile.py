@@ -26,8 +26,8 @@ def find(sub, pat):
 def family(name):
     """rocprof kernel name -> the library profiler's name for the same instantiation."""
     m = re.search(r"rs_onesweep_kernel<(unsigned int|unsigned long), (unsigned int|unsigned long|cdb::NoVal), "
-                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|NoGen), (unsigned char|unsigned short|unsigned int|cdb::NoVal)"
-                  r"(?:, cdb::(NoSeg|SegArgs|SegFinalArgs|SegFinalKeepArgs))?>", name)
+                  r"cdb::RsCfg<(\d+), \w+, \w+, (\d+)[^>]*>, cdb::(TextGen|TextGenPair|TextGenRec|NoGen), (unsigned char|unsigned short|unsigned int|cdb::NoVal)"
+                  r"(?:, cdb::(NoSeg|SegArgs|SegFinalArgs|SegFinalKeepArgs|SegFinalKeepMsdArgs))?>", name)
     if m:
         k = {"unsigned int": "k32", "unsigned long": "k64"}[m.group(1)]
         v = {"unsigned int": "_v32", "unsigned long": "_v64", "cdb::NoVal": ""}[m.group(2)]
@@ -37,10 +37,16 @@ def family(name):
             return f"rs_seg_final{aux}_t{tile}"
         if m.group(7) == "SegArgs":
             return f"rs_seg_{k}{v}{aux}_t{tile}"
+        if m.group(7) == "SegFinalKeepMsdArgs":
+            return f"rs_seg_{k}{v}_flags_t{tile}"  # last pass of an MSD-first sort (the library profiler's own name)
         if m.group(7) == "SegFinalKeepArgs":
             # the last pass of a single sort below 2^32 writes the flags beside its records: the LSD split sort reads an
             # auxiliary byte, the MSD-first sort does not — their profiler names differ, the instantiation is the same one
             return f"rs_keep_flags_{k}{v}{aux}_t{tile}"
+        if m.group(5) == "TextGenPair":
+            return f"rs_onesweep_textgen_msd_t{tile}"
+        if m.group(5) == "TextGenRec":
+            return f"rs_onesweep_textgen_records{aux}_t{tile}"
         if m.group(5) == "TextGen":
             return f"rs_onesweep_textgen{'_split' if aux else ''}_t{tile}"
         return f"rs_onesweep_{k}{v}{aux}_t{tile}"
