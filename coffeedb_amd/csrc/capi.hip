@@ -345,6 +345,12 @@ void cdb_destroy(cdb_index* h) {
     query_resident_stop(h->ix);
     if (s) (void)hipStreamSynchronize(s);
     if (h->ix.res_stream) (void)hipStreamDestroy(h->ix.res_stream);
+    if (h->ix.aux_stream) {
+        (void)hipStreamSynchronize(h->ix.aux_stream);
+        (void)hipStreamDestroy(h->ix.aux_stream);
+    }
+    for (hipEvent_t e : h->ix.aux_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->ix.h_res) (void)hipHostFree(h->ix.h_res);
     if (h->ix.h_single) (void)hipHostFree(h->ix.h_single);
     h->ix.stream = nullptr;
@@ -1386,6 +1392,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "key_symbols")) ix.key_symbols = (int)value;
     else if (!std::strcmp(name, "msd_first")) ix.msd_first = value != 0;
     else if (!std::strcmp(name, "msd_pair")) ix.msd_pair = value != 0;
+    else if (!std::strcmp(name, "overlap_paircount")) ix.overlap_paircount = value != 0;
     else if (!std::strcmp(name, "key_directory")) { ix.key_directory = value != 0; ix.h_keydir.clear(); ix.keydir_tried = false; }
     else if (!std::strcmp(name, "fuse_records")) ix.fuse_records = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;

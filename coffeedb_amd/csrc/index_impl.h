@@ -80,6 +80,10 @@ struct Index {
     void* h_res = nullptr;        // the mailbox (+ its device address)
     void* d_res = nullptr;
     hipStream_t res_stream = nullptr;
+    // second stream of the build (sa_build.hip): the pair count of the MSD-first sort runs beside the key-width sample
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    bool overlap_paircount = true;  // option: 0 = the pair count waits for the sample (one stream)
     bool res_running = false;
     uint32_t res_seq = 0;         // requests posted so far
     SingleKeys res_keys;          // the key arrays the running workgroup was started with

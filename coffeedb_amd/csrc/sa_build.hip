@@ -1563,6 +1563,38 @@ void build_typed(Index& ix, bool big) {
     const int symbits = std::max(1, bit_width64((uint64_t)sigma));
     CDB_HIP(hipMemcpyAsync(d_symmap.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
 
+    // Speculative pair count of the MSD-first sort (pair form) on a SECOND stream, beside the key-width sample below: both only
+    // need the symbol codes, the sample is a chain of small latency-bound kernels (0.7 ms) and the count a 0.4 ms sweep.
+    // Whether the sort takes the pair form is known only after the sample (6-symbol keys); if not, the counts are dropped.
+    DevBuf d_pc_spec;
+    bool pc_spec = false;
+    struct AuxJoin {  // (declared after the buffer: an exception on the way still waits for the second stream before the
+        hipStream_t a = nullptr;  //  buffer goes back to the pool)
+        ~AuxJoin() { if (a) (void)hipStreamSynchronize(a); }
+    } aux_join;
+    if (!big && sizeof(V) == 4 && n >= (1ull << 24) && ix.overlap_paircount && ix.msd_first && ix.msd_pair && ix.narrow_keys &&
+        ix.fuse_keygen && ix.flags_in_last_pass && ix.initial_passes == 0 && ix.digit_bits == 0 && ix.key_coding != 1 && sigma + 1 <= 128 &&
+        (ix.sort_variant == 0 || ix.sort_variant == 31 || ix.sort_variant == 33) && rs_variant_has_gen(ix.sort_variant) && rs_atomic_rank_ok(s)) {
+        if (!ix.aux_stream) CDB_HIP(hipStreamCreateWithFlags(&ix.aux_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : ix.aux_ev)
+            if (!e) CDB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const uint32_t pb = (uint32_t)sigma + 1u, np = pb * pb;
+        d_pc_spec.alloc((size_t)np * sizeof(uint64_t));
+        CDB_HIP(hipMemsetAsync(d_pc_spec.p, 0, (size_t)np * sizeof(uint64_t), s));
+        CDB_HIP(hipEventRecord(ix.aux_ev[0], s));
+        CDB_HIP(hipStreamWaitEvent(ix.aux_stream, ix.aux_ev[0], 0));
+        aux_join.a = ix.aux_stream;
+        int t = ix.prof.begin(ix.aux_stream);
+        // (one workgroup per CU: the sample's kernels find room beside it)
+        hipLaunchKernelGGL(sa_paircode_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(n, 1024 * 16 * 4), 256))), dim3(1024),
+                           np * sizeof(uint32_t), ix.aux_stream, text, n, (const uint16_t*)d_symmap.as<uint16_t>(), pb, d_pc_spec.as<unsigned long long>());
+        hipLaunchKernelGGL(sa_docend_pair_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))), dim3(256), 0,
+                           ix.aux_stream, text, doc_start, D, n, (const uint16_t*)d_symmap.as<uint16_t>(), pb, d_pc_spec.as<unsigned long long>());
+        ix.prof.end(t, "sa_paircode", n + D * 18, ix.aux_stream);
+        CDB_HIP(hipEventRecord(ix.aux_ev[1], ix.aux_stream));
+        pc_spec = true;
+    }
+
     // Key width of the initial sort.  Every suffix left unresolved costs a refinement round (compaction,
     // gathers, a further sort, inverse-array traffic for doubling) that is an order of magnitude more
     // expensive per element than one more radix pass, so the key takes as many symbols as it needs for
@@ -1731,7 +1763,20 @@ void build_typed(Index& ix, bool big) {
         msd_span = (uint32_t)std::min<uint64_t>((1ull << 32) / P4, (uint64_t)kbase * kbase);
         if (ceil_div((uint64_t)kbase * kbase, (uint64_t)msd_span) > 256) msd_span = 0;
     }
-    if (msd_span) {
+    if (pc_spec) {  // the second stream joins the first (whether or not its counts are used)
+        CDB_HIP(hipStreamWaitEvent(s, ix.aux_ev[1], 0));
+        aux_join.a = nullptr;
+    }
+    if (msd_span && pc_spec) {
+        msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
+        const uint32_t np = kbase * kbase;
+        std::vector<uint64_t> pc(np);
+        CDB_HIP(hipMemcpyAsync(pc.data(), d_pc_spec.p, (size_t)np * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        h_top.assign(256, 0);
+        for (uint32_t a = 0; a < np; ++a) h_top[a / msd_span] += pc[a];
+        st.msd_first = 2;
+    } else if (msd_span) {
         msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
         const uint32_t np = kbase * kbase;
         DevBuf d_pc;
