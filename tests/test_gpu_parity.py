@@ -818,6 +818,30 @@ def test_single_keyword_wavefront_path(G):
             assert g2.query(kw) == o2.query(kw), kw
 
 
+def test_key_directory_over_every_kept_key_layout(G):
+    # the host-side key directory of the lone-keyword path is built from the kept search keys in whatever layout the build
+    # left them: u32, u32 + low byte (LSD split sort and the MSD-first sort's last pass), u32 + two low bytes, u64.  Same rows
+    # as the oracle for keywords that hit, miss, are prefixes of each other, or exceed the key width; resident workgroup too.
+    cases = [(W.ascii_corpus(600, 300, seed=21, lo=0x61, hi=0x66), dict()),                                   # 6 symbols: u32 keys
+             (W.ascii_corpus(700, 256, seed=22), dict(key_coding=2, key_symbols=6, sort_variant=31)),         # MSD-first: u32 + low byte
+             (W.ascii_corpus(700, 256, seed=23), dict(key_coding=2, key_symbols=6, sort_variant=31, msd_first=0)),  # LSD split
+             (W.ascii_corpus(500, 400, seed=24, lo=0x20, hi=0xE7), dict(key_coding=2, key_symbols=6, reference_compat=0)),  # 200 symbols: two low bytes
+             (W.ascii_corpus(500, 400, seed=25, lo=0x00, hi=0xFF), dict(reference_compat=0))]                 # all byte values: u64 keys
+    for (blob, ds), opts in cases:
+        ids = np.arange(len(ds) - 1, dtype=np.int64) * 5 + 2
+        o = _oracle(blob, ds, ids) if opts.get("reference_compat", 1) else None
+        g = _gpu(G, blob, ds, ids, **opts)
+        gr = _gpu(G, blob, ds, ids, resident_query=1, **opts)
+        gn = _gpu(G, blob, ds, ids, key_directory=0, **opts)
+        pb, po = W.sample_patterns(blob, ds, 250, 1, 12, seed=6, miss_frac=0.15, miss_byte=int(blob[0]))
+        for j in range(250):
+            kw = bytes(pb[int(po[j]):int(po[j + 1])])
+            want = o.query(kw) if o is not None else gn.query(kw)
+            assert g.query(kw) == want, (opts, kw)
+            assert gr.query(kw) == want, (opts, kw)
+        assert g.stat("key_directory_cells") >= 256 and gn.stat("key_directory_cells") == 0, opts
+
+
 @pytest.mark.parametrize("variant", [31, 33])
 def test_group_flags_written_by_the_last_radix_pass(G, variant):
     # builds below 2^32: the last pass of the initial sort writes the group flags (and the tile sums of the first
