@@ -186,6 +186,11 @@ constexpr int RS_GEN_LOOK = 64;
 #ifndef RS_GEN_ABL
 #define RS_GEN_ABL 0
 #endif
+// ... and of the final pass of a segmented sort (WRONG results): 1 = no flag stores, 2 = no entry stores, 4 = no neighbour
+// compares.  Compile-time (make HIPFLAGS+=-DRS_SEG_ABL=n): the product kernel carries no checks for them.
+#ifndef RS_SEG_ABL
+#define RS_SEG_ABL 0
+#endif
 
 
 // floor(x / d) for x < 2^24 as one multiply-high: with L = ceil(log2 d) and m = ceil(2^(24+L) / d) (< 2^25, error
@@ -242,7 +247,6 @@ struct SegFinalArgs : SegArgs {
     int low_bits = 0;           // key = (k32 << low_bits) | (aux & (2^low_bits - 1))
     uint32_t kbase = 2;
     unsigned long long kmagic = 0;
-    int abl = 0;                // timing experiments only (WRONG results): 1 = no flag stores, 2 = no entry stores, 4 = no neighbour compares
 };
 
 // The last pass of an ordinary (single-segment) sort of split records can do the same and still write its records (the
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     if constexpr (!KEEPM) ac = (uint32_t)s_aux[HAS_W ? i : 0] & lmask;
                     bool head = true, tail = true;
                     bool cmp = true;
-                    if constexpr (FINAL) cmp = !(seg.abl & 4);
+                    if constexpr (FINAL) cmp = !(RS_SEG_ABL & 4);
                     if constexpr (KEEPM) {
                         if (i > 0) head = s_keys[i - 1] != k;
                         if (i + 1 < valid) tail = s_keys[i + 1] != k;
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                         if (!exhausted) f |= 2u;
                     }
                     if constexpr (FINAL) {
-                        if (!(seg.abl & 1)) seg.flags[rs_seg_rotated(si, s_gbase[dd] + i)] = (uint8_t)f;
+                        if (!(RS_SEG_ABL & 1)) seg.flags[rs_seg_rotated(si, s_gbase[dd] + i)] = (uint8_t)f;
                         continue;
                     } else {
                         const uint64_t slot = s_gbase[dd] + i;
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         for (int j = 0; j < IPT; ++j) {
             const uint32_t i = j * NT + tid;
             if constexpr (FINAL) {
-                if (i < valid && !(seg.abl & 2))
+                if (i < valid && !(RS_SEG_ABL & 2))
                     seg.eout[rs_seg_rotated(si, s_gbase[dig[j]] + i)] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
             } else {
                 if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);

@@ -2283,7 +2283,6 @@ void build_typed(Index& ix, bool big) {
                         fin.low_bits = blow;
                         fin.kbase = bbase;
                         fin.kmagic = bmagic;
-                        if (const char* ab = getenv("CDB_SEG_ABL")) fin.abl = std::atoi(ab);
                         radix_sort_segmented<W>(s, ix.rws, ix.prof, kbp[0], kbp[1], ebp[0], ebp[1], wb[0].as<W>(), wb[1].as<W>(), g.elems,
                                                 (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), (const uint32_t*)tile_seg.as<uint32_t>(), gb,
                                                 g.tiles, (const unsigned long long*)d_bh2.as<unsigned long long>(),
