@@ -158,16 +158,17 @@ struct TextGen {
     int msd_shift = 0;  // > 0 (split records, MSD-first sort): the generated pass sorts on the key's TOP digit, key >> msd_shift,
                         // which is then implied by the bucket an element sits in — the records are (u32 key, entry) with no
                         // auxiliary byte at all, and the remaining passes sort every bucket on its own (radix_sort_msd)
-    // MSD-first sort, pair form (6-symbol keys): top digit = (first two symbols as a number A) / span, i.e. key / M with
-    // M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count of the text instead of
-    // a sweep that evaluates every key.  The generated pass then works in 32-bit part arithmetic (G = three symbols as a
-    // number, key = G(p) base^3 + G(p + 3)): no rolling 64-bit key.  rs_div24: floor(x / d) for x < 2^24 from (mul, sh).
     // Bucket-wise build, fused form (sa_build.hip): the generated pass writes the bucket RECORDS itself instead of partitioning
     // the entries for a later gather — sort digit = bucket slot of the suffix's first symbol (slotmap[code]), key = the
     // nsym - 1 symbols behind it as a dense number (k32 = key >> rec_low_bits), W = its low digits | entry bits 32.. above
     // them, value = entry bits 0..31.  16 Ki-key tiles only (thread-consecutive rolling keys); kernels of type TextGenRec.
     const uint8_t* slotmap = nullptr;  // [257] symbol code -> bucket slot
     int rec_low_bits = 0;
+    // MSD-first sort, pair form (6-symbol keys; kernels of type TextGenPair): top digit = (first two symbols as a number A) /
+    // span, i.e. key / M with M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count
+    // of the text instead of a sweep that evaluates every key.  The generated pass works in 32-bit part arithmetic (G = three
+    // symbols as a number, key = G(p) base^3 + G(p + 3)), lane-striped: every element straight from the staged codes.
+    // rs_div24: floor(x / d) for x < 2^24 from (mul, sh).
     bool msd_pair = false;
     uint32_t msd_span_mul = 0, msd_span_sh = 0;  // / span
     uint32_t msd_mlo = 0;                        // M mod 2^32
@@ -191,6 +192,7 @@ constexpr int RS_GEN_LOOK = 64;
 #ifndef RS_SEG_ABL
 #define RS_SEG_ABL 0
 #endif
+
 
 
 // floor(x / d) for x < 2^24 as one multiply-high: with L = ceil(log2 d) and m = ceil(2^(24+L) / d) (< 2^25, error
@@ -477,7 +479,62 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         uint64_t ebase = 0;
         const int nsym = gen.nsym;
         const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
-        if constexpr (BLK) {
+        if constexpr (GM_PAIR) {
+            // Lane-striped generation of the pair form: a key is two 3-symbol parts of the six codes at its position — cheap
+            // enough (four multiply-adds) to be evaluated per element straight from the staged codes, in the order the ranking
+            // wants them: no transposition of keys, digits and entries through the staging buffer, no barriers.
+            const uint32_t B = gen.base, W3 = B * B * B;
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t li = wbase + j * 64;
+                key[j] = (K)~(K)0;
+                val[j] = VS(0);
+                aux[j] = WS(0);
+                if (li < valid) {
+                    if (li >= dend_l) {  // (also the first element: dend_l = 0)
+                        const uint64_t p = base + li;
+                        uint64_t ds, de;
+                        if (docs_in_lds) {
+                            d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
+                            ds = s_docs[d - dlo];
+                            de = s_docs[d - dlo + 1];
+                        } else {
+                            d = rs_doc_upper(gen.doc_start, d, dhi, p);
+                            ds = gen.doc_start[d];
+                            de = gen.doc_start[d + 1];
+                        }
+                        const uint64_t rel = de - base;
+                        dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
+                        ebase = d - (ds << gen.bits);
+                    }
+                    const uint32_t wi = li >> 2, sel = li & 3u;
+                    const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
+                    const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
+                    uint32_t a = __umul24(x0 & 0xFFu, B) + ((x0 >> 8) & 0xFFu);
+                    uint32_t g0 = __umul24(a, B) + ((x0 >> 16) & 0xFFu);
+                    uint32_t g3 = __umul24(__umul24(x0 >> 24, B) + (x1 & 0xFFu), B) + ((x1 >> 8) & 0xFFu);
+                    const uint32_t rem = dend_l - li;  // symbols left in the document (>= 1)
+                    if (rem < 6u) {  // (rare) the symbols behind the document end count as 0: truncate the parts
+                        if (rem <= 3u) {
+                            g3 = 0;
+                            if (rem < 3u) {
+                                const bool one = rem == 1u;
+                                g0 = rs_div24(g0, one ? gen.div_b2_mul : gen.div_b_mul, one ? gen.div_b2_sh : gen.div_b_sh) * (one ? B * B : B);
+                            }
+                        } else {
+                            const bool four = rem == 4u;
+                            g3 = rs_div24(g3, four ? gen.div_b2_mul : gen.div_b_mul, four ? gen.div_b2_sh : gen.div_b_sh) * (four ? B * B : B);
+                        }
+                        a = rs_div24(g0, gen.div_b_mul, gen.div_b_sh);
+                    }
+                    const uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
+                    key[j] = (K)(g0 * W3 + g3 - top * gen.msd_mlo);  // key - top * M (< 2^32: exact modulo 2^32)
+                    aux[j] = (WS)top;
+                    val[j] = (VS)((((uint32_t)base + li) << gen.bits) + (uint32_t)ebase);
+                }
+            }
+        } else if constexpr (BLK) {
             // Thread-consecutive generation: a thread owns IPT consecutive positions, so inside a document
             //   key(q + 1) = (key(q) - code(q) * base^(nsym-1)) * base + code(q + nsym)   [0 behind the document end]
             // and only the first position of a thread or of a document pays for a full Horner evaluation; the
@@ -491,66 +548,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             uint32_t ent[IPT];
             uint32_t auxc[W32G ? IPT : 1] = {};  // (W32G) the auxiliary words of the thread's consecutive positions
             uint64_t kk = 0;
-            if constexpr (GM_PAIR) {  // MSD-first sort, pair form: 6-symbol keys in 32-bit part arithmetic
-                const uint32_t B = gen.base, W3 = B * B * B;
-                uint32_t cw[6];  // codes of the thread's 16 positions + 5 of look-ahead (+ 3 unused)
-                {
-                    const uint4 ca = *reinterpret_cast<const uint4*>(s_text + q0);
-                    const uint2 cb = *reinterpret_cast<const uint2*>(s_text + q0 + 16);
-                    cw[0] = ca.x; cw[1] = ca.y; cw[2] = ca.z; cw[3] = ca.w; cw[4] = cb.x; cw[5] = cb.y;
-                }
-                auto code = [&](int t) -> uint32_t { return (cw[t >> 2] >> (8 * (t & 3))) & 0xFFu; };
-                uint32_t A[IPT + 3], G[IPT + 3];  // A(t) = first two symbols at q0 + t as a number, G(t) = first three
-#pragma unroll
-                for (int t = 0; t < IPT + 3; ++t) {
-                    A[t] = __umul24(code(t), B) + code(t + 1);
-                    G[t] = __umul24(A[t], B) + code(t + 2);
-                }
-#pragma unroll
-                for (int j = 0; j < IPT; ++j) {
-                    const uint32_t q = q0 + j;
-                    ent[j] = 0;
-                    if (q < valid) {
-                        if (j == 0 || q >= dend_l) {
-                            const uint64_t p = base + q;
-                            uint64_t ds, de;
-                            if (docs_in_lds) {
-                                d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
-                                ds = s_docs[d - dlo];
-                                de = s_docs[d - dlo + 1];
-                            } else {
-                                d = rs_doc_upper(gen.doc_start, d, dhi, p);
-                                ds = gen.doc_start[d];
-                                de = gen.doc_start[d + 1];
-                            }
-                            const uint64_t rel = de - base;
-                            dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
-                            ebase = d - (ds << gen.bits);
-                        }
-                        uint32_t g0 = G[j], g3 = G[j + 3], a = A[j];
-                        const uint32_t rem = dend_l - q;  // symbols left in the document (>= 1)
-                        if (rem < 6u) {  // (rare) the symbols behind the document end count as 0: truncate the parts
-                            if (rem <= 3u) {
-                                g3 = 0;
-                                if (rem < 3u) {
-                                    const bool one = rem == 1u;
-                                    g0 = rs_div24(g0, one ? gen.div_b2_mul : gen.div_b_mul, one ? gen.div_b2_sh : gen.div_b_sh) * (one ? B * B : B);
-                                }
-                            } else {
-                                const bool four = rem == 4u;
-                                g3 = rs_div24(g3, four ? gen.div_b2_mul : gen.div_b_mul, four ? gen.div_b2_sh : gen.div_b_sh) * (four ? B * B : B);
-                            }
-                            a = rs_div24(g0, gen.div_b_mul, gen.div_b_sh);
-                        }
-                        uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
-                        uint32_t kp = g0 * W3 + g3 - top * gen.msd_mlo;  // key - top * M (< 2^32: exact modulo 2^32)
-                        if (RS_GEN_ABL & 1) { top = q & 127u; kp = q * 2654435761u; }
-                        kt[swz(q)] = kp;
-                        if constexpr (HAS_W && !W32G) s_aux[swz(q)] = (WS)top;
-                        ent[j] = (((uint32_t)base + q) << gen.bits) + (uint32_t)ebase;
-                    }
-                }
-            } else if constexpr (GM_REC) {  // bucket records: key = the nsym - 1 symbols BEHIND the first one, 40-bit entries
+            if constexpr (GM_REC) {  // bucket records: key = the nsym - 1 symbols BEHIND the first one, 40-bit entries
                 const int ns1 = nsym - 1;
                 uint64_t top1 = 1;  // weight of the symbol that leaves the (shifted) window
                 for (int q = 1; q < ns1; ++q) top1 *= gen.base;
