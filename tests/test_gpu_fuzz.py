@@ -61,6 +61,16 @@ def test_fuzz_parity(seed):
     rng2 = np.random.default_rng(50_000 + seed)   # (its own stream: the draws above keep their seeds' meaning)
     if rng2.random() < 0.35:                       # the lone-keyword path through the resident workgroup
         opts["resident_query"] = 1
+    if rng2.random() < 0.35 and "initial_passes" not in opts:
+        # the 16 Ki-tile sorts with a forced key width: keys of 33..40 bits take the MSD-first sort (pair form for 6 symbols)
+        opts["sort_variant"] = int(rng2.choice([31, 33]))
+        opts["key_coding"] = 2
+        opts["key_symbols"] = int(rng2.integers(3, 14))
+        opts.pop("fuse_keygen", None)
+        if rng2.random() < 0.3: opts["msd_first"] = 0
+        if rng2.random() < 0.3: opts["msd_pair"] = 0
+    if rng2.random() < 0.2: opts["key_directory"] = 0
+    if rng2.random() < 0.2: opts["overlap_paircount"] = 0
     o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(2); o.canonicalize()
     g = capi.GpuStringIndex()
     for k, v in opts.items():
