@@ -134,19 +134,29 @@ int main(int argc, char** argv) {
     std::map<std::string, double> best;
     {   // the generated pass alone, with the timing ablations of the pass itself (no look-back, linear write-out: safe for
         // any key distribution, which the ablations of the generator (RS_GEN_ABL) need)
-        using CfgA = RsCfg<16, true, true, 1024, false, 1, 3, 4, false, true, true, 1, RS_GROUP>;
-        using CfgN = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
-        const uint32_t tiles = (uint32_t)ceil_div(n, (uint64_t)RS_SEG_TILE);
-        ws.prepare(n + 256 * (uint64_t)RS_SEG_TILE, RS_SEG_TILE, s);
+#ifndef GEN_NT
+#define GEN_NT 1024
+#endif
+#ifndef GEN_GROUP
+#define GEN_GROUP RS_GROUP
+#endif
+#ifndef GEN_LB
+#define GEN_LB 4
+#endif
+        using CfgA = RsCfg<16, true, true, GEN_NT, false, 1, 3, GEN_LB, false, true, true, 1, GEN_GROUP>;
+        using CfgN = RsCfg<16, true, true, GEN_NT, false, 1, 0, GEN_LB, false, true, true, 1, GEN_GROUP>;
+        constexpr uint64_t GT = 16 * GEN_NT;  // tile of the stand-alone generated pass
+        const uint32_t tiles = (uint32_t)ceil_div(n, GT);
+        ws.prepare(n + 256 * (uint64_t)RS_SEG_TILE, (int)GT, s);
         ws.tile_doc.ensure(((size_t)tiles + 1) * 8);
         hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles + 1, 256)), dim3(256), 0, s, (const uint64_t*)d_ds, D, n,
-                           (uint64_t)RS_SEG_TILE, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
+                           GT, (uint64_t)tiles, ws.tile_doc.as<uint64_t>());
         TextGen g2 = gen;
         g2.tile_doc = ws.tile_doc.as<uint64_t>();
         unsigned long long* d_start = ws.hist.as<unsigned long long>();
         CDB_HIP(hipMemcpyAsync(d_start, h_top.data(), 256 * 8, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(rs_digit_start_kernel, dim3(1), dim3(256), 0, s, d_start, d_start + RS_MAX_PASSES * 256);
-        const uint32_t grid = (uint32_t)(ceil_div(tiles, 8u * RS_GROUP) * 8u * RS_GROUP);
+        const uint32_t grid = (uint32_t)(ceil_div(tiles, 8u * GEN_GROUP) * 8u * GEN_GROUP);
         for (int abl = 0; abl < 2; ++abl) {
             if (RS_GEN_ABL != 0 && abl == 0) continue;  // (an ablated generator only with the safe write-out)
             double bms = 1e30;
@@ -159,19 +169,19 @@ int main(int argc, char** argv) {
                     TextGenPair gp;
                     static_cast<TextGen&>(gp) = g2;
                     if (abl)
-                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGenPair, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGenPair, uint8_t>), dim3(grid), dim3(GEN_NT), 0, s, (const uint32_t*)nullptr,
                                            k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
                                            ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
                     else
-                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGenPair, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                        hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGenPair, uint8_t>), dim3(grid), dim3(GEN_NT), 0, s, (const uint32_t*)nullptr,
                                            k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
                                            ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
                 } else if (abl)
-                    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgA, TextGen, uint8_t>), dim3(grid), dim3(GEN_NT), 0, s, (const uint32_t*)nullptr,
                                        k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
                                        ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
                 else
-                    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGen, uint8_t>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr,
+                    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGen, uint8_t>), dim3(grid), dim3(GEN_NT), 0, s, (const uint32_t*)nullptr,
                                        k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
                                        ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), g2, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
                 CDB_HIP(hipEventRecord(b, s));
@@ -183,7 +193,7 @@ int main(int argc, char** argv) {
             std::printf("generated pass alone, RS_GEN_ABL=%d, %s: %.3f ms\n", RS_GEN_ABL, abl ? "no look-back + linear write-out" : "as in production", bms);
         }
     }
-    if (RS_GEN_ABL != 0) return 0;
+    if (RS_GEN_ABL != 0 || GEN_NT != 1024) return 0;  // (GEN_NT=512 needs BLK in radix_sort.h relaxed to NT == 512: an experiment)
     for (int r = 0; r <= rounds; ++r) {
         prof.reset();
         SortStats st;
