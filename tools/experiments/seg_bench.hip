@@ -21,6 +21,10 @@ __global__ void fill_kernel(uint32_t* k, uint32_t* v, uint64_t n) {
     k[i] = mix((uint32_t)i * 2654435761u + 12345u);
     v[i] = (uint32_t)i;
 }
+__global__ void pack_kernel(const uint32_t* k, const uint32_t* v, uint64_t* r, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) r[i] = ((uint64_t)k[i] << 32) | v[i];
+}
 // hist[g][p][d] over the elements of segment g
 __global__ void seg_hist_kernel(const uint32_t* k, const SegInfo* segs, unsigned long long* hist) {
     __shared__ uint32_t sh[4 * 256];
@@ -94,6 +98,65 @@ int main(int argc, char** argv) {
         std::printf("whole array, (u32, u32) records:        %.3f ms per pass  %.0f GB/s algorithmic (16 B x n)\n", best, 16.0 * n / (best * 1e-3) / 1e9);
         ws.release();
     }
+#ifdef SEG_AOS
+    {   // (c) array of structures: one u64 per record (key << 32 | entry), key-only passes on the high word, segmented
+        using CfgK = RsCfg<16, false, false, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+        const uint32_t nseg = nseg_arg;
+        std::vector<SegInfo> h_segs(nseg);
+        uint32_t tiles = 0;
+        for (uint32_t g = 0; g < nseg; ++g) {
+            const uint64_t b = n * g / nseg, e = n * (g + 1) / nseg;
+            h_segs[g] = SegInfo{b, e, tiles, 0u, 0ull, 0ull};
+            tiles += (uint32_t)ceil_div(e - b, (uint64_t)RS_SEG_TILE);
+        }
+        SegInfo* d_segs; uint32_t* d_tile_seg; unsigned long long *d_hist, *d_starts;
+        CDB_HIP(hipMalloc(&d_segs, nseg * sizeof(SegInfo)));
+        CDB_HIP(hipMalloc(&d_tile_seg, tiles * 4));
+        CDB_HIP(hipMalloc(&d_hist, (size_t)nseg * 8 * 256 * 8));
+        CDB_HIP(hipMalloc(&d_starts, (size_t)nseg * 8 * 256 * 8));
+        CDB_HIP(hipMemcpy(d_segs, h_segs.data(), nseg * sizeof(SegInfo), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(tiles, 256u)), dim3(256), 0, s, d_segs, nseg, tiles, d_tile_seg);
+        RadixWorkspace ws;
+        ws.prepare((uint64_t)tiles * RS_SEG_TILE, RS_SEG_TILE, s);
+        SegArgs sa; sa.tile_seg = d_tile_seg; sa.segs = d_segs; sa.tiles = tiles; sa.start_stride = 8 * 256;
+        const uint32_t grid = (uint32_t)(ceil_div(tiles, 8u * RS_GROUP) * 8u * RS_GROUP);
+        uint64_t* r[2] = {reinterpret_cast<uint64_t*>(k[0]), reinterpret_cast<uint64_t*>(k[1])};  // (k[0], v[0] are separate blocks:
+        CDB_HIP(hipFree(v[0])); CDB_HIP(hipFree(v[1]));                                               //  reallocate as 8 n bytes)
+        CDB_HIP(hipFree(k[0])); CDB_HIP(hipFree(k[1]));
+        CDB_HIP(hipMalloc(&r[0], n * 8 + 256)); CDB_HIP(hipMalloc(&r[1], n * 8 + 256));
+        uint32_t *tk, *tv;
+        CDB_HIP(hipMalloc(&tk, n * 4 + 256)); CDB_HIP(hipMalloc(&tv, n * 4 + 256));
+        double best = 1e30;
+        for (int rr = 0; rr <= rounds; ++rr) {
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, tk, tv, n);
+            hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, tk, tv, r[0], n);
+            CDB_HIP(hipMemsetAsync(d_hist, 0, (size_t)nseg * 8 * 256 * 8, s));
+            hipLaunchKernelGGL(seg_hist_kernel, dim3(std::max(1u, 2048u / nseg), nseg), dim3(256), 0, s, tk, d_segs, d_hist);
+            hipLaunchKernelGGL(rs_seg_digit_start_kernel, dim3(nseg), dim3(256), 0, s, d_hist, d_segs, 4, d_starts);
+            prof.reset();
+            int cur = 0;
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t e = ws.next_epoch(s);
+                int t = prof.begin(s);
+                hipLaunchKernelGGL((rs_onesweep_kernel<uint64_t, NoVal, CfgK, NoGen, NoVal, SegArgs>), dim3(grid), dim3(1024), 0, s,
+                                   (const uint64_t*)r[cur], r[cur ^ 1], (const NoVal*)nullptr, (NoVal*)nullptr, n, 32 + 8 * p, 0xFFu,
+                                   (const unsigned long long*)(d_starts + (size_t)p * 256), ws.status.as<uint64_t>(), ws.xticket_ptr(e), e,
+                                   ws.err_ptr(), NoGen(), (const NoVal*)nullptr, (NoVal*)nullptr, -1, sa);
+                prof.end(t, "rs_aos", 2 * n * 8, s);
+                cur ^= 1;
+            }
+            CDB_HIP(hipStreamSynchronize(s));
+            radix_check_error(s, ws);
+            prof.resolve();
+            double ms = 0; uint64_t launches = 0;
+            for (auto& kv : prof.recs)
+                if (kv.first.rfind("rs_aos", 0) == 0) { ms += kv.second.ms; launches += kv.second.launches; }
+            if (rr > 0) best = std::min(best, ms / (double)launches);
+        }
+        std::printf("%4u segments, u64 (key << 32 | entry) records: %.3f ms per pass  %.0f GB/s algorithmic (16 B x n)\n", nseg, best, 16.0 * n / (best * 1e-3) / 1e9);
+        return 0;
+    }
+#endif
     // (b) segments
     for (uint32_t nseg : {nseg_arg, 16u, 1u}) {
         std::vector<SegInfo> h_segs(nseg);
