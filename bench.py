@@ -175,6 +175,10 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
                dist=None, world=1):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
+    clamp_note = None
+    if cfg.get("total"):  # BASELINE configs[3] / [4] as worded: a FIXED corpus cut into `world` doc-aligned shards
+        total_bytes = cfg["bytes"] if cfg["kind"] == "utf8" else cfg["docs"] * cfg["doclen"]
+        cfg, clamp_note = per_rank_cfg(cfg, world, "strong")
     if make_merger is not None and merge_mode == "full" and cfg["npat"] > 1_000_000:
         # full all-gatherv merge: every rank ends up holding the merged rows of ALL shards; 10^7 patterns x N shards would
         # be ~10^9 rows per rank — the batch is cut to 10^6 patterns (the counts-only merge runs the whole batch)
@@ -197,6 +201,10 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
     out = {"workload": f"{name}: " + describe(cfg, n, ndocs), "generate_s": round(t_gen, 2)}
+    if cfg.get("total"):
+        out["workload"] += (f" per GPU; fixed corpus of {total_bytes / 2**30:.0f} GiB split into {world} doc-aligned shards (--scaling strong)"
+                            + (f" ({clamp_note})" if clamp_note else ""))
+        out["scaling"] = "strong"
     try:
         bms = []
         for i in range(reps + 1):
@@ -459,6 +467,31 @@ def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
     return out
 
 
+def launch_plan(gpus, env, argv, share_gpu=False, device_count=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) must still run N ranks — a
+    line that says "n_gpus": 1 for a --gpus 8 command would void a scaling curve.  Returns the command that re-runs this
+    script under torch.distributed.run with one rank per GPU, or None when the process is already a rank (or N = 1).
+    Exits non-zero when the box has fewer than N GPUs (unless --share-gpu: the one-GPU test of the N > 1 code path)."""
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}: need at least one GPU")
+    if gpus == 1 or "WORLD_SIZE" in env:
+        return None
+    if not share_gpu:
+        if device_count is None:
+            import torch
+            device_count = torch.cuda.device_count()
+        if device_count < gpus:
+            raise SystemExit(f"bench.py --gpus {gpus}: only {device_count} GPU(s) visible on this node — refusing to "
+                             f"print a line for fewer GPUs than asked for")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -467,7 +500,7 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--configs", default="auto",
                     help="comma-separated extra configurations for the \"configs\" block (auto: c2,utf8_4g,c4shard at N = 1 on "
-                         "the default workload, c3shard at N = 4, c4shard at N = 8; none: skip)")
+                         "the default workload, c3 at N = 4, c4 at N = 8 — the fixed 32 / 128 GiB corpora split across the ranks; none: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full-budget", type=float, default=300.0,
                     help="seconds the CPU baseline may spend on the WHOLE bench corpus (0: prefix only); it runs when the "
@@ -477,6 +510,8 @@ def main():
                     help="rendezvous backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
                          "exercise the N > 1 code path on a one-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (testing only)")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="print the self-launch decision for --gpus N (the torch.distributed.run command, or null) and exit")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the RCCL merge of the N > 1 step with a one-rank communicator (testing the plumbing on one GPU)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -487,11 +522,19 @@ def main():
                          "(cdb_comm_merge_counts; host / rank-local consumers); full = all-gatherv of all rows to every rank")
     args = ap.parse_args()
 
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:], share_gpu=args.share_gpu)
+    if args.print_launch:
+        print(json.dumps({"launch": plan}))
+        return
+    if plan is not None:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one per GPU) and hand rank 0's line through.
+        # The child ranks inherit stdout / stderr, the exit code is the job's.
+        raise SystemExit(subprocess.call(plan))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong GPU count")
 
     import torch
     import torch.distributed as dist
@@ -604,6 +647,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
     hits, rows = int(r.nhits), int(r.nrows)
+    rows_per_rank = [rows]
+    if world > 1:  # rows every rank contributed to the merged result of the last step
+        mine = torch.tensor([rows], dtype=torch.int64, device=coll_device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows_per_rank = [int(x.item()) for x in allr]
 
     prof = g.profile()
     steps = args.steps
@@ -643,6 +692,8 @@ def main():
             },
             "commit": git_head(),
             "merge": merger.note if merger is not None else None,
+            "rccl_ranks": int(merger.comm.world) if (merger is not None and merger.comm is not None) else None,
+            "rows_per_rank": rows_per_rank,
             "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
             "query_hits_per_batch": hits,
@@ -698,7 +749,7 @@ def main():
     extra = args.configs
     if extra == "auto":
         extra = ("c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
-                 "c3shard" if world == 4 else "c4shard" if world == 8 else "none")
+                 "c3" if world == 4 else "c4" if world == 8 else "none")  # C3 / C4 as BASELINE.json words them
     if rank == 0 and world == 1 and small and not args.no_pcie:
         try:
             out["pcie_inclusive"] = pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat)
