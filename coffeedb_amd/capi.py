@@ -647,8 +647,17 @@ def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):
     keep = []
     lead = None
     for k, (ix, data) in enumerate(keys):
+        if ix is not None and not isinstance(ix, (GpuShards, GpuStringIndex)):
+            raise TypeError(f"query_and: key {k} is neither a GpuStringIndex, a GpuShards nor None")
+        if sharded and isinstance(ix, GpuStringIndex):
+            # a plain index beside sharded keys: cdb_shards_key_query.shards must be a cdb_shards* — handing it a cdb_index*
+            # would be reinterpreted.  Resolve the key with its own OR (ascending id) and pass the rows.
+            if not data:
+                raise RuntimeError("The constraint list cannot be empty")
+            ix, data = None, ix.query_or(list(data))
         if ix is not None:
-            lead = lead or ix
+            if lead is None or (sharded and not isinstance(lead, GpuShards)):
+                lead = ix
             blob = np.frombuffer(b"".join(data), dtype=np.uint8)
             offs = np.zeros(len(data) + 1, dtype=np.uint64)
             np.cumsum([len(x) for x in data], out=offs[1:])
@@ -668,7 +677,7 @@ def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):
     fn = lib.cdb_shards_query_and if sharded else lib.cdb_query_and  # (cdb_shards_key_query has cdb_key_query's layout)
     rc_ = fn(arr, len(keys), 1 if ranked else 0, int(lo), int(hi), int(limit), C.byref(ids), C.byref(cnt), C.byref(n))
     if rc_ != 0:
-        err = lib.cdb_shards_last_error if sharded else lib.cdb_last_error
+        err = lib.cdb_shards_last_error if isinstance(lead, GpuShards) else lib.cdb_last_error
         raise RuntimeError(err(lead._h).decode(errors="replace") if lead is not None else "cdb_query_and: no string key")
     out = [(ids[i], cnt[i]) for i in range(n.value)]
     lib.cdb_free(ids)

@@ -136,6 +136,7 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
                 for (int q = 0; q < 2; ++q)
                     if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
             } catch (const std::exception& e) {
+                (void)hipStreamSynchronize(s);  // a DMA out of the pinned blocks may still be in flight: it ends before they go back
                 std::lock_guard<std::mutex> g(fmu);
                 if (failure.empty()) failure = e.what();
             }
@@ -193,6 +194,7 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
             for (int q = 0; q < 2; ++q)
                 if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
         } catch (const std::exception& e) {
+            (void)hipStreamSynchronize(s);  // a DMA out of the pinned blocks may still be in flight: it ends before they go back
             std::lock_guard<std::mutex> g(fmu);
             if (failure.empty()) failure = e.what();
         }
@@ -1383,6 +1385,14 @@ int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes) {
 int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     if (!h || !name) return CDB_E_INVALID;
     Index& ix = h->ix;
+    // The resident query workgroup keeps the key arrays / symbol count it was launched with, while a request only carries
+    // what query_single_launch encodes under the CURRENT options: every option that changes that encoding stops the
+    // workgroup first (the next lone keyword starts a fresh one under the new settings).
+    for (const char* o : {"fast_search", "key_directory", "single_query", "search_lanes", "keep_keys", "reference_compat"})
+        if (!std::strcmp(name, o)) {
+            std::lock_guard<std::mutex> g(ix.mu);
+            query_resident_stop(ix);
+        }
     if (!std::strcmp(name, "profile")) ix.prof.enabled = value != 0;
     else if (!std::strcmp(name, "reference_compat")) ix.reference_compat = value != 0;
     else if (!std::strcmp(name, "force_doubling")) ix.force_doubling = value != 0;

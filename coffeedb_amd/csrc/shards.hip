@@ -491,6 +491,40 @@ const char* cdb_comm_transport(const cdb_comm* c) { return (c && c->mr.tr) ? c->
 // lock, every query holds it shared for the whole call, so a query never sees a destroyed handle or a half-built set.
 // Device work of one shard is serialised by that shard's own ix.mu; code that holds several of them at once (the
 // lone-keyword fan-out, the device merge) takes them in ascending shard order.
+// Shared / exclusive lock that PREFERS the writer: glibc's rwlock lets new readers in while a writer waits, so
+// two client threads with overlapping queries could keep a finished build from ever taking over.  Here a waiting writer
+// closes the door for new readers; the ones inside finish, the generation swap runs, the door opens.  (No thread takes
+// the shared side twice: nothing below nests two shared sections.)
+class StateLock {
+    std::mutex m;
+    std::condition_variable cv;
+    int readers = 0, writers_waiting = 0;
+    bool writer = false;
+
+public:
+    void lock_shared() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !writer && writers_waiting == 0; });
+        ++readers;
+    }
+    void unlock_shared() {
+        std::unique_lock<std::mutex> l(m);
+        if (--readers == 0) cv.notify_all();
+    }
+    void lock() {
+        std::unique_lock<std::mutex> l(m);
+        ++writers_waiting;
+        cv.wait(l, [&] { return !writer && readers == 0; });
+        --writers_waiting;
+        writer = true;
+    }
+    void unlock() {
+        std::unique_lock<std::mutex> l(m);
+        writer = false;
+        cv.notify_all();
+    }
+};
+
 struct cdb_shards {
     std::vector<int> devices;
     std::vector<cdb_index*> shard;                  // one handle per device slot
@@ -508,8 +542,9 @@ struct cdb_shards {
     bool device_merge = false;               // cdb_shards_query_batch merges on the devices (RCCL all-gatherv) instead of the host
     bool replace_in_place = false;           // build: destroy the serving shards FIRST (a column whose old + new arrays do not
                                              // fit together; the reference keeps both, database.cpp:276-280)
-    std::vector<std::pair<std::string, int64_t>> options;
-    std::shared_mutex state;
+    std::vector<std::pair<std::string, int64_t>> options;  // guarded by opt_mu
+    std::mutex opt_mu;
+    StateLock state;
     std::mutex staging_mu;                   // add* / build read and write the staged column
     std::mutex err_mu;
     std::string err;
@@ -580,14 +615,20 @@ void make_merge(const std::vector<int>& devices, const std::vector<cdb_index*>& 
 }
 
 // fresh handles for every device slot, with the options set so far
-std::vector<cdb_index*> fresh_handles(cdb_shards* h) {
+std::vector<cdb_index*> fresh_handles(cdb_shards* h, size_t* options_seen = nullptr) {
     std::vector<cdb_index*> fresh;
+    std::vector<std::pair<std::string, int64_t>> options;
+    {
+        std::lock_guard<std::mutex> g(h->opt_mu);
+        options = h->options;  // snapshot: cdb_shards_set_option may append while a build runs (install() replays the rest)
+    }
+    if (options_seen) *options_seen = options.size();
     try {
         for (size_t i = 0; i < h->devices.size(); ++i) {
             cdb_index* p = nullptr;
             if (cdb_create(&p, h->devices[i]) != CDB_OK) throw Error("HIP error: cannot create a shard handle");
             fresh.push_back(p);
-            for (auto& kv : h->options) (void)cdb_set_option(p, kv.first.c_str(), kv.second);
+            for (auto& kv : options) (void)cdb_set_option(p, kv.first.c_str(), kv.second);
         }
     } catch (...) {
         for (cdb_index* p : fresh) cdb_destroy(p);
@@ -598,7 +639,12 @@ std::vector<cdb_index*> fresh_handles(cdb_shards* h) {
 
 // a new generation of shards takes over (exclusive lock held by the caller); the old handles are destroyed
 void install(cdb_shards* h, std::vector<cdb_index*>& fresh, int used, std::vector<uint64_t>& bounds,
-             std::vector<std::unique_ptr<MergeRank>>& ranks, std::shared_ptr<Transport>& tr) {
+             std::vector<std::unique_ptr<MergeRank>>& ranks, std::shared_ptr<Transport>& tr, size_t options_seen = ~size_t(0)) {
+    {   // options set while this generation was being built reached the OLD handles only: replay them on the new ones
+        std::lock_guard<std::mutex> g(h->opt_mu);
+        for (size_t k = options_seen; k < h->options.size(); ++k)
+            for (cdb_index* p : fresh) (void)cdb_set_option(p, h->options[k].first.c_str(), h->options[k].second);
+    }
     h->ranks.swap(ranks);   // (the old merge ranks borrow the old handles' streams: they go first)
     ranks.clear();
     h->tr.swap(tr);
@@ -706,7 +752,7 @@ int cdb_shards_add(cdb_shards* h, int64_t id, const char* value, size_t len) {
     return guarded_on(h, [&] {
         std::lock_guard<std::mutex> g(h->staging_mu);  // (lock order everywhere: staging_mu, then state)
         {
-            std::shared_lock<std::shared_mutex> st(h->state);
+            std::shared_lock<StateLock> st(h->state);
             fetch_staging(h);
         }
         h->text.append(value, len);
@@ -723,7 +769,7 @@ int cdb_shards_add_bulk(cdb_shards* h, const int64_t* ids, const char* blob, con
             if (doc_start[d + 1] < doc_start[d]) throw Error("doc_start must be non-decreasing");
         std::lock_guard<std::mutex> g(h->staging_mu);
         {
-            std::shared_lock<std::shared_mutex> st(h->state);
+            std::shared_lock<StateLock> st(h->state);
             fetch_staging(h);
         }
         h->ids.reserve(h->ids.size() + ndocs);
@@ -745,7 +791,7 @@ int cdb_shards_add_raw_dir(cdb_shards* h, const char* dir, const char* key, uint
     return guarded_on(h, [&] {
         std::lock_guard<std::mutex> g(h->staging_mu);
         {
-            std::shared_lock<std::shared_mutex> st(h->state);
+            std::shared_lock<StateLock> st(h->state);
             fetch_staging(h);
         }
         uint64_t nrec = 0, nadd = 0;
@@ -773,7 +819,7 @@ int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value) {
         h->replace_in_place = value != 0;
         return CDB_OK;
     }
-    std::shared_lock<std::shared_mutex> st(h->state);
+    std::shared_lock<StateLock> st(h->state);
     for (cdb_index* p : h->shard) {
         const int rc = cdb_set_option(p, name, value);
         if (rc != CDB_OK) {
@@ -782,7 +828,10 @@ int cdb_shards_set_option(cdb_shards* h, const char* name, int64_t value) {
             return rc;
         }
     }
-    h->options.emplace_back(name, value);  // (replayed on the fresh handles of every rebuild)
+    {
+        std::lock_guard<std::mutex> g(h->opt_mu);
+        h->options.emplace_back(name, value);  // (replayed on the fresh handles of every rebuild)
+    }
     return CDB_OK;
 }
 
@@ -795,7 +844,7 @@ int cdb_shards_build(cdb_shards* h) {
     return guarded_on(h, [&] {
         std::lock_guard<std::mutex> sg(h->staging_mu);  // (the column must not move while the shards upload it)
         {
-            std::shared_lock<std::shared_mutex> st(h->state);
+            std::shared_lock<StateLock> st(h->state);
             fetch_staging(h);
         }
         const int G = (int)h->devices.size();
@@ -805,14 +854,15 @@ int cdb_shards_build(cdb_shards* h) {
         used = std::max(1, std::min<int>(used, (int)std::max<uint64_t>(nd, 1)));
         std::vector<uint64_t> b = shard_bounds(h->doc_start, used);
         if (h->replace_in_place) {  // the caller accepts an unbuilt window: the old arrays go first
-            std::unique_lock<std::shared_mutex> st(h->state);
+            std::unique_lock<StateLock> st(h->state);
             std::vector<cdb_index*> empty = fresh_handles(h);
             std::vector<uint64_t> nb{0};
             std::vector<std::unique_ptr<MergeRank>> nr;
             std::shared_ptr<Transport> nt;
             install(h, empty, 0, nb, nr, nt);
         }
-        std::vector<cdb_index*> fresh = fresh_handles(h);
+        size_t opts_seen = 0;
+        std::vector<cdb_index*> fresh = fresh_handles(h, &opts_seen);
         std::vector<std::unique_ptr<MergeRank>> ranks;
         std::shared_ptr<Transport> tr;
         try {
@@ -827,8 +877,8 @@ int cdb_shards_build(cdb_shards* h) {
             for (cdb_index* p : fresh) cdb_destroy(p);
             throw;
         }
-        std::unique_lock<std::shared_mutex> st(h->state);
-        install(h, fresh, used, b, ranks, tr);
+        std::unique_lock<StateLock> st(h->state);
+        install(h, fresh, used, b, ranks, tr, opts_seen);
     });
 }
 
@@ -845,7 +895,8 @@ int cdb_shards_build_views(cdb_shards* h, const int64_t* ids, const char* const*
         int used = h->use_all ? G : (int)std::min<uint64_t>((uint64_t)G, std::max<uint64_t>(1, ceil_div(total, h->max_shard_bytes)));
         used = std::max(1, std::min<int>(used, (int)std::max<uint64_t>(ndocs, 1)));
         std::vector<uint64_t> b = shard_bounds(ds, used);
-        std::vector<cdb_index*> fresh = fresh_handles(h);
+        size_t opts_seen = 0;
+        std::vector<cdb_index*> fresh = fresh_handles(h, &opts_seen);
         std::vector<std::unique_ptr<MergeRank>> ranks;
         std::shared_ptr<Transport> tr;
         try {
@@ -860,8 +911,8 @@ int cdb_shards_build_views(cdb_shards* h, const int64_t* ids, const char* const*
             for (cdb_index* p : fresh) cdb_destroy(p);
             throw;
         }
-        std::unique_lock<std::shared_mutex> st(h->state);
-        install(h, fresh, used, b, ranks, tr);
+        std::unique_lock<StateLock> st(h->state);
+        install(h, fresh, used, b, ranks, tr, opts_seen);
         h->ids.clear();
         h->doc_start.assign(1, 0);
         std::string().swap(h->text);
@@ -876,7 +927,7 @@ constexpr uint64_t SHARDS_MAGIC = 0x3130485344424443ull;  // "CDBDSH01"
 int cdb_shards_save(cdb_shards* h, const char* path) {
     if (!h || !path) return CDB_E_INVALID;
     return guarded_on(h, [&] {
-        std::shared_lock<std::shared_mutex> st(h->state);
+        std::shared_lock<StateLock> st(h->state);
         if (h->used < 1) throw Error("index has not been built");
         for (int i = 0; i < h->used; ++i) check_shard(h, i, cdb_save(h->shard[i], (std::string(path) + "." + std::to_string(i)).c_str()));
         FILE* fp = std::fopen(path, "wb");
@@ -906,7 +957,8 @@ int cdb_shards_load(cdb_shards* h, const char* path) {
         }
         const int used = (int)hd[1];
         if (used > (int)h->devices.size()) throw Error("saved index has more shards than this handle has devices");
-        std::vector<cdb_index*> fresh = fresh_handles(h);
+        size_t opts_seen = 0;
+        std::vector<cdb_index*> fresh = fresh_handles(h, &opts_seen);
         std::vector<std::unique_ptr<MergeRank>> ranks;
         std::shared_ptr<Transport> tr;
         try {
@@ -921,8 +973,8 @@ int cdb_shards_load(cdb_shards* h, const char* path) {
             for (cdb_index* p : fresh) cdb_destroy(p);
             throw;
         }
-        std::unique_lock<std::shared_mutex> st(h->state);
-        install(h, fresh, used, b, ranks, tr);
+        std::unique_lock<StateLock> st(h->state);
+        install(h, fresh, used, b, ranks, tr, opts_seen);
         h->ids.clear();
         h->doc_start.assign(1, 0);
         std::string().swap(h->text);
@@ -946,7 +998,7 @@ int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** i
     *nrows = 0;
     return guarded_on(h, [&] {
         if (len == 0) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
-        std::shared_lock<std::shared_mutex> st(h->state);
+        std::shared_lock<StateLock> st(h->state);
         const int G = std::max(h->used, 1);
         struct Part {
             int64_t *ids = nullptr, *counts = nullptr;
@@ -960,21 +1012,36 @@ int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** i
         } cleanup{part};
         {
             std::vector<std::unique_lock<std::mutex>> locks;  // ascending shard order
-            for (int i = 0; i < G; ++i) {
-                Index& ix = h->shard[i]->ix;
-                locks.emplace_back(ix.mu);
-                CDB_HIP(hipSetDevice(ix.device));
-                StreamScope ss(ix.stream);
-                part[i].state = query_single_launch(ix, keyword, len);
-            }
-            for (int i = 0; i < G; ++i) {
-                Index& ix = h->shard[i]->ix;
-                if (part[i].state == SingleLaunch::Absent) query_single_empty(ix, &part[i].ids, &part[i].counts, &part[i].n);
-                else if (part[i].state == SingleLaunch::Launched) {
+            std::vector<char> in_flight(G, 0);                // launched, answer not collected yet
+            try {
+                for (int i = 0; i < G; ++i) {
+                    Index& ix = h->shard[i]->ix;
+                    locks.emplace_back(ix.mu);
                     CDB_HIP(hipSetDevice(ix.device));
                     StreamScope ss(ix.stream);
-                    if (!query_single_collect(ix, &part[i].ids, &part[i].counts, &part[i].n)) part[i].state = SingleLaunch::NotApplicable;
+                    part[i].state = query_single_launch(ix, keyword, len);
+                    in_flight[i] = part[i].state == SingleLaunch::Launched;
                 }
+                for (int i = 0; i < G; ++i) {
+                    Index& ix = h->shard[i]->ix;
+                    if (part[i].state == SingleLaunch::Absent) query_single_empty(ix, &part[i].ids, &part[i].counts, &part[i].n);
+                    else if (part[i].state == SingleLaunch::Launched) {
+                        CDB_HIP(hipSetDevice(ix.device));
+                        StreamScope ss(ix.stream);
+                        in_flight[i] = 0;  // (collect waits for the answer or throws after the stream was synchronised)
+                        if (!query_single_collect(ix, &part[i].ids, &part[i].counts, &part[i].n)) part[i].state = SingleLaunch::NotApplicable;
+                    }
+                }
+            } catch (...) {
+                // kernels of the shards already launched would answer LATER into their host-mapped result blocks — over the
+                // next query's "not answered yet" mark.  They finish (or the resident workgroup leaves) before the locks go.
+                for (int i = 0; i < (int)locks.size(); ++i) {
+                    Index& ix = h->shard[i]->ix;
+                    (void)hipSetDevice(ix.device);
+                    if (ix.resident_query) query_resident_stop(ix);
+                    else if (in_flight[i]) (void)hipStreamSynchronize(ix.stream);
+                }
+                throw;
             }
         }
         std::vector<std::pair<int64_t, int64_t>> rows;
@@ -992,7 +1059,7 @@ int cdb_shards_query(cdb_shards* h, const char* keyword, size_t len, int64_t** i
 namespace {
 void shards_or_rows(cdb_shards* h, const char* blob, const uint64_t* offsets, uint64_t nkw, bool ranked, int64_t lo, int64_t hi,
                     uint64_t limit, std::vector<std::pair<int64_t, int64_t>>& rows) {
-    std::shared_lock<std::shared_mutex> st(h->state);
+    std::shared_lock<StateLock> st(h->state);
     const int G = std::max(h->used, 1);
     std::vector<std::vector<std::pair<int64_t, int64_t>>> part(G);
     parallel_shards(G, [&](int i) {
@@ -1083,7 +1150,7 @@ int cdb_shards_query_and(const cdb_shards_key_query* keys, int nkeys, int ranked
                 flat[k].nrows = q.nrows;
             }
         }
-        std::shared_lock<std::shared_mutex> st(lead->state);
+        std::shared_lock<StateLock> st(lead->state);
         cdb_index* dev = lead->shard[0];
         check_handle(dev, query_and_with_lead(dev, flat.data(), nkeys, ranked, corr_lo, corr_hi, limit, ids, counts, nrows));
     });
@@ -1093,7 +1160,7 @@ int cdb_shards_query_spans(cdb_shards* h, const char* blob, const uint64_t* offs
     if (!h || !out || (nkw && !offsets)) return CDB_E_INVALID;
     std::memset(out, 0, sizeof(*out));
     const int rc = guarded_on(h, [&] {
-        std::shared_lock<std::shared_mutex> st(h->state);
+        std::shared_lock<StateLock> st(h->state);
         std::vector<cdb_spans> parts(std::max(h->used, 1));
         for (auto& x : parts) std::memset(&x, 0, sizeof(cdb_spans));
         struct Cleanup {
@@ -1251,7 +1318,7 @@ int shards_batch_impl(cdb_shards* h, const char* blob, const uint64_t* offsets, 
     const int rc = guarded_on(h, [&] {
         for (uint64_t j = 0; j < npat; ++j)
             if (offsets[j + 1] <= offsets[j]) throw Error("Empty keywords are not allowed");  // index.cpp:239-241
-        std::shared_lock<std::shared_mutex> st(h->state);
+        std::shared_lock<StateLock> st(h->state);
         const int G = std::max(h->used, 1);
         if (G == 1) {
             check_shard(h, 0, hits ? cdb_query_batch_offsets(h->shard[0], blob, offsets, npat, out, hits)

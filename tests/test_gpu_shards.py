@@ -111,6 +111,14 @@ def test_sharded_and_persistence_raw_ingest(tmp_path):
         got = capi.query_and([(sa, kws_a), (sb, kws_b), (None, rows_c)], ranked=ranked, **kw)
         want = capi.query_and([(one_a, kws_a), (one_b, kws_b), (None, rows_c)], ranked=ranked, **kw)
         assert got == want and len(want) > 0
+        # a plain index beside a sharded key (the binding used to hand the cdb_index* over as a cdb_shards*)
+        mixed = capi.query_and([(one_a, kws_a), (sb, kws_b), (None, rows_c)], ranked=ranked, **kw)
+        assert mixed == want
+        assert capi.query_and([(sa, kws_a), (one_b, kws_b), (None, rows_c)], ranked=ranked, **kw) == want
+    with pytest.raises(RuntimeError, match="Empty keywords"):
+        capi.query_and([(sa, kws_a), (one_b, [b""])])              # the error comes from the plain index, reported by type
+    with pytest.raises(TypeError):
+        capi.query_and([(sa, kws_a), (object(), kws_b)])
     # save / load: same shards, same answers; the column comes back for a later add + rebuild
     path = str(tmp_path / "col.cdbs")
     sa.save(path)
@@ -194,13 +202,19 @@ def test_sharded_queries_run_while_a_rebuild_takes_over():
     th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
     for t in th:
         t.start()
+    import time
+    took = []
     for r in range(3):
         sh.add(10_000 + r, b"zzzz" + kws[0])
+        sh.set_option("fast_search", r % 2)                       # options set around / during rebuilds reach the NEW generation
+        t0 = time.perf_counter()
         sh.build()
+        took.append(time.perf_counter() - t0)
     stop.set()
     for t in th:
         t.join()
     assert not errors, errors[:3]
+    assert max(took) < 30, took                                   # the writer is not starved by four overlapping readers
     assert sh.query(b"zzzz") == [(10_000 + r, 1) for r in range(3)]
     sh.close()
 
