@@ -125,18 +125,45 @@ def describe(cfg, n, ndocs):
             + (" with occurrence offsets" if cfg.get("offsets") else "") + (" + $correlation ranking" if cfg.get("ranked") else ""))
 
 
-def dominant(prof, n_elems=None):
-    """The kernel with the largest share of the HIP-event time, with its algorithmic bytes per launch."""
+def dominant(prof, builds=None):
+    """The kernel with the largest share of the HIP-event time, with its algorithmic bytes per launch.  `builds` = builds the
+    profile covers: the per-build figures are what stays comparable when two profilers cut a pass into launches differently."""
     if not prof:
         return None
     name = max(prof, key=lambda k: prof[k]["ms"])
     k = prof[name]
     avg_ms = k["ms"] / max(k["launches"], 1)
     gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] else 0.0
-    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
-            "algorithmic_bytes_per_launch": k["bytes"] // max(k["launches"], 1),
-            "share_of_kernel_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 3)}
+    out = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": k["launches"],
+           "algorithmic_bytes_per_launch": k["bytes"] // max(k["launches"], 1),
+           "share_of_kernel_time": round(k["ms"] / sum(v["ms"] for v in prof.values()), 3)}
+    if builds:
+        out["launches_per_build"] = round(k["launches"] / builds, 2)
+        out["algorithmic_bytes_per_build"] = int(k["bytes"] // builds)
+        out["ms_per_build"] = round(k["ms"] / builds, 3)
+    return out
+
+
+def attach_traffic(roof, tr, note):
+    """PMC traffic of the dominant kernel from a committed rocprofv3 profile, in THIS run's launch definition: rocprofv3 counts
+    every kernel launch, the library's profiler may merge or split the launches of one pass (bucket groups), so the profile's
+    bytes are carried over per BUILD and divided by this run's launches per build — `traffic` and
+    `algorithmic_bytes_per_launch` then describe the same launch (85.5 GB measured beside 103.1 GB algorithmic)."""
+    if not roof:
+        return
+    ent = (tr or {}).get("kernels", {}).get(roof["kernel"])
+    if not ent:
+        roof["traffic"] = None
+        return
+    per_build = ent["hbm_bytes_per_launch"] * ent.get("launches", 1)
+    lpb = roof.get("launches_per_build") or ent.get("launches", 1)
+    roof["traffic"] = round(per_build / lpb)
+    roof["traffic_per_build"] = round(per_build)
+    roof["traffic_over_algorithmic"] = round(per_build / roof["algorithmic_bytes_per_build"], 3) if roof.get("algorithmic_bytes_per_build") else None
+    roof["traffic_profile_launches_per_build"] = ent.get("launches", 1)
+    roof["traffic_source"] = {k: tr.get(k) for k in ("profile", "commit", "source") if tr.get(k)}
+    roof["traffic_note"] = note
 
 
 def build_stats(g):
@@ -198,6 +225,8 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
     #  build — pays 1.1 x a warm build: tools/big_one.py)
     torch.cuda.empty_cache()
     t_gen = time.perf_counter() - t_gen
+    capi.load_library().cdb_release_cached_memory()
+    capi.memory_reset_peak()
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
     out = {"workload": f"{name}: " + describe(cfg, n, ndocs), "generate_s": round(t_gen, 2)}
@@ -221,14 +250,13 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         out["first_build_vram"] = "recycled: released by this process just before, scrubbed by the driver on re-allocation (untouched VRAM: ~1.1 x a warm build, DESIGN.md §5)"
         out["sa_build_GiB_per_s"] = round(n / 2**30 / (min(bms[1:]) * 1e-3), 3)
         out["build_stats"] = build_stats(g)
-        out["roofline"] = dominant(prof_build)
-        tr = pmc_traffic(name)
-        if tr and out["roofline"] and out["roofline"]["kernel"] in tr.get("kernels", {}):
-            out["roofline"]["traffic"] = round(tr["kernels"][out["roofline"]["kernel"]]["hbm_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = {k: tr.get(k) for k in ("profile", "commit")}
-            out["roofline"]["traffic_note"] = "committed PMC profile of this configuration (not measured in this run)"
-        elif out["roofline"]:
-            out["roofline"]["traffic"] = None
+        out["roofline"] = dominant(prof_build, builds=reps)
+        attach_traffic(out["roofline"], pmc_traffic(name), "committed PMC profile of this configuration (not measured in this run)")
+        mem_in_use, mem_peak, _ = capi.memory_stats()
+        out["peak_hbm_bytes"] = int(mem_peak + n)   # library allocations at their peak + the caller's resident text
+        out["index_hbm_bytes"] = int(mem_in_use + n)
+        out["hbm_note"] = ("peak = most device memory the library held during a build (index + scratch) + the resident text; index = what "
+                           "stays after it.  A rebuild beside a serving index (database.cpp:276-280) needs index + peak <= 288 GB")
         kern_ms = sum(v["ms"] for v in prof_build.values()) / reps
         kern_bytes = sum(v["bytes"] for v in prof_build.values()) / reps
         out["build_kernels_ms"] = round(kern_ms, 2)
@@ -423,6 +451,22 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0):
     return out
 
 
+def host_caller(*argv, timeout=600):
+    """tests/cpp/test_index_shim (the database.cpp-style C++ caller over shim/index.{h,cpp}) in one of its timing modes; returns
+    its JSON line.  A process of its own: no torch, no warm block cache."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_index_shim")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.dirname(exe), "test_index_shim"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        p = subprocess.run([exe] + [str(a) for a in argv], capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": (p.stdout + p.stderr)[-300:], "rc": p.returncode}
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001 - reported in the line
+        return {"error": repr(e)[:300]}
+
+
 def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
     """The same work through the host entry points: cdb_add_bulk (host staging) + cdb_build (H2D of text and tables
     inside the timed call) and cdb_query_batch (patterns up, CSR rows down)."""
@@ -506,6 +550,9 @@ def main():
                     help="seconds the CPU baseline may spend on the WHOLE bench corpus (0: prefix only); it runs when the "
                          "128 MiB prefix predicts it fits")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-cold-start", action="store_true",
+                    help="skip the cold-start leg (a fresh C++ process builds a 4 GiB UTF-8 column from host memory once, before "
+                         "this process touches the GPU; N = 1, default workload only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="rendezvous backend for N > 1 (nccl = RCCL over xGMI; gloo + --share-gpu only exists to "
                          "exercise the N > 1 code path on a one-GPU box)")
@@ -535,6 +582,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong GPU count")
+
+    cold = None
+    if world == 1 and args.workload == "c1" and args.configs == "auto" and not args.no_cold_start:
+        # server.cpp:44: the start-up build of a fresh process — measured FIRST, while this process has not touched the GPU
+        # (VRAM a process released just before is scrubbed by the driver on re-allocation: the recycled case the configs
+        # blocks measure)
+        cold = host_caller("cold", 4 << 30)
 
     import torch
     import torch.distributed as dist
@@ -659,14 +713,10 @@ def main():
     out = None
     if rank == 0:
         gib_total = world * n * steps / 2**30
-        roof = dominant(prof)
+        roof = dominant(prof, builds=steps)
         traffic = pmc_traffic()
-        if traffic and roof and roof["kernel"] in traffic.get("kernels", {}) and traffic.get("suffixes") in (None, n):
-            roof["traffic"] = round(traffic["kernels"][roof["kernel"]]["hbm_bytes_per_launch"])
-            roof["traffic_source"] = {k: traffic.get(k) for k in ("profile", "commit", "source")}
-            roof["traffic_note"] = "committed PMC profile of this same command (not measured in this run)"
-        elif roof:
-            roof["traffic"] = None
+        attach_traffic(roof, traffic if (traffic and traffic.get("suffixes") in (None, n)) else None,
+                       "committed PMC profile of this same command (not measured in this run)")
         build_kernels = {k: v for k, v in prof.items() if not k.startswith("q_")}
         kern_ms = sum(v["ms"] for v in build_kernels.values()) / steps
         kern_bytes = sum(v["bytes"] for v in build_kernels.values()) / steps
@@ -748,7 +798,7 @@ def main():
             out["single_query_us"] = {"error": repr(e)[:200]}
     extra = args.configs
     if extra == "auto":
-        extra = ("c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
+        extra = ("c0,c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
                  "c3" if world == 4 else "c4" if world == 8 else "none")  # C3 / C4 as BASELINE.json words them
     if rank == 0 and world == 1 and small and not args.no_pcie:
         try:
@@ -756,10 +806,17 @@ def main():
             # SURVEY §8(d) defines the metric INCLUDING the transfers: host column in, index built (cdb_build_view), and host
             # patterns in, host rows out (cdb_query_batch) — `value` above is the HBM-resident rate the task contract asks for
             out["pcie_inclusive_sa_build_GiB_per_s"] = out["pcie_inclusive"]["build_view_GiB_per_s"]
+            out["sa_build_GiB_per_s_incl_h2d"] = out["pcie_inclusive"]["build_view_GiB_per_s"]  # (beside `value`: SURVEY §8(d)'s definition)
             out["pcie_inclusive_query_patterns_per_s"] = out["pcie_inclusive"]["query_patterns_per_s"]
         except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
             out["pcie_inclusive"] = {"error": repr(e)[:300]}
     g.close()
+    if rank == 0 and world == 1 and small and not args.no_pcie and isinstance(out.get("pcie_inclusive"), dict):
+        # what the SHIM's build() really calls (shim/index.cpp: cdb_build_views over one std::string per document,
+        # database.cpp:262-264): the C++ caller of tests/cpp at this workload's shape, in a process of its own
+        out["pcie_inclusive"]["build_views"] = host_caller("views", ndocs, cfg.get("doclen", 1024), 3)
+    if cold is not None:
+        out["cold_start"] = cold
     del text, d_blob, d_offs
     torch.cuda.empty_cache()
     capi.load_library().cdb_release_cached_memory()

@@ -19,7 +19,7 @@ EXPORTS = [
     "cdb_create", "cdb_destroy", "cdb_last_error", "cdb_add", "cdb_add_bulk", "cdb_build", "cdb_build_view", "cdb_build_views", "cdb_build_device", "cdb_build_resident", "cdb_raw_record_find_string", "cdb_add_raw_record", "cdb_add_raw_dir", "cdb_save", "cdb_load",
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
-    "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit",
+    "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit", "cdb_memory_stats", "cdb_memory_reset_peak",
     "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_layout_rule", "cdb_debug_query_latency",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
@@ -137,6 +137,10 @@ def load_library():
     lib.cdb_release_cached_memory.restype = None
     lib.cdb_set_cache_limit.argtypes = [u64]
     lib.cdb_set_cache_limit.restype = None
+    lib.cdb_memory_stats.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    lib.cdb_memory_stats.restype = None
+    lib.cdb_memory_reset_peak.argtypes = []
+    lib.cdb_memory_reset_peak.restype = None
     lib.cdb_cached_memory_bytes.argtypes = []
     lib.cdb_cached_memory_bytes.restype = u64
     lib.cdb_debug_verify.argtypes = [vp, C.POINTER(u64)]
@@ -635,6 +639,18 @@ class ShardComm:
             self._h = None
 
     __del__ = close
+
+
+def memory_stats():
+    """(in_use, peak, cached) bytes of device memory as the library's allocator sees the process (cdb_memory_stats)."""
+    lib = load_library()
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    lib.cdb_memory_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def memory_reset_peak():
+    load_library().cdb_memory_reset_peak()
 
 
 def query_and(keys, ranked=False, lo=1, hi=(1 << 62), limit=0):

@@ -155,7 +155,10 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
 void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start, uint64_t ndocs, size_t bytes, hipStream_t s,
                   int device) {
     constexpr size_t CHUNK = 16u << 20;
-    const int T = bytes >= 4 * CHUNK ? 4 : 1;
+    // (the gather of scattered 1 KiB strings runs at ~5 GB/s per host thread: four threads would make it — not the PCIe link
+    //  at ~52 GB/s — the bound of the shim's build(); up to twelve keep the link busy)
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int T = bytes >= 4 * CHUNK ? std::max(4, std::min({12, hw / 2, (int)(bytes / (2 * CHUNK))})) : 1;
     const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
     std::string failure;
     std::mutex fmu;
@@ -1416,7 +1419,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = value != 0;
-    else if (!std::strcmp(name, "self_check")) ix.self_check = value != 0;
+    else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 2 ? 2 : (int)value;  // 0 off, 1 sample, 2 every pair
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
@@ -1449,7 +1452,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
@@ -1608,6 +1611,14 @@ void cdb_release_cached_memory(void) {
 }
 
 void cdb_set_cache_limit(uint64_t bytes) { DevPool::get().set_limit((size_t)bytes); }
+void cdb_memory_stats(uint64_t* in_use_bytes, uint64_t* peak_bytes, uint64_t* cached_bytes) {
+    size_t a = 0, b = 0, c = 0;
+    DevPool::get().stats(a, b, c);
+    if (in_use_bytes) *in_use_bytes = a;
+    if (peak_bytes) *peak_bytes = b;
+    if (cached_bytes) *cached_bytes = c;
+}
+void cdb_memory_reset_peak(void) { DevPool::get().reset_peak(); }
 
 uint64_t cdb_cached_memory_bytes(void) { return (uint64_t)DevPool::get().cached_bytes(); }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +90,7 @@ public:
                 cached_ -= b.bytes;
                 if (b.ev) put_event(b.device, b.ev);
                 actual = b.bytes;
+                account(actual);
                 return b.p;
             }
             if (best_busy >= 0) {  // waiting for the other stream beats a fresh hipMalloc ...
@@ -107,6 +109,10 @@ public:
                 put_event(busy.device, busy.ev);
             }
             actual = busy.bytes;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                account(actual);
+            }
             return busy.p;
         }
         void* p = nullptr;
@@ -121,9 +127,29 @@ public:
             throw Error(std::string("HIP error in hipMalloc: ") + hipGetErrorString(e));
         }
         actual = need;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            account(actual);
+        }
         return p;
     }
+    // bytes handed out right now / the most ever handed out since reset_peak() (what an index and its build really hold
+    // in HBM: cdb_memory_stats; cached blocks are not counted, the caller's own buffers — a resident text — neither)
+    void stats(size_t& in_use, size_t& peak, size_t& cached) {
+        std::lock_guard<std::mutex> g(mu_);
+        in_use = in_use_;
+        peak = peak_;
+        cached = cached_;
+    }
+    void reset_peak() {
+        std::lock_guard<std::mutex> g(mu_);
+        peak_ = in_use_;
+    }
     void free(void* p, size_t bytes, int device) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            in_use_ -= std::min(in_use_, bytes);
+        }
         // work queued on the releasing thread's stream may still use the block
         hipStream_t st = tls_stream;
         hipEvent_t ev = nullptr;
@@ -220,9 +246,14 @@ private:
         return e;
     }
     void put_event(int, hipEvent_t e) { (void)hipEventDestroy(e); }
+    void account(size_t bytes) {  // (mu_ held)
+        in_use_ += bytes;
+        if (in_use_ > peak_) peak_ = in_use_;
+    }
     std::mutex mu_;
     std::vector<Block> free_;
     size_t cached_ = 0;
+    size_t in_use_ = 0, peak_ = 0;
     size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
                                  // the working set of a multi-GiB build costs more than the build itself
 };

@@ -170,7 +170,9 @@ struct Index {
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
-    bool self_check = true;           // spot check of random adjacent pairs after every build (verify.hip); a failure makes
+    uint64_t self_check_pairs = 0;    // adjacent pairs the last build's check compared (size - 1 with self_check = 2)
+    double self_check_ms = 0;
+    int self_check = 1;           // spot check of random adjacent pairs after every build (verify.hip); a failure makes
                                       // the build fall back to the ballot ranking once, then fail
     int self_check_fallbacks = 0;
     bool debug_fail_self_check = false;  // test hook: the first spot check of a build reports a failure

@@ -168,12 +168,8 @@ struct TextGen {
     // span, i.e. key / M with M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count
     // of the text instead of a sweep that evaluates every key.  The generated pass works in 32-bit part arithmetic (G = three
     // symbols as a number, key = G(p) base^3 + G(p + 3)), lane-striped: every element straight from the staged codes.
-    // rs_div24: floor(x / d) for x < 2^24 from (mul, sh).
     bool msd_pair = false;
-    uint32_t msd_span_mul = 0, msd_span_sh = 0;  // / span
-    uint32_t msd_mlo = 0;                        // M mod 2^32
-    uint32_t div_b_mul = 0, div_b_sh = 0;        // / base
-    uint32_t div_b2_mul = 0, div_b2_sh = 0;      // / base^2
+    uint32_t pair_span = 0, pair_r = 0, pair_s = 0;  // floor(a / span) = (a * pair_r) >> pair_s for every a < base^2 (rs_pair_setup)
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
 };
 // The generator's FORM is part of the kernel's type: the 16 Ki-tile pass is ~15 k instructions of straight-line code per
@@ -205,6 +201,29 @@ inline RsDiv24 rs_div24_make(uint32_t d) {
     return RsDiv24{(uint32_t)(m << 7), L + 7};
 }
 __device__ __forceinline__ uint32_t rs_div24(uint32_t x, uint32_t mul, uint32_t sh) { return __umulhi(x << 8, mul) >> sh; }
+
+// Pair form of the generated pass (TextGenPair): constants for top = floor(a / span), a < base^2, as one 24-bit multiply and a
+// shift, and the range conditions of its 24-bit products.  false = this (base, span) cannot take the pair form.
+template <typename G>
+inline bool rs_pair_setup(G& gen, uint32_t base, uint32_t span) {
+    const uint64_t b2 = (uint64_t)base * base;
+    if (base < 2 || base > 255 || span == 0 || span >= (1u << 24) || b2 >= (1u << 24)) return false;
+    if ((uint64_t)span * b2 >= (1u << 24)) return false;              // (a - top span) B^2 + m stays below 2^24
+    if ((uint64_t)span * b2 * b2 > (1ull << 32)) return false;         // key - top M < M <= 2^32
+    for (uint32_t sh = 0; sh < 32; ++sh) {
+        const uint64_t r = ((1ull << sh) + span - 1) / span;
+        if (r >= (1u << 24) || (b2 - 1) * r >= (1ull << 32)) break;
+        bool ok = true;
+        for (uint64_t a = 0; a < b2 && ok; ++a) ok = ((a * r) >> sh) == a / span;
+        if (ok) {
+            gen.pair_span = span;
+            gen.pair_r = (uint32_t)r;
+            gen.pair_s = sh;
+            return true;
+        }
+    }
+    return false;
+}
 
 // Segmented passes (the bucket-wise build of corpora >= 2^32, sa_build.hip): ONE launch sorts every first-symbol
 // bucket ("segment") of a bucket group on its own — a tile belongs to exactly one segment (tile_seg), takes its digit
@@ -378,7 +397,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     VS* s_vals = reinterpret_cast<VS*>(s_stage + (REUSE ? 0 : STAGE_K));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if constexpr (Cfg::GROUP > 0) {
+    if constexpr (Cfg::GROUP > 0 && !Cfg::TICKET) {
+        // static form of the XCD-aware order (experiment): no atomic round trip in front of the tile; relies on workgroups
+        // being dispatched in blockIdx order inside an XCD (bounded spins catch a violation)
+    } else if constexpr (Cfg::GROUP > 0) {
         if (tid == 0) {
             const uint32_t x = blockIdx.x & 7u;
             const uint32_t slot = atomicAdd(ticket + x, 1u);
@@ -389,7 +411,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     }
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t tile = (Cfg::TICKET || Cfg::GROUP > 0) ? (uint64_t)s_tile : (uint64_t)blockIdx.x;
+    uint64_t tile;
+    if constexpr (Cfg::GROUP > 0 && !Cfg::TICKET) {
+        const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        tile = (uint64_t)((slot / Cfg::GROUP) * 8u + x) * Cfg::GROUP + slot % Cfg::GROUP;
+    } else {
+        tile = (Cfg::TICKET || Cfg::GROUP > 0) ? (uint64_t)s_tile : (uint64_t)blockIdx.x;
+    }
     uint64_t base = tile * TILE;
     uint64_t tile0 = 0;     // first tile of the look-back chain this tile belongs to
     uint64_t seg_n = n;     // end of the element range the tile may read
@@ -437,14 +465,27 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         constexpr uint32_t DOC_OFF = GEN_TEXTB + 512;
         constexpr uint32_t DOC_CAP = BLK ? GEN_DOCS : (uint32_t)((STAGE_BYTES - DOC_OFF) / 8);
         uint64_t* s_docs = reinterpret_cast<uint64_t*>(gbuf + DOC_OFF);
+        // (one workgroup per CU: every dependent global round trip at the head of a tile — ~1-2 us each — is dead time for
+        //  the whole CU.  The text of a 16 Ki tile is ONE 16-byte load per thread: it is issued first, beside the tile's
+        //  document range, and lands while the document table and the code map are staged)
+        constexpr bool PRELOAD = BLK;  // (16 Ki tiles: TILE == 16 * NT; the look-ahead is a second load of the first threads)
+        uint4 tw0 = make_uint4(0, 0, 0, 0), tw1 = make_uint4(0, 0, 0, 0);
+        bool tw0_ok = false, tw1_ok = false;
+        if constexpr (PRELOAD) {
+            const uint64_t g0 = base + (uint64_t)tid * 16, g1 = base + (uint64_t)TILE + (uint64_t)tid * 16;
+            tw0_ok = gen.padded ? (g0 < n + RS_GEN_LOOK) : (g0 + 16 <= n);
+            tw1_ok = (uint32_t)tid * 16 < (uint32_t)RS_GEN_LOOK && (gen.padded ? (g1 < n + RS_GEN_LOOK) : (g1 + 16 <= n));
+            if (tw0_ok) tw0 = *reinterpret_cast<const uint4*>(gen.text + g0);
+            if (tw1_ok) tw1 = *reinterpret_cast<const uint4*>(gen.text + g1);
+        }
         const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
-        const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOC_CAP;
-        if (docs_in_lds)
-            for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
         for (int i = tid; i < 256; i += NT) s_map[i] = gen.symmap[i];
         if constexpr (recs) {
             if (tid < 257) (gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8)[tid] = gen.slotmap[tid];
         }
+        const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOC_CAP;
+        if (docs_in_lds)
+            for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
         __syncthreads();
         // bytes -> symbol codes on their way into LDS: one table lookup per text byte instead of one per
         // (suffix, symbol)
@@ -452,7 +493,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             if (RS_GEN_ABL & 4) break;
             const uint64_t g = base + i;
             uint32_t x[4];
-            if (gen.padded ? (g < n + RS_GEN_LOOK) : (g + 16 <= n)) {
+            if (PRELOAD && (i < (uint32_t)TILE ? tw0_ok : tw1_ok)) {
+                const uint4 w = i < (uint32_t)TILE ? tw0 : tw1;
+                x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+            } else if (!PRELOAD && (gen.padded ? (g < n + RS_GEN_LOOK) : (g + 16 <= n))) {
                 const uint4 w = *reinterpret_cast<const uint4*>(gen.text + g);
                 x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
             } else {
@@ -483,7 +527,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             // Lane-striped generation of the pair form: a key is two 3-symbol parts of the six codes at its position — cheap
             // enough (four multiply-adds) to be evaluated per element straight from the staged codes, in the order the ranking
             // wants them: no transposition of keys, digits and entries through the staging buffer, no barriers.
-            const uint32_t B = gen.base, W3 = B * B * B;
+            // Arithmetic (round 4): the six codes at a position are three PAIRS a = c0 B + c1, m = c2 B + c3, r = c4 B + c5 — one
+            // v_dot4_u32_u8 each on the byte-aligned code windows — and with top = floor(a / span), M = span B^4:
+            //     key - top M = ((a - top span) B^2 + m) B^2 + r,
+            // all products of operands below 2^24 (v_mul_u32_u24 / v_mad_u32_u24, full rate; the 3-symbol parts of round 3
+            // needed two 32-bit multiplies and a multiply-high per suffix, quarter rate each).  floor(a / span) = (a R) >> s
+            // with (R, s) checked on the host for every a < B^2 (rs_pair_setup).
+            const uint32_t B = gen.base, B2 = B * B;
+            const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const uint32_t li = wbase + j * 64;
@@ -509,27 +560,19 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     }
                     const uint32_t wi = li >> 2, sel = li & 3u;
                     const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
-                    const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
-                    uint32_t a = __umul24(x0 & 0xFFu, B) + ((x0 >> 8) & 0xFFu);
-                    uint32_t g0 = __umul24(a, B) + ((x0 >> 16) & 0xFFu);
-                    uint32_t g3 = __umul24(__umul24(x0 >> 24, B) + (x1 & 0xFFu), B) + ((x1 >> 8) & 0xFFu);
+                    uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
+                    uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
                     const uint32_t rem = dend_l - li;  // symbols left in the document (>= 1)
-                    if (rem < 6u) {  // (rare) the symbols behind the document end count as 0: truncate the parts
-                        if (rem <= 3u) {
-                            g3 = 0;
-                            if (rem < 3u) {
-                                const bool one = rem == 1u;
-                                g0 = rs_div24(g0, one ? gen.div_b2_mul : gen.div_b_mul, one ? gen.div_b2_sh : gen.div_b_sh) * (one ? B * B : B);
-                            }
-                        } else {
-                            const bool four = rem == 4u;
-                            g3 = rs_div24(g3, four ? gen.div_b2_mul : gen.div_b_mul, four ? gen.div_b2_sh : gen.div_b_sh) * (four ? B * B : B);
-                        }
-                        a = rs_div24(g0, gen.div_b_mul, gen.div_b_sh);
+                    if (rem < 6u) {  // (rare) the symbols behind the document end count as 0
+                        x0 = rem >= 4u ? x0 : (x0 & ((1u << (8u * rem)) - 1u));
+                        x1 = rem <= 4u ? 0u : (x1 & 0xFFu);
                     }
-                    const uint32_t top = rs_div24(a, gen.msd_span_mul, gen.msd_span_sh);
-                    key[j] = (K)(g0 * W3 + g3 - top * gen.msd_mlo);  // key - top * M (< 2^32: exact modulo 2^32)
+                    const uint32_t a = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
+                    const uint32_t m = __builtin_amdgcn_udot4(x0, whi, 0u, false);
+                    const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
+                    const uint32_t top = __umul24(a, gen.pair_r) >> gen.pair_s;
+                    const uint32_t a2 = a - __umul24(top, gen.pair_span);
+                    key[j] = (K)(__umul24(__umul24(a2, B2) + m, B2) + r);  // key - top * M (< M <= 2^32)
                     aux[j] = (WS)top;
                     val[j] = (VS)((((uint32_t)base + li) << gen.bits) + (uint32_t)ebase);
                 }

@@ -1757,11 +1757,13 @@ void build_typed(Index& ix, bool big) {
     // top digit is key >> 32, counted by the key sweep
     unsigned long long msd_m = 1ull << 32;
     uint32_t msd_span = 0;
+    struct { uint32_t pair_span = 0, pair_r = 0, pair_s = 0; } pair_consts;
     std::vector<uint64_t> h_top;
     if (use_msd && ix.msd_pair && nsym == 6 && kbase <= 128) {
         const uint64_t P4 = (uint64_t)kbase * kbase * kbase * kbase;  // (< 2^28)
         msd_span = (uint32_t)std::min<uint64_t>((1ull << 32) / P4, (uint64_t)kbase * kbase);
         if (ceil_div((uint64_t)kbase * kbase, (uint64_t)msd_span) > 256) msd_span = 0;
+        if (msd_span && !rs_pair_setup(pair_consts, kbase, msd_span)) msd_span = 0;  // (24-bit arithmetic of the pair generator)
     }
     if (pc_spec) {  // the second stream joins the first (whether or not its counts are used)
         CDB_HIP(hipStreamWaitEvent(s, ix.aux_ev[1], 0));
@@ -1894,11 +1896,9 @@ void build_typed(Index& ix, bool big) {
                 // the final pass writes the kept keys in the split layout (u32 = key >> 8, low byte), entries and flags
                 if (msd_span) {
                     gen.msd_pair = true;
-                    const RsDiv24 ds = rs_div24_make(msd_span), db = rs_div24_make(kbase), db2 = rs_div24_make(kbase * kbase);
-                    gen.msd_span_mul = ds.mul; gen.msd_span_sh = ds.sh;
-                    gen.div_b_mul = db.mul; gen.div_b_sh = db.sh;
-                    gen.div_b2_mul = db2.mul; gen.div_b2_sh = db2.sh;
-                    gen.msd_mlo = (uint32_t)msd_m;
+                    gen.pair_span = pair_consts.pair_span;
+                    gen.pair_r = pair_consts.pair_r;
+                    gen.pair_s = pair_consts.pair_s;
                 } else {
                     gen.msd_shift = 32;
                 }
@@ -2769,7 +2769,14 @@ void build_suffix_array(Index& ix) {
     if (ix.self_check && ix.size >= 2) {
         uint64_t sc[2] = {0, 0};
         auto check = [&]() {
-            spot_check_suffix_array(ix, 1u << 15, sc);
+            // self_check = 1: 2^15 random adjacent pairs (a sample: notices a ranking that went wrong, which scatters inversions
+            // over the whole array; proves nothing about one stray pair).  self_check = 2: EVERY adjacent pair — a proof of the
+            // order at the cost of one sweep over the array with a random text access per entry (DESIGN §4.4 has the times).
+            const double tc = now_ms();
+            const uint32_t samples = ix.self_check >= 2 ? 0u : (uint32_t)std::min<uint64_t>(1u << 15, ix.size - 1);
+            spot_check_suffix_array(ix, samples, sc);
+            ix.self_check_pairs = samples ? samples : ix.size - 1;
+            ix.self_check_ms = now_ms() - tc;
             if (ix.debug_fail_self_check && ix.self_check_fallbacks == 0) sc[0] += 1;
             return sc[0] == 0 && sc[1] == 0;
         };

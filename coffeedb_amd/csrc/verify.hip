@@ -84,18 +84,26 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict_
                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
                                                             uint64_t mask, uint32_t samples, uint64_t seed, bool plain,
                                                             unsigned long long* __restrict__ out) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= samples || n < 2) return;
-    uint64_t h = seed + 0x9E3779B97F4A7C15ull * (t + 1);
-    h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
-    h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
-    h ^= h >> 31;
-    const uint64_t i = 1 + h % (n - 1);
+    // samples == 0: the FULL sweep (option self_check = 2) — every adjacent pair, grid-stride; a proof instead of a sample
+    if (n < 2) return;
+    const uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = samples ? ~0ull : (uint64_t)gridDim.x * 256;
+    unsigned long long nbad = 0, ninvalid = 0;
+    for (uint64_t t = t0; t < (samples ? (uint64_t)samples : n - 1); t += stride) {
+    uint64_t i = t + 1;
+    if (samples) {
+        uint64_t h = seed + 0x9E3779B97F4A7C15ull * (t + 1);
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+        i = 1 + h % (n - 1);
+    }
     const V ea = sa[i - 1], eb = sa[i];
     const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits, db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
     if (da >= ndocs || db >= ndocs || oa >= doc_start[da + 1] - doc_start[da] || ob >= doc_start[db + 1] - doc_start[db]) {
-        atomicAdd(&out[1], 1ull);
-        return;
+        ninvalid += 1;
+        if (stride == ~0ull) break;
+        continue;
     }
     const uint8_t* pa = text + doc_start[da] + oa;
     const uint8_t* pb = text + doc_start[db] + ob;
@@ -107,7 +115,11 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict_
     bool bad = false;
     if (l == len) bad = la > lb || (la == lb && da >= db);
     else if (l < cap) bad = pa[l] > pb[l] && (plain || ((pa[l] ^ pb[l]) & 0x80u) == 0);
-    if (bad) atomicAdd(&out[0], 1ull);
+    if (bad) nbad += 1;
+    if (stride == ~0ull) break;  // (sampled form: one pair per thread)
+    }
+    if (nbad) atomicAdd(&out[0], nbad);
+    if (ninvalid) atomicAdd(&out[1], ninvalid);
 }
 
 // ---- the REFERENCE's order --------------------------------------------------------------
@@ -260,7 +272,8 @@ uint64_t count_invalid_entries(hipStream_t s, const void* d_sa, int width, uint6
     return bad;
 }
 
-// pairs out of order / invalid entries among `samples` random adjacent pairs (see sa_spot_check_kernel)
+// pairs out of order / invalid entries among `samples` random adjacent pairs, or among ALL of them (samples = 0); see
+// sa_spot_check_kernel
 void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
     out[0] = out[1] = 0;
     if (ix.size < 2 || ix.width == 0) return;
@@ -268,7 +281,8 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
     DevBuf d_out;
     d_out.alloc(2 * sizeof(uint64_t));
     CDB_HIP(hipMemsetAsync(d_out.p, 0, 2 * sizeof(uint64_t), s));
-    const unsigned grid = (unsigned)ceil_div(samples, 256);
+    // samples == 0: every adjacent pair (grid-stride sweep)
+    const unsigned grid = samples ? (unsigned)ceil_div(samples, 256) : (unsigned)std::min<uint64_t>(ceil_div(ix.size - 1, 256), 1u << 16);
     if (ix.width == 4)
         hipLaunchKernelGGL((sa_spot_check_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
                            ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask,

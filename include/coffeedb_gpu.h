@@ -346,6 +346,12 @@ void cdb_release_cached_memory(void);
 uint64_t cdb_cached_memory_bytes(void);
 /* upper bound of the block cache (default: unlimited); blocks released beyond it go back to the driver */
 void cdb_set_cache_limit(uint64_t bytes);
+/* Device memory of the whole process as the library's allocator sees it: bytes handed out right now (indexes + builds
+ * in flight), the most ever handed out since cdb_memory_reset_peak(), and the bytes sitting in the block cache.  What
+ * database.cpp:276-280 needs to know before it builds a new index beside the serving one: peak - in_use of one build is
+ * the head room a rebuild wants.  Buffers the caller owns (cdb_build_device / _resident: the text) are not counted. */
+void cdb_memory_stats(uint64_t* in_use_bytes, uint64_t* peak_bytes, uint64_t* cached_bytes);
+void cdb_memory_reset_peak(void);
 
 /* Test hook: size-independent checks of the built suffix array, computed on the GPU by plain adjacent-
  * suffix comparison (verify.hip).  out[0] = adjacent pairs out of unsigned byte order, out[1] = equal

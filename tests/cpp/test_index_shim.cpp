@@ -2,8 +2,15 @@
 // (make_unique<string_index>, dynamic_cast, add, build through index*, query through index*).
 // usage: test_index_shim numeric   — CPU-only parts (no GPU needed)
 //        test_index_shim all       — also the GPU string index (README known answers)
+//        test_index_shim views [docs] [doclen] [reps]  — timing: string_index::build() over separately allocated strings (JSON)
+//        test_index_shim cold [bytes]                  — timing: a fresh process builds one large UTF-8 column once (JSON)
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
+#include <thread>
+#include <vector>
 #include <memory>
 #include <string>
 
@@ -113,7 +120,130 @@ static void gpu_string() {
     CHECK((indices["secret"]->query("o") == R{{1, 2}}));
 }
 
+// ---- what the reference's caller pays (bench.py: pcie_inclusive.build_views, cold_start) -------------------------------
+// database.cpp:262-264 keeps every value in its own std::string and hands string_index::add a VIEW of it; build() then has
+// to gather a million scattered strings (cdb_build_views).  `views` times exactly that at a given shape; `cold` is
+// server.cpp:44 — a fresh process (no torch, no warm block cache) building one large column from host memory once.
+static inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// valid UTF-8: 50 % ASCII, 30 % two-byte, 20 % three-byte code points (SURVEY §8d's C4 mix), cut at code-point boundaries
+static void fill_utf8(std::string& s, size_t want, uint64_t seed) {
+    s.clear();
+    s.reserve(want + 4);
+    uint64_t k = seed * 0x100000001B3ull;
+    while (s.size() < want) {
+        const uint64_t r = mix64(k++);
+        const uint32_t kind = (uint32_t)(r % 10);
+        if (kind < 5) {
+            s.push_back((char)(0x20 + (r >> 8) % 95));
+        } else if (kind < 8) {
+            const uint32_t cp = 0x80 + (uint32_t)((r >> 8) % (0x800 - 0x80));
+            s.push_back((char)(0xC0 | (cp >> 6)));
+            s.push_back((char)(0x80 | (cp & 0x3F)));
+        } else {
+            uint32_t cp = 0x800 + (uint32_t)((r >> 8) % (0x10000 - 0x800));
+            if (cp >= 0xD800 && cp < 0xE000) cp -= 0x800;  // (no surrogates)
+            s.push_back((char)(0xE0 | (cp >> 12)));
+            s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+            s.push_back((char)(0x80 | (cp & 0x3F)));
+        }
+    }
+}
+static int bench_views(size_t docs, size_t doclen, int reps) {
+    // one heap block per value, like the map<string, var> values of database.cpp:22 (allocated in shuffled order so that
+    // neighbouring documents are not neighbours in memory)
+    std::vector<std::string> values(docs);
+    std::vector<uint32_t> order(docs);
+    for (size_t i = 0; i < docs; ++i) order[i] = (uint32_t)i;
+    for (size_t i = docs; i > 1; --i) std::swap(order[i - 1], order[mix64(i) % i]);
+    const unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            for (size_t k = t; k < docs; k += T) {
+                std::string& v = values[order[k]];
+                v.resize(doclen);
+                uint64_t x = mix64(order[k]);
+                for (size_t b = 0; b < doclen; ++b) {
+                    if ((b & 7) == 0) x = mix64(x);
+                    v[b] = (char)(0x20 + ((x >> (8 * (b & 7))) & 0xFF) % 95);
+                }
+            }
+        });
+    for (auto& x : th) x.join();
+    std::vector<double> add_ms, build_ms;
+    size_t hits = 0;
+    for (int r = 0; r < reps + 1; ++r) {   // fresh object per build, as database.cpp:255 does; repetition 0 is the cold one
+        auto ix = std::make_unique<string_index>();
+        double t = now_ms();
+        for (size_t i = 0; i < docs; ++i) ix->add((int64_t)i, values[i]);
+        add_ms.push_back(now_ms() - t);
+        t = now_ms();
+        static_cast<index*>(ix.get())->build();
+        build_ms.push_back(now_ms() - t);
+        hits += static_cast<index*>(ix.get())->query(values[docs / 2].substr(3, 8)).size();
+    }
+    if (!hits) { std::printf("{\"error\": \"the built index did not answer\"}\n"); return 1; }
+    std::printf("{\"docs\": %zu, \"doclen\": %zu, \"bytes\": %zu, \"first_build_ms\": %.2f, \"build_ms\": [", docs, doclen, docs * doclen, build_ms[0]);
+    double best = 1e30;
+    for (int r = 1; r <= reps; ++r) {
+        std::printf("%s%.2f", r > 1 ? ", " : "", build_ms[r]);
+        best = std::min(best, build_ms[r]);
+    }
+    std::printf("], \"add_ms\": %.2f, \"build_views_GiB_per_s\": %.3f, \"note\": \"string_index::add of %zu separately allocated std::strings + "
+                "string_index::build() = cdb_build_views (gather into pinned chunks + upload + device build), C++ caller, fresh object per build\"}\n",
+                add_ms.back(), (double)(docs * doclen) / (1ull << 30) / (best * 1e-3), docs);
+    return 0;
+}
+static int bench_cold(size_t bytes) {
+    const size_t doclen = 1024, docs = bytes / doclen;
+    std::vector<std::string> values(docs);
+    const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    const double tg = now_ms();
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([&, t] { for (size_t k = t; k < docs; k += T) fill_utf8(values[k], doclen, k); });
+    for (auto& x : th) x.join();
+    const double gen_ms = now_ms() - tg;
+    size_t total = 0;
+    for (auto& v : values) total += v.size();
+    const double t0 = now_ms();
+    auto ix = std::make_unique<string_index>();   // (device + stream creation: part of a cold start)
+    const double t1 = now_ms();
+    for (size_t i = 0; i < docs; ++i) ix->add((int64_t)i, values[i]);
+    const double t2 = now_ms();
+    static_cast<index*>(ix.get())->build();
+    const double t3 = now_ms();
+    const size_t rows = static_cast<index*>(ix.get())->query(values[docs / 2].substr(0, 2)).size();
+    const double t4 = now_ms();
+    auto again = std::make_unique<string_index>();
+    for (size_t i = 0; i < docs; ++i) again->add((int64_t)i, values[i]);
+    const double t5 = now_ms();
+    static_cast<index*>(again.get())->build();
+    const double t6 = now_ms();
+    std::printf("{\"bytes\": %zu, \"docs\": %zu, \"generate_ms\": %.0f, \"create_ms\": %.1f, \"add_ms\": %.1f, \"first_build_ms\": %.1f, "
+                "\"first_query_ms\": %.2f, \"first_query_rows\": %zu, \"second_build_ms\": %.1f, \"cold_over_warm\": %.2f, "
+                "\"first_build_GiB_per_s\": %.3f, \"note\": \"fresh process, no torch, no warm block cache: string_index over %zu separately "
+                "allocated strings of valid UTF-8, build() = gather + upload + device build incl. every first-use allocation (server.cpp:44); "
+                "second_build = a new object beside the first (database.cpp:276-280), blocks partly from the cache\"}\n",
+                total, docs, gen_ms, t1 - t0, t2 - t1, t3 - t2, t4 - t3, rows, t6 - t5, (t3 - t2) / (t6 - t5),
+                (double)total / (1ull << 30) / ((t3 - t2) * 1e-3), docs);
+    (void)rows;  // (under reference_compat a UTF-8 keyword may find nothing: the reference's own behaviour on bytes >= 0x80)
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "views")
+        return bench_views(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (1u << 20), argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1024,
+                           argc > 4 ? std::atoi(argv[4]) : 3);
+    if (argc > 1 && std::string(argv[1]) == "cold") return bench_cold(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (4ull << 30));
     const bool all = argc > 1 && std::string(argv[1]) == "all";
     numeric();
     if (all) gpu_string();

@@ -431,3 +431,74 @@ def test_c3_shard_8gib_ascii():
         a, b = int(rp[j]), int(rp[j + 1])
         assert np.array_equal(ri[a:b], wd.cpu().numpy()) and np.array_equal(rc[a:b], wc.cpu().numpy()), (j, bytes(kw))
     g.close()
+
+
+def test_rebuild_8gib_column_beside_the_serving_index():
+    """database.cpp:276-280: build() prepares the NEW index while the old one keeps answering, and frees the old one only
+    afterwards — two generations of an 8 GiB column (8-byte entries: 64 GiB of suffix array each) and the build's scratch
+    must fit the 288 GB together.  The build sizes its bucket groups from the memory that is really free
+    (sa_build.hip: hipMemGetInfo + the block cache), so beside a serving index it takes several groups instead of failing.
+    Checked: the new generation verifies, the old one answered every batch meanwhile with its own rows, both are resident
+    at the end; the memory figures go to stdout (pytest -s) and into DESIGN §3."""
+    import threading
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    nd, dl = 1 << 23, 1024
+    n = nd * dl
+    ds = W.uniform_docs(nd, dl)
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    d_ids = torch.arange(nd, dtype=torch.int64, device="cuda")
+    gens = []
+    capi.load_library().cdb_release_cached_memory()
+    capi.memory_reset_peak()
+    text_a = W.random_bytes_torch(n, 77, device="cuda")
+    pa_blob, pa_offs, pa_bytes = W.sample_patterns_torch(text_a, d_ds, 20_000, 6, 14, seed=5, miss_byte=0x7F)
+    torch.cuda.synchronize()
+    old = capi.GpuStringIndex()
+    old.build_resident(text_a.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), nd)
+    assert old.sa_width == 8 and old.stat("self_check_fallbacks") == 0
+    gens.append(dict(zip(("in_use", "peak", "cached"), capi.memory_stats()), groups=old.stat("bucket_groups"), fused=old.stat("fused_records")))
+    want = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)
+    want_rows, want_hits = int(want.nrows), int(want.nhits)
+    assert want_hits >= 18_000
+    capi.load_library().cdb_release_cached_memory()          # (what a long-running server's cache may or may not hold: start clean)
+    capi.memory_reset_peak()
+
+    stop, errors, served = threading.Event(), [], [0]
+
+    def serve():
+        try:
+            while not stop.is_set():
+                r = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)
+                assert (int(r.nrows), int(r.nhits)) == (want_rows, want_hits)
+                served[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = threading.Thread(target=serve)
+    th.start()
+    text_b = W.random_bytes_torch(n, 78, device="cuda")        # the new generation of the column (database.cpp:171-172)
+    torch.cuda.synchronize()
+    new = capi.GpuStringIndex()
+    new.build_resident(text_b.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), nd)
+    b_ms = new.stat("build_ms")
+    stop.set()
+    th.join()
+    assert not errors, errors[:2]
+    assert served[0] >= 1
+    assert new.stat("self_check_fallbacks") == 0 and new.stat("group_fallbacks") == 0
+    v = new.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
+    gens.append(dict(zip(("in_use", "peak", "cached"), capi.memory_stats()), groups=new.stat("bucket_groups"), fused=new.stat("fused_records"), build_ms=b_ms,
+                     served_batches=served[0]))
+    free, total = torch.cuda.mem_get_info()
+    print("\nrebuild beside a serving index, 8 GiB columns:", gens, f"device free {free / 2**30:.1f} of {total / 2**30:.1f} GiB at the end")
+    # both generations answer; then the old one goes (database.cpp:280)
+    r = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)
+    assert int(r.nrows) == want_rows
+    old.close()
+    pb_blob, pb_offs, pb_bytes = W.sample_patterns_torch(text_b, d_ds, 20_000, 6, 14, seed=6, miss_byte=0x7F)
+    torch.cuda.synchronize()
+    r = new.query_batch_device(pb_blob.data_ptr(), pb_offs.data_ptr(), 20_000, pb_bytes)
+    assert int(r.nhits) >= 18_000
+    new.close()

@@ -113,11 +113,7 @@ int main(int argc, char** argv) {
     TextGen gen{text, d_ds, d_map, D, bits, B, 6, 0, true};
     if (pair) {
         gen.msd_pair = true;
-        const RsDiv24 ds = rs_div24_make(span), db = rs_div24_make(B), db2 = rs_div24_make(B * B);
-        gen.msd_span_mul = ds.mul; gen.msd_span_sh = ds.sh;
-        gen.div_b_mul = db.mul; gen.div_b_sh = db.sh;
-        gen.div_b2_mul = db2.mul; gen.div_b2_sh = db2.sh;
-        gen.msd_mlo = (uint32_t)m;
+        if (!rs_pair_setup(gen, B, span)) { std::printf("pair form not applicable\n"); return 1; }
     } else {
         gen.msd_shift = 32;
     }
@@ -140,11 +136,14 @@ int main(int argc, char** argv) {
 #ifndef GEN_GROUP
 #define GEN_GROUP RS_GROUP
 #endif
+#ifndef GEN_TICKET
+#define GEN_TICKET true
+#endif
 #ifndef GEN_LB
 #define GEN_LB 4
 #endif
-        using CfgA = RsCfg<16, true, true, GEN_NT, false, 1, 3, GEN_LB, false, true, true, 1, GEN_GROUP>;
-        using CfgN = RsCfg<16, true, true, GEN_NT, false, 1, 0, GEN_LB, false, true, true, 1, GEN_GROUP>;
+        using CfgA = RsCfg<16, true, true, GEN_NT, false, 1, 3, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
+        using CfgN = RsCfg<16, true, true, GEN_NT, false, 1, 0, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
         constexpr uint64_t GT = 16 * GEN_NT;  // tile of the stand-alone generated pass
         const uint32_t tiles = (uint32_t)ceil_div(n, GT);
         ws.prepare(n + 256 * (uint64_t)RS_SEG_TILE, (int)GT, s);
