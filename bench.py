@@ -608,6 +608,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    trace = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("CDB_BENCH_TRACE") else (lambda m: None)
     cfg, clamp_note = per_rank_cfg(WORKLOADS[args.workload], world, args.scaling)
     if cfg.get("total") and args.scaling != "strong":
         raise SystemExit(f"--workload {args.workload} is a fixed-size corpus: run it with --scaling strong")
@@ -665,7 +666,9 @@ def main():
 
     def step():
         # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
+        trace("build")
         g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), ndocs)
+        trace(f"query (build {g.stat('build_ms'):.1f} ms, group_fallbacks {g.stat('group_fallbacks'):.0f})")
         tb = g.stat("build_ms")
         if cfg.get("offsets"):
             r, _ = g.query_batch_offsets_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
@@ -673,10 +676,13 @@ def main():
             r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
         tq = g.stat("query_ms")
         if merger is not None:
+            trace("merge")
             merger.merge(r, npat)
+        trace("step done")
         return tb, tq, r
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
+    trace("inputs ready")
     for _ in range(args.warmup):
         step()
     g.profile_reset()
@@ -700,6 +706,7 @@ def main():
         t = torch.tensor([elapsed, build_ms, query_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, build_ms, query_ms = (float(x) for x in t.tolist())
+    trace("timed region done")
     hits, rows = int(r.nhits), int(r.nrows)
     rows_per_rank = [rows]
     if world > 1:  # rows every rank contributed to the merged result of the last step

@@ -1418,7 +1418,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
-    else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = value != 0;
+    else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = (int)value;  // 1 = reported after the sorts, 2 = error flag up before the initial sort
     else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 2 ? 2 : (int)value;  // 0 off, 1 sample, 2 every pair
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;

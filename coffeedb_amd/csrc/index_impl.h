@@ -176,7 +176,7 @@ struct Index {
                                       // the build fall back to the ballot ranking once, then fail
     int self_check_fallbacks = 0;
     bool debug_fail_self_check = false;  // test hook: the first spot check of a build reports a failure
-    bool debug_starve_group = false;  // test hook: a build in XCD-aware tile order reports a look-back timeout once
+    int debug_starve_group = 0;     // test hook: a build in XCD-aware tile order reports a look-back timeout once
     bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
     bool fuse_keygen = true;  // first radix pass computes keys from the text (no key/entry materialisation)

@@ -29,7 +29,8 @@ namespace cdb {
 
 constexpr int RS_MAX_PASSES = 16;
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
-constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 18;  // bounded look-back spin (~0.3-0.5 s of polling): a predecessor that has not answered by
+                                              // then is not coming (starved XCD-ordered pass); 2^22 held a starved build for ~8 s per wait
 // XCD-aware tile order of the big-tile configurations: groups of RS_GROUP consecutive tiles go to one XCD (RsCfg::GROUP).
 // Tiles are reserved for workgroups that have not started yet, so up to 7 * RS_GROUP resident workgroups can wait for
 // one that is still to be dispatched: the pass needs more than that many resident at a time (it has 256 when it runs
@@ -409,6 +410,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     } else if constexpr (Cfg::TICKET) {
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     }
+    // A pass whose look-back timed out leaves its output partly unwritten; a LATER pass over that output would see digit
+    // counts its digit starts were not made for and scatter out of bounds (seen as GPU memory faults when two processes
+    // shared one device and starved each other's XCD-ordered passes).  Once the error flag is up every tile only publishes
+    // an (empty) inclusive prefix — nobody waits for it — and leaves; the host finds the flag and redoes the sort.
+    __shared__ uint32_t s_bad;
+    if (tid == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     __syncthreads();
     uint64_t tile;
@@ -436,6 +443,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         if (base >= n) return;  // (the grid is rounded up to whole groups; nobody looks back at a tile behind the input)
     }
     const uint32_t valid = (uint32_t)((seg_n - base) < (uint64_t)TILE ? (seg_n - base) : (uint64_t)TILE);
+    if (s_bad) {
+        if (tid < 256) rs_st_status(status + tile * 256 + tid, ((uint64_t)epoch << 56) | (2ull << 54));
+        return;
+    }
 
     // ---- load keys (and values), wave-striped: lane-contiguous 512 B per load instruction
     K key[IPT];
@@ -1171,9 +1182,10 @@ static __global__ __launch_bounds__(256) void rs_seg_edge_fix_kernel(const SegEd
                                                                      const SegInfo* __restrict__ segs, uint32_t tiles,
                                                                      uint8_t* __restrict__ flags, uint32_t kbase, unsigned long long kmagic,
                                                                      unsigned long long* __restrict__ tile_sums = nullptr,
-                                                                     uint32_t sums_tile = 1) {
+                                                                     uint32_t sums_tile = 1, const uint32_t* __restrict__ err = nullptr) {
     const uint32_t t = blockIdx.x, d = threadIdx.x;
     if (t >= tiles) return;
+    if (err && *err) return;  // (a failed pass left edge records unwritten: their stale slots must not be touched)
     const SegEdge e = edges[(size_t)t * 256 + d];
     if (!e.cnt) return;
     const SegInfo si = segs[tile_seg ? tile_seg[t] : 0u];
@@ -1273,6 +1285,7 @@ static __global__ __launch_bounds__(256) void rs_lane_order_probe_kernel(uint32_
 struct RsRankCache {
     std::mutex mu;
     std::map<int, bool> ok;
+    std::map<int, bool> starved;  // a pass in XCD-aware tile order starved on this device: the process keeps plain tickets there
     static RsRankCache& get() {
         static RsRankCache c;
         return c;
@@ -1283,6 +1296,20 @@ inline void rs_atomic_rank_disable(int dev) {
     RsRankCache& c = RsRankCache::get();
     std::lock_guard<std::mutex> g(c.mu);
     c.ok[dev] = false;
+}
+// An XCD-ordered pass starved on `dev` (other kernels — another process sharing the GPU — held the CUs its reserved tiles
+// needed): every later build of this process on that device takes plain ticket order from the start instead of paying the
+// look-back timeout again per handle (database.cpp builds a fresh index object per rebuild).
+inline void rs_group_order_disable(int dev) {
+    RsRankCache& c = RsRankCache::get();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.starved[dev] = true;
+}
+inline bool rs_group_order_starved(int dev) {
+    RsRankCache& c = RsRankCache::get();
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.starved.find(dev);
+    return it != c.starved.end() && it->second;
 }
 inline bool rs_atomic_rank_ok(hipStream_t s) {
     std::mutex& mu = RsRankCache::get().mu;
@@ -1330,6 +1357,8 @@ struct RadixWorkspace {
     // suffix-array build sets allow_group for its own sorts and falls back to plain_order after a look-back timeout
     bool allow_group = false;
     bool plain_order = false;
+    bool debug_poison = false;  // test hook: the next sort finds the error flag already up — what the passes BEHIND a starved
+                                // pass see: they must leave their (stale) buffers alone, and the host must notice
 
     void prepare(uint64_t n, int tile, hipStream_t s) {
         const uint64_t tiles = ceil_div(n, (uint64_t)tile);
@@ -1337,6 +1366,10 @@ struct RadixWorkspace {
         if (!tickets.p) {
             tickets.alloc((260 + 256 * 8) * sizeof(uint32_t));
             CDB_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes, s));
+        }
+        if (debug_poison) {
+            CDB_HIP(hipMemsetAsync(err_ptr(), 0xFF, sizeof(uint32_t), s));
+            debug_poison = false;
         }
         const size_t need = (size_t)tiles * 256 * sizeof(uint64_t);
         if (need > status.bytes) {
@@ -1521,7 +1554,7 @@ int radix_sort_cfg(hipStream_t s, RadixWorkspace& ws, Profiler& prof, K* k0, K* 
                                        Cfg::GROUP > 0 ? ws.xticket_ptr(e) : ws.ticket_ptr(e), e, ws.err_ptr(), NoGen(),
                                        (const W*)wb[cur], wb[cur ^ 1], aux_shift, ka);
                     hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(tiles), dim3(256), 0, s, (const SegEdge*)ka.edges, (const uint32_t*)nullptr,
-                                       (const SegInfo*)ws.seg1.as<SegInfo>(), tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile);
+                                       (const SegInfo*)ws.seg1.as<SegInfo>(), tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile, (const uint32_t*)ws.err_ptr());
                     kept = true;
                     ws.keep_applied = true;
                 }
@@ -1769,7 +1802,7 @@ void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uin
     }
     int t = prof.begin(s);
     hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(tiles), dim3(256), 0, s, (const SegEdge*)fin.edges, d_tile_seg, d_segs, tiles,
-                       fin.flags, fin.kbase, fin.kmagic);
+                       fin.flags, fin.kbase, fin.kmagic, (unsigned long long*)nullptr, 1u, (const uint32_t*)ws.err_ptr());
     prof.end(t, "rs_seg_edge_fix", (uint64_t)tiles * 256 * sizeof(SegEdge), s);
     CDB_HIP(hipGetLastError());
 }
@@ -1979,7 +2012,7 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
     {
         int t = prof.begin(s);
         hipLaunchKernelGGL(rs_seg_edge_fix_kernel, dim3(seg_tiles), dim3(256), 0, s, (const SegEdge*)ka.edges, (const uint32_t*)mw.tile_seg.as<uint32_t>(),
-                           (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile);
+                           (const SegInfo*)mw.segs.as<SegInfo>(), seg_tiles, ka.flags, ka.kbase, ka.kmagic, ka.tile_sums, ka.sums_tile, (const uint32_t*)ws.err_ptr());
         prof.end(t, "rs_seg_edge_fix", (uint64_t)seg_tiles * 256 * sizeof(SegEdge), s);
     }
     ws.keep_applied = true;

@@ -1644,6 +1644,7 @@ void build_typed(Index& ix, bool big) {
         const double need = pc < 0.999 ? std::log(64.0 * (double)n) / -std::log(pc) : 1e9;
         nsym = (int)std::min<double>(std::ceil(need), 64.0);
     }
+    if (ix.debug_starve_group == 2 && !ix.rws.plain_order) ix.rws.debug_poison = true;  // (test hook: the initial sort "starves")
     if (ix.key_symbols > 0 && ix.initial_passes == 0) nsym = ix.key_symbols;
     nsym = std::min(std::max(nsym, 1), std::min(64 / symbits, 32));
     // digit width of the initial sort: whole symbols per digit when that costs no extra pass — the
@@ -2072,6 +2073,7 @@ void build_typed(Index& ix, bool big) {
             const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
             (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
                                           &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
+            radix_check_error(s, ix.rws);  // (the gathers below read the text through these entries)
         }
         if (root_folded) {
             uint64_t at = 0;
@@ -2507,7 +2509,9 @@ void build_typed(Index& ix, bool big) {
         }
         ix.prof.end(t, "sa_initflags", n * (layout == WIDE ? 9 : 5 + low_bytes), s);
     }
-    CDB_HIP(hipStreamSynchronize(s));
+    // (a starved pass of the initial sort left garbage entries: the refinement below would index the text with them —
+    //  the error surfaces HERE, before anything dereferences an entry; build_suffix_array redoes the build in plain order)
+    radix_check_error(s, ix.rws);
     ta = now_ms();
     // The sorted keys stay valid for the finished array: refinement only permutes entries inside groups
     // of equal keys.  They let a search probe decide on ONE load (query.hip) — kept when affordable.
@@ -2646,6 +2650,7 @@ void build_typed(Index& ix, bool big) {
         }
         const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
                                                sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss, ix.sort_variant);
+        radix_check_error(s, ix.rws);  // (sa_update scatters through the sorted values: never after a failed sort)
         hipLaunchKernelGGL((sa_newhead_kernel<I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                            (const uint64_t*)skey[rs].as<uint64_t>(), (const I*)U.as<I>(),
                            (const uint8_t*)flags.as<uint8_t>(), m, nh.as<uint8_t>());
@@ -2672,7 +2677,7 @@ void build_typed(Index& ix, bool big) {
         if (st.rounds > 80) throw Error("suffix-array refinement did not converge (internal error)");
     }
     if (ix.debug_fail_build) throw Error("debug: build failure requested (test hook)");
-    if (ix.debug_starve_group && !ix.rws.plain_order) throw Error("radix sort look-back timed out (test hook)");
+    if (ix.debug_starve_group == 1 && !ix.rws.plain_order) throw Error("radix sort look-back timed out (test hook)");
     st.final_depth = h;
     st.sort_passes = ss.passes_run;
     st.sort_passes_skipped = ss.passes_skipped;
@@ -2723,6 +2728,7 @@ void build_suffix_array(Index& ix) {
         explicit GroupScope(RadixWorkspace& w) : ws(w) { ws.allow_group = true; }
         ~GroupScope() { ws.allow_group = false; }
     } gscope(ix.rws);
+    if (!ix.debug_starve_group && rs_group_order_starved(ix.device)) ix.rws.plain_order = true;  // (learnt by an earlier handle)
     auto run = [&]() {
         const bool wide = ix.size + ix.ndocs + 2 >= (1ull << 32) || ix.force_big_path;
         if (wide && ix.width != 8 && !ix.force_big_path) throw Error("internal: a corpus >= 2^32 bytes must have 8-byte entries");
@@ -2747,6 +2753,7 @@ void build_suffix_array(Index& ix) {
             ix.d_sa.release();
             ix.drop_keys();
             ix.rws.plain_order = true;
+            if (!ix.debug_starve_group) rs_group_order_disable(ix.device);  // (the test hook leaves the device alone)
             ix.group_fallbacks += 1;
             run();
         }

@@ -643,6 +643,14 @@ def test_xcd_tile_order_and_fallback_to_plain_tickets(G):
     g.build()                                   # the handle stays in plain order: no second fallback
     assert g.stat("group_fallbacks") == 1
     _check_parity(G, blob, ds, patterns=pats, sort_variant=31, plain_tile_order=1)
+    # a REAL starved pass leaves its output partly unwritten, and the passes behind it would scatter by digit starts that
+    # no longer fit what they read (GPU memory faults, seen when two processes shared the device).  Test hook 2 raises the
+    # error flag in front of the initial sort: every pass must leave the (stale, recycled) buffers alone, the host must
+    # notice before anything dereferences an entry, and the rebuild in plain ticket order must be the right array —
+    # below 2^32 (MSD-first and LSD split sorts) and through the bucket-wise path (fused records, partition + gather)
+    for opts in (dict(sort_variant=31), dict(sort_variant=31, msd_first=0), dict(force_big_path=1), dict(force_big_path=1, fuse_records=0)):
+        g, _ = _check_parity(G, blob, ds, patterns=pats, debug_starve_group=2, **opts)
+        assert g.stat("group_fallbacks") == 1, opts
     blob, ds = W.ascii_corpus(9000, 1024, seed=9)     # 9 Mi suffixes: the configuration the size rule picks itself
     g, _ = _check_parity(G, blob, ds)
     v = g.verify()

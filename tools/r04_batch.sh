@@ -1,5 +1,5 @@
-set -x
-python -m pytest tests/test_gpu_fullsize.py -k "rebuild_8gib" -x -q -s 2>&1 | tail -15 | cut -c1-900
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sort.py -x -q 2>&1 | tail -5
-python bench.py --cpu-full-budget 0 --configs c0,utf8_4g > gpurun_out/r04_bench3.json 2> gpurun_out/r04_bench3.err; tail -c 300 gpurun_out/r04_bench3.json; tail -3 gpurun_out/r04_bench3.err
-python tools/single_breakdown.py 2>&1 | tail -6
+export CDB_BENCH_TRACE=1
+for i in $(seq 1 70); do
+python bench.py --gpus 2 --backend gloo --share-gpu --workload mid --steps 2 --warmup 1 --configs none --no-cpu-baseline > gpurun_out/r04_sl_x.json 2> gpurun_out/r04_sl_x.err; rc=$?; fb=$(grep -c 'group_fallbacks 1' gpurun_out/r04_sl_x.err); if [ $rc != 0 ] || [ $fb != 0 ]; then echo "run $i rc=$rc t=$SECONDS fallbacks=$fb"; grep "bench rank\|fault\|rror" gpurun_out/r04_sl_x.err | tail -14; cp gpurun_out/r04_sl_x.err gpurun_out/r04_sl_fail_$i.err; fi
+done
+echo "done t=$SECONDS"
