@@ -219,7 +219,7 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
 void reset_unbuilt(Index& ix) {
     query_resident_stop(ix);  // (the resident query workgroup reads the arrays released below)
     (void)hipStreamSynchronize(ix.stream);
-    ix.d_sa.release();
+    ix.release_sa();
     ix.drop_keys();
     ix.d_pivots.release();
     ix.pivot_levels = 0;
@@ -577,7 +577,18 @@ int cdb_save(cdb_index* h, const char* path) {
             }
         };
         dump(ix.d_text, ix.size);
-        dump(ix.d_sa.p, ix.size * (uint64_t)ix.width);
+        if (ix.sa_packed) {  // the file holds the reference's u64 entries whatever the storage: expanded chunk by chunk
+            DevBuf chunk;
+            const uint64_t per = std::max<uint64_t>(buf.size() / 8, 1);
+            chunk.alloc(per * 8);
+            for (uint64_t first = 0; first < ix.size && ok; first += per) {
+                const uint64_t cnt = std::min<uint64_t>(per, ix.size - first);
+                sa_expand(ix, first, cnt, chunk.as<uint64_t>());
+                dump(chunk.p, cnt * 8);
+            }
+        } else {
+            dump(ix.d_sa.p, ix.size * (uint64_t)ix.width);
+        }
         if (!ok) throw Error(std::string("Cannot write file: ") + path);
     });
 }
@@ -647,6 +658,7 @@ int cdb_load(cdb_index* h, const char* path) {
         ix.d_sa = std::move(sa);
         ix.d_doc_start = std::move(d_start);
         ix.d_ids = std::move(d_ids);
+        if (sa_packable(ix)) sa_pack_inplace(ix);  // (the same storage a build of this column would leave)
     });
 }
 
@@ -1378,7 +1390,17 @@ int cdb_sa_copy(cdb_index* h, void* host_out, uint64_t capacity_bytes) {
         DeviceScope dscope(ix);
         const uint64_t need = ix.size * (uint64_t)ix.width;
         if (capacity_bytes < need) throw Error("cdb_sa_copy: buffer too small");
-        if (need) {
+        if (need && ix.sa_packed) {  // the caller sees the reference's u64 entries (index.cpp:203-208), expanded chunk by chunk
+            DevBuf chunk;
+            const uint64_t per = std::min<uint64_t>(ix.size, 32ull << 20);
+            chunk.alloc(per * 8);
+            for (uint64_t first = 0; first < ix.size; first += per) {
+                const uint64_t cnt = std::min<uint64_t>(per, ix.size - first);
+                sa_expand(ix, first, cnt, chunk.as<uint64_t>());
+                CDB_HIP(hipMemcpyAsync(static_cast<char*>(host_out) + first * 8, chunk.p, cnt * 8, hipMemcpyDeviceToHost, ix.stream));
+                CDB_HIP(hipStreamSynchronize(ix.stream));
+            }
+        } else if (need) {
             CDB_HIP(hipMemcpyAsync(host_out, ix.d_sa.p, need, hipMemcpyDeviceToHost, ix.stream));
             CDB_HIP(hipStreamSynchronize(ix.stream));
         }
@@ -1408,6 +1430,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "overlap_paircount")) ix.overlap_paircount = value != 0;
     else if (!std::strcmp(name, "key_directory")) { ix.key_directory = value != 0; ix.h_keydir.clear(); ix.keydir_tried = false; }
     else if (!std::strcmp(name, "fuse_records")) ix.fuse_records = value != 0;
+    else if (!std::strcmp(name, "pack_sa")) ix.pack_sa = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;
     else if (!std::strcmp(name, "fold_root")) ix.fold_root = value != 0;
@@ -1452,7 +1475,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

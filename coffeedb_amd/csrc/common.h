@@ -133,6 +133,27 @@ public:
         }
         return p;
     }
+    // true when `bytes` can be had WITHOUT giving cached blocks back to the driver: a cached block of a fitting size exists, or
+    // the driver still has that much untouched.  (A failed hipMalloc makes alloc() trim the whole cache and ask again — seconds
+    // at tens of GiB, the driver scrubs what it hands out; optional scratch is better skipped than paid for like that.)
+    bool can_serve(size_t bytes, int device) {
+        const size_t gran = bytes >= (8u << 20) ? (2u << 20) : 256;
+        const size_t need = (bytes + gran - 1) / gran * gran;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (const Block& b : free_) {
+                if (b.device != device || b.bytes < need) continue;
+                const size_t slack = need >= (64u << 20) ? need / 4 : need + (1u << 20);
+                if (b.bytes <= need + slack) return true;
+            }
+        }
+        size_t fre = 0, tot = 0;
+        if (hipMemGetInfo(&fre, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return (double)fre >= (double)need * 1.05 + (double)(256u << 20);
+    }
     // bytes handed out right now / the most ever handed out since reset_peak() (what an index and its build really hold
     // in HBM: cdb_memory_stats; cached blocks are not counted, the caller's own buffers — a resident text — neither)
     void stats(size_t& in_use, size_t& peak, size_t& cached) {

@@ -60,6 +60,44 @@ struct SingleKeys {
     uint64_t lo0 = 0, hi0 = 0;
 };
 
+// ---- suffix-array storage as the kernels see it ------------------------------------------------------------------------
+// Plain: an array of V (u32 / u64 — the reference's own widths, index.cpp:203-208).  Packed: 8-byte entries whose bits all lie
+// below 2^40 (document bits + offset bits <= 40: every >= 2^32 configuration of BASELINE.json) are STORED as u32 low words +
+// u8 high bytes — 5 instead of 8 bytes per suffix; cdb_sa_copy / cdb_save expand them to the reference's u64 encoding, so
+// nothing outside the library sees the difference.  Kernels are templated on a tag T (uint32_t, uint64_t, Packed40);
+// SaOf<T>::ptr is what they index, SaOf<T>::val the entry type they compute with.
+struct Sa40 {
+    const uint32_t* __restrict__ lo;
+    const uint8_t* __restrict__ hi;
+    __device__ __forceinline__ uint64_t operator[](uint64_t i) const { return (uint64_t)lo[i] | ((uint64_t)hi[i] << 32); }
+};
+struct Packed40 {};
+template <typename T> struct SaOf {
+    using val = T;
+    using ptr = const T* __restrict__;
+};
+template <> struct SaOf<Packed40> {
+    using val = uint64_t;
+    using ptr = Sa40;
+};
+// ... and as the build's refinement writes it
+template <typename V> struct SaRW {
+    V* p;
+    using val = V;
+    __device__ __forceinline__ V load(uint64_t i) const { return p[i]; }
+    __device__ __forceinline__ void store(uint64_t i, V v) const { p[i] = v; }
+};
+struct Sa40RW {
+    uint32_t* lo;
+    uint8_t* hi;
+    using val = uint64_t;
+    __device__ __forceinline__ uint64_t load(uint64_t i) const { return (uint64_t)lo[i] | ((uint64_t)hi[i] << 32); }
+    __device__ __forceinline__ void store(uint64_t i, uint64_t v) const {
+        lo[i] = (uint32_t)v;
+        hi[i] = (uint8_t)(v >> 32);
+    }
+};
+
 struct Index {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -109,7 +147,16 @@ struct Index {
     bool text_padded = false;
     DevBuf d_doc_start;               // ndocs + 1 u64
     DevBuf d_ids;                     // ndocs i64
-    DevBuf d_sa;                      // size * width bytes
+    DevBuf d_sa;                      // size * width bytes — or, packed, the entries' low words (size * 4 bytes)
+    DevBuf d_sa_hi;                   // packed: bits 32..39 of every entry (size bytes)
+    bool sa_packed = false;           // 5-byte storage of 8-byte entries (Sa40 above)
+    bool pack_sa = true;              // option: builds with 8-byte entries below 2^40 store them packed
+    void release_sa() {
+        d_sa.release();
+        d_sa_hi.release();
+        sa_packed = false;
+    }
+    template <typename T> typename SaOf<T>::ptr sa_view() const;  // (below)
     bool sa_sorted = false;           // SA is globally sorted in unsigned byte order (false only for
                                       // reference_compat orderings of text with bytes >= 0x80)
     DevBuf d_keys;                    // optional: the sorted initial keys (first key_nsym symbol codes of every
@@ -206,6 +253,9 @@ void build_suffix_array(Index& ix);
 
 // verify.hip — out = {inversions, tie-order violations, wrapped sum of entries, invalid entries, expected sum}
 void verify_suffix_array(Index& ix, uint64_t out[5]);
+void sa_expand(Index& ix, uint64_t first, uint64_t cnt, uint64_t* d_out);  // verify.hip: packed entries -> u64 (on ix.stream)
+void sa_pack_inplace(Index& ix);                                           // verify.hip: u64 entries in d_sa -> packed storage
+inline bool sa_packable(const Index& ix) { return ix.pack_sa && ix.width == 8 && (int)ix.bits + ix.off_bits <= 40; }
 void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // verify.hip: the check behind every build
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
 // out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,
@@ -254,6 +304,17 @@ struct DeviceRows {
     uint64_t n;
 };
 DeviceCsr and_merge_on_device(Index& ix, const std::vector<DeviceRows>& lists, bool ranked, int64_t lo, int64_t hi, uint64_t limit);
+
+
+template <> inline SaOf<uint32_t>::ptr Index::sa_view<uint32_t>() const { return d_sa.as<uint32_t>(); }
+template <> inline SaOf<uint64_t>::ptr Index::sa_view<uint64_t>() const { return d_sa.as<uint64_t>(); }
+template <> inline SaOf<Packed40>::ptr Index::sa_view<Packed40>() const { return Sa40{d_sa.as<uint32_t>(), d_sa_hi.as<uint8_t>()}; }
+// f(tag) with the tag of the index's storage: the one place that knows the three forms
+template <typename F> inline auto sa_dispatch(const Index& ix, F&& f) {
+    if (ix.sa_packed) return f(Packed40{});
+    if (ix.width == 8) return f(uint64_t{});
+    return f(uint32_t{});
+}
 
 }  // namespace cdb
 

@@ -44,7 +44,7 @@ __device__ __forceinline__ int cmp_common(const uint8_t* __restrict__ k, uint64_
 }
 
 template <typename V>
-__global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void q_search_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                        const uint8_t* __restrict__ text,
                                                        const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                        const uint8_t* __restrict__ blob,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa,
     int64_t L = 0, R = (int64_t)n - 1;
     while (L < R) {
         const int64_t M = L + (R - L) / 2;
-        const V e = sa[M];
+        const auto e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
         const int c = cmp_common(k, m, text + b, sl);
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void q_search_kernel(const V* __restrict__ sa,
     R = (int64_t)n - 1;
     while (L < R) {
         const int64_t M = L + (R - L + 1) / 2;
-        const V e = sa[M];
+        const auto e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
         const bool pref = sl >= m && cmp_common(k, m, text + b, sl) == 0;
@@ -102,7 +102,7 @@ struct Pivot {
 };
 
 template <typename V>
-__global__ __launch_bounds__(256) void q_pivots_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void q_pivots_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                        const uint8_t* __restrict__ text,
                                                        const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                        int levels, Pivot* __restrict__ piv) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void q_pivots_kernel(const V* __restrict__ sa,
     Pivot p{0, 0, 0};
     if (!dead && L < R) {
         const int64_t M = L + (R - L) / 2;
-        const V e = sa[M];
+        const auto e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b0 = doc_start[d] + off, sl = doc_start[d + 1] - b0;
         uint64_t w[2] = {0, 0};
@@ -149,7 +149,7 @@ __device__ __forceinline__ int kw_le_pivot(uint64_t khi, uint64_t klo, uint64_t 
 // pivot levels at 2^30 suffixes) for G times the loads: the better trade while a batch is too small to fill the GPU
 // with one thread per keyword.  The array is sorted, so every search strategy finds the same bounds.
 template <typename V, int G>
-__global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void q_search_fast_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                             const uint8_t* __restrict__ text,
                                                             const uint64_t* __restrict__ doc_start, int bits,
                                                             uint64_t mask, const uint8_t* __restrict__ blob,
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void q_search_fast_kernel(const V* __restrict_
         return sk < klo ? -1 : (sk > khi ? 1 : 0);
     };
     auto suffix_of = [&](int64_t M, const uint8_t*& sp, uint64_t& sl) {
-        const V e = sa[M];
+        const auto e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b = doc_start[d] + off;
         sp = text + b;
@@ -372,7 +372,7 @@ struct HitsOut2 {
 // pattern's hit offset and its row count; after a scan of the row counts phase 2 moves the rows to
 // their CSR position and maps documents to object ids.
 template <typename V>
-__global__ __launch_bounds__(256) void q_wave_rows_kernel(const V* __restrict__ sa, uint64_t mask,
+__global__ __launch_bounds__(256) void q_wave_rows_kernel(typename SaOf<V>::ptr sa, uint64_t mask,
                                                           const int64_t* __restrict__ left,
                                                           const uint64_t* __restrict__ hits,
                                                           const uint64_t* __restrict__ hoff, uint64_t npat,
@@ -454,7 +454,7 @@ struct HitsOut {
 // one thread per hit slot of the chunk [j0, j1) of patterns: find the owning pattern (binary search
 // over the hit offsets), emit ((pattern - j0) << dbits) | doc
 template <typename V>
-__global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa, uint64_t mask, int dbits, int bits,
+__global__ __launch_bounds__(256) void q_expand_kernel(typename SaOf<V>::ptr sa, uint64_t mask, int dbits, int bits,
                                                        int obits, const int64_t* __restrict__ left,
                                                        const uint64_t* __restrict__ hoff, uint64_t j0, uint64_t j1,
                                                        uint64_t H, uint64_t* __restrict__ keys) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void q_expand_kernel(const V* __restrict__ sa,
     const uint64_t j = lo;
     const uint64_t i = (uint64_t)left[j] + (slot - hoff[j]);
     // obits > 0: the occurrence offset rides along as the least significant field (offset emission)
-    const V e = sa[i];
+    const auto e = sa[i];
     const uint64_t pd = ((j - j0) << dbits) | ((uint64_t)e & mask);
     keys[t] = obits ? (pd << obits) | ((uint64_t)e >> bits) : pd;
 }
@@ -540,7 +540,7 @@ void grow_keep(DevBuf& b, size_t need, size_t used, hipStream_t s) {
 template <typename V>
 void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
     hipStream_t s = ix.stream;
-    const V* sa = ix.d_sa.as<V>();
+    const auto sa = ix.sa_view<V>();
     const uint64_t* doc_start = ix.d_doc_start.as<uint64_t>();
     int t = ix.prof.begin(s);
     if (ix.sa_sorted && ix.use_fast_search && ix.size >= 4096) {
@@ -583,7 +583,7 @@ void launch_search(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uin
 
 // ---- OR over the keywords of one key (interface.cpp:78-113): per-document totals by atomics ------
 template <typename V>
-__global__ __launch_bounds__(256) void q_count_docs_kernel(const V* __restrict__ sa, uint64_t mask,
+__global__ __launch_bounds__(256) void q_count_docs_kernel(typename SaOf<V>::ptr sa, uint64_t mask,
                                                            const int64_t* __restrict__ left,
                                                            const uint64_t* __restrict__ hoff, uint64_t npat, uint64_t H,
                                                            unsigned long long* __restrict__ doc_count) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void q_unflip_kernel(const uint64_t* __restric
 // entry >> bits), so no document has to be re-scanned: occurrences are sorted by (doc, begin) and a
 // segmented running maximum of the ends decides where a new span starts.
 template <typename V>
-__global__ __launch_bounds__(256) void q_expand_occ_kernel(const V* __restrict__ sa, uint64_t mask, int bits, int obits,
+__global__ __launch_bounds__(256) void q_expand_occ_kernel(typename SaOf<V>::ptr sa, uint64_t mask, int bits, int obits,
                                                            const int64_t* __restrict__ left,
                                                            const uint64_t* __restrict__ hoff,
                                                            const uint64_t* __restrict__ offs, uint64_t npat, uint64_t H,
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void q_expand_occ_kernel(const V* __restrict__
             const uint64_t mid = lo + (hi - lo + 1) / 2;
             if (hoff[mid] <= t) lo = mid; else hi = mid - 1;
         }
-        const V e = sa[(uint64_t)left[lo] + (t - hoff[lo])];
+        const auto e = sa[(uint64_t)left[lo] + (t - hoff[lo])];
         const uint64_t doc = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         keys[t] = (doc << obits) | off;
         ends[t] = off + (offs[lo + 1] - offs[lo]);  // one past the last byte of the occurrence
@@ -788,7 +788,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         CDB_HIP(hipStreamSynchronize(s));
         return out;
     }
-    const V* sa = ix.d_sa.as<V>();
+    const auto sa = ix.sa_view<V>();
     ix.q_left.ensure(npat * 8);
     ix.q_right.ensure(npat * 8);  // hit counts
     ix.q_hoff.ensure((npat + 1) * 8);
@@ -819,7 +819,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
                            (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_right.as<uint64_t>(),
                            (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, ix.q_keys0.as<uint32_t>(), ix.q_keys1.as<uint32_t>(),
                            ix.q_flags.as<uint64_t>(), cap, ix.q_spec.as<unsigned long long>() + 2);
-        ix.prof.end(t, "q_wave_rows", cap * (sizeof(V) + 8), s);
+        ix.prof.end(t, "q_wave_rows", cap * (sizeof(typename SaOf<V>::val) + 8), s);
         NrowsIn nin{ix.q_flags.as<uint64_t>()};
         scan_totals_device<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0);
         scan_apply<uint64_t>(s, ix.scan_partials, nin, npat, OpAdd{}, (uint64_t)0, HitsOut{ix.q_rowptr.as<uint64_t>(), npat});
@@ -861,7 +861,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
                            (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_right.as<uint64_t>(),
                            (const uint64_t*)ix.q_hoff.as<uint64_t>(), npat, ix.q_keys0.as<uint32_t>(), ix.q_keys1.as<uint32_t>(),
                            ix.q_flags.as<uint64_t>(), H, (unsigned long long*)nullptr);
-        ix.prof.end(t, "q_wave_rows", H * (sizeof(V) + 8), s);
+        ix.prof.end(t, "q_wave_rows", H * (sizeof(typename SaOf<V>::val) + 8), s);
         NrowsIn nin{ix.q_flags.as<uint64_t>()};
         // rows <= hits, so the result arrays are sized by H and the number of rows is fetched together with
         // the final synchronisation instead of costing a round trip of its own
@@ -927,7 +927,7 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         hipLaunchKernelGGL((q_expand_kernel<V>), dim3((unsigned)ceil_div(Hc, 256)), dim3(256), 0, s, sa, ix.mask, dbits,
                            (int)ix.bits, obits, (const int64_t*)ix.q_left.as<int64_t>(), (const uint64_t*)ix.q_hoff.as<uint64_t>(), j0, j1, Hc,
                            ix.q_keys0.as<uint64_t>());
-        ix.prof.end(t, "q_expand", Hc * (sizeof(V) + 8), s);
+        ix.prof.end(t, "q_expand", Hc * (sizeof(typename SaOf<V>::val) + 8), s);
         // stable sort of the chunk by (pattern ∘ doc); passes over constant digits are skipped
         const int sel = radix_sort<uint64_t, NoVal>(s, ix.rws, ix.prof, ix.q_keys0.as<uint64_t>(), ix.q_keys1.as<uint64_t>(),
                                                     (NoVal*)nullptr, (NoVal*)nullptr, Hc, 0, dbits + jbits + obits, nullptr);
@@ -974,7 +974,7 @@ DeviceCsr query_or_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_off
     ix.q_ids.ensure(16);
     ix.q_counts.ensure(16);
     if (npat == 0 || ix.size == 0 || ix.width == 0) return out;
-    const V* sa = ix.d_sa.as<V>();
+    const auto sa = ix.sa_view<V>();
     ix.q_left.ensure(npat * 8);
     ix.q_right.ensure(npat * 8);
     ix.q_hoff.ensure((npat + 1) * 8);
@@ -1020,7 +1020,7 @@ SpanResult query_spans_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d
     hipStream_t s = ix.stream;
     SpanResult out;
     if (npat == 0 || ix.size == 0 || ix.width == 0) return out;
-    const V* sa = ix.d_sa.as<V>();
+    const auto sa = ix.sa_view<V>();
     const int obits = ix.width * 8 - (int)ix.bits;  // offset bits of an entry
     const bool by_scan = !ix.sa_sorted;  // reference-compat ordering: occurrences come from the text itself
     uint64_t H = 0;
@@ -1130,7 +1130,7 @@ struct SingleOut {
 // The answer to one keyword (k[0 .. m) in LDS) by one workgroup of 256 threads; every thread enters and leaves together
 // (the resident kernel below calls it once per request).  `done` = the word that announces the rows (written last).
 template <typename V>
-__device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64_t n, const uint8_t* __restrict__ text,
+__device__ __forceinline__ void q_single_answer(typename SaOf<V>::ptr sa, uint64_t n, const uint8_t* __restrict__ text,
                                                 const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                 const int64_t* __restrict__ ids, const uint8_t* k, uint64_t m,
                                                 SingleOut* __restrict__ out, bool sorted, const SingleKeys& sk) {
@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64
             }
             // the suffix starts with the keyword's first symbols and the keyword is longer than the key: the text decides
         }
-        const V e = sa[M];
+        const auto e = sa[M];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t b = doc_start[d] + off, sl = doc_start[d + 1] - b;
         const int c = cmp_common(k, m, text + b, sl);
@@ -1245,7 +1245,7 @@ __device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64
         const int64_t M = L + lane;
         bool le = true, pf = false;
         const bool probed = M < R;
-        V ew = 0;
+        typename SaOf<V>::val ew = 0;
         if (probed) {
             ew = sa[M];       // (fetched beside the probe: if the hits end inside this window they are already here)
             probe(M, le, pf);  // (slot R itself is the saturated answer)
@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64
             in_window = true;
             right_w = L + (__ffsll((unsigned long long)nomatch) - 1);
             const uint32_t lo = __shfl((uint32_t)ew, (lane + f) & 63);
-            const uint32_t hi = sizeof(V) == 8 ? __shfl((uint32_t)((uint64_t)ew >> 32), (lane + f) & 63) : 0u;
+            const uint32_t hi = sizeof(typename SaOf<V>::val) == 8 ? __shfl((uint32_t)((uint64_t)ew >> 32), (lane + f) & 63) : 0u;
             s_win[lane] = ((uint64_t)hi << 32) | lo;  // entries of slots left, left + 1, ... (lanes behind the window: junk)
         }
         L += f;
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ void q_single_answer(const V* __restrict__ sa, uint64
 }
 
 template <typename V>
-__global__ __launch_bounds__(256) void q_single_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void q_single_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                       const uint8_t* __restrict__ text,
                                                       const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                       const int64_t* __restrict__ ids, SingleKw kw, SingleOut* __restrict__ out,
@@ -1446,7 +1446,7 @@ struct ResidentBox {
 };
 
 template <typename V>
-__global__ __launch_bounds__(256) void q_resident_kernel(const V* __restrict__ sa, uint64_t n, const uint8_t* __restrict__ text,
+__global__ __launch_bounds__(256) void q_resident_kernel(typename SaOf<V>::ptr sa, uint64_t n, const uint8_t* __restrict__ text,
                                                         const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
                                                         const int64_t* __restrict__ ids, ResidentBox* __restrict__ box,
                                                         SingleOut* __restrict__ out, bool sorted, SingleKeys sk, uint32_t seq0) {
@@ -1528,14 +1528,12 @@ void query_resident_ensure(Index& ix, const SingleKeys& sk) {
     ix.res_keys = base;
     const uint32_t seq0 = ix.res_seq - 1u;
     SingleOut* out = static_cast<SingleOut*>(ix.d_single);
-    if (ix.width == 8)
-        hipLaunchKernelGGL((q_resident_kernel<uint64_t>), dim3(1), dim3(256), 0, ix.res_stream, (const uint64_t*)ix.d_sa.as<uint64_t>(),
-                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), static_cast<ResidentBox*>(ix.d_res), out, ix.sa_sorted, base, seq0);
-    else
-        hipLaunchKernelGGL((q_resident_kernel<uint32_t>), dim3(1), dim3(256), 0, ix.res_stream, (const uint32_t*)ix.d_sa.as<uint32_t>(),
-                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), static_cast<ResidentBox*>(ix.d_res), out, ix.sa_sorted, base, seq0);
+    sa_dispatch(ix, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL((q_resident_kernel<T>), dim3(1), dim3(256), 0, ix.res_stream, ix.sa_view<T>(), ix.size, ix.d_text,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, (const int64_t*)ix.d_ids.as<int64_t>(),
+                           static_cast<ResidentBox*>(ix.d_res), out, ix.sa_sorted, base, seq0);
+    });
     CDB_HIP(hipGetLastError());
     ix.res_running = true;
 }
@@ -1680,14 +1678,12 @@ SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
         query_resident_ensure(ix, sk);
         return SingleLaunch::Launched;
     }
-    if (ix.width == 8)
-        hipLaunchKernelGGL((q_single_kernel<uint64_t>), dim3(1), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size,
-                           ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
-    else
-        hipLaunchKernelGGL((q_single_kernel<uint32_t>), dim3(1), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(), ix.size,
-                           ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
-                           (const int64_t*)ix.d_ids.as<int64_t>(), k, static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
+    sa_dispatch(ix, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL((q_single_kernel<T>), dim3(1), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask, (const int64_t*)ix.d_ids.as<int64_t>(), k,
+                           static_cast<SingleOut*>(ix.d_single), ix.sa_sorted, sk);
+    });
     CDB_HIP(hipGetLastError());
     return SingleLaunch::Launched;
 }
@@ -1759,8 +1755,7 @@ bool query_single_on_device(Index& ix, const char* kw, size_t len, int64_t** ids
 void query_single_empty(Index& ix, int64_t** ids_out, int64_t** counts_out, size_t* nrows) { single_empty_rows(ix, ids_out, counts_out, nrows); }
 
 DeviceCsr query_batch_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, bool with_offsets) {
-    DeviceCsr r = ix.width == 8 ? query_typed<uint64_t>(ix, d_blob, d_offs, npat, with_offsets)
-                                : query_typed<uint32_t>(ix, d_blob, d_offs, npat, with_offsets);
+    DeviceCsr r = sa_dispatch(ix, [&](auto tag) { return query_typed<decltype(tag)>(ix, d_blob, d_offs, npat, with_offsets); });
     ix.prof.resolve();
     return r;
 }
@@ -1829,7 +1824,7 @@ static DeviceCsr rank_rows_on_device(Index& ix, DeviceCsr r, int64_t lo, int64_t
 
 DeviceCsr query_ranked_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat, int64_t lo, int64_t hi,
                                  uint64_t limit) {
-    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat) : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    DeviceCsr r = sa_dispatch(ix, [&](auto tag) { return query_or_typed<decltype(tag)>(ix, d_blob, d_offs, npat); });
     return rank_rows_on_device(ix, r, lo, hi, limit);
 }
 
@@ -1904,16 +1899,14 @@ DeviceCsr and_merge_on_device(Index& ix, const std::vector<DeviceRows>& lists, b
 }
 
 DeviceCsr query_or_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat) {
-    DeviceCsr r = ix.width == 8 ? query_or_typed<uint64_t>(ix, d_blob, d_offs, npat)
-                                : query_or_typed<uint32_t>(ix, d_blob, d_offs, npat);
+    DeviceCsr r = sa_dispatch(ix, [&](auto tag) { return query_or_typed<decltype(tag)>(ix, d_blob, d_offs, npat); });
     ix.prof.resolve();
     return r;
 }
 
 SpanResult query_spans_on_device(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, uint64_t npat,
                                  uint64_t total_pattern_bytes) {
-    SpanResult r = ix.width == 8 ? query_spans_typed<uint64_t>(ix, d_blob, d_offs, npat, total_pattern_bytes)
-                                 : query_spans_typed<uint32_t>(ix, d_blob, d_offs, npat, total_pattern_bytes);
+    SpanResult r = sa_dispatch(ix, [&](auto tag) { return query_spans_typed<decltype(tag)>(ix, d_blob, d_offs, npat, total_pattern_bytes); });
     ix.prof.resolve();
     return r;
 }

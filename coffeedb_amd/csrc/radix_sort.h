@@ -172,6 +172,7 @@ struct TextGen {
     bool msd_pair = false;
     uint32_t pair_span = 0, pair_r = 0, pair_s = 0;  // floor(a / span) = (a * pair_r) >> pair_s for every a < base^2 (rs_pair_setup)
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
+    uint8_t* vout_hi = nullptr;  // 8-byte values (first_only partition): write them packed — low words to (uint32_t*)vout, bits 32..39 here
 };
 // The generator's FORM is part of the kernel's type: the 16 Ki-tile pass is ~15 k instructions of straight-line code per
 // form (everything is unrolled 16 x), and a kernel that carries all three runs 4 % slower than one that carries its own
@@ -263,6 +264,8 @@ struct SegEdge {
 };
 struct SegFinalArgs : SegArgs {
     uint64_t* eout = nullptr;   // entries of the group (already offset to the group's first slot)
+    uint32_t* elo = nullptr;    // ... or, packed storage (index_impl.h: Sa40): their low words and
+    uint8_t* ehi = nullptr;     //     their bits 32..39 (elo != nullptr selects this form)
     uint8_t* flags = nullptr;   // ... and its flags
     SegEdge* edges = nullptr;   // [tiles][256]
     int hi_shift = 0;           // entry bits 32.. sit above this many bits of the auxiliary word
@@ -1165,9 +1168,28 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         for (int j = 0; j < IPT; ++j) {
             const uint32_t i = j * NT + tid;
             if constexpr (FINAL) {
-                if (i < valid && !(RS_SEG_ABL & 2))
-                    seg.eout[rs_seg_rotated(si, s_gbase[dig[j]] + i)] = ((uint64_t)((uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift) << 32) | (uint64_t)s_vals[i];
+                if (i < valid && !(RS_SEG_ABL & 2)) {
+                    const unsigned long long slot = rs_seg_rotated(si, s_gbase[dig[j]] + i);
+                    const uint32_t hi32 = (uint32_t)s_aux[HAS_W ? i : 0] >> seg.hi_shift;
+                    if (seg.elo) {  // (uniform) 5 bytes per entry instead of 8
+                        seg.elo[slot] = (uint32_t)s_vals[i];
+                        seg.ehi[slot] = (uint8_t)hi32;
+                    } else {
+                        seg.eout[slot] = ((uint64_t)hi32 << 32) | (uint64_t)s_vals[i];
+                    }
+                }
             } else {
+                if constexpr (GEN && sizeof(VS) == 8) {
+                    if (gen.vout_hi) {  // (uniform) entries-only partition of 8-byte entries below 2^40: written packed (Sa40)
+                        if (i < valid) {
+                            const uint64_t dst = s_gbase[dig[j]] + i;
+                            const uint64_t e = (uint64_t)s_vals[i];
+                            reinterpret_cast<uint32_t*>(vout)[dst] = (uint32_t)e;
+                            gen.vout_hi[dst] = (uint8_t)(e >> 32);
+                        }
+                        continue;
+                    }
+                }
                 if (i < valid) rs_store<NTM>(vout + s_gbase[dig[j]] + i, (V)s_vals[i]);
             }
         }
@@ -1790,7 +1812,7 @@ void radix_sort_segmented(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uin
         if (p == npass - 1) {
             if (grouped) CDB_SEG_LAUNCH(CfgG, SegFinalArgs, fin);
             else CDB_SEG_LAUNCH(CfgP, SegFinalArgs, fin);
-            prof.end(t, (std::string("rs_seg_final") + wn + "_t16384").c_str(), m * (rec + 9), s);
+            prof.end(t, (std::string("rs_seg_final") + wn + "_t16384").c_str(), m * (rec + (fin.elo ? 6 : 9)), s);
         } else {
             if (grouped) CDB_SEG_LAUNCH(CfgG, SegArgs, sa);
             else CDB_SEG_LAUNCH(CfgP, SegArgs, sa);

@@ -699,8 +699,8 @@ struct BucketItem {
 };
 
 // bounds[b * (nch + 1) + x] = first index in bucket b's entry range whose text position is >= x * chunk
-template <typename V>
-__global__ __launch_bounds__(256) void sa_bucket_bounds_kernel(const V* __restrict__ ent,
+template <typename V>  // (V = storage tag of the partitioned entries: uint32_t / uint64_t / Packed40)
+__global__ __launch_bounds__(256) void sa_bucket_bounds_kernel(typename SaOf<V>::ptr ent,
                                                                const unsigned long long* __restrict__ bstart /*[nb + 1]*/,
                                                                uint32_t nb, uint32_t nch, uint64_t chunk,
                                                                const uint64_t* __restrict__ doc_start, int bits, uint64_t mask,
@@ -910,8 +910,8 @@ __global__ __launch_bounds__(256) void sa_gather_emit_kernel(const unsigned long
 }
 
 // the gather of sa_bucket_records_packed_kernel, persistent: workgroup w serves list w % 8 until it is empty
-template <typename W>
-__global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(const uint64_t* __restrict__ ent, const BucketItem* __restrict__ items,
+template <typename W, typename ET = uint64_t>  // (ET = storage tag of the partitioned entries: uint64_t or Packed40)
+__global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(typename SaOf<ET>::ptr ent, const BucketItem* __restrict__ items,
                                                                       const uint32_t* __restrict__ list_len, uint32_t* __restrict__ tickets,
                                                                       const uint8_t* __restrict__ text, uint64_t n,
                                                                       const uint64_t* __restrict__ doc_start,
@@ -1035,9 +1035,11 @@ struct FlagIn {
 // compaction of the unresolved entries + construction of their sort keys
 // compaction of the unresolved entries: slot number, entry and group id of every unresolved entry
 // (the sort key's minor part is filled in by sa_round_keys_kernel, one dense thread per entry)
-template <typename V, typename I>
+// (SAW = how the suffix array is stored: SaRW<V> or the packed Sa40RW, index_impl.h)
+template <typename SAW, typename I>
 struct CompactOut {
-    const V* sa;
+    using V = typename SAW::val;
+    SAW sa;
     I* U;
     uint64_t* skey;
     V* sval;
@@ -1047,7 +1049,7 @@ struct CompactOut {
         const uint64_t j = ex.a;
         U[j] = (I)i;
         skey[j] = (in.b - 1) << kbits;  // group id
-        sval[j] = sa[i];
+        sval[j] = sa.load(i);
     }
 };
 
@@ -1143,11 +1145,11 @@ __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restr
     nh[j] = (uint8_t)(oldhead || j == 0 || skey[j] != skey[j - 1]);
 }
 
-template <typename V, typename I>
-__device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const V* sval, const I* U, const uint8_t* nh,
-                                         const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, V* sa,
+template <typename SAW, typename I>
+__device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename SAW::val* sval, const I* U, const uint8_t* nh,
+                                         const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, SAW sa,
                                          uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open) {
-    const V v = sval[j];
+    const typename SAW::val v = sval[j];
     const uint64_t i = U[j];
     const bool head = nh[j];
     const bool last = j + 1 == m || nh[j + 1];
@@ -1156,23 +1158,23 @@ __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const V* sval, 
     const uint64_t rem = doc_start[d + 1] - ds - off;
     const bool exhausted = rem < hnew;
     const bool open = !(head && last) && !exhausted;
-    sa[i] = v;
+    sa.store(i, v);
     flags[i] = (uint8_t)((head ? 1 : 0) | (open ? 2 : 0));
     if (open) atomicAdd(still_open, 1ull);  // the compiler folds this into one add per wave
     ext_pos = ds + d + off;
 }
 
-template <typename V, typename I>
-__global__ __launch_bounds__(256) void sa_update_kernel(const V* __restrict__ sval, const I* __restrict__ U,
+template <typename SAW, typename I>
+__global__ __launch_bounds__(256) void sa_update_kernel(const typename SAW::val* __restrict__ sval, const I* __restrict__ U,
                                                         const uint8_t* __restrict__ nh, uint64_t m,
                                                         const uint64_t* __restrict__ doc_start, int bits,
-                                                        uint64_t mask, uint64_t hnew, V* __restrict__ sa,
+                                                        uint64_t mask, uint64_t hnew, SAW sa,
                                                         uint8_t* __restrict__ flags,
                                                         unsigned long long* __restrict__ still_open) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     uint64_t q;
-    sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
+    sa_place<SAW, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
 }
 
 template <typename I>
@@ -1200,8 +1202,9 @@ struct SlotOrder {
     }
 };
 
-template <typename V, typename I, typename R>
+template <typename SAW, typename I, typename R>
 struct UpdateOut {
+    using V = typename SAW::val;
     const V* sval;
     const I* U;
     const uint8_t* nh;
@@ -1209,14 +1212,14 @@ struct UpdateOut {
     const uint64_t* doc_start;
     int bits;
     uint64_t mask, hnew;
-    V* sa;
+    SAW sa;
     uint8_t* flags;
     R* rank;
     unsigned long long* still_open;
     SlotOrder order;
     __device__ __forceinline__ void operator()(uint64_t j, uint64_t, uint64_t incl) const {
         uint64_t q;
-        sa_place<V, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
+        sa_place<SAW, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
         rank[q] = (R)(order(incl - 1) + 1);  // (incl = the group's first slot + 1)
     }
 };
@@ -1226,16 +1229,16 @@ struct AllHeadIn {
     const uint8_t* flags;
     __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return (flags[i] & 1) ? i + 1 : 0ull; }
 };
-template <typename V, typename R>
+template <typename SAW, typename R>
 struct IsaOut {
-    const V* sa;
+    SAW sa;
     const uint64_t* doc_start;
     int bits;
     uint64_t mask;
     R* rank;
     SlotOrder order;
     __device__ __forceinline__ void operator()(uint64_t i, uint64_t, uint64_t incl) const {
-        const V v = sa[i];
+        const auto v = sa.load(i);
         const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
         rank[doc_start[d] + d + off] = (R)(order(incl - 1) + 1);
     }
@@ -1256,7 +1259,7 @@ struct CompatBucket {
 };
 
 template <typename V>
-__global__ __launch_bounds__(320) void compat_bounds_kernel(const V* __restrict__ sa,
+__global__ __launch_bounds__(320) void compat_bounds_kernel(typename SaOf<V>::ptr sa,
                                                             const uint8_t* __restrict__ text,
                                                             const uint64_t* __restrict__ doc_start, int bits,
                                                             uint64_t mask, const CompatBucket* __restrict__ buckets,
@@ -1271,7 +1274,7 @@ __global__ __launch_bounds__(320) void compat_bounds_kernel(const V* __restrict_
     }
     while (lo < hi) {  // first slot whose symbol at `depth` is >= c
         const uint64_t mid = lo + (hi - lo) / 2;
-        const V e = sa[mid];
+        const auto e = sa[mid];
         const uint64_t d = (uint64_t)e & mask, off = (uint64_t)e >> bits;
         const uint64_t p = doc_start[d] + off + depth;
         const uint32_t sym = p == doc_start[d + 1] ? 0u : (uint32_t)text[p] + 1u;
@@ -1296,8 +1299,15 @@ __global__ __launch_bounds__(256) void compat_reverse_kernel(V* __restrict__ x, 
 
 // roots (optional): the bucket-wise build already laid its first-symbol buckets out in the reference's root order —
 // the walk starts one level down, with those buckets as nodes
+// (V = storage tag: uint32_t / uint64_t entries in sa_buf, or Packed40 — low words in sa_buf, high bytes in *sa_hi)
 template <typename V>
-void apply_reference_order(Index& ix, V* sa, const std::vector<CompatBucket>* roots = nullptr) {
+void apply_reference_order(Index& ix, DevBuf& sa_buf, DevBuf* sa_hi, const std::vector<CompatBucket>* roots = nullptr) {
+    constexpr bool PK = std::is_same<V, Packed40>::value;
+    using EV = typename std::conditional<PK, uint32_t, typename SaOf<V>::val>::type;  // element type of sa_buf
+    EV* sa = sa_buf.as<EV>();
+    typename SaOf<V>::ptr sa_r;
+    if constexpr (PK) sa_r = Sa40{sa_buf.as<uint32_t>(), sa_hi->as<uint8_t>()};
+    else sa_r = sa_buf.as<EV>();
     hipStream_t s = ix.stream;
     const uint64_t n = ix.size;
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
@@ -1315,8 +1325,11 @@ void apply_reference_order(Index& ix, V* sa, const std::vector<CompatBucket>* ro
     const int tprof = ix.prof.begin(s);
     auto reverse = [&](uint64_t at, uint64_t len) {
         if (len > 1) {
-            hipLaunchKernelGGL((compat_reverse_kernel<V>), dim3((unsigned)std::min<uint64_t>(ceil_div(len / 2, 256), 1u << 20)), dim3(256),
+            hipLaunchKernelGGL((compat_reverse_kernel<EV>), dim3((unsigned)std::min<uint64_t>(ceil_div(len / 2, 256), 1u << 20)), dim3(256),
                                0, s, sa + at, len);
+            if constexpr (PK)
+                hipLaunchKernelGGL((compat_reverse_kernel<uint8_t>), dim3((unsigned)std::min<uint64_t>(ceil_div(len / 2, 256), 1u << 20)),
+                                   dim3(256), 0, s, sa_hi->as<uint8_t>() + at, len);
             moved += len;
         }
     };
@@ -1325,7 +1338,7 @@ void apply_reference_order(Index& ix, V* sa, const std::vector<CompatBucket>* ro
         d_buckets.ensure(nb * sizeof(CompatBucket));
         d_bounds.ensure(nb * 258 * sizeof(uint64_t));
         CDB_HIP(hipMemcpyAsync(d_buckets.p, level.data(), nb * sizeof(CompatBucket), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL((compat_bounds_kernel<V>), dim3((unsigned)nb), dim3(320), 0, s, (const V*)sa, ix.d_text,
+        hipLaunchKernelGGL((compat_bounds_kernel<V>), dim3((unsigned)nb), dim3(320), 0, s, sa_r, ix.d_text,
                            (const uint64_t*)ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask,
                            (const CompatBucket*)d_buckets.as<CompatBucket>(), depth,
                            d_bounds.as<unsigned long long>());
@@ -1354,7 +1367,7 @@ void apply_reference_order(Index& ix, V* sa, const std::vector<CompatBucket>* ro
         ++depth;
     }
     ix.bstats.compat_depth = depth;
-    ix.prof.end(tprof, "sa_compat_rotate", 2 * moved * sizeof(V), s);
+    ix.prof.end(tprof, "sa_compat_rotate", 2 * moved * (PK ? 5 : sizeof(EV)), s);
     CDB_HIP(hipStreamSynchronize(s));
 }
 
@@ -1381,7 +1394,10 @@ struct CompatNode {
 
 // returns false (nothing done) when the scratch array cannot be had; sa_buf is replaced by the reordered array
 template <typename V>
-bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, const std::vector<CompatBucket>* roots = nullptr) {
+bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, DevBuf* sa_hi, const std::vector<CompatBucket>* roots = nullptr) {
+    constexpr bool PK = std::is_same<V, Packed40>::value;
+    using EV = typename std::conditional<PK, uint32_t, typename SaOf<V>::val>::type;  // element type of sa_buf
+    constexpr size_t ESZ = PK ? 5 : sizeof(EV);
     hipStream_t s = ix.stream;
     const uint64_t n = ix.size;
     const uint64_t chuck = std::max<uint64_t>(4096, n / 256);  // index.cpp:218
@@ -1389,15 +1405,21 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, const std::vector<Comp
     {   // only when the second array fits comfortably: a failed allocation would flush the block cache for nothing
         size_t fre = 0, tot = 0;
         CDB_HIP(hipMemGetInfo(&fre, &tot));
-        if ((double)n * sizeof(V) > 0.8 * ((double)fre + (double)DevPool::get().cached_bytes())) return false;
+        if ((double)n * ESZ > 0.8 * ((double)fre + (double)DevPool::get().cached_bytes())) return false;
+        // ... and only when the pool can hand it out as it stands (a cached block of that size, or untouched VRAM): a hipMalloc
+        // that fails first makes the pool return its whole cache to the driver — 2.5-5 s per 16 GiB build when it happened
+        if (!DevPool::get().can_serve(n * sizeof(EV), ix.device)) return false;
     }
-    DevBuf dst;
+    DevBuf dst, dst_hi;
     try {
-        dst.alloc(n * sizeof(V));
+        dst.alloc(n * sizeof(EV));
+        if (PK) dst_hi.alloc(n);
     } catch (const Error&) {
         return false;
     }
-    const V* sa = sa_buf.as<V>();
+    typename SaOf<V>::ptr sa;
+    if constexpr (PK) sa = Sa40{sa_buf.as<uint32_t>(), sa_hi->as<uint8_t>()};
+    else sa = sa_buf.as<EV>();
     std::vector<CompatNode> level{{0ull, (unsigned long long)n, 0ull}};
     std::vector<CompatSeg> segs;
     auto emit = [&](uint64_t src, uint64_t dstpos, uint64_t len) {
@@ -1474,9 +1496,12 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, const std::vector<Comp
         d_segs.alloc(segs.size() * sizeof(CompatSeg));
         CDB_HIP(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(CompatSeg), hipMemcpyHostToDevice, s));
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL((compat_segcopy_kernel<V>), dim3((unsigned)segs.size()), dim3(256), 0, s, sa, dst.as<V>(),
+        hipLaunchKernelGGL((compat_segcopy_kernel<EV>), dim3((unsigned)segs.size()), dim3(256), 0, s, (const EV*)sa_buf.as<EV>(), dst.as<EV>(),
                            (const CompatSeg*)d_segs.as<CompatSeg>());
-        ix.prof.end(t, "sa_compat_copy", 2 * n * sizeof(V), s);
+        if constexpr (PK)
+            hipLaunchKernelGGL((compat_segcopy_kernel<uint8_t>), dim3((unsigned)segs.size()), dim3(256), 0, s, (const uint8_t*)sa_hi->as<uint8_t>(),
+                               dst_hi.as<uint8_t>(), (const CompatSeg*)d_segs.as<CompatSeg>());
+        ix.prof.end(t, "sa_compat_copy", 2 * n * ESZ, s);
     }
     // the kept search keys make the same trip, so that probes on the reordered array can still be decided from
     // one load (query.hip follows the reference's probe sequence there, with the same comparisons)
@@ -1500,6 +1525,7 @@ bool apply_reference_order_oop(Index& ix, DevBuf& sa_buf, const std::vector<Comp
     }
     CDB_HIP(hipStreamSynchronize(s));
     sa_buf = std::move(dst);
+    if constexpr (PK) *sa_hi = std::move(dst_hi);
     return true;
 }
 
@@ -1521,7 +1547,7 @@ void build_typed(Index& ix, bool big) {
         // the previous suffix array and kept keys go back to the block cache first: a rebuild of the same
         // corpus shape then finds every buffer it needs there instead of asking the driver for fresh memory
         const double tf = now_ms();
-        ix.d_sa.release();
+        ix.release_sa();
         ix.drop_keys();
         ix.d_pivots.release();
         ix.pivot_levels = 0;
@@ -1712,6 +1738,8 @@ void build_typed(Index& ix, bool big) {
 
     // ---- 2 + 3. keys + entries, initial sort
     DevBuf sorted_keys, sa_buf, flags;
+    DevBuf sa_hi_buf;         // packed output (index_impl.h: Sa40): bits 32..39 of every entry; sa_buf then holds the low words
+    bool packed_out = false;
     struct Depth1Fold {
         uint64_t nend = 0, nlow = 0, nhigh = 0;
         bool fold = false, done = false;  // done: the segmented sort really wrote the bucket with its blocks swapped
@@ -2038,28 +2066,49 @@ void build_typed(Index& ix, bool big) {
             const double avail = (double)fre + (double)DevPool::get().cached_bytes();
             const int recb0 = 4 + (blow == 0 ? 1 : (blow == 8 ? 2 : 4)) + 4;
             // (no separate entry array: the last pass writes the finished entries over the record buffer it does not read)
-            fuse_rec = avail * 0.85 / (2.0 * recb0 + 1.0) >= (double)n;
+            fuse_rec = avail * 0.85 / (2.0 * recb0 + 1.0 + (sa_packable(ix) ? 1.0 : 0.0)) >= (double)n;
         }
+        // packed output (index_impl.h: Sa40): the last pass writes u32 low words over the KEY half it does not read and the high
+        // bytes into their own array — 5 instead of 8 bytes written per suffix, and the index keeps 5 n bytes instead of 8 n
+        const bool want_pack = sizeof(V) == 8 && sa_packable(ix);
         // (allocate the record buffers NOW: if the device cannot provide them after all — fragmentation, other handles —
         //  nothing has happened yet and the build takes partition + gather instead of failing)
-        DevBuf fr_kv[2], fr_w[2];
+        DevBuf fr_kv[2], fr_e[2], fr_w[2];
         if (fuse_rec) {
             const size_t auxb0 = blow == 0 ? 1 : (blow == 8 ? 2 : 4);
             try {
                 for (int q = 0; q < 2; ++q) {
-                    fr_kv[q].alloc(n * 2 * sizeof(uint32_t));
+                    if (want_pack) {  // key and entry halves as blocks of their own: the key half of the dead buffer BECOMES the array
+                        fr_kv[q].alloc(n * sizeof(uint32_t));
+                        fr_e[q].alloc(n * sizeof(uint32_t));
+                    } else {
+                        fr_kv[q].alloc(n * 2 * sizeof(uint32_t));
+                    }
                     fr_w[q].alloc(n * auxb0);
                 }
+                if (want_pack) sa_hi_buf.alloc(n);
             } catch (const std::exception&) {
                 for (int q = 0; q < 2; ++q) {
                     fr_kv[q].release();
+                    fr_e[q].release();
                     fr_w[q].release();
                 }
+                sa_hi_buf.release();
                 (void)hipGetLastError();
                 fuse_rec = false;
             }
         }
-        if (!fuse_rec) E.alloc(n * sizeof(V));
+        packed_out = fuse_rec && want_pack;
+        // partition + gather with packed output: the partitioned entries ARE stored packed from the start (E = low words,
+        // sa_hi_buf = bits 32..39): the gather reads them through Sa40, the last pass of every group writes the finished
+        // entries back in that form — 16 GiB of text: 80 instead of 128 GiB of suffix array, during the build and after it
+        const bool pack_E = !fuse_rec && want_pack && packed && ix.segmented_sort && rs_atomic_rank_ok(s);
+        if (pack_E) {
+            E.alloc(n * sizeof(uint32_t));
+            sa_hi_buf.alloc(n);
+        } else if (!fuse_rec) {
+            E.alloc(n * sizeof(V));
+        }
         st.alloc_ms += now_ms() - ta;
         st.fused_records = fuse_rec ? 1 : 0;
         DevBuf d_slotmap;
@@ -2071,6 +2120,7 @@ void build_typed(Index& ix, bool big) {
             gen.first_only = true;
             gen.symmap = d_symmap_first.as<uint16_t>();
             const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
+            if (pack_E) gen.vout_hi = sa_hi_buf.as<uint8_t>();
             (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
                                           &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
             radix_check_error(s, ix.rws);  // (the gathers below read the text through these entries)
@@ -2136,7 +2186,11 @@ void build_typed(Index& ix, bool big) {
             d_bstart.alloc((nb + 1) * 8);
             d_bounds.alloc(fuse_rec ? 8 : (size_t)nb * (nch + 1) * 8);
             CDB_HIP(hipMemcpyAsync(d_bstart.p, bstart.data(), (nb + 1) * 8, hipMemcpyHostToDevice, s));
-            if (!fuse_rec)
+            if (pack_E)
+            hipLaunchKernelGGL((sa_bucket_bounds_kernel<Packed40>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
+                               Sa40{E.as<uint32_t>(), sa_hi_buf.as<uint8_t>()}, (const unsigned long long*)d_bstart.as<unsigned long long>(), nb,
+                               nch, chunk, doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
+            else if (!fuse_rec)
             hipLaunchKernelGGL((sa_bucket_bounds_kernel<V>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
                                (const V*)E.as<V>(), (const unsigned long long*)d_bstart.as<unsigned long long>(), nb, nch, chunk,
                                doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
@@ -2160,7 +2214,25 @@ void build_typed(Index& ix, bool big) {
                 }
                 if (fuse_rec) seg_cap = n;  // (decided with the same bound before the entries were NOT partitioned)
             }
+            if (!fuse_rec && getenv("CDB_DEBUG_NO_SEGCAP")) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
+            if (pack_E && !seg_cap) {
+                // (a bucket larger than the record memory: the per-bucket forms below work on plain 8-byte entries)
+                if constexpr (sizeof(V) == 8) {
+                    DevBuf wide;
+                    wide.alloc(n * sizeof(uint64_t));
+                    Index tmp_view;  // (sa_expand wants an Index: borrow the two arrays for one call)
+                    tmp_view.stream = s;
+                    tmp_view.d_sa = std::move(E);
+                    tmp_view.d_sa_hi = std::move(sa_hi_buf);
+                    tmp_view.sa_packed = true;
+                    sa_expand(tmp_view, 0, n, wide.as<uint64_t>());
+                    CDB_HIP(hipStreamSynchronize(s));
+                    tmp_view.stream = nullptr;
+                    E = std::move(wide);
+                }
+            }
+            const bool pack_seg = pack_E && seg_cap;
             auto run_segmented = [&](auto wtag) {
                 using W = decltype(wtag);
                 if constexpr (sizeof(V) == 8) {
@@ -2216,7 +2288,12 @@ void build_typed(Index& ix, bool big) {
                         if (fuse_rec) {
                             kb[q] = std::move(fr_kv[q]);  // (allocated when the fused form was chosen: max_elems = n)
                             kbp[q] = kb[q].as<uint32_t>();
-                            ebp[q] = kbp[q] + max_elems;
+                            if (packed_out) {
+                                eb[q] = std::move(fr_e[q]);
+                                ebp[q] = eb[q].as<uint32_t>();
+                            } else {
+                                ebp[q] = kbp[q] + max_elems;
+                            }
                             wb[q] = std::move(fr_w[q]);
                             continue;
                         } else {
@@ -2267,6 +2344,14 @@ void build_typed(Index& ix, bool big) {
                         ix.prof.end(t, "sa_gather_plan", (uint64_t)g.cells * 24 + (g.elems / BR_ITEM) * sizeof(BucketItem), s);
                         t = ix.prof.begin(s);
                         static const unsigned gather_wgs = getenv("CDB_GATHER_WGS") ? (unsigned)std::atoi(getenv("CDB_GATHER_WGS")) : 256u * 8u;
+                        if (pack_seg)
+                        hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W, Packed40>), dim3(gather_wgs), dim3(256), 0, s,
+                                           Sa40{E.as<uint32_t>(), sa_hi_buf.as<uint8_t>()},
+                                           (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
+                                           (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
+                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>(),
+                                           getenv("CDB_GATHER_ABL") ? std::atoi(getenv("CDB_GATHER_ABL")) : 0);
+                        else
                         hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(gather_wgs), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
@@ -2278,7 +2363,15 @@ void build_typed(Index& ix, bool big) {
                                            (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
                         }
                         SegFinalArgs fin;
-                        fin.eout = (fuse_rec ? kb[dead].as<uint64_t>() : E.as<uint64_t>()) + g.gstart;
+                        if (pack_seg) {
+                            fin.elo = E.as<uint32_t>() + g.gstart;
+                            fin.ehi = sa_hi_buf.as<uint8_t>() + g.gstart;
+                        } else if (packed_out) {
+                            fin.elo = kbp[dead] + g.gstart;
+                            fin.ehi = sa_hi_buf.as<uint8_t>() + g.gstart;
+                        } else {
+                            fin.eout = (fuse_rec ? kb[dead].as<uint64_t>() : E.as<uint64_t>()) + g.gstart;
+                        }
                         fin.flags = flags.as<uint8_t>() + g.gstart;
                         fin.edges = edges.as<SegEdge>();
                         fin.hi_shift = blow;
@@ -2293,6 +2386,7 @@ void build_typed(Index& ix, bool big) {
                     }
                     CDB_HIP(hipStreamSynchronize(s));  // (h_segs and the group scratch go out of scope)
                     if (fuse_rec) E = std::move(kb[dead]);
+                    if (pack_seg) packed_out = true;
                     st.segmented = 1;
                 }
             };
@@ -2530,7 +2624,6 @@ void build_typed(Index& ix, bool big) {
         sorted_low.release();
     }
     st.free_ms += now_ms() - ta;
-    V* sa = sa_buf.as<V>();
 
     // ---- 4. refinement rounds
     // slot order of the array as the bucket-wise build laid it out -> plain unsigned order (ranks of prefix doubling)
@@ -2580,6 +2673,9 @@ void build_typed(Index& ix, bool big) {
     uint64_t cap = 0;
     DevBuf d_open;  // entries still unresolved after the last round (saves a full flag scan to learn "none")
     d_open.alloc(sizeof(uint64_t));
+    // (generic over the array's storage: SaRW<V> = plain entries, Sa40RW = packed 5-byte entries, index_impl.h)
+    auto refine = [&](auto sa) {
+    using SAW = decltype(sa);
     for (;;) {
         FlagIn fin{flags.as<uint8_t>()};
         if (st.rounds > 0) {
@@ -2612,7 +2708,7 @@ void build_typed(Index& ix, bool big) {
                 CDB_HIP(hipMemsetAsync(rank.p, 0, (n + D + 1) * sizeof(R), s));
                 AllHeadIn ain{flags.as<uint8_t>()};
                 (void)scan_totals<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0);
-                IsaOut<V, R> iout{sa, doc_start, (int)ix.bits, ix.mask, rank.as<R>(), order};
+                IsaOut<SAW, R> iout{sa, doc_start, (int)ix.bits, ix.mask, rank.as<R>(), order};
                 int t = ix.prof.begin(s);
                 scan_apply<uint64_t>(s, ix.scan_partials, ain, n, OpMax{}, (uint64_t)0, iout);
                 ix.prof.end(t, "sa_isa_init", n * (1 + sizeof(V) + sizeof(R)), s);
@@ -2635,7 +2731,7 @@ void build_typed(Index& ix, bool big) {
         }
         {
             int t = ix.prof.begin(s);
-            CompactOut<V, I> co{sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
+            CompactOut<SAW, I> co{sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
             hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
                                (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
             if (isa)
@@ -2660,12 +2756,12 @@ void build_typed(Index& ix, bool big) {
             if (isa) {
                 HeadIn<I> hin{nh.as<uint8_t>(), U.as<I>()};
                 (void)scan_totals<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0);
-                UpdateOut<V, I, R> uo{sval[rs].as<V>(), U.as<I>(), nh.as<uint8_t>(), m, doc_start, (int)ix.bits,
+                UpdateOut<SAW, I, R> uo{sval[rs].as<V>(), U.as<I>(), nh.as<uint8_t>(), m, doc_start, (int)ix.bits,
                                       ix.mask, hnew, sa, flags.as<uint8_t>(), rank.as<R>(), d_open.as<unsigned long long>(), order};
                 scan_apply<uint64_t>(s, ix.scan_partials, hin, m, OpMax{}, (uint64_t)0, uo);
                 st.dbl_rounds++;
             } else {
-                hipLaunchKernelGGL((sa_update_kernel<V, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
+                hipLaunchKernelGGL((sa_update_kernel<SAW, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[rs].as<V>(), (const I*)U.as<I>(), (const uint8_t*)nh.as<uint8_t>(), m,
                                    doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>(), d_open.as<unsigned long long>());
                 st.ext_rounds++;
@@ -2675,6 +2771,13 @@ void build_typed(Index& ix, bool big) {
         h = hnew;
         st.rounds++;
         if (st.rounds > 80) throw Error("suffix-array refinement did not converge (internal error)");
+    }
+    };
+    if constexpr (sizeof(V) == 8) {
+        if (packed_out) refine(Sa40RW{sa_buf.as<uint32_t>(), sa_hi_buf.as<uint8_t>()});
+        else refine(SaRW<V>{sa_buf.as<V>()});
+    } else {
+        refine(SaRW<V>{sa_buf.as<V>()});
     }
     if (ix.debug_fail_build) throw Error("debug: build failure requested (test hook)");
     if (ix.debug_starve_group == 1 && !ix.rws.plain_order) throw Error("radix sort look-back timed out (test hook)");
@@ -2710,12 +2813,19 @@ void build_typed(Index& ix, bool big) {
             folded_roots.swap(nodes);
         }
         const std::vector<CompatBucket>* roots = folded_roots.empty() ? nullptr : &folded_roots;
-        if (!apply_reference_order_oop<V>(ix, sa_buf, roots)) {
-            apply_reference_order<V>(ix, sa, roots);  // in place when no second array fits
-            ix.drop_keys();                           // ... which moves the entries away from their keys
-        }
+        auto reorder = [&](auto tag) {
+            using T = decltype(tag);
+            if (!apply_reference_order_oop<T>(ix, sa_buf, &sa_hi_buf, roots)) {
+                apply_reference_order<T>(ix, sa_buf, &sa_hi_buf, roots);  // in place when no second array fits
+                ix.drop_keys();                                           // ... which moves the entries away from their keys
+            }
+        };
+        if (packed_out) reorder(Packed40{});
+        else reorder(V{});
     }
     ix.d_sa = std::move(sa_buf);
+    ix.d_sa_hi = std::move(sa_hi_buf);
+    ix.sa_packed = packed_out;
 }
 
 }  // namespace
@@ -2750,7 +2860,7 @@ void build_suffix_array(Index& ix) {
             if (ix.rws.plain_order || std::strstr(e.what(), "look-back timed out") == nullptr) throw;
             (void)hipStreamSynchronize(ix.stream);
             ix.prof.resolve();
-            ix.d_sa.release();
+            ix.release_sa();
             ix.drop_keys();
             ix.rws.plain_order = true;
             if (!ix.debug_starve_group) rs_group_order_disable(ix.device);  // (the test hook leaves the device alone)
@@ -2762,7 +2872,7 @@ void build_suffix_array(Index& ix) {
         //  stream, so no other stream gets them before the kernels queued here have finished — common.h: DevPool)
         (void)hipStreamSynchronize(ix.stream);
         ix.prof.resolve();
-        ix.d_sa.release();
+        ix.release_sa();
         ix.drop_keys();
         ix.width = 0;  // back to "never built": queries answer {} instead of touching a half-built array
         ix.size = 0;
@@ -2770,6 +2880,17 @@ void build_suffix_array(Index& ix) {
     }
     CDB_HIP(hipStreamSynchronize(ix.stream));
     ix.prof.resolve();
+    // 8-byte entries below 2^40 are stored packed (index_impl.h: Sa40).  The fused bucket-wise build writes that form itself;
+    // the other paths with 8-byte entries (partition + gather, columns below 2^32 bytes with many documents) pack here
+    auto pack_now = [&]() {
+        if (sa_packable(ix) && !ix.sa_packed) {
+            int t = ix.prof.begin(ix.stream);
+            sa_pack_inplace(ix);
+            ix.prof.end(t, "sa_pack", ix.size * 13, ix.stream);
+            ix.prof.resolve();
+        }
+    };
+    pack_now();
     // Spot check of the finished array (verify.hip).  The stable ranking of the passes rests on observed LDS behaviour
     // (radix_sort.h: one-atomic ranking, self-tested per device); should a build ever come out wrong, this process
     // switches the device to the ballot ranking, rebuilds once, and fails loudly if that does not help either.
@@ -2791,23 +2912,24 @@ void build_suffix_array(Index& ix) {
             const bool was_atomic = rs_atomic_rank_ok(ix.stream);
             if (was_atomic && !ix.debug_fail_self_check) rs_atomic_rank_disable(ix.device);  // (the test hook leaves the device alone)
             ix.self_check_fallbacks += 1;
-            ix.d_sa.release();  // (the failed array and its keys go first: the rebuild needs their memory on large corpora)
+            ix.release_sa();  // (the failed array and its keys go first: the rebuild needs their memory on large corpora)
             ix.drop_keys();
             try {
                 run();
                 CDB_HIP(hipStreamSynchronize(ix.stream));
                 ix.prof.resolve();
+                pack_now();
             } catch (...) {
                 (void)hipStreamSynchronize(ix.stream);
                 ix.prof.resolve();
-                ix.d_sa.release();
+                ix.release_sa();
                 ix.drop_keys();
                 ix.width = 0;
                 ix.size = 0;
                 throw;
             }
             if (!check()) {
-                ix.d_sa.release();
+                ix.release_sa();
                 ix.drop_keys();
                 ix.width = 0;
                 ix.size = 0;

@@ -12,7 +12,7 @@ namespace cdb {
 namespace {
 
 template <typename V>
-__global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void sa_verify_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                         const uint8_t* __restrict__ text,
                                                         const uint64_t* __restrict__ doc_start, uint64_t ndocs,
                                                         int bits, uint64_t mask, unsigned long long* __restrict__ out) {
@@ -22,13 +22,13 @@ __global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa
     unsigned long long inv = 0, tie = 0, sum = 0, bad = 0;
     const uint64_t stride = (uint64_t)gridDim.x * 256;  // grid-stride: n may exceed 2^32 threads
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const V eb = sa[i];
+        const auto eb = sa[i];
         const uint64_t db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
         sum += (unsigned long long)eb;
         if (db >= ndocs || ob >= doc_start[db + 1] - doc_start[db]) {
             bad += 1;
         } else if (i > 0) {
-            const V ea = sa[i - 1];
+            const auto ea = sa[i - 1];
             const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits;
             if (da < ndocs && oa < doc_start[da + 1] - doc_start[da]) {
                 const uint8_t* pa = text + doc_start[da] + oa;
@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void sa_verify_kernel(const V* __restrict__ sa
 }
 
 template <typename V>
-__global__ __launch_bounds__(256) void sa_entry_check_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void sa_entry_check_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                              const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
                                                              uint64_t mask, unsigned long long* __restrict__ bad) {
     unsigned long long b = 0;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const V e = sa[i];
+        const auto e = sa[i];
         const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
         if (d >= ndocs || o >= doc_start[d + 1] - doc_start[d]) b += 1;
     }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void sa_entry_check_kernel(const V* __restrict
 // first differing bytes of the same sign class ascend; a byte >= 0x80 against one < 0x80 must ascend only when the array
 // is in plain unsigned order (`plain`), otherwise that pair is skipped (the reference's order depends on bucket sizes).
 template <typename V>
-__global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict__ sa, uint64_t n,
+__global__ __launch_bounds__(256) void sa_spot_check_kernel(typename SaOf<V>::ptr sa, uint64_t n,
                                                             const uint8_t* __restrict__ text,
                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
                                                             uint64_t mask, uint32_t samples, uint64_t seed, bool plain,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict_
         h ^= h >> 31;
         i = 1 + h % (n - 1);
     }
-    const V ea = sa[i - 1], eb = sa[i];
+    const auto ea = sa[i - 1], eb = sa[i];
     const uint64_t da = (uint64_t)ea & mask, oa = (uint64_t)ea >> bits, db = (uint64_t)eb & mask, ob = (uint64_t)eb >> bits;
     if (da >= ndocs || db >= ndocs || oa >= doc_start[da + 1] - doc_start[da] || ob >= doc_start[db + 1] - doc_start[db]) {
         ninvalid += 1;
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(const V* __restrict_
 // of the l-prefix bucket is found by galloping outwards from the pair until the prefix no longer matches.
 template <typename V>
 struct RefOrderCtx {
-    const V* sa;
+    typename SaOf<V>::ptr sa;
     uint64_t n;
     const uint8_t* text;
     const uint64_t* doc_start;
     int bits;
     uint64_t mask;
     __device__ __forceinline__ void suffix(uint64_t i, const uint8_t*& p, uint64_t& len) const {
-        const V e = sa[i];
+        const auto e = sa[i];
         const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
         p = text + doc_start[d] + o;
         len = doc_start[d + 1] - doc_start[d] - o;
@@ -241,13 +241,11 @@ void verify_reference_order(Index& ix, uint64_t out[4]) {
     const uint64_t chuck = std::max<uint64_t>(4096, ix.size / 256);  // index.cpp:218
     if (ix.size > 1) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 20);
-        if (ix.width == 4) {
-            RefOrderCtx<uint32_t> c{ix.d_sa.as<uint32_t>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
-            hipLaunchKernelGGL((sa_verify_reference_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, c, chuck, d_out.as<unsigned long long>());
-        } else {
-            RefOrderCtx<uint64_t> c{ix.d_sa.as<uint64_t>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
-            hipLaunchKernelGGL((sa_verify_reference_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, c, chuck, d_out.as<unsigned long long>());
-        }
+        sa_dispatch(ix, [&](auto tag) {
+            using T = decltype(tag);
+            RefOrderCtx<T> c{ix.sa_view<T>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
+            hipLaunchKernelGGL((sa_verify_reference_kernel<T>), dim3(grid), dim3(256), 0, s, c, chuck, d_out.as<unsigned long long>());
+        });
     }
     CDB_HIP(hipMemcpyAsync(out, d_out.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
@@ -283,16 +281,52 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
     CDB_HIP(hipMemsetAsync(d_out.p, 0, 2 * sizeof(uint64_t), s));
     // samples == 0: every adjacent pair (grid-stride sweep)
     const unsigned grid = samples ? (unsigned)ceil_div(samples, 256) : (unsigned)std::min<uint64_t>(ceil_div(ix.size - 1, 256), 1u << 16);
-    if (ix.width == 4)
-        hipLaunchKernelGGL((sa_spot_check_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
-                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask,
-                           samples, ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
-    else
-        hipLaunchKernelGGL((sa_spot_check_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(),
-                           ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask,
-                           samples, ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
+    sa_dispatch(ix, [&](auto tag) {
+        using T = decltype(tag);
+        hipLaunchKernelGGL((sa_spot_check_kernel<T>), dim3(grid), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
+                           (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, samples,
+                           ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
+    });
     CDB_HIP(hipMemcpyAsync(out, d_out.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
+}
+
+// ---- packed storage (index_impl.h: Sa40) <-> the reference's u64 entries ---------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sa_expand_kernel(Sa40 sa, uint64_t first, uint64_t cnt, uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += stride) out[i] = sa[first + i];
+}
+__global__ __launch_bounds__(256) void sa_pack_kernel(const uint64_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ lo,
+                                                      uint8_t* __restrict__ hi) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const uint64_t e = in[i];
+        lo[i] = (uint32_t)e;
+        hi[i] = (uint8_t)(e >> 32);
+    }
+}
+}  // namespace
+
+// entries [first, first + cnt) of a packed index as u64 in d_out (cdb_sa_copy, cdb_save)
+void sa_expand(Index& ix, uint64_t first, uint64_t cnt, uint64_t* d_out) {
+    if (!cnt) return;
+    hipLaunchKernelGGL(sa_expand_kernel, dim3((unsigned)std::min<uint64_t>(ceil_div(cnt, 256), 1u << 16)), dim3(256), 0, ix.stream,
+                       ix.sa_view<Packed40>(), first, cnt, d_out);
+}
+// ix.d_sa holds size u64 entries below 2^40 (cdb_load; builds that could not write the packed form themselves): store them
+// packed.  Costs one sweep (8 B read, 5 B written per entry); the u64 block goes back to the pool.
+void sa_pack_inplace(Index& ix) {
+    if (ix.sa_packed || ix.width != 8 || !ix.size) return;
+    DevBuf lo, hi;
+    lo.alloc(ix.size * sizeof(uint32_t));
+    hi.alloc(ix.size);
+    hipLaunchKernelGGL(sa_pack_kernel, dim3((unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16)), dim3(256), 0, ix.stream,
+                       (const uint64_t*)ix.d_sa.as<uint64_t>(), ix.size, lo.as<uint32_t>(), hi.as<uint8_t>());
+    CDB_HIP(hipStreamSynchronize(ix.stream));
+    ix.d_sa = std::move(lo);
+    ix.d_sa_hi = std::move(hi);
+    ix.sa_packed = true;
 }
 
 void verify_suffix_array(Index& ix, uint64_t out[5]) {
@@ -302,14 +336,11 @@ void verify_suffix_array(Index& ix, uint64_t out[5]) {
     CDB_HIP(hipMemsetAsync(d_out.p, 0, 4 * sizeof(uint64_t), s));
     if (ix.size) {
         const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 22);
-        if (ix.width == 4)
-            hipLaunchKernelGGL((sa_verify_kernel<uint32_t>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ix.d_sa.as<uint32_t>(),
-                               ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits,
-                               ix.mask, d_out.as<unsigned long long>());
-        else
-            hipLaunchKernelGGL((sa_verify_kernel<uint64_t>), dim3(grid), dim3(256), 0, s, (const uint64_t*)ix.d_sa.as<uint64_t>(),
-                               ix.size, ix.d_text, (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits,
-                               ix.mask, d_out.as<unsigned long long>());
+        sa_dispatch(ix, [&](auto tag) {
+            using T = decltype(tag);
+            hipLaunchKernelGGL((sa_verify_kernel<T>), dim3(grid), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
+                               (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, d_out.as<unsigned long long>());
+        });
     }
     CDB_HIP(hipMemcpyAsync(out, d_out.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));

@@ -133,6 +133,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     if rng.random() < 0.3: opts["force_doubling"] = 1
     if rng.random() < 0.2: opts["reference_compat"] = 0
     if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
+    if rng.random() < 0.3: opts["pack_sa"] = 0          # (plain 8-byte storage; default: packed 5-byte storage)
     g = capi.GpuStringIndex()
     for k, v in opts.items():
         g.set_option(k, v)

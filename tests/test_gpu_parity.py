@@ -678,6 +678,66 @@ def test_build_self_check_and_its_fallback(G):
         assert g2.stat("self_check_fallbacks") == 1
 
 
+def test_packed_suffix_array_storage(G, tmp_path):
+    # 8-byte entries whose bits lie below 2^40 are STORED as u32 low words + u8 high bytes (5 instead of 8 bytes per suffix,
+    # index_impl.h: Sa40); cdb_sa_copy / cdb_save hand out the reference's u64 entries (index.cpp:203-208) either way.
+    # Same array and rows with pack_sa = 0 and 1 — through the fused bucket-wise build (which writes the packed form itself),
+    # partition + gather, the small path with many documents (packed at the end), bytes >= 0x80 (reference order: the block
+    # copies move both halves), duplicates (prefix doubling writes through the packed accessor) — and across save / load
+    def corpus(seed, lo, hi, dup=False):
+        lens = (W.random_bytes(40000, seed, 0, 5)).astype(np.uint64)        # 40000 tiny documents (16 bits) ...
+        lens[321] = 70000                                                    # ... and one of 70000 bytes (17 bits): 8-byte entries
+        ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        blob = W.random_bytes(int(ds[-1]), seed + 1, lo, hi)
+        if dup:
+            third = len(blob) // 3
+            blob[third:2 * third] = blob[:third]                             # equal suffixes across documents: groups that never resolve
+        return blob, ds
+    cases = [
+        (corpus(3, 0x61, 0x66), dict()),                                     # below 2^32: packed at the end of the build
+        (corpus(5, 0x61, 0x64), dict(force_big_path=1)),                     # fused records: the last pass writes the packed form
+        (corpus(5, 0x61, 0x64), dict(force_big_path=1, fuse_records=0)),     # partition + gather
+        (corpus(7, 0x00, 0xFF), dict(force_big_path=1)),                     # all byte values
+        (corpus(9, 0x70, 0x90), dict(force_big_path=1)),                     # bytes on both sides of 0x80: reference order
+        (corpus(9, 0x70, 0x90), dict(force_big_path=1, fold_root=0, fold_depth1=0)),   # ... by the block copies afterwards
+        (corpus(11, 0x61, 0x62, dup=True), dict(force_big_path=1, force_doubling=1)),  # prefix doubling through the accessor
+        (corpus(11, 0x61, 0x63, dup=True), dict(force_big_path=1)),
+    ]
+    for (blob, ds), opts in cases:
+        nd = len(ds) - 1
+        ids = np.arange(nd, dtype=np.int64) * (1 << 33) + 5          # (object ids are unrelated to the entry width)
+        pats = W.sample_patterns(blob, ds, 150, 1, 6, seed=2, miss_frac=0.1)
+        g1, o = _check_parity(G, blob, ds, ids=ids, patterns=pats, **opts)
+        assert g1.sa_width == 8 and g1.stat("sa_packed") == 1 and g1.stat("sa_bytes_per_entry") == 5, opts
+        g0, _ = _check_parity(G, blob, ds, ids=ids, patterns=pats, pack_sa=0, **opts)
+        assert g0.stat("sa_packed") == 0 and np.array_equal(g0.sa(), g1.sa())
+        for kw in (b"a", b"ab", bytes(blob[5:9]), bytes(blob[120000:120007])):
+            assert g1.query(kw) == g0.query(kw) == o.query(kw)
+        if opts.get("fuse_records") == 0:
+            # a bucket that does not fit the record memory sends the partitioned (packed) entries back to plain 8-byte form
+            # for the per-bucket sorts (test hook); the array is packed at the end of the build instead
+            os.environ["CDB_DEBUG_NO_SEGCAP"] = "1"
+            try:
+                g4, _ = _check_parity(G, blob, ds, ids=ids, patterns=pats, **opts)
+            finally:
+                del os.environ["CDB_DEBUG_NO_SEGCAP"]
+            assert g4.stat("sa_packed") == 1 and g4.stat("segmented") == 0 and np.array_equal(g4.sa(), g1.sa())
+        if "fuse_records" in opts or "fold_root" in opts:
+            continue                                                     # (save / load once per storage path is enough)
+        path = str(tmp_path / "packed.cdb")
+        g1.save(path)
+        g2 = G()
+        g2.load(path)
+        assert g2.stat("sa_packed") == 1 and np.array_equal(g2.sa(), g1.sa())
+        rp, gi, gc, hits = g2.query_batch(*pats)
+        orp, oi, oc, ohits = o.query_batch(*pats, nthreads=2)
+        assert hits == ohits and np.array_equal(rp, orp) and np.array_equal(gi, oi) and np.array_equal(gc, oc)
+        g3 = G()
+        g3.set_option("pack_sa", 0)
+        g3.load(path)
+        assert g3.stat("sa_packed") == 0 and np.array_equal(g3.sa(), g1.sa())
+
+
 def test_failed_build_leaves_index_unbuilt(G):
     # a build that cannot complete (test hook: it throws after its sorts) must leave a queryable "never built" index
     # behind, not a half-built one

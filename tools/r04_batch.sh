@@ -1,5 +1,2 @@
-export CDB_BENCH_TRACE=1
-for i in $(seq 1 70); do
-python bench.py --gpus 2 --backend gloo --share-gpu --workload mid --steps 2 --warmup 1 --configs none --no-cpu-baseline > gpurun_out/r04_sl_x.json 2> gpurun_out/r04_sl_x.err; rc=$?; fb=$(grep -c 'group_fallbacks 1' gpurun_out/r04_sl_x.err); if [ $rc != 0 ] || [ $fb != 0 ]; then echo "run $i rc=$rc t=$SECONDS fallbacks=$fb"; grep "bench rank\|fault\|rror" gpurun_out/r04_sl_x.err | tail -14; cp gpurun_out/r04_sl_x.err gpurun_out/r04_sl_fail_$i.err; fi
-done
-echo "done t=$SECONDS"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -12 | cut -c1-700
+python bench.py --cpu-full-budget 0 --no-cold-start --no-pcie --configs c4shard > gpurun_out/r04_bench5.json 2> gpurun_out/r04_bench5.err; tail -c 200 gpurun_out/r04_bench5.json; tail -3 gpurun_out/r04_bench5.err
