@@ -1661,6 +1661,27 @@ void build_typed(Index& ix, bool big) {
                 break;
             }
         }
+        // Bucket-wise build: one symbol fewer can save a whole radix pass AND a narrower auxiliary word in every record (16 GiB of
+        // UTF-8: 7 symbols = 6 passes over 12-byte records, 6 symbols = 5 passes over 10-byte records), which is worth more than
+        // the refinement of the extra unresolved suffixes as long as those stay few.  Compared in bytes moved per suffix:
+        // passes x 2 x record bytes against (unresolved share) x ~2000 B — what a text-extension round costs per unresolved
+        // suffix (compaction, a 64-bit sort, gathers; measured on that corpus: 694 instead of 729 ms with 1.9 % unresolved).
+        if (big && ix.key_cost_model && nsym >= 3 && sizeof(V) == 8) {
+            auto plan_bytes = [&](int k) -> double {
+                unsigned __int128 v = 1;
+                for (int i = 0; i + 1 < k; ++i) {
+                    v *= (unsigned)(sigma + 1);
+                    if (v > ((unsigned __int128)1 << 56)) return 1e9;
+                }
+                const int bb = bit_width64((uint64_t)(v - 1));
+                const int w = bb <= 32 ? 1 : (bb <= 40 ? 2 : 4);
+                return (double)std::max(1, (bb + 7) / 8) * 2.0 * (8.0 + w);
+            };
+            const double refine_bytes = 2000.0;
+            const int k1 = nsym - 1;
+            const double u0 = (double)n * ((double)h_eq[nsym] / pairs), u1 = (double)n * ((double)h_eq[k1] / pairs);
+            if (u1 <= 1.0 / 40.0 && plan_bytes(k1) + u1 * refine_bytes < plan_bytes(nsym) + u0 * refine_bytes) nsym = k1;
+        }
     } else {
         double pc = 0;
         for (int b = 0; b < 256; ++b) {
