@@ -1528,6 +1528,17 @@ int cdb_debug_verify(cdb_index* h, uint64_t out[5]) {
     });
 }
 
+int cdb_debug_self_check(cdb_index* h, int full, uint64_t out[2]) {
+    if (!h || !out) return CDB_E_INVALID;
+    return guarded(h, [&] {
+        Index& ix = h->ix;
+        std::lock_guard<std::mutex> g(ix.mu);
+        DeviceScope dscope(ix);
+        if (ix.width == 0) throw Error("index has not been built");
+        spot_check_suffix_array(ix, full ? 0u : (uint32_t)std::min<uint64_t>(1u << 15, ix.size > 1 ? ix.size - 1 : 1), out);
+    });
+}
+
 int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]) {
     if (!h || !out) return CDB_E_INVALID;
     return guarded(h, [&] {

@@ -122,6 +122,102 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(typename SaOf<V>::pt
     if (ninvalid) atomicAdd(&out[1], ninvalid);
 }
 
+// The FULL sweep (self_check = 2) by the same rules, laid out for throughput: every lane fetches ONE suffix — its entry, the
+// document bounds and the first 16 bytes as two big-endian words — and gets its left neighbour's through a lane shuffle, so a
+// pair costs one random 64-byte sector instead of two and is decided by two 64-bit compares; only pairs that agree on
+// 16 bytes walk on byte by byte (and the first lane of a wavefront fetches its neighbour itself).
+struct SfxHead {
+    uint64_t w0, w1;   // first 16 bytes, big-endian, bytes behind the suffix's end are 0
+    uint64_t len, doc, pos;
+    uint32_t ok;
+};
+template <typename V>
+__device__ __forceinline__ SfxHead sfx_head(typename SaOf<V>::ptr sa, uint64_t i, uint64_t n, const uint8_t* __restrict__ text,
+                                            const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits, uint64_t mask) {
+    SfxHead h{0, 0, 0, 0, 0, 0u};
+    const auto e = sa[i];
+    const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
+    if (d >= ndocs) return h;
+    const uint64_t ds = doc_start[d], de = doc_start[d + 1];
+    if (o >= de - ds) return h;
+    h.ok = 1u;
+    h.doc = d;
+    h.pos = ds + o;
+    h.len = de - h.pos;
+    typedef uint64_t __attribute__((aligned(1))) u64u;
+    uint64_t a = 0, b = 0;
+    if (h.pos + 16 <= n) {
+        a = __builtin_bswap64(*reinterpret_cast<const u64u*>(text + h.pos));
+        b = __builtin_bswap64(*reinterpret_cast<const u64u*>(text + h.pos + 8));
+    } else {
+        for (uint64_t k = 0; k < 16 && h.pos + k < n; ++k) {
+            const uint64_t c = text[h.pos + k];
+            if (k < 8) a |= c << (56 - 8 * k); else b |= c << (56 - 8 * (k - 8));
+        }
+    }
+    if (h.len < 16) {  // bytes behind the end of the suffix (the next document's) do not count
+        if (h.len <= 8) {
+            b = 0;
+            a = h.len == 8 ? a : (a & ~(~0ull >> (8 * h.len)));
+        } else {
+            b &= ~(~0ull >> (8 * (h.len - 8)));
+        }
+    }
+    h.w0 = a;
+    h.w1 = b;
+    return h;
+}
+template <typename V>
+__global__ __launch_bounds__(256) void sa_full_check_kernel(typename SaOf<V>::ptr sa, uint64_t n, const uint8_t* __restrict__ text,
+                                                            const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
+                                                            uint64_t mask, bool plain, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    unsigned long long nbad = 0, ninvalid = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < n; base += stride) {  // (uniform trip count: the shuffles need every lane)
+        const uint64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        SfxHead b = valid ? sfx_head<V>(sa, i, n, text, doc_start, ndocs, bits, mask) : SfxHead{0, 0, 0, 0, 0, 0u};
+        if (valid && !b.ok) ninvalid += 1;
+        SfxHead a;
+        a.w0 = __shfl_up(b.w0, 1);
+        a.w1 = __shfl_up(b.w1, 1);
+        a.len = __shfl_up(b.len, 1);
+        a.doc = __shfl_up(b.doc, 1);
+        a.pos = __shfl_up(b.pos, 1);
+        a.ok = __shfl_up(b.ok, 1);
+        if (lane == 0 && valid && i > 0) a = sfx_head<V>(sa, i - 1, n, text, doc_start, ndocs, bits, mask);
+        if (!valid || i == 0 || !a.ok || !b.ok) continue;
+        const uint64_t len = a.len < b.len ? a.len : b.len;
+        bool bad = false;
+        if (a.w0 != b.w0 || a.w1 != b.w1) {
+            // first differing byte (inside min(len, 16) bytes unless one suffix ends first: its padding is 0 there)
+            const uint64_t x = a.w0 != b.w0 ? a.w0 : a.w1, y = a.w0 != b.w0 ? b.w0 : b.w1;
+            const uint32_t byte = (uint32_t)__builtin_clzll(x ^ y) >> 3;
+            const uint64_t l = (a.w0 != b.w0 ? 0u : 8u) + byte;
+            if (l >= len) {  // one is a prefix of the other: the shorter one must come first
+                bad = a.len > b.len;
+            } else {
+                const uint32_t ca = (uint32_t)(x >> (56 - 8 * byte)) & 0xFFu, cb = (uint32_t)(y >> (56 - 8 * byte)) & 0xFFu;
+                bad = ca > cb && (plain || ((ca ^ cb) & 0x80u) == 0);
+            }
+        } else if (len <= 16) {  // equal through the end of the shorter one
+            bad = a.len > b.len || (a.len == b.len && a.doc >= b.doc);
+        } else {  // 16 equal bytes: walk on (long common prefixes — duplicate documents — are taken on trust beyond 4096)
+            const uint8_t* pa = text + a.pos;
+            const uint8_t* pb = text + b.pos;
+            const uint64_t cap = len < 4096 ? len : 4096;
+            uint64_t l = 16;
+            while (l < cap && pa[l] == pb[l]) ++l;
+            if (l == len) bad = a.len > b.len || (a.len == b.len && a.doc >= b.doc);
+            else if (l < cap) bad = pa[l] > pb[l] && (plain || ((pa[l] ^ pb[l]) & 0x80u) == 0);
+        }
+        if (bad) nbad += 1;
+    }
+    if (nbad) atomicAdd(&out[0], nbad);
+    if (ninvalid) atomicAdd(&out[1], ninvalid);
+}
+
 // ---- the REFERENCE's order --------------------------------------------------------------
 // For text with bytes >= 0x80 the reference's array is not globally sorted: a radix node (bucket of more than
 // chuck_size = max(4096, n / 256) suffixes, index.cpp:96-126,218) lays its children out by
@@ -281,6 +377,15 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
     CDB_HIP(hipMemsetAsync(d_out.p, 0, 2 * sizeof(uint64_t), s));
     // samples == 0: every adjacent pair (grid-stride sweep)
     const unsigned grid = samples ? (unsigned)ceil_div(samples, 256) : (unsigned)std::min<uint64_t>(ceil_div(ix.size - 1, 256), 1u << 16);
+    if (!samples) {
+        sa_dispatch(ix, [&](auto tag) {
+            using T = decltype(tag);
+            const unsigned g2 = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16);
+            hipLaunchKernelGGL((sa_full_check_kernel<T>), dim3(g2), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
+                               (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, ix.sa_sorted,
+                               d_out.as<unsigned long long>());
+        });
+    } else
     sa_dispatch(ix, [&](auto tag) {
         using T = decltype(tag);
         hipLaunchKernelGGL((sa_spot_check_kernel<T>), dim3(grid), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,

@@ -370,6 +370,9 @@ int cdb_debug_verify(cdb_index* h, uint64_t out[5]);
  * ascending by document.  On pure-ASCII text, or with reference_compat = 0 on text without big mixed buckets, it
  * degenerates to the plain sortedness check. */
 int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]);
+/* Test hook: the check every build ends with (option self_check), run on the index as it stands — on 2^15 random adjacent
+ * pairs, or (full != 0) on every adjacent pair.  out[0] = pairs out of order, out[1] = entries that are no valid (doc, off). */
+int cdb_debug_self_check(cdb_index* h, int full, uint64_t out[2]);
 
 /* Test hook for the radix-sort primitive (tests/test_gpu_sort.py, tools/sort_bench.py): stable sort of
  * n 64-bit keys (+ optional 4- or 8-byte values, val_bytes = 0/4/8) held in DEVICE memory by key bits

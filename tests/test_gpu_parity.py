@@ -738,6 +738,60 @@ def test_packed_suffix_array_storage(G, tmp_path):
         assert g3.stat("sa_packed") == 0 and np.array_equal(g3.sa(), g1.sa())
 
 
+def test_full_self_check_finds_what_a_sample_can_miss(G, tmp_path):
+    # the full sweep (self_check = 2) against deliberately damaged arrays: ONE swapped adjacent pair, one duplicated entry and
+    # one entry that names no (document, offset) — each must be reported by the sweep (a 2^15-pair sample of 10^5.6 pairs may
+    # or may not see it); the undamaged array must come out clean.  Plain 4-byte, plain 8-byte and packed storage.
+    import struct
+    lens = (W.random_bytes(30000, 3, 1, 24)).astype(np.uint64)
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = W.random_bytes(int(ds[-1]), 4, 0x61, 0x68)
+    lens8 = lens.copy()
+    lens8[77] = 70000                                           # (8-byte entries)
+    ds8 = np.concatenate([[0], np.cumsum(lens8)]).astype(np.uint64)
+    blob8 = W.random_bytes(int(ds8[-1]), 5, 0x61, 0x68)
+    for (b_, d_), opts in (((blob, ds), {}), ((blob8, ds8), {}), ((blob8, ds8), {"pack_sa": 0})):
+        nd = len(d_) - 1
+        g = G()
+        for k, v in opts.items():
+            g.set_option(k, v)
+        g.add_bulk(np.arange(nd, dtype=np.int64), b_, d_)
+        g.build()
+        assert g.self_check(full=True) == (0, 0) and g.self_check() == (0, 0)
+        path = str(tmp_path / "sc.cdb")
+        g.save(path)
+        raw = bytearray(open(path, "rb").read())
+        w = g.sa_width
+        sa_off = len(raw) - g.size * w                          # (the entries are the file's tail)
+        fmt = "<I" if w == 4 else "<Q"
+
+        def entry(i):
+            return struct.unpack_from(fmt, raw, sa_off + i * w)[0]
+
+        def put(i, v):
+            struct.pack_into(fmt, raw, sa_off + i * w, v)
+        sa = g.sa()
+        k = next(i for i in range(1000, g.size - 1) if True)    # any slot: adjacent suffixes of this text always differ
+        for name, damage in (("swap", lambda: (put(k, int(sa[k + 1])), put(k + 1, int(sa[k])))),
+                             ("duplicate", lambda: put(k, int(sa[k + 7]))),
+                             ("no such document", lambda: put(k, int(g.mask)))):
+            saved = entry(k), entry(k + 1)
+            damage()
+            bad_path = str(tmp_path / "bad.cdb")
+            open(bad_path, "wb").write(bytes(raw))
+            put(k, saved[0]); put(k + 1, saved[1])
+            h = G()
+            for kk, v in opts.items():
+                h.set_option(kk, v)
+            try:
+                h.load(bad_path)
+            except RuntimeError:
+                assert name == "no such document"                # (cdb_load refuses entries that name nothing)
+                continue
+            wrong, invalid = h.self_check(full=True)
+            assert wrong + invalid >= 1, (name, opts)
+
+
 def test_failed_build_leaves_index_unbuilt(G):
     # a build that cannot complete (test hook: it throws after its sorts) must leave a queryable "never built" index
     # behind, not a half-built one

@@ -27,7 +27,7 @@ for i in range(builds):
     free, total = torch.cuda.mem_get_info()
     print(json.dumps({"build": i, "wall_ms": round(wall, 1), "build_ms": round(g.stat("build_ms"), 1), "alloc_ms": round(g.stat("alloc_ms"), 1),
                       "free_ms": round(g.stat("free_ms"), 1), "kernels_ms": round(sum(v["ms"] for v in prof.values()), 1),
-                      "groups": g.stat("bucket_groups"), "fused": g.stat("fused_records"), "packed": g.stat("sa_packed"),
+                      "self_check_ms": round(g.stat("self_check_ms"), 2), "self_check_pairs": g.stat("self_check_pairs"), "groups": g.stat("bucket_groups"), "fused": g.stat("fused_records"), "packed": g.stat("sa_packed"),
                       "mem": dict(zip(("in_use", "peak", "cached"), [round(x / 2**30, 1) for x in capi.memory_stats()])),
                       "device_free_GiB": round(free / 2**30, 1)}), flush=True)
 g.close()
