@@ -158,7 +158,8 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
     // (the gather of scattered 1 KiB strings runs at ~5 GB/s per host thread: four threads would make it — not the PCIe link
     //  at ~52 GB/s — the bound of the shim's build(); up to twelve keep the link busy)
     const int hw = (int)std::thread::hardware_concurrency();
-    const int T = bytes >= 4 * CHUNK ? std::max(4, std::min({12, hw / 2, (int)(bytes / (2 * CHUNK))})) : 1;
+    static const int t_env = getenv("CDB_UPLOAD_THREADS") ? std::atoi(getenv("CDB_UPLOAD_THREADS")) : 0;  // (measurements)
+    const int T = bytes >= 4 * CHUNK ? std::max(4, std::min({t_env > 0 ? t_env : 12, hw / 2, (int)(bytes / (2 * CHUNK))})) : 1;
     const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
     std::string failure;
     std::mutex fmu;

@@ -1870,27 +1870,58 @@ __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __res
         const SegInfo si = segs[g];
         const uint64_t base = si.begin + (uint64_t)(t - si.tile_begin) * RS_SEG_TILE;
         const uint32_t valid = (uint32_t)((si.end - base) < (uint64_t)RS_SEG_TILE ? (si.end - base) : (uint64_t)RS_SEG_TILE);
+        // 16-byte loads (four records per lane and instruction; round 4: 4-byte loads left the sweep issue-bound at 3.4 TB/s):
+        // the tile's records [base, end) = up to three in front of the first 4-aligned index, whole quads, up to three behind
+        auto count = [&](uint32_t k, uint32_t a) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // 16 records per thread, four loads in flight
-            uint32_t k[4], a[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
-                k[q] = li < valid ? keys[base + li] : 0u;
-                a[q] = (li < valid && lead > 0) ? (uint32_t)aux[base + li] : 0u;
+            for (int p = 0; p < 8; ++p) {
+                if (p < npass) {
+                    const uint32_t dg = p < lead ? (a >> (8 * p)) & 0xFFu : (k >> (8 * (p - lead))) & 0xFFu;
+                    atomicAdd(&sh[p][dg], 1u);
+                }
             }
+        };
+        const uint64_t end = base + valid;
+        const uint64_t a0 = (base + 3) & ~3ull;  // (the arrays are 256-byte aligned blocks: index alignment = address alignment)
+        const uint64_t q0 = a0 < end ? a0 : end;
+        const uint32_t nquad = (uint32_t)((end - q0) / 4);
+        if ((uint64_t)tid < q0 - base) count(keys[base + tid], lead > 0 ? (uint32_t)aux[base + tid] : 0u);
+        {
+            const uint64_t tb = q0 + 4ull * nquad;
+            if ((uint64_t)tid < end - tb) count(keys[tb + tid], lead > 0 ? (uint32_t)aux[tb + tid] : 0u);
+        }
+        constexpr int QPT = RS_SEG_TILE / 4 / 1024;  // quads per thread of a full tile
+        uint4 kq[QPT];
+        uint32_t aq[QPT][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t li = (uint32_t)(r * 4 + q) * 1024u + (uint32_t)tid;
-                if (li < valid) {
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        if (p < npass) {
-                            const uint32_t dg = p < lead ? (a[q] >> (8 * p)) & 0xFFu : (k[q] >> (8 * (p - lead))) & 0xFFu;
-                            atomicAdd(&sh[p][dg], 1u);
-                        }
+        for (int r = 0; r < QPT; ++r) {
+            const uint32_t g = (uint32_t)r * 1024u + (uint32_t)tid;
+            kq[r] = make_uint4(0, 0, 0, 0);
+            aq[r][0] = aq[r][1] = aq[r][2] = aq[r][3] = 0;
+            if (g < nquad) {
+                kq[r] = *reinterpret_cast<const uint4*>(keys + q0 + 4ull * g);
+                if (lead > 0) {
+                    if constexpr (sizeof(W) == 4) {
+                        const uint4 w = *reinterpret_cast<const uint4*>(aux + q0 + 4ull * g);
+                        aq[r][0] = w.x; aq[r][1] = w.y; aq[r][2] = w.z; aq[r][3] = w.w;
+                    } else if constexpr (sizeof(W) == 2) {
+                        const uint2 w = *reinterpret_cast<const uint2*>(aux + q0 + 4ull * g);
+                        aq[r][0] = w.x & 0xFFFFu; aq[r][1] = w.x >> 16; aq[r][2] = w.y & 0xFFFFu; aq[r][3] = w.y >> 16;
+                    } else {
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(aux + q0 + 4ull * g);
+                        aq[r][0] = w & 0xFFu; aq[r][1] = (w >> 8) & 0xFFu; aq[r][2] = (w >> 16) & 0xFFu; aq[r][3] = w >> 24;
                     }
                 }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < QPT; ++r) {
+            const uint32_t g = (uint32_t)r * 1024u + (uint32_t)tid;
+            if (g < nquad) {
+                count(kq[r].x, aq[r][0]);
+                count(kq[r].y, aq[r][1]);
+                count(kq[r].z, aq[r][2]);
+                count(kq[r].w, aq[r][3]);
             }
         }
     }
