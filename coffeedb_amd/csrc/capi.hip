@@ -101,13 +101,31 @@ void upload_tables(Index& ix, const std::vector<uint64_t>& doc_start, const std:
 // Host-to-device copy of a large PAGEABLE buffer (the staged column).  The runtime moves pageable memory through its own
 // staging at ~11 GB/s (95 ms per GiB on MI355X); here four host threads copy 16 MiB chunks into pinned blocks of the
 // host cache and queue the DMA behind each, so the page-touching memcpy of one chunk overlaps the DMA of the others.
-void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, int device) {
+// s2 (optional): a second stream for every other host thread's chunks — one stream keeps one SDMA engine busy at 55 GB/s, two
+// reach the link's 57 GB/s (tools/experiments/h2d_bw.hip); s2 first waits for the work already queued on s (the destination block
+// may come from the pool with work of s still pending on it), and every copy has completed when the function returns.
+hipStream_t upload_stream(Index& ix) {  // the index's second stream (also the build's: sa_build.hip), created on first use
+    if (!ix.aux_stream) CDB_HIP(hipStreamCreateWithFlags(&ix.aux_stream, hipStreamNonBlocking));
+    return ix.aux_stream;
+}
+void upload_fork(hipStream_t s, hipStream_t s2) {
+    if (!s2) return;
+    hipEvent_t ev = nullptr;
+    CDB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t e1 = hipEventRecord(ev, s), e2 = e1 == hipSuccess ? hipStreamWaitEvent(s2, ev, 0) : e1;
+    (void)hipEventDestroy(ev);
+    CDB_HIP(e2);
+}
+void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, int device, hipStream_t s2 = nullptr) {
     constexpr size_t CHUNK = 16u << 20;
-    constexpr int T = 4;
+    // (a host thread fills pinned chunks at ~10 GB/s: four of them stay below the link's 57 GB/s, eight do not)
+    static const int t_env = getenv("CDB_UPLOAD_THREADS") ? std::atoi(getenv("CDB_UPLOAD_THREADS")) : 0;
+    const int T = std::max(2, std::min({t_env > 0 ? t_env : 8, (int)std::thread::hardware_concurrency() / 2, (int)(bytes / (2 * CHUNK))}));
     if (bytes < 4 * CHUNK) {
         if (bytes) CDB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return;
     }
+    upload_fork(s, s2);
     const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
     std::string failure;
     std::mutex fmu;
@@ -129,14 +147,16 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
                     const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
                     if (used[k]) CDB_HIP(hipEventSynchronize(ev[k]));  // the DMA out of this block has finished
                     std::memcpy(pin[k], src + off, len);
-                    CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, s));
-                    CDB_HIP(hipEventRecord(ev[k], s));
+                    hipStream_t cs = (s2 && (t & 1)) ? s2 : s;
+                    CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, cs));
+                    CDB_HIP(hipEventRecord(ev[k], cs));
                     used[k] = true;
                 }
                 for (int q = 0; q < 2; ++q)
                     if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
             } catch (const std::exception& e) {
                 (void)hipStreamSynchronize(s);  // a DMA out of the pinned blocks may still be in flight: it ends before they go back
+                if (s2) (void)hipStreamSynchronize(s2);
                 std::lock_guard<std::mutex> g(fmu);
                 if (failure.empty()) failure = e.what();
             }
@@ -153,7 +173,7 @@ void upload_pageable(void* dst, const char* src, size_t bytes, hipStream_t s, in
 // state (index.h:58: non-owning string_views into database.cpp's strings).  The gather into the pinned chunks IS the
 // staging copy (there is no other one); doc_start = the running sum of lens.
 void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start, uint64_t ndocs, size_t bytes, hipStream_t s,
-                  int device) {
+                  int device, hipStream_t s2 = nullptr) {
     constexpr size_t CHUNK = 16u << 20;
     // (the gather of scattered 1 KiB strings runs at ~5 GB/s per host thread: four threads would make it — not the PCIe link
     //  at ~52 GB/s — the bound of the shim's build(); up to twelve keep the link busy)
@@ -161,6 +181,8 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
     static const int t_env = getenv("CDB_UPLOAD_THREADS") ? std::atoi(getenv("CDB_UPLOAD_THREADS")) : 0;  // (measurements)
     const int T = bytes >= 4 * CHUNK ? std::max(4, std::min({t_env > 0 ? t_env : 12, hw / 2, (int)(bytes / (2 * CHUNK))})) : 1;
     const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
+    if (T > 1) upload_fork(s, s2);
+    else s2 = nullptr;
     std::string failure;
     std::mutex fmu;
     std::vector<std::thread> th;
@@ -191,14 +213,16 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
                     }
                     ++d;
                 }
-                CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, s));
-                CDB_HIP(hipEventRecord(ev[k], s));
+                hipStream_t cs = (s2 && (t & 1)) ? s2 : s;
+                CDB_HIP(hipMemcpyAsync(static_cast<char*>(dst) + off, pin[k], len, hipMemcpyHostToDevice, cs));
+                CDB_HIP(hipEventRecord(ev[k], cs));
                 used[k] = true;
             }
             for (int q = 0; q < 2; ++q)
                 if (used[q]) CDB_HIP(hipEventSynchronize(ev[q]));
         } catch (const std::exception& e) {
             (void)hipStreamSynchronize(s);  // a DMA out of the pinned blocks may still be in flight: it ends before they go back
+            if (s2) (void)hipStreamSynchronize(s2);
             std::lock_guard<std::mutex> g(fmu);
             if (failure.empty()) failure = e.what();
         }
@@ -678,7 +702,7 @@ int cdb_build(cdb_index* h) {
             text.alloc(n + TEXT_PAD);
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
             const double tu = wall_ms();
-            upload_pageable(text.p, ix.host_text.data(), n, ix.stream, ix.device);
+            upload_pageable(text.p, ix.host_text.data(), n, ix.stream, ix.device, upload_stream(ix));
             upload_tables(ix, ix.doc_start, ix.ids, L.ndocs, d_start, d_ids);
             committed = true;
             reset_unbuilt(ix);  // (waits for the stream: the old arrays are idle; ix.mu keeps queries out)
@@ -782,7 +806,9 @@ int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uin
             text.alloc(n + TEXT_PAD);
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
             const double tu = wall_ms();
-            if (n) upload_pageable(text.p, blob + first, n, ix.stream, ix.device);
+            if (n) upload_pageable(text.p, blob + first, n, ix.stream, ix.device, upload_stream(ix));
+            // (tried: the 16 MB of document tables on a helper thread beside the text — the runtime's pageable staging then competes
+            //  with the chunk copies: 21.4 instead of 20.1 ms)
             upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
             committed = true;
             reset_unbuilt(ix);
@@ -830,7 +856,7 @@ int cdb_build_views(cdb_index* h, const int64_t* ids, const char* const* ptrs, c
             text.alloc(n + TEXT_PAD);
             CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n, 0, TEXT_PAD, ix.stream));
             const double tu = wall_ms();
-            if (n) upload_views(text.p, ptrs, hstart.data(), ndocs, n, ix.stream, ix.device);
+            if (n) upload_views(text.p, ptrs, hstart.data(), ndocs, n, ix.stream, ix.device, upload_stream(ix));
             upload_tables(ix, hstart, hid, ndocs, d_start, d_ids);
             committed = true;
             reset_unbuilt(ix);
