@@ -2960,6 +2960,9 @@ void build_suffix_array(Index& ix) {
         }
     }
     ix.bstats.build_ms = now_ms() - t0;
+    if (getenv("CDB_BUILD_TRACE"))
+        std::fprintf(stderr, "[build] n=%llu: %.1f ms (allocation %.1f ms, release %.1f ms, self check %.2f ms), host upload before it %.1f ms\n",
+                     (unsigned long long)ix.size, ix.bstats.build_ms, ix.bstats.alloc_ms, ix.bstats.free_ms, ix.self_check_ms, ix.host_upload_ms);
 }
 
 }  // namespace cdb
