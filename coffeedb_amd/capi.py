@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcoffeedb_gpu.so")
+if os.environ.get("CDB_LIB_PATH"):   # (timing experiments with ablated builds of the library: tools/experiments/abl/)
+    LIB_PATH = os.environ["CDB_LIB_PATH"]
 _LIB = None
 
 EXPORTS = [
