@@ -770,7 +770,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             }
         }
         }
-        __syncthreads();  // the staging buffer is reused for the sorted keys below
+        // the staging buffer is reused for the sorted keys below (the pair generator never touched it: its codes, code table and
+        // document table live in s_gen, which nothing writes before the next barrier)
+        if constexpr (!GM_PAIR) __syncthreads();
     } else if constexpr (Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
         // Keys and values travel global -> LDS by 16-byte-per-lane DMA (global_load_lds: full-rate 1 KiB
         // per wave instruction, no staging registers) into this wave's slice of the still unused
