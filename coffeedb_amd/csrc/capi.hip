@@ -1459,6 +1459,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "fuse_records")) ix.fuse_records = value != 0;
     else if (!std::strcmp(name, "pack_sa")) ix.pack_sa = value != 0;
     else if (!std::strcmp(name, "key_cost_model")) ix.key_cost_model = value != 0;
+    else if (!std::strcmp(name, "records_lane_striped")) ix.records_lane_striped = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;
     else if (!std::strcmp(name, "fold_root")) ix.fold_root = value != 0;

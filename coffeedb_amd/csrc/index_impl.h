@@ -150,6 +150,7 @@ struct Index {
     DevBuf d_sa;                      // size * width bytes — or, packed, the entries' low words (size * 4 bytes)
     DevBuf d_sa_hi;                   // packed: bits 32..39 of every entry (size bytes)
     bool sa_packed = false;           // 5-byte storage of 8-byte entries (Sa40 above)
+    bool records_lane_striped = true; // option: the fused records pass generates lane-striped (TextGenRecL) where it can (0 = rolling keys)
     bool key_cost_model = true;       // option: bucket-wise builds weigh one key symbol fewer (a pass saved) against the refinement it costs
     bool pack_sa = true;              // option: builds with 8-byte entries below 2^40 store them packed
     void release_sa() {

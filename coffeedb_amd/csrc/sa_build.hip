@@ -2352,7 +2352,7 @@ void build_typed(Index& ix, bool big) {
                                 radix_gen_records<W>(s, ix.rws, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n,
                                                      first_digit.data(), rg, (const uint32_t*)tile_seg.as<uint32_t>(),
                                                      (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
-                                                     d_bh2.as<unsigned long long>(), &ss);
+                                                     d_bh2.as<unsigned long long>(), &ss, ix.records_lane_striped);
                             }
                         } else {
                         CDB_HIP(hipMemsetAsync(d_bh2.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));

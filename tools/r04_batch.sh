@@ -1,2 +1,6 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_sort.py -x -q 2>&1 | tail -4 | cut -c1-500
-python bench.py --cpu-full-budget 0 --no-cold-start --no-pcie --configs c2,utf8_4g > gpurun_out/r04_bench7.json 2> gpurun_out/r04_bench7.err; tail -2 gpurun_out/r04_bench7.err
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -5
+for w in utf8_4g c2; do
+CDB_OPTS=records_lane_striped=0 python tools/alloc_probe.py $w 3 2>&1 | grep build | tail -1 | cut -c1-110
+python tools/alloc_probe.py $w 3 2>&1 | grep build | tail -1 | cut -c1-110
+done
+python tools/keywidth_ab.py utf8_4g 0 2 2>&1 | grep workload | cut -c1-800
