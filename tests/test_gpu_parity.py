@@ -738,6 +738,25 @@ def test_packed_suffix_array_storage(G, tmp_path):
         assert g3.stat("sa_packed") == 0 and np.array_equal(g3.sa(), g1.sa())
 
 
+def test_records_generators_at_the_alphabet_edge(G):
+    # the fused records pass generates lane-striped (TextGenRecL: symbol codes weighted by B in a v_dot4_u32_u8) while the base
+    # alphabet + 1 fits a byte weight (<= 255) and the key has <= 10 symbols behind the bucket symbol; 255 symbols (base 256) and
+    # longer keys take the rolling form.  Both forms, both sides of the edge, odd and even key lengths, against the oracle.
+    lens = (W.random_bytes(40000, 21, 0, 5)).astype(np.uint64)
+    lens[99] = 70000
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for lo, hi in ((1, 254), (0, 254), (0x30, 0x39)):
+        blob = W.random_bytes(int(ds[-1]), 22 + lo, lo, hi)
+        pats = W.sample_patterns(blob, ds, 120, 1, 5, seed=4, miss_frac=0.1)
+        for ks in (0, 2, 3, 4, 7, 10, 12):
+            for striped in (1, 0):
+                opts = dict(force_big_path=1, records_lane_striped=striped)
+                if ks:
+                    opts["key_symbols"] = ks
+                g, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
+                assert g.stat("fused_records") == 1, (lo, hi, opts)
+
+
 def test_full_self_check_finds_what_a_sample_can_miss(G, tmp_path):
     # the full sweep (self_check = 2) against deliberately damaged arrays: ONE swapped adjacent pair, one duplicated entry and
     # one entry that names no (document, offset) — each must be reported by the sweep (a 2^15-pair sample of 10^5.6 pairs may
