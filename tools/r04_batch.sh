@@ -1,6 +1,6 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -5
-for w in utf8_4g c2; do
-CDB_OPTS=records_lane_striped=0 python tools/alloc_probe.py $w 3 2>&1 | grep build | tail -1 | cut -c1-110
-python tools/alloc_probe.py $w 3 2>&1 | grep build | tail -1 | cut -c1-110
+export CDB_BENCH_TRACE=1
+fails=0
+for i in $(seq 1 40); do
+python bench.py --gpus 2 --backend gloo --share-gpu --workload mid --steps 2 --warmup 1 --configs none --no-cpu-baseline > gpurun_out/r04_sl_x.json 2> gpurun_out/r04_sl_x.err; rc=$?; fb=$(grep -c 'group_fallbacks 1' gpurun_out/r04_sl_x.err); if [ $rc != 0 ] || [ $fb != 0 ]; then echo "run $i rc=$rc fallbacks=$fb"; grep "fault\|rror" gpurun_out/r04_sl_x.err | tail -4; fi; if [ $rc != 0 ]; then fails=$((fails+1)); fi
 done
-python tools/keywidth_ab.py utf8_4g 0 2 2>&1 | grep workload | cut -c1-800
+echo "done t=$SECONDS fails=$fails"
