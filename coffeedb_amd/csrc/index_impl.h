@@ -31,6 +31,7 @@ struct BuildStats {
     int root_folded = 0;         // ... first-symbol buckets laid out in the reference's root order (bytes >= 0x80 first)
     int flags_in_last_pass = 0;  // single sort: group flags written by the last radix pass (no flag kernel)
     int msd_first = 0;           // single sort: top digit first, then (u32, u32) records sorted bucket by bucket (radix_sort_msd)
+    int gen_prebased = 0;        // ... generated pass without look-back (counted tile bases)
     int fused_records = 0;       // ... bucket records written by the generated pass itself (one bucket group): no partition + gather
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     uint64_t gather_items = 0;
@@ -150,6 +151,9 @@ struct Index {
     DevBuf d_sa;                      // size * width bytes — or, packed, the entries' low words (size * 4 bytes)
     DevBuf d_sa_hi;                   // packed: bits 32..39 of every entry (size bytes)
     bool sa_packed = false;           // 5-byte storage of 8-byte entries (Sa40 above)
+    bool gen_prebased = true;         // option: generated passes take their tile bases from counted per-tile digits (no look-back, two
+                                      // 8 Ki-key workgroups per CU; radix_sort.h: TextGen::tile_base)
+    TileBaseWorkspace tbw;
     bool records_lane_striped = true; // option: the fused records pass generates lane-striped (TextGenRecL) where it can (0 = rolling keys)
     bool key_cost_model = true;       // option: bucket-wise builds weigh one key symbol fewer (a pass saved) against the refinement it costs
     bool pack_sa = true;              // option: builds with 8-byte entries below 2^40 store them packed

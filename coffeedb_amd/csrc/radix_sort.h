@@ -28,6 +28,7 @@
 namespace cdb {
 
 constexpr int RS_MAX_PASSES = 16;
+
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 18;  // bounded look-back spin (~0.3-0.5 s of polling): a predecessor that has not answered by
                                               // then is not coming (starved XCD-ordered pass); 2^22 held a starved build for ~8 s per wait
@@ -172,6 +173,11 @@ struct TextGen {
     bool msd_pair = false;
     uint32_t pair_span = 0, pair_r = 0, pair_s = 0;  // floor(a / span) = (a * pair_r) >> pair_s for every a < base^2 (rs_pair_setup)
     const uint64_t* tile_doc = nullptr;  // [tiles + 1] document of each tile's first position (set by the driver)
+    // Look-back-free form (round 4): tile_base[tile * 256 + d] = the output slot of the tile's first element of digit d, from a
+    // counting pre-pass over the text + a scan over the tiles (the digit of a generated pass is a function of one or two symbols, so
+    // its per-tile counts cost one cheap sweep).  The pass then needs no status words, no tile order and waits for nobody — which
+    // is what lets two 8 Ki-key workgroups share a CU (with the chained scan, twice the tiles cost more than the overlap gained)
+    const unsigned long long* tile_base = nullptr;
     uint8_t* vout_hi = nullptr;  // 8-byte values (first_only partition): write them packed — low words to (uint32_t*)vout, bits 32..39 here
 };
 // The generator's FORM is part of the kernel's type: the 16 Ki-tile pass is ~15 k instructions of straight-line code per
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // BLK: the generated pass of the big 32-bit-record configuration computes its keys thread-consecutively
     // (rolling, see below); text codes, code table and document table then live in their own LDS region
     // because the staging buffer carries the transposition
-    constexpr bool BLK = GEN && sizeof(K) == 4 && sizeof(VS) == 4 && IPT == 16 && NT == 1024;
+    constexpr bool BLK = GEN && sizeof(K) == 4 && sizeof(VS) == 4 && IPT == 16 && (NT == 1024 || NT == 512);
     constexpr uint32_t GEN_TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
     constexpr uint32_t GEN_DOCS = 1024;
     __shared__ __attribute__((aligned(16))) unsigned char s_stage[STAGE_BYTES];
@@ -448,6 +454,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     }
     const uint32_t valid = (uint32_t)((seg_n - base) < (uint64_t)TILE ? (seg_n - base) : (uint64_t)TILE);
     if (s_bad) {
+        if constexpr (GEN) {
+            if (gen.tile_base) return;  // (no status words in the look-back-free form: nobody waits for this tile)
+        }
         if (tid < 256) rs_st_status(status + tile * 256 + tid, ((uint64_t)epoch << 56) | (2ull << 54));
         return;
     }
@@ -996,6 +1005,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     uint64_t real = 0;
     const uint64_t tag = (uint64_t)epoch << 56;
     uint64_t* my = status + tile * 256 + (d & 255);
+    bool prebased = false;  // (generated passes with counted tile bases: no status words, no look-back)
+    uint64_t pre = 0;
+    if constexpr (GEN) {
+        prebased = gen.tile_base != nullptr;
+        if (prebased && tid < 256) pre = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)d];
+    }
     if (tid < 256) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -1006,7 +1021,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         // real (in-range) count of this digit: padding only ever sits in digit 255
         real = d == 255 ? (uint64_t)cnt - (uint64_t)(TILE - valid) : (uint64_t)cnt;
         // publish the aggregate as early as possible: successors can already add it up
-        rs_st_status(my, tag | ((tile == tile0 ? 2ull : 1ull) << 54) | real);
+        if (!prebased) rs_st_status(my, tag | ((tile == tile0 ? 2ull : 1ull) << 54) | real);
         // exclusive scan of cnt over the 256 digits: wave scan, then across the 4 digit-owning waves
         incl = cnt;
 #pragma unroll
@@ -1061,7 +1076,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     // the walk gets ever longer.  LB predecessors are therefore fetched per round trip and consumed
     // nearest-first up to the first inclusive prefix.
     uint64_t excl = 0;
-    if (tid < 256 && tile != tile0 && !(Cfg::ABL & 1)) {
+    if (tid < 256 && tile != tile0 && !(Cfg::ABL & 1) && !prebased) {
         constexpr int LB = Cfg::LB;
         int64_t p = (int64_t)tile - 1;
         uint32_t spins = 0;
@@ -1103,7 +1118,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     if (tid < 256) {
         if constexpr (SEG) dstart = (uint64_t)digit_start[(size_t)sg * seg.start_stride + d];
         else dstart = (uint64_t)digit_start[d];
-        s_gbase[d] = (Cfg::ABL & 2) ? base : dstart + excl - (uint64_t)tstart;
+        s_gbase[d] = (Cfg::ABL & 2) ? base : (prebased ? pre : dstart + excl) - (uint64_t)tstart;
     }
     __syncthreads();
     if constexpr (FLAGS) {
@@ -2005,6 +2020,84 @@ __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __res
     flush();
 }
 
+// ---------------------------------------------------------------------------------------------
+// tile bases of the look-back-free generated passes (TextGen::tile_base)
+// ---------------------------------------------------------------------------------------------
+// counts[rows][256] (u32) = how many elements of tile `row` carry each digit, from a counting sweep over the text (the digit of a
+// generated pass is a function of one or two symbols).  base[row][d] = digit_start[d] + sum of counts[r][d] over r < row: the
+// output slot of the tile's first element of digit d.  Column d of the result reads column src_col[d] of the counts (nullptr =
+// identity; 0xFFFF = no such column: the bucket-wise passes count raw bytes and sort on bucket slots).  Three small kernels:
+// column sums per block of RS_TB_ROWS rows, a scan over the blocks, the running sums inside every block.
+constexpr int RS_GEN8_TILE = 8192;  // 512 threads x 16 keys: two workgroups per CU
+constexpr uint32_t RS_TB_ROWS = 256;
+static __global__ __launch_bounds__(256) void rs_tilecol_sum_kernel(const uint32_t* __restrict__ counts, uint32_t rows, const uint16_t* __restrict__ src_col,
+                                                                    unsigned long long* __restrict__ partial) {
+    const uint32_t d = threadIdx.x, b = blockIdx.x;
+    const uint32_t c = src_col ? (uint32_t)src_col[d] : d;
+    const uint32_t r0 = b * RS_TB_ROWS, r1 = r0 + RS_TB_ROWS < rows ? r0 + RS_TB_ROWS : rows;
+    unsigned long long sum = 0;
+    if (c < 256u)
+        for (uint32_t r = r0; r < r1; ++r) sum += counts[(size_t)r * 256 + c];
+    partial[(size_t)b * 256 + d] = sum;
+}
+// totals[d] = column sums over all blocks (what the host wants as the digit histogram)
+static __global__ __launch_bounds__(256) void rs_tilecol_total_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
+                                                                      unsigned long long* __restrict__ totals) {
+    const uint32_t d = threadIdx.x;
+    unsigned long long sum = 0;
+    for (uint32_t b = 0; b < blocks; ++b) sum += partial[(size_t)b * 256 + d];
+    totals[d] = sum;
+}
+// blockbase[b][d] = digit_start[d] + sum of partial[b'][d], b' < b
+static __global__ __launch_bounds__(256) void rs_tilecol_scan_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
+                                                                     const unsigned long long* __restrict__ digit_start,
+                                                                     unsigned long long* __restrict__ blockbase) {
+    const uint32_t d = threadIdx.x;
+    unsigned long long run = digit_start[d];
+    for (uint32_t b = 0; b < blocks; ++b) {
+        blockbase[(size_t)b * 256 + d] = run;
+        run += partial[(size_t)b * 256 + d];
+    }
+}
+static __global__ __launch_bounds__(256) void rs_tilecol_apply_kernel(const uint32_t* __restrict__ counts, uint32_t rows, const uint16_t* __restrict__ src_col,
+                                                                      const unsigned long long* __restrict__ blockbase,
+                                                                      unsigned long long* __restrict__ base) {
+    const uint32_t d = threadIdx.x, b = blockIdx.x;
+    const uint32_t c = src_col ? (uint32_t)src_col[d] : d;
+    const uint32_t r0 = b * RS_TB_ROWS, r1 = r0 + RS_TB_ROWS < rows ? r0 + RS_TB_ROWS : rows;
+    unsigned long long run = blockbase[(size_t)b * 256 + d];
+    for (uint32_t r = r0; r < r1; ++r) {
+        base[(size_t)r * 256 + d] = run;
+        if (c < 256u) run += counts[(size_t)r * 256 + c];
+    }
+}
+struct TileBaseWorkspace {
+    DevBuf partial, blockbase, totals, base;
+    void release() { partial.release(); blockbase.release(); totals.release(); base.release(); }
+};
+// column totals of the counts (device, [256] u64) — the digit histogram the host builds its buckets from
+inline const unsigned long long* rs_tile_totals(hipStream_t s, TileBaseWorkspace& tb, const uint32_t* d_counts, uint32_t rows, const uint16_t* d_src_col) {
+    const uint32_t blocks = (uint32_t)ceil_div((uint64_t)rows, (uint64_t)RS_TB_ROWS);
+    tb.partial.ensure((size_t)blocks * 256 * sizeof(uint64_t));
+    tb.totals.ensure(256 * sizeof(uint64_t));
+    hipLaunchKernelGGL(rs_tilecol_sum_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col, tb.partial.as<unsigned long long>());
+    hipLaunchKernelGGL(rs_tilecol_total_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
+                       tb.totals.as<unsigned long long>());
+    return tb.totals.as<unsigned long long>();
+}
+// ... and the tile bases, once the digit starts are on the device (rs_tile_totals ran before)
+inline const unsigned long long* rs_tile_bases(hipStream_t s, TileBaseWorkspace& tb, const uint32_t* d_counts, uint32_t rows, const uint16_t* d_src_col,
+                                               const unsigned long long* d_digit_start) {
+    const uint32_t blocks = (uint32_t)ceil_div((uint64_t)rows, (uint64_t)RS_TB_ROWS);
+    tb.blockbase.ensure((size_t)blocks * 256 * sizeof(uint64_t));
+    tb.base.ensure((size_t)rows * 256 * sizeof(uint64_t));
+    hipLaunchKernelGGL(rs_tilecol_scan_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
+                       d_digit_start, tb.blockbase.as<unsigned long long>());
+    hipLaunchKernelGGL(rs_tilecol_apply_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col,
+                       (const unsigned long long*)tb.blockbase.as<unsigned long long>(), tb.base.as<unsigned long long>());
+    return tb.base.as<unsigned long long>();
+}
+
 struct MsdWorkspace {
     DevBuf segs, tile_seg, hist, starts;
     void release() { segs.release(); tile_seg.release(); hist.release(); starts.release(); }
@@ -2015,7 +2108,8 @@ struct MsdWorkspace {
 // flags / edge fixes / tile sums of `keep` written by the last pass.  k0 / v0 are scratch.
 inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, Profiler& prof, uint32_t* k0, uint32_t* k1,
                            uint32_t* v0, uint32_t* v1, uint8_t* wout, uint64_t n, const uint64_t* h_top, const TextGen& gen_in,
-                           unsigned long long msd_m, const SegFinalKeepArgs& keep_in, SortStats* stats) {
+                           unsigned long long msd_m, const SegFinalKeepArgs& keep_in, SortStats* stats,
+                           const uint32_t* d_tile_counts = nullptr, TileBaseWorkspace* tbw = nullptr) {
     // gen_in says how the generated pass splits a key into (top digit, u32 rest): msd_shift = 32 (msd_m = 2^32) or the pair
     // form (msd_m = span * base^4); the last pass puts the full key together again as top * msd_m + rest
     if (!rs_atomic_rank_ok(s)) throw Error("radix_sort_msd: needs the one-atomic ranking (internal)");
@@ -2055,7 +2149,35 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
                        seg_tiles, mw.tile_seg.as<uint32_t>());
     CDB_HIP(hipMemsetAsync(mw.hist.p, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
     // ---- generated pass: partition by the top digit, records (u32 key, entry)
-    {
+    if (d_tile_counts && tbw && gen_in.msd_pair) {
+        // look-back-free form: per-tile counts of the top digit (sa_build.hip: sa_tile_paircount_kernel, rs_tile_totals already ran on
+        // them) -> tile bases; 8 Ki-key tiles, two workgroups per CU, no status words, no waiting for other tiles
+        constexpr int GT = RS_GEN8_TILE;
+        using CfgG8 = RsCfg<16, true, true, 512, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+        using CfgP8 = RsCfg<16, true, true, 512, false, 1, 0, 4, false, true>;
+        const uint32_t gen_tiles8 = (uint32_t)ceil_div(n, (uint64_t)GT);
+        TextGenPair gp;
+        static_cast<TextGen&>(gp) = gen_in;
+        gp.low_bits = 0;
+        gp.tile_base = rs_tile_bases(s, *tbw, d_tile_counts, gen_tiles8, nullptr, (const unsigned long long*)d_start);
+        ws.tile_doc.ensure(((size_t)gen_tiles8 + 1) * sizeof(uint64_t));
+        hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)gen_tiles8 + 1, 256)), dim3(256), 0, s, gp.doc_start, gp.ndocs,
+                           n, (uint64_t)GT, (uint64_t)gen_tiles8, ws.tile_doc.as<uint64_t>());
+        gp.tile_doc = ws.tile_doc.as<uint64_t>();
+        const uint32_t e = ws.next_epoch(s);
+        const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles8, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles8;
+        int t = prof.begin(s);
+        if (grouped)
+            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG8, TextGenPair, uint8_t>), dim3(grid), dim3(512), 0, s, (const uint32_t*)nullptr,
+                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                               ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+        else
+            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP8, TextGenPair, uint8_t>), dim3(grid), dim3(512), 0, s, (const uint32_t*)nullptr,
+                               k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
+                               ws.ticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+        prof.end(t, "rs_onesweep_textgen_msd_t8192", n * 9, s);
+        if (stats) stats->passes_run++;
+    } else {
         TextGen g2 = gen_in;
         g2.low_bits = 0;
         ws.tile_doc.ensure(((size_t)gen_tiles + 1) * sizeof(uint64_t));

@@ -131,6 +131,87 @@ __global__ __launch_bounds__(256) void sa_docend_pair_kernel(const uint8_t* __re
         if (s_end[c]) atomicAdd(&cnt[c * kbase], (unsigned long long)s_end[c]);
 }
 
+// Look-back-free generated pass of the MSD-first sort (radix_sort.h: TextGen::tile_base): per tile of RS_GEN8_TILE positions, how many
+// suffixes carry each TOP digit — the digit is floor((c0 B + c1) / span) of the first two symbol codes, (a R) >> s in the pass's own
+// arithmetic (rs_pair_setup).  One workgroup per tile, wave-private LDS counters (the digit has ~200 values: shared counters would
+// serialise), the pair of the last position of every document counted with the byte BEHIND the document and moved to (c0, end) by
+// sa_tile_docend_fix_kernel.  The column sums of the table are the top-digit histogram (it replaces the pair count).
+constexpr uint32_t TPC_TILES_PER_WAVE = 8;  // tiles a wavefront counts one after the other (a workgroup: 4 x 8 tiles)
+__global__ __launch_bounds__(256) void sa_tile_paircount_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint16_t* __restrict__ symmap,
+                                                                uint32_t kbase, uint32_t pair_r, uint32_t pair_s, uint32_t tiles,
+                                                                uint32_t* __restrict__ counts) {
+    // every wavefront counts its own tiles into its own counters: no workgroup barrier after the code table is staged
+    // (four copies of a wavefront's counters, by lane: the digit has only ~200 values, 64 lanes on one copy collide three deep)
+    __shared__ uint32_t s_cnt[4][4][256];
+    __shared__ uint16_t s_map[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    s_map[tid] = symmap[tid];
+    __syncthreads();
+    uint32_t* cnt = s_cnt[wave][lane & 3];
+    uint32_t* call = &s_cnt[wave][0][0];
+    for (uint32_t k = 0; k < TPC_TILES_PER_WAVE; ++k) {
+        const uint32_t tile = (blockIdx.x * 4u + (uint32_t)wave) * TPC_TILES_PER_WAVE + k;
+        if (tile >= tiles) break;  // (uniform per wavefront)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) call[q * 64 + lane] = 0;
+        const uint64_t b0 = (uint64_t)tile * RS_GEN8_TILE;
+        constexpr int VEC = RS_GEN8_TILE / 16 / 64;  // 16-byte vectors per lane and tile
+#pragma unroll 2
+        for (int r = 0; r < VEC; ++r) {
+            const uint64_t p = b0 + ((uint64_t)r * 64 + lane) * 16;
+            if (p >= n) continue;
+            uint32_t c[17];
+            if (p + 16 <= n) {
+                const uint4 v = *reinterpret_cast<const uint4*>(text + p);
+                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c[4 * q] = s_map[x[q] & 0xFF];
+                    c[4 * q + 1] = s_map[(x[q] >> 8) & 0xFF];
+                    c[4 * q + 2] = s_map[(x[q] >> 16) & 0xFF];
+                    c[4 * q + 3] = s_map[x[q] >> 24];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) c[q] = p + q < n ? (uint32_t)s_map[text[p + q]] : 0u;
+            }
+            c[16] = p + 16 < n ? (uint32_t)s_map[text[p + 16]] : 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (p + q < n) {
+                    const uint32_t a = __umul24(c[q], kbase) + c[q + 1];
+                    atomicAdd(&cnt[__umul24(a, pair_r) >> pair_s], 1u);
+                }
+            }
+        }
+        // (the wavefront's own LDS traffic is ordered: its counters are complete when its atomics have returned)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dgt = q * 64 + lane;
+            counts[(size_t)tile * 256 + dgt] = call[dgt] + call[256 + dgt] + call[512 + dgt] + call[768 + dgt];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(256) void sa_tile_docend_fix_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_start,
+                                                                 uint64_t ndocs, uint64_t n, const uint16_t* __restrict__ symmap, uint32_t kbase,
+                                                                 uint32_t pair_r, uint32_t pair_s, uint32_t* __restrict__ counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d < ndocs; d += stride) {
+        const uint64_t b0 = doc_start[d], e = doc_start[d + 1];
+        if (e == b0 || e >= n) continue;  // (the last position of the text was counted with "end" already)
+        const uint32_t c0 = symmap[text[e - 1]], c1 = symmap[text[e]];
+        const uint32_t t_old = __umul24(__umul24(c0, kbase) + c1, pair_r) >> pair_s, t_new = __umul24(__umul24(c0, kbase), pair_r) >> pair_s;
+        if (t_old != t_new) {
+            uint32_t* row = counts + (size_t)((e - 1) / RS_GEN8_TILE) * 256;
+            atomicAdd(row + t_old, ~0u);  // (- 1)
+            atomicAdd(row + t_new, 1u);
+        }
+    }
+}
+
 // Reference order, one level below the root (bucket-wise build): how the suffixes of every first byte split by what
 // FOLLOWS that byte — a byte below 0x80, a byte from 0x80, or the end of the document.  Inside a first-symbol bucket that
 // the reference treats as a radix node its children come [end][0x80..0xFF][0x00..0x7F] (index.h:66-73); with these counts
@@ -1592,8 +1673,9 @@ void build_typed(Index& ix, bool big) {
     // Speculative pair count of the MSD-first sort (pair form) on a SECOND stream, beside the key-width sample below: both only
     // need the symbol codes, the sample is a chain of small latency-bound kernels (0.7 ms) and the count a 0.4 ms sweep.
     // Whether the sort takes the pair form is known only after the sample (6-symbol keys); if not, the counts are dropped.
-    DevBuf d_pc_spec;
-    bool pc_spec = false;
+    DevBuf d_pc_spec, d_tc;  // d_tc: per-tile top-digit counts of the look-back-free generated pass (option gen_prebased)
+    bool pc_spec = false, tc_spec = false;
+    const unsigned long long* d_tc_totals = nullptr;
     struct AuxJoin {  // (declared after the buffer: an exception on the way still waits for the second stream before the
         hipStream_t a = nullptr;  //  buffer goes back to the pool)
         ~AuxJoin() { if (a) (void)hipStreamSynchronize(a); }
@@ -1605,6 +1687,31 @@ void build_typed(Index& ix, bool big) {
         for (hipEvent_t& e : ix.aux_ev)
             if (!e) CDB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const uint32_t pb = (uint32_t)sigma + 1u, np = pb * pb;
+        // look-back-free generated pass (radix_sort.h: TextGen::tile_base): count the top digit per 8 Ki-position tile instead of
+        // the pairs of the whole text — same sweep, and the column sums are the top-digit histogram
+        struct { uint32_t pair_span = 0, pair_r = 0, pair_s = 0; } pcs;
+        uint32_t span_spec = 0;
+        if (ix.gen_prebased) {
+            const uint64_t P4 = (uint64_t)pb * pb * pb * pb;
+            span_spec = (uint32_t)std::min<uint64_t>((1ull << 32) / P4, (uint64_t)np);
+            if (span_spec == 0 || ceil_div((uint64_t)np, (uint64_t)span_spec) > 256 || !rs_pair_setup(pcs, pb, span_spec)) span_spec = 0;
+        }
+        if (span_spec) {
+            const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_GEN8_TILE);
+            d_tc.alloc((size_t)tiles8 * 256 * sizeof(uint32_t));
+            CDB_HIP(hipEventRecord(ix.aux_ev[0], s));
+            CDB_HIP(hipStreamWaitEvent(ix.aux_stream, ix.aux_ev[0], 0));
+            aux_join.a = ix.aux_stream;
+            int t = ix.prof.begin(ix.aux_stream);
+            hipLaunchKernelGGL(sa_tile_paircount_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TPC_TILES_PER_WAVE))), dim3(256), 0, ix.aux_stream,
+                               text, n, (const uint16_t*)d_symmap.as<uint16_t>(), pb, pcs.pair_r, pcs.pair_s, tiles8, d_tc.as<uint32_t>());
+            hipLaunchKernelGGL(sa_tile_docend_fix_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))), dim3(256), 0,
+                               ix.aux_stream, text, doc_start, D, n, (const uint16_t*)d_symmap.as<uint16_t>(), pb, pcs.pair_r, pcs.pair_s, d_tc.as<uint32_t>());
+            d_tc_totals = rs_tile_totals(ix.aux_stream, ix.tbw, d_tc.as<uint32_t>(), tiles8, nullptr);
+            ix.prof.end(t, "sa_tile_paircount", n + D * 18 + (uint64_t)tiles8 * 2048, ix.aux_stream);
+            CDB_HIP(hipEventRecord(ix.aux_ev[1], ix.aux_stream));
+            pc_spec = tc_spec = true;
+        } else {
         d_pc_spec.alloc((size_t)np * sizeof(uint64_t));
         CDB_HIP(hipMemsetAsync(d_pc_spec.p, 0, (size_t)np * sizeof(uint64_t), s));
         CDB_HIP(hipEventRecord(ix.aux_ev[0], s));
@@ -1619,6 +1726,7 @@ void build_typed(Index& ix, bool big) {
         ix.prof.end(t, "sa_paircode", n + D * 18, ix.aux_stream);
         CDB_HIP(hipEventRecord(ix.aux_ev[1], ix.aux_stream));
         pc_spec = true;
+        }
     }
 
     // Key width of the initial sort.  Every suffix left unresolved costs a refinement round (compaction,
@@ -1819,7 +1927,13 @@ void build_typed(Index& ix, bool big) {
         CDB_HIP(hipStreamWaitEvent(s, ix.aux_ev[1], 0));
         aux_join.a = nullptr;
     }
-    if (msd_span && pc_spec) {
+    if (msd_span && tc_spec) {  // the column sums of the per-tile counts ARE the top-digit histogram
+        msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
+        h_top.assign(256, 0);
+        CDB_HIP(hipMemcpyAsync(h_top.data(), d_tc_totals, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        st.msd_first = 2;
+    } else if (msd_span && pc_spec) {
         msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
         const uint32_t np = kbase * kbase;
         std::vector<uint64_t> pc(np);
@@ -1827,6 +1941,23 @@ void build_typed(Index& ix, bool big) {
         CDB_HIP(hipStreamSynchronize(s));
         h_top.assign(256, 0);
         for (uint32_t a = 0; a < np; ++a) h_top[a / msd_span] += pc[a];
+        st.msd_first = 2;
+    } else if (msd_span && ix.gen_prebased) {  // (no speculative count on the second stream: the same kernels on this one)
+        msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
+        const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_GEN8_TILE);
+        d_tc.alloc((size_t)tiles8 * 256 * sizeof(uint32_t));
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_tile_paircount_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TPC_TILES_PER_WAVE))), dim3(256), 0, s, text, n,
+                           (const uint16_t*)d_symmap.as<uint16_t>(), kbase, pair_consts.pair_r, pair_consts.pair_s, tiles8, d_tc.as<uint32_t>());
+        hipLaunchKernelGGL(sa_tile_docend_fix_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))), dim3(256), 0, s,
+                           text, doc_start, D, n, (const uint16_t*)d_symmap.as<uint16_t>(), kbase, pair_consts.pair_r, pair_consts.pair_s,
+                           d_tc.as<uint32_t>());
+        d_tc_totals = rs_tile_totals(s, ix.tbw, d_tc.as<uint32_t>(), tiles8, nullptr);
+        ix.prof.end(t, "sa_tile_paircount", n + D * 18 + (uint64_t)tiles8 * 2048, s);
+        h_top.assign(256, 0);
+        CDB_HIP(hipMemcpyAsync(h_top.data(), d_tc_totals, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        tc_spec = true;
         st.msd_first = 2;
     } else if (msd_span) {
         msd_m = (unsigned long long)msd_span * kbase * kbase * kbase * kbase;
@@ -1952,8 +2083,13 @@ void build_typed(Index& ix, bool big) {
                 } else {
                     gen.msd_shift = 32;
                 }
+                const bool prebased = tc_spec && msd_span != 0;  // (the counts were made with this span: same rule, same alphabet)
                 radix_sort_msd(s, ix.rws, ix.msd_ws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<uint32_t>(),
-                               vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_top.data(), gen, msd_m, keep, &ss);
+                               vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_top.data(), gen, msd_m, keep, &ss,
+                               prebased ? (const uint32_t*)d_tc.as<uint32_t>() : nullptr, prebased ? &ix.tbw : nullptr);
+                st.gen_prebased = prebased ? 1 : 0;
+                d_tc.release();
+                ix.tbw.base.release();
                 sel = 1;
                 sorted_low = std::move(low[1]);
                 flags_by_sort = ix.rws.keep_applied;

@@ -61,6 +61,48 @@ __global__ void check_kernel(const uint32_t* k, const uint8_t* w, const uint32_t
     }
 }
 
+// ---- look-back-free form: per-tile top-digit counts by brute force, scanned over the tiles into tile bases
+__global__ void tile_top_count(const uint8_t* t, uint64_t n, uint32_t dlen, unsigned long long m, uint32_t gt, uint32_t* counts) {
+    __shared__ uint32_t sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)blockIdx.x * gt;
+    for (uint64_t p = b0 + threadIdx.x; p < b0 + gt && p < n; p += 256) {
+        const uint32_t rem = dlen - (uint32_t)(p % dlen);
+        uint64_t key = 0;
+        for (uint32_t q = 0; q < 6; ++q) key = key * 96 + (q < rem ? (uint64_t)(t[p + q] - 0x20 + 1) : 0ull);
+        atomicAdd(&sh[(uint32_t)(key / m)], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)blockIdx.x * 256 + threadIdx.x] = sh[threadIdx.x];
+}
+__global__ void tile_scan(const uint32_t* counts, uint32_t tiles, const unsigned long long* digit_start, unsigned long long* base) {
+    const uint32_t d = threadIdx.x;
+    unsigned long long run = digit_start[d];
+    for (uint32_t t = 0; t < tiles; ++t) {
+        base[(size_t)t * 256 + d] = run;
+        run += counts[(size_t)t * 256 + d];
+    }
+}
+__global__ void check_pass(const uint32_t* k, const uint32_t* v, const uint8_t* t, uint64_t n, uint32_t dlen, int bits, unsigned long long m,
+                           const unsigned long long* digit_start, unsigned long long* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = v[i];
+    const uint64_t doc = e & ((1u << bits) - 1u), off = e >> bits, p = doc * dlen + off;
+    const uint32_t rem = dlen - (uint32_t)off;
+    uint64_t key = 0;
+    for (uint32_t q = 0; q < 6; ++q) key = key * 96 + (q < rem ? (uint64_t)(t[p + q] - 0x20 + 1) : 0ull);
+    const uint32_t top = (uint32_t)(key / m);
+    if (i < digit_start[top] || (top < 255 && i >= digit_start[top + 1] && digit_start[top + 1] > digit_start[top])) atomicAdd(&out[0], 1ull);
+    if ((uint32_t)(key - (uint64_t)top * m) != k[i]) atomicAdd(&out[1], 1ull);
+    if (i > 0) {
+        const uint32_t e0 = v[i - 1];
+        const uint64_t p0 = (uint64_t)(e0 & ((1u << bits) - 1u)) * dlen + (e0 >> bits);
+        if (i != digit_start[top] && p0 >= p) atomicAdd(&out[2], 1ull);  // inside a bucket: text order (stable)
+    }
+}
+
 int main(int argc, char** argv) {
     const int lg = argc > 1 ? std::atoi(argv[1]) : 30;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 3;
@@ -142,7 +184,10 @@ int main(int argc, char** argv) {
 #ifndef GEN_LB
 #define GEN_LB 4
 #endif
-        using CfgA = RsCfg<16, true, true, GEN_NT, false, 1, 3, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
+        #ifndef GEN_ABL
+#define GEN_ABL 3
+#endif
+        using CfgA = RsCfg<16, true, true, GEN_NT, false, 1, GEN_ABL, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
         using CfgN = RsCfg<16, true, true, GEN_NT, false, 1, 0, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
         constexpr uint64_t GT = 16 * GEN_NT;  // tile of the stand-alone generated pass
         const uint32_t tiles = (uint32_t)ceil_div(n, GT);
@@ -191,6 +236,47 @@ int main(int argc, char** argv) {
             }
             std::printf("generated pass alone, RS_GEN_ABL=%d, %s: %.3f ms\n", RS_GEN_ABL, abl ? "no look-back + linear write-out" : "as in production", bms);
         }
+    }
+    if (pair && RS_GEN_ABL == 0) {   // the same pass without status words or look-back: tile bases from counted per-tile digits
+        constexpr uint64_t GT = 16 * GEN_NT;
+        const uint32_t tiles = (uint32_t)ceil_div(n, GT);
+        uint32_t* d_cnt;
+        unsigned long long* d_base;
+        CDB_HIP(hipMalloc(&d_cnt, (size_t)tiles * 256 * 4));
+        CDB_HIP(hipMalloc(&d_base, (size_t)tiles * 256 * 8));
+        unsigned long long* d_start = ws.hist.as<unsigned long long>();
+        hipLaunchKernelGGL(tile_top_count, dim3(tiles), dim3(256), 0, s, text, n, dlen, m, (uint32_t)GT, d_cnt);
+        hipLaunchKernelGGL(tile_scan, dim3(1), dim3(256), 0, s, (const uint32_t*)d_cnt, tiles, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256), d_base);
+        CDB_HIP(hipStreamSynchronize(s));
+        using CfgN = RsCfg<16, true, true, GEN_NT, false, 1, 0, GEN_LB, false, true, GEN_TICKET, 1, GEN_GROUP>;
+        TextGenPair gp;
+        static_cast<TextGen&>(gp) = gen;
+        gp.tile_doc = ws.tile_doc.as<uint64_t>();
+        gp.tile_base = d_base;
+        const uint32_t grid = (uint32_t)(ceil_div(tiles, 8u * GEN_GROUP) * 8u * GEN_GROUP);
+        double bms = 1e30;
+        for (int r = 0; r <= rounds; ++r) {
+            const uint32_t e = ws.next_epoch(s);
+            hipEvent_t a, b;
+            CDB_HIP(hipEventCreate(&a)); CDB_HIP(hipEventCreate(&b));
+            CDB_HIP(hipEventRecord(a, s));
+            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgN, TextGenPair, uint8_t>), dim3(grid), dim3(GEN_NT), 0, s, (const uint32_t*)nullptr,
+                               k[1], (const uint32_t*)nullptr, v[1], n, 0, 0xFFu, (const unsigned long long*)(d_start + RS_MAX_PASSES * 256),
+                               ws.status.as<uint64_t>(), ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
+            CDB_HIP(hipEventRecord(b, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            float ms = 0;
+            CDB_HIP(hipEventElapsedTime(&ms, a, b));
+            if (r > 0) bms = std::min(bms, (double)ms);
+        }
+        CDB_HIP(hipMemsetAsync(d_out, 0, 4 * 8, s));
+        hipLaunchKernelGGL(check_pass, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, (const uint32_t*)k[1], (const uint32_t*)v[1], text, n, dlen, bits, m,
+                           (const unsigned long long*)(d_start + RS_MAX_PASSES * 256), d_out);
+        unsigned long long out[4];
+        CDB_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, s));
+        CDB_HIP(hipStreamSynchronize(s));
+        std::printf("generated pass alone, counted tile bases (no look-back), %d threads x 16: %.3f ms   check: wrong bucket %llu, wrong key %llu, out of text order %llu\n",
+                    GEN_NT, bms, out[0], out[1], out[2]);
     }
     if (RS_GEN_ABL != 0 || GEN_NT != 1024) return 0;  // (GEN_NT=512 needs BLK in radix_sort.h relaxed to NT == 512: an experiment)
     for (int r = 0; r <= rounds; ++r) {
