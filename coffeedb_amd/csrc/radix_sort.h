@@ -2085,12 +2085,15 @@ inline const unsigned long long* rs_tile_totals(hipStream_t s, TileBaseWorkspace
                        tb.totals.as<unsigned long long>());
     return tb.totals.as<unsigned long long>();
 }
-// ... and the tile bases, once the digit starts are on the device (rs_tile_totals ran before)
+// ... and the tile bases, once the digit starts are on the device (the block sums are taken again: the column map may differ
+// from the one the totals were made with — raw bytes there, bucket slots here)
 inline const unsigned long long* rs_tile_bases(hipStream_t s, TileBaseWorkspace& tb, const uint32_t* d_counts, uint32_t rows, const uint16_t* d_src_col,
                                                const unsigned long long* d_digit_start) {
     const uint32_t blocks = (uint32_t)ceil_div((uint64_t)rows, (uint64_t)RS_TB_ROWS);
+    tb.partial.ensure((size_t)blocks * 256 * sizeof(uint64_t));
     tb.blockbase.ensure((size_t)blocks * 256 * sizeof(uint64_t));
     tb.base.ensure((size_t)rows * 256 * sizeof(uint64_t));
+    hipLaunchKernelGGL(rs_tilecol_sum_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col, tb.partial.as<unsigned long long>());
     hipLaunchKernelGGL(rs_tilecol_scan_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
                        d_digit_start, tb.blockbase.as<unsigned long long>());
     hipLaunchKernelGGL(rs_tilecol_apply_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col,
@@ -2278,7 +2281,8 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
 template <typename W>
 void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const uint64_t* h_first,
                        const TextGen& gen_in, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles, int lead,
-                       int npass, unsigned long long* d_hist_out, SortStats* stats, bool lane_striped = true) {
+                       int npass, unsigned long long* d_hist_out, SortStats* stats, bool lane_striped = true,
+                       const uint32_t* d_tile_counts = nullptr, const uint16_t* d_src_col = nullptr, TileBaseWorkspace* tbw = nullptr) {
     if (!rs_atomic_rank_ok(s)) throw Error("radix_gen_records: needs the one-atomic ranking (internal)");
     constexpr int TILE = RS_SEG_TILE;
     using CfgG = RsCfg<16, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
@@ -2304,7 +2308,35 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
     // lane-striped generator (TextGenRecL) where its arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the
     // key's nsym - 1 symbols come from three code windows (<= 10 symbols); otherwise the rolling form
     const bool striped = lane_striped && g2.base <= 255u && g2.nsym - 1 <= 10 && g2.nsym >= 2;
-    if (striped) {
+    if (d_tile_counts && tbw) {
+        // look-back-free form (TextGen::tile_base): per-tile byte counts (sa_build.hip: sa_tile_bytecount_kernel), columns mapped
+        // byte -> bucket slot, scanned over the tiles; 8 Ki-key tiles, two workgroups per CU
+        constexpr int GT = RS_GEN8_TILE;
+        using CfgG8 = RsCfg<16, true, true, 512, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+        using CfgP8 = RsCfg<16, true, true, 512, false, 1, 0, 4, false, true>;
+        const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)GT);
+        g2.tile_base = rs_tile_bases(s, *tbw, d_tile_counts, tiles8, d_src_col, (const unsigned long long*)d_start);
+        ws.tile_doc.ensure(((size_t)tiles8 + 1) * sizeof(uint64_t));
+        hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8 + 1, 256)), dim3(256), 0, s, g2.doc_start, g2.ndocs, n,
+                           (uint64_t)GT, (uint64_t)tiles8, ws.tile_doc.as<uint64_t>());
+        g2.tile_doc = ws.tile_doc.as<uint64_t>();
+        const uint32_t grid8 = grouped ? (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP) : tiles8;
+        uint32_t* tk = grouped ? ws.xticket_ptr(e) : ws.ticket_ptr(e);
+#define CDB_REC8(CFG, GENT, GENV)                                                                                                      \
+    hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, GENT, W>), dim3(grid8), dim3(512), 0, s, (const uint32_t*)nullptr, k, \
+                       (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(), tk, e,    \
+                       ws.err_ptr(), GENV, (const W*)nullptr, w, -1)
+        if (striped) {
+            TextGenRecL g3;
+            static_cast<TextGen&>(g3) = g2;
+            if (grouped) CDB_REC8(CfgG8, TextGenRecL, g3);
+            else CDB_REC8(CfgP8, TextGenRecL, g3);
+        } else {
+            if (grouped) CDB_REC8(CfgG8, TextGenRec, g2);
+            else CDB_REC8(CfgP8, TextGenRec, g2);
+        }
+#undef CDB_REC8
+    } else if (striped) {
         TextGenRecL g3;
         static_cast<TextGen&>(g3) = g2;
         if (grouped)

@@ -71,6 +71,53 @@ __global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __rest
     if (s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
+// The same per tile of RS_GEN8_TILE positions (bucket-wise builds with look-back-free generated passes, radix_sort.h:
+// TextGen::tile_base): counts[tile][byte] — every position starts a suffix whose bucket is its first byte's, so these rows, with
+// their columns mapped byte -> bucket slot, are the per-tile digit counts of the records / partition pass, and their column sums
+// are the byte histogram.  Wave-autonomous like sa_tile_paircount_kernel below.
+constexpr uint32_t TBC_TILES_PER_WAVE = 8;
+__global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t tiles, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_cnt[4][4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t* cnt = s_cnt[wave][lane & 3];
+    uint32_t* call = &s_cnt[wave][0][0];
+    for (uint32_t k = 0; k < TBC_TILES_PER_WAVE; ++k) {
+        const uint32_t tile = (blockIdx.x * 4u + (uint32_t)wave) * TBC_TILES_PER_WAVE + k;
+        if (tile >= tiles) break;  // (uniform per wavefront)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) call[q * 64 + lane] = 0;
+        const uint64_t b0 = (uint64_t)tile * RS_GEN8_TILE;
+        constexpr int VEC = RS_GEN8_TILE / 16 / 64;
+#pragma unroll 2
+        for (int r = 0; r < VEC; ++r) {
+            const uint64_t p = b0 + ((uint64_t)r * 64 + lane) * 16;
+            if (p >= n) continue;
+            if (p + 16 <= n) {
+                const uint4 v = *reinterpret_cast<const uint4*>(text + p);
+                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    atomicAdd(&cnt[x[q] & 0xFF], 1u);
+                    atomicAdd(&cnt[(x[q] >> 8) & 0xFF], 1u);
+                    atomicAdd(&cnt[(x[q] >> 16) & 0xFF], 1u);
+                    atomicAdd(&cnt[x[q] >> 24], 1u);
+                }
+            } else {
+                for (int q = 0; q < 16; ++q)
+                    if (p + q < n) atomicAdd(&cnt[text[p + q]], 1u);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dgt = q * 64 + lane;
+            counts[(size_t)tile * 256 + dgt] = call[dgt] + call[256 + dgt] + call[512 + dgt] + call[768 + dgt];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // MSD-first initial sort, pair form (radix_sort.h: TextGen::msd_pair): how often every pair of symbol CODES (c0, c1) starts
 // a suffix, as the number c0 * base + c1 — c1 = 0 where the document ends behind c0.  The sweep ignores document ends (and
 // counts nothing for the last byte of the text); sa_docend_pair_kernel moves the last position of every document from the
@@ -1650,7 +1697,20 @@ void build_typed(Index& ix, bool big) {
     d_counts.alloc(256 * sizeof(uint64_t));
     d_symmap.alloc(256 * sizeof(uint16_t));
     CDB_HIP(hipMemsetAsync(d_counts.p, 0, 256 * sizeof(uint64_t), s));
-    {
+    // bucket-wise builds with look-back-free generated passes count the bytes per 8 Ki-position tile (the rows become the tile
+    // bases of the records / partition pass, radix_sort.h: TextGen::tile_base); their column sums are the histogram
+    DevBuf d_tbc;
+    const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_GEN8_TILE);
+    const bool tile_bytes = big && sizeof(V) == 8 && ix.gen_prebased && ix.segmented_sort && rs_atomic_rank_ok(s);
+    const unsigned long long* d_count_src = d_counts.as<unsigned long long>();
+    if (tile_bytes) {
+        d_tbc.alloc((size_t)tiles8 * 256 * sizeof(uint32_t));
+        int t = ix.prof.begin(s);
+        hipLaunchKernelGGL(sa_tile_bytecount_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TBC_TILES_PER_WAVE))), dim3(256), 0, s, text, n,
+                           tiles8, d_tbc.as<uint32_t>());
+        d_count_src = rs_tile_totals(s, ix.tbw, d_tbc.as<uint32_t>(), tiles8, nullptr);
+        ix.prof.end(t, "sa_tile_bytecount", n + (uint64_t)tiles8 * 2048, s);
+    } else {
         const int grid = (int)std::min<uint64_t>(ceil_div(n, 256 * 16 * 4), 256 * 8);
         int t = ix.prof.begin(s);
         hipLaunchKernelGGL(sa_bytecount_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, text, n,
@@ -1658,7 +1718,7 @@ void build_typed(Index& ix, bool big) {
         ix.prof.end(t, "sa_bytecount", n, s);
     }
     uint64_t h_counts[256];
-    CDB_HIP(hipMemcpyAsync(h_counts, d_counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipMemcpyAsync(h_counts, d_count_src, sizeof(h_counts), hipMemcpyDeviceToHost, s));
     CDB_HIP(hipStreamSynchronize(s));
     uint16_t h_map[256];
     int sigma = 0;
@@ -2183,6 +2243,16 @@ void build_typed(Index& ix, bool big) {
         DevBuf d_symmap_first;
         d_symmap_first.alloc(256 * sizeof(uint16_t));
         CDB_HIP(hipMemcpyAsync(d_symmap_first.p, h_map_first, sizeof(h_map_first), hipMemcpyHostToDevice, s));
+        // (look-back-free generated passes: which byte's per-tile counts feed bucket slot d; 0xFFFF = no such slot)
+        DevBuf d_src_col;
+        uint16_t h_src_col[256];
+        for (int d = 0; d < 256; ++d) h_src_col[d] = 0xFFFFu;
+        for (int b = 0; b < 256; ++b)
+            if (h_map[b]) h_src_col[h_map_first[b]] = (uint16_t)b;
+        if (tile_bytes) {
+            d_src_col.alloc(sizeof(h_src_col));
+            CDB_HIP(hipMemcpyAsync(d_src_col.p, h_src_col, sizeof(h_src_col), hipMemcpyHostToDevice, s));
+        }
         CDB_HIP(hipStreamSynchronize(s));  // (h_map_first is a stack array)
         uint64_t maxb = 0;
         for (int c = 1; c <= sigma; ++c) maxb = std::max(maxb, h_first[c]);
@@ -2488,7 +2558,10 @@ void build_typed(Index& ix, bool big) {
                                 radix_gen_records<W>(s, ix.rws, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n,
                                                      first_digit.data(), rg, (const uint32_t*)tile_seg.as<uint32_t>(),
                                                      (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
-                                                     d_bh2.as<unsigned long long>(), &ss, ix.records_lane_striped);
+                                                     d_bh2.as<unsigned long long>(), &ss, ix.records_lane_striped,
+                                                     tile_bytes ? (const uint32_t*)d_tbc.as<uint32_t>() : nullptr,
+                                                     tile_bytes ? (const uint16_t*)d_src_col.as<uint16_t>() : nullptr, tile_bytes ? &ix.tbw : nullptr);
+                                st.gen_prebased = tile_bytes ? 1 : 0;
                             }
                         } else {
                         CDB_HIP(hipMemsetAsync(d_bh2.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
