@@ -33,6 +33,7 @@ struct BuildStats {
     int msd_first = 0;           // single sort: top digit first, then (u32, u32) records sorted bucket by bucket (radix_sort_msd)
     int gen_prebased = 0;        // ... generated pass without look-back (counted tile bases)
     int fused_records = 0;       // ... bucket records written by the generated pass itself (one bucket group): no partition + gather
+    int sweep_records = 0;       // ... bucket records of every bucket group written by a sweep over the text (records_sweep.h): no partition + gather
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -216,6 +217,7 @@ struct Index {
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)
     bool fuse_records = true;  // bucket-wise build with ONE bucket group: the generated pass writes the records (0 = partition + gather)
+    bool sweep_records = true; // bucket-wise build with several bucket groups: one sweep over the text per group writes its records (0 = partition + gather)
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
     bool msd_first = true;    // keys of 33..40 bits below 2^32 suffixes: top digit first, then every bucket on its own with
                               // (u32, u32) records (radix_sort_msd); 0 = LSD split sort with the low digit as a travelling byte

@@ -1,0 +1,267 @@
+// records_sweep.h — bucket records of ONE GROUP of first-symbol buckets straight from the text (round 4).
+//
+// The bucket-wise build (sa_build.hip, >= 2^32 suffixes) whose records do not fit the device all at once used to PARTITION the
+// entries by first symbol (one generated pass over the text, 5-8 B written per suffix) and then, group of buckets by group,
+// GATHER every bucket's records through those entries (entries re-read, the text re-read in bucket order, records written):
+// 16 GiB of UTF-8: 82 + 129 ms of 692.  The look-back-free form of the generated passes (radix_sort.h: TextGen::tile_base)
+// makes both unnecessary: with the per-tile byte counts scanned over the tiles, every tile knows where its suffixes of every
+// bucket go, so a sweep over the text can write the records of ANY subset of the buckets in place — one sweep per group, each
+// reading the text once (1 B per suffix) and writing only its group's records.
+//
+// A sweep must be cheap for the suffixes it does NOT keep (two thirds of them with three groups), so the kernel ranks first and
+// generates afterwards: phase A looks at one staged symbol per position (bucket slot -> LDS counter -> rank), phase B walks the
+// tile's KEPT positions in output order, evaluates their records (the arithmetic of TextGenRecL: nsym - 1 <= 10 codes behind the
+// bucket symbol as a number in base B <= 255, pairs by v_dot4_u32_u8, Horner in base B^2) and writes them lane-consecutively —
+// no record ever crosses the LDS, only a 16-bit position, its bucket slot and its document do.
+//
+// reference: the records are the sort keys of src/index.h:66-101 (radix_sort on the suffixes' leading bytes), restated as dense
+// numbers per first-symbol bucket; DESIGN.md §4.2.
+#pragma once
+#include "radix_sort.h"
+
+namespace cdb {
+
+constexpr int RS_SWEEP_TILE = RS_GEN8_TILE;  // 512 threads x 16 positions: two workgroups per CU
+constexpr uint32_t RS_SWEEP_DOCS = 1024;     // document starts of a tile kept in LDS (more: binary searches in global memory)
+
+// gen: text, doc_start, bits, base, nsym, rec_low_bits, padded, tile_doc (per RS_SWEEP_TILE), tile_base ([tiles][256]: array-wide
+// output slot of the tile's first suffix of every bucket slot); codeslot[byte] = symbol code | bucket slot << 8.
+// Keeps the suffixes whose bucket slot is in [g0, g1); record r of the group lands at index tile_base - gstart.
+template <typename W>
+__global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
+                                                                  uint32_t g0, uint32_t g1, uint64_t gstart, uint32_t* __restrict__ kout,
+                                                                  uint32_t* __restrict__ vout, W* __restrict__ wout) {
+    constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
+    static_assert(NT * IPT == TILE, "tile shape");
+    constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
+    __shared__ uint16_t s_cs[256];
+    __shared__ uint64_t s_docs[RS_SWEEP_DOCS];
+    __shared__ uint32_t s_whist[NW][256];
+    __shared__ uint32_t s_tstart[256];
+    __shared__ uint64_t s_gbase[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint16_t s_idx[TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dig[TILE];  // staged bucket slots by position, then by output slot
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware static tile map (no look-back, so no order between tiles is needed for progress): workgroup b runs on XCD b % 8,
+    // which takes the tile groups x, x + 8, ... of RS_GROUP consecutive tiles each — neighbouring output runs meet in one L2
+    const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint64_t tile = (uint64_t)((slot / RS_GROUP) * 8u + x) * RS_GROUP + slot % RS_GROUP;
+    if (tile >= (uint64_t)tiles) return;
+    const uint64_t base = tile * TILE;
+    const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
+
+    // ---- everything the tile needs from global memory is requested up front, in ONE round trip where possible: its text (16 B
+    // per thread), the byte table, its tile bases (one per thread and bucket slot of the group), its document range
+    const uint64_t ga = base + (uint64_t)tid * 16, gb = base + (uint64_t)TILE + (uint64_t)tid * 16;
+    const bool has_b = (uint32_t)tid * 16 < TEXTB - (uint32_t)TILE;
+    const bool oka = gen.padded ? (ga < n + RS_GEN_LOOK) : (ga + 16 <= n);
+    const bool okb = has_b && (gen.padded ? (gb < n + RS_GEN_LOOK) : (gb + 16 <= n));
+    uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
+    if (oka) ta = *reinterpret_cast<const uint4*>(gen.text + ga);
+    if (okb) tb = *reinterpret_cast<const uint4*>(gen.text + gb);
+    uint64_t my_base = 0;
+    if ((uint32_t)tid >= g0 && (uint32_t)tid < g1) my_base = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)tid];
+    if (tid < 256) s_cs[tid] = codeslot[tid];
+    const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
+    for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
+    // (the document starts are wanted in phase B only: their loads have the staging and the ranking to land)
+    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)RS_SWEEP_DOCS;
+    if (docs_in_lds)
+        for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
+    __syncthreads();
+
+    // ---- staging: one table lookup per byte gives the symbol code (kept for phase B) and the bucket slot; both go to the LDS as
+    // the 16-byte vectors the thread loaded
+    auto fetch = [&](uint64_t g, bool ok, uint4 w, uint32_t* c) {
+        c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = w.w;
+        if (!ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) c[q] |= (uint32_t)((g + 4 * q + b < n) ? gen.text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+            }
+        }
+    };
+    {
+        uint32_t c[4];
+        fetch(ga, oka, ta, c);
+        uint32_t e[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) e[k] = s_cs[(c[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+        uint32_t codes[4], slots[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            codes[q] = (e[4 * q] & 0xFFu) | ((e[4 * q + 1] & 0xFFu) << 8) | ((e[4 * q + 2] & 0xFFu) << 16) | ((e[4 * q + 3] & 0xFFu) << 24);
+            slots[q] = (e[4 * q] >> 8) | ((e[4 * q + 1] >> 8) << 8) | ((e[4 * q + 2] >> 8) << 16) | ((e[4 * q + 3] >> 8) << 24);
+        }
+        *reinterpret_cast<uint4*>(&s_text[(uint32_t)tid * 16]) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
+        *reinterpret_cast<uint4*>(&s_dig[(uint32_t)tid * 16]) = make_uint4(slots[0], slots[1], slots[2], slots[3]);
+        if (has_b) {  // the look-ahead behind the tile: codes only
+            fetch(gb, okb, tb, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                c[q] = (uint32_t)(s_cs[c[q] & 0xFF] & 0xFFu) | ((uint32_t)(s_cs[(c[q] >> 8) & 0xFF] & 0xFFu) << 8) |
+                       ((uint32_t)(s_cs[(c[q] >> 16) & 0xFF] & 0xFFu) << 16) | ((uint32_t)(s_cs[c[q] >> 24] & 0xFFu) << 24);
+            *reinterpret_cast<uint4*>(&s_text[(uint32_t)TILE + (uint32_t)tid * 16]) = make_uint4(c[0], c[1], c[2], c[3]);
+        }
+    }
+    __syncthreads();
+    // ---- phase A: rank the kept positions, lane-striped (position = wave chunk + j * 64 + lane): one returning LDS atomic on the
+    // wave's counter of the slot per kept position.  The atomics of a wave instruction are served in lane order
+    // (rs_atomic_rank_ok), so ranks ascend with the position: every bucket's records stay in TEXT order, which the stable passes
+    // behind them hand on to suffixes with equal keys.  No dependent chain between positions: 16 reads, then 16 atomics.
+    constexpr int WCHUNK = IPT * 64;
+    const uint32_t wbase = wave * WCHUNK + lane;
+    uint32_t info[IPT];  // rank | slot << 16, ~0 = not kept
+    {
+        uint32_t sl[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) sl[j] = s_dig[wbase + j * 64];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const bool keep = wbase + j * 64 < valid && sl[j] >= g0 && sl[j] < g1;
+            uint32_t inf = ~0u;
+            if (keep) inf = atomicAdd(&s_whist[wave][sl[j]], 1u) | (sl[j] << 16);
+            info[j] = inf;
+        }
+    }
+    __syncthreads();
+    // ---- per-slot totals of the tile: exclusive prefix across the waves, then across the slots
+    uint32_t cnt = 0, incl = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t t = s_whist[w][tid];
+            s_whist[w][tid] = cnt;
+            cnt += t;
+        }
+        incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+    }
+    __syncthreads();
+    const uint32_t kept = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    if (tid < 256) {
+        uint32_t wpre = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) wpre += s_wsum[w];
+        const uint32_t tstart = wpre + incl - cnt;
+        s_tstart[tid] = tstart;
+        s_gbase[tid] = my_base - gstart - (uint64_t)tstart;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        if (info[k] != ~0u) {
+            const uint32_t sl = (info[k] >> 16) & 0xFFu;
+            const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
+            s_idx[pos] = (uint16_t)(wbase + k * 64);
+            s_dig[pos] = (uint8_t)sl;  // (the staged slots are dead since the barrier behind phase A)
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: the kept positions in output order: record = (key >> low bits, entry low word, key low bits | entry high bits)
+    const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
+    const uint32_t B = gen.base, B2 = B * B;
+    const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
+    const int ns1 = gen.nsym - 1;
+    const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
+    const uint32_t ndl = (uint32_t)(dhi - dlo);
+#pragma unroll 2
+    for (uint32_t p = tid; p < kept; p += NT) {
+        const uint32_t li = s_idx[p], sl = s_dig[p];
+        const uint64_t pos = base + li;
+        uint64_t dd, ds, de;
+        if (docs_in_lds) {
+            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
+            }
+            dd = dlo + lo;
+            ds = s_docs[lo];
+            de = s_docs[lo + 1];
+        } else {
+            dd = rs_doc_upper(gen.doc_start, dlo, dhi, pos);
+            ds = gen.doc_start[dd];
+            de = gen.doc_start[dd + 1];
+        }
+        const uint64_t e64 = ((pos - ds) << gen.bits) + dd;
+        const uint64_t left = de - pos - 1ull;  // key symbols left in the document
+        const uint32_t rem1 = left < 64ull ? (uint32_t)left : 64u;
+        const uint32_t l1 = li + 1u, wi = l1 >> 2, sel = l1 & 3u;
+        const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+        uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li + 1 .. li + 4
+        uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 5 .. li + 8
+        uint32_t x2 = 0;
+        if (ns1 > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
+        if (rem1 < (uint32_t)ns1) {  // (rare) the symbols behind the document end count as 0
+            x0 = rem1 >= 4u ? x0 : (rem1 == 0u ? 0u : (x0 & ((1u << (8u * rem1)) - 1u)));
+            x1 = rem1 >= 8u ? x1 : (rem1 <= 4u ? 0u : (x1 & ((1u << (8u * (rem1 - 4u))) - 1u)));
+            x2 = rem1 >= 12u ? x2 : (rem1 <= 8u ? 0u : (x2 & ((1u << (8u * (rem1 - 8u))) - 1u)));
+        }
+        uint64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (2 * q < ns1) {  // (uniform)
+                const uint32_t xw = q < 2 ? x0 : (q < 4 ? x1 : x2);
+                uint32_t pv, mult;
+                if (2 * q + 1 < ns1) {
+                    pv = __builtin_amdgcn_udot4(xw, (q & 1) ? whi : wlo, 0u, false);
+                    mult = B2;
+                } else {  // an odd number of symbols: the last one stands alone
+                    pv = (q & 1) ? ((xw >> 16) & 0xFFu) : (xw & 0xFFu);
+                    mult = B;
+                }
+                if (q == 0) acc = pv;
+                else if (q == 1) acc = (uint64_t)(uint32_t)acc * mult + pv;  // (below 2^16 x 2^16: one v_mad_u64_u32)
+                else acc = acc * (uint64_t)mult + pv;
+            }
+        }
+        const uint64_t dst = s_gbase[sl] + (uint64_t)p;
+        kout[dst] = (uint32_t)(acc >> gen.rec_low_bits);
+        vout[dst] = (uint32_t)e64;
+        wout[dst] = (W)((acc & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+    }
+}
+
+// whether the sweep's arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the key's nsym - 1 symbols come
+// from three code windows (<= 10 symbols after the first 4 + 4 ... see TextGenRecL)
+inline bool rs_sweep_records_ok(uint32_t base, int nsym) { return base <= 255u && nsym >= 2 && nsym - 1 <= 10; }
+
+// One group: records of the buckets [g0, g1) into (k, v, w) at group-local indices, then the digit histograms of every bucket's
+// passes from the records (d_hist_out: [nseg][8][256], zeroed here).  d_tile_doc: [tiles8 + 1] (rs_tiledoc_kernel over
+// RS_SWEEP_TILE); gen_in.tile_base: array-wide tile bases of all bucket slots (rs_tile_bases).
+template <typename W>
+void radix_sweep_records(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const TextGen& gen_in, const uint16_t* d_codeslot,
+                         uint32_t g0, uint32_t g1,
+                         uint64_t gstart, uint64_t gelems, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles,
+                         int lead, int npass, unsigned long long* d_hist_out, SortStats* stats) {
+    if (!gen_in.tile_base || !gen_in.tile_doc || !d_codeslot) throw Error("radix_sweep_records: tile bases / documents / slots missing (internal)");
+    if (!rs_sweep_records_ok(gen_in.base, gen_in.nsym)) throw Error("radix_sweep_records: key shape (internal)");
+    const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_SWEEP_TILE);
+    const uint32_t grid = (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP);
+    CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
+    int t = prof.begin(s);
+    hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w);
+    prof.end(t, (std::string("rs_sweep_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t8192").c_str(),
+             n + gelems * (8 + sizeof(W)), s);
+    if (stats) stats->passes_run++;
+    t = prof.begin(s);
+    hipLaunchKernelGGL((rs_seg_hist_kernel<W>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s, (const uint32_t*)k,
+                       (const W*)w, lead, npass, d_tile_seg, d_segs, seg_tiles, d_hist_out);
+    prof.end(t, "rs_seg_hist", gelems * (4 + (lead > 0 ? sizeof(W) : 0)), s);
+    CDB_HIP(hipGetLastError());
+}
+
+}  // namespace cdb

@@ -36,6 +36,7 @@
 #include <cstring>
 
 #include "index_impl.h"
+#include "records_sweep.h"
 #include "scan.h"
 
 namespace cdb {
@@ -2326,6 +2327,10 @@ void build_typed(Index& ix, bool big) {
             }
         }
         packed_out = fuse_rec && want_pack;
+        // SWEEP form (records_sweep.h): the records do not fit at once, but with counted tile bases a sweep over the text can write
+        // the records of any bucket group in place — the entries are not partitioned and no gather re-reads them and the text
+        bool sweep_rec = !fuse_rec && tile_bytes && ix.sweep_records && brecords && packed && sigma <= 255 && ix.segmented_sort &&
+                         sizeof(V) == 8 && rs_atomic_rank_ok(s) && rs_sweep_records_ok(bbase, nsym);
         // partition + gather with packed output: the partitioned entries ARE stored packed from the start (E = low words,
         // sa_hi_buf = bits 32..39): the gather reads them through Sa40, the last pass of every group writes the finished
         // entries back in that form — 16 GiB of text: 80 instead of 128 GiB of suffix array, during the build and after it
@@ -2339,11 +2344,12 @@ void build_typed(Index& ix, bool big) {
         st.alloc_ms += now_ms() - ta;
         st.fused_records = fuse_rec ? 1 : 0;
         DevBuf d_slotmap;
-        if (fuse_rec) {
+        if (fuse_rec || sweep_rec) {
             d_slotmap.alloc(260);
             CDB_HIP(hipMemcpyAsync(d_slotmap.p, h_slotmap, 260, hipMemcpyHostToDevice, s));
             CDB_HIP(hipStreamSynchronize(s));  // (h_slotmap is a stack array)
-        } else {
+        }
+        auto partition_entries = [&]() {
             gen.first_only = true;
             gen.symmap = d_symmap_first.as<uint16_t>();
             const int fbits = std::max(1, bit_width64((uint64_t)sigma - 1));
@@ -2351,7 +2357,8 @@ void build_typed(Index& ix, bool big) {
             (void)radix_sort<uint64_t, V>(s, ix.rws, ix.prof, (uint64_t*)nullptr, (uint64_t*)nullptr, (V*)nullptr, E.as<V>(), n, 0, fbits,
                                           &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
             radix_check_error(s, ix.rws);  // (the gathers below read the text through these entries)
-        }
+        };
+        if (!fuse_rec && !sweep_rec) partition_entries();
         if (root_folded) {
             uint64_t at = 0;
             for (int k = 0; k < sigma; ++k) {
@@ -2413,6 +2420,7 @@ void build_typed(Index& ix, bool big) {
             d_bstart.alloc((nb + 1) * 8);
             d_bounds.alloc(fuse_rec ? 8 : (size_t)nb * (nch + 1) * 8);
             CDB_HIP(hipMemcpyAsync(d_bstart.p, bstart.data(), (nb + 1) * 8, hipMemcpyHostToDevice, s));
+            auto bucket_bounds = [&]() {
             if (pack_E)
             hipLaunchKernelGGL((sa_bucket_bounds_kernel<Packed40>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
                                Sa40{E.as<uint32_t>(), sa_hi_buf.as<uint8_t>()}, (const unsigned long long*)d_bstart.as<unsigned long long>(), nb,
@@ -2421,6 +2429,34 @@ void build_typed(Index& ix, bool big) {
             hipLaunchKernelGGL((sa_bucket_bounds_kernel<V>), dim3((unsigned)ceil_div((uint64_t)nb * (nch + 1), 256)), dim3(256), 0, s,
                                (const V*)E.as<V>(), (const unsigned long long*)d_bstart.as<unsigned long long>(), nb, nch, chunk,
                                doc_start, (int)ix.bits, ix.mask, d_bounds.as<unsigned long long>());
+            };
+            if (!sweep_rec) bucket_bounds();
+            // sweep form: array-wide tile bases of every bucket slot (4 GiB of them for 16 GiB of text: allocated BEFORE the record
+            // memory is sized; the counts they were made from go back to the pool), the document of every tile's first position
+            DevBuf sweep_doc, d_codeslot;
+            const unsigned long long* sweep_base = nullptr;
+            if (sweep_rec) {
+                std::vector<uint16_t> codeslot(256, 0);  // byte -> symbol code | bucket slot << 8 (one lookup per text byte)
+                for (int b = 0; b < 256; ++b) codeslot[b] = (uint16_t)(h_map[b] | ((uint32_t)h_slotmap[h_map[b]] << 8));
+                d_codeslot.alloc(256 * sizeof(uint16_t));
+                CDB_HIP(hipMemcpyAsync(d_codeslot.p, codeslot.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+                std::vector<uint64_t> slot_start(256, n);
+                for (uint32_t b = 0; b < nb; ++b) slot_start[b] = bstart[b];
+                DevBuf d_slot_start;
+                d_slot_start.alloc(256 * sizeof(uint64_t));
+                CDB_HIP(hipMemcpyAsync(d_slot_start.p, slot_start.data(), 256 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+                int t = ix.prof.begin(s);
+                sweep_base = rs_tile_bases(s, ix.tbw, d_tbc.as<uint32_t>(), tiles8, d_src_col.as<uint16_t>(),
+                                           (const unsigned long long*)d_slot_start.as<unsigned long long>());
+                sweep_doc.alloc(((size_t)tiles8 + 1) * sizeof(uint64_t));
+                hipLaunchKernelGGL(rs_tiledoc_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8 + 1, 256)), dim3(256), 0, s, doc_start, D, n,
+                                   (uint64_t)RS_SWEEP_TILE, (uint64_t)tiles8, sweep_doc.as<uint64_t>());
+                ix.prof.end(t, "rs_tile_bases", (uint64_t)tiles8 * 256 * (4 + 8), s);
+                CDB_HIP(hipStreamSynchronize(s));  // (slot_start, d_slot_start, codeslot)
+                d_tbc.release();
+                ix.tbw.partial.release();
+                ix.tbw.blockbase.release();
+            }
             // groups of consecutive buckets whose records (4 + lowb bytes per suffix) fit the memory left
             size_t fre = 0, tot = 0;
             CDB_HIP(hipMemGetInfo(&fre, &tot));
@@ -2443,6 +2479,13 @@ void build_typed(Index& ix, bool big) {
             }
             if (!fuse_rec && getenv("CDB_DEBUG_NO_SEGCAP")) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
+            if (sweep_rec && !seg_cap) {  // (a bucket larger than the record memory: partition + gather, bucket by bucket)
+                sweep_rec = false;
+                sweep_doc.release();
+                ix.tbw.base.release();
+                partition_entries();
+                bucket_bounds();
+            }
             if (pack_E && !seg_cap) {
                 // (a bucket larger than the record memory: the per-bucket forms below work on plain 8-byte entries)
                 if constexpr (sizeof(V) == 8) {
@@ -2563,6 +2606,20 @@ void build_typed(Index& ix, bool big) {
                                                      tile_bytes ? (const uint16_t*)d_src_col.as<uint16_t>() : nullptr, tile_bytes ? &ix.tbw : nullptr);
                                 st.gen_prebased = tile_bytes ? 1 : 0;
                             }
+                        } else if (sweep_rec) {
+                            hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,
+                                               (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, tile_seg.as<uint32_t>());
+                            TextGen rg{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, bbase, nsym, 0, ix.text_padded};
+                            rg.slotmap = d_slotmap.as<uint8_t>();
+                            rg.rec_low_bits = blow;
+                            rg.tile_doc = sweep_doc.as<uint64_t>();
+                            rg.tile_base = sweep_base;
+                            radix_sweep_records<W>(s, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n, rg, (const uint16_t*)d_codeslot.as<uint16_t>(), g.b0, g.b1,
+                                                   g.gstart, g.elems,
+                                                   (const uint32_t*)tile_seg.as<uint32_t>(), (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb,
+                                                   g.tiles, lowb, bpass, d_bh2.as<unsigned long long>(), &ss);
+                            st.sweep_records = 1;
+                            st.gen_prebased = 1;
                         } else {
                         CDB_HIP(hipMemsetAsync(d_bh2.p, 0, (size_t)gb * 8 * 256 * sizeof(uint64_t), s));
                         int t = ix.prof.begin(s);
@@ -2615,6 +2672,7 @@ void build_typed(Index& ix, bool big) {
                         st.bucket_groups++;
                     }
                     CDB_HIP(hipStreamSynchronize(s));  // (h_segs and the group scratch go out of scope)
+                    if (sweep_rec) ix.tbw.base.release();
                     if (fuse_rec) E = std::move(kb[dead]);
                     if (pack_seg) packed_out = true;
                     st.segmented = 1;

@@ -241,6 +241,15 @@ def test_bucket_sorts_with_packed_entries(G, pack):
             if fused:
                 g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, fuse_records=0, **opts)
                 assert g2.stat("fused_records") == 0 and g2.stat("unresolved_after_initial") == g.stat("unresolved_after_initial")
+            # several bucket groups: one sweep over the text per group writes its records (records_sweep.h) where the lane-wise
+            # record arithmetic applies (base <= 255, <= 10 symbols behind the bucket symbol); sweep_records = 0 is partition + gather
+            swept = pack == 1 and group_limit > 0 and g.stat("alphabet") <= 254 and g.stat("key_symbols") <= 11
+            assert g.stat("sweep_records") == int(swept), (seed, g.stat("alphabet"), g.stat("key_symbols"))
+            if swept:
+                assert g.stat("bucket_groups") > 1
+                g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, sweep_records=0, **opts)
+                assert g2.stat("sweep_records") == 0 and g2.stat("unresolved_after_initial") == g.stat("unresolved_after_initial")
+                assert np.array_equal(g.sa(), g2.sa())
     assert (5 in {l for l, _ in layouts}) == bool(pack), layouts
     assert not pack or {d for _, d in layouts} == {0, 1, 2, 3}, layouts   # u8 / u16 / u32 auxiliary arrays
 

@@ -21,6 +21,9 @@ for k in syms:
     g = capi.GpuStringIndex(device=0)
     g.set_option("profile", 1)
     g.set_option("key_symbols", k)
+    for kv in os.environ.get("CDB_OPTS", "").split(","):   # e.g. CDB_OPTS=sweep_records=0
+        if "=" in kv:
+            g.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ms = []
     for i in range(reps + 1):
         if i == 1:
@@ -29,11 +32,11 @@ for k in syms:
         ms.append(g.stat("build_ms"))
     prof = g.profile()
     v = g.verify_reference() if cfg["kind"] == "utf8" else g.verify()
-    top = {kk: round(vv["ms"] / reps, 2) for kk, vv in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:7]}
+    top = {kk: round(vv["ms"] / reps, 2) for kk, vv in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get('CDB_TOP', '7'))]}
     st = bench.build_stats(g)
     print(json.dumps({"workload": name, "key_symbols_option": k, "key_symbols": st.get("key_symbols"), "build_ms": [round(x, 2) for x in ms[1:]],
                       "unresolved_after_initial": st.get("unresolved_after_initial"), "unresolved_share": round(st.get("unresolved_after_initial", 0) / n, 5),
-                      "sort_passes": st.get("sort_passes"), "ext_rounds": st.get("ext_rounds"), "dbl_rounds": st.get("dbl_rounds"),
+                      "sort_passes": st.get("sort_passes"), "bucket_groups": st.get("bucket_groups"), "sweep_records": st.get("sweep_records"), "ext_rounds": st.get("ext_rounds"), "dbl_rounds": st.get("dbl_rounds"),
                       "alg_bytes_per_suffix": round(sum(x["bytes"] for x in prof.values()) / reps / n, 1), "kernels_ms": top,
                       "verify": {kk: int(vv) for kk, vv in v.items() if kk in ("inversions", "tie_violations", "invalid_entries", "violations")}}), flush=True)
     g.close()

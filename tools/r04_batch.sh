@@ -1,5 +1,2 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -5
-for w in utf8_4g c2; do
-CDB_OPTS=gen_prebased=0 python tools/alloc_probe.py $w 3 2>&1 | grep build | tail -1 | cut -c1-110
-python tools/keywidth_ab.py $w 0 2 2>&1 | grep workload | cut -c1-800
-done
+python -m pytest tests/test_gpu_parity.py -x -q -k "bucket or segmented or packed or reference_order or 256" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+CDB_TOP=12 timeout 600 python tools/keywidth_ab.py c4shard 0 2 2>&1 | grep -E "workload|Error|error" | cut -c1-1500
