@@ -30,7 +30,7 @@ constexpr uint32_t RS_SWEEP_DOCS = 1024;     // document starts of a tile kept i
 template <typename W>
 __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
                                                                   uint32_t g0, uint32_t g1, uint64_t gstart, uint32_t* __restrict__ kout,
-                                                                  uint32_t* __restrict__ vout, W* __restrict__ wout) {
+                                                                  uint32_t* __restrict__ vout, W* __restrict__ wout, int abl) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
     static_assert(NT * IPT == TILE, "tile shape");
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
         }
     }
     __syncthreads();
+    if (abl & 2) return;  // (timing only: staging alone)
     // ---- phase A: rank the kept positions, lane-striped (position = wave chunk + j * 64 + lane): one returning LDS atomic on the
     // wave's counter of the slot per kept position.  The atomics of a wave instruction are served in lane order
     // (rs_atomic_rank_ok), so ranks ascend with the position: every bucket's records stay in TEXT order, which the stable passes
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     }
     __syncthreads();
 
+    if (abl & 1) return;  // (timing only: no records)
     // ---- phase B: the kept positions in output order: record = (key >> low bits, entry low word, key low bits | entry high bits)
     const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
     const uint32_t B = gen.base, B2 = B * B;
@@ -182,7 +184,11 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
         const uint32_t li = s_idx[p], sl = s_dig[p];
         const uint64_t pos = base + li;
         uint64_t dd, ds, de;
-        if (docs_in_lds) {
+        if (abl & 4) {  // (timing only: no document search)
+            dd = dlo;
+            ds = s_docs[0];
+            de = ds + (1ull << 40);
+        } else if (docs_in_lds) {
             uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
             while (lo < hi) {
                 const uint32_t mid = lo + (hi - lo + 1) / 2;
@@ -229,6 +235,10 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
             }
         }
         const uint64_t dst = s_gbase[sl] + (uint64_t)p;
+        if (abl & 8) {  // (timing only: no stores)
+            if (acc == 0x123456789ull && e64 == 77) kout[dst] = 1;
+            continue;
+        }
         kout[dst] = (uint32_t)(acc >> gen.rec_low_bits);
         vout[dst] = (uint32_t)e64;
         wout[dst] = (W)((acc & lmask) | ((e64 >> 32) << gen.rec_low_bits));
@@ -252,8 +262,9 @@ void radix_sweep_records(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v
     const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_SWEEP_TILE);
     const uint32_t grid = (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP);
     CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
+    static const int abl = getenv("CDB_SWEEP_ABL") ? std::atoi(getenv("CDB_SWEEP_ABL")) : 0;  // timing-only ablations (WRONG results)
     int t = prof.begin(s);
-    hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w);
+    hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w, abl);
     prof.end(t, (std::string("rs_sweep_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t8192").c_str(),
              n + gelems * (8 + sizeof(W)), s);
     if (stats) stats->passes_run++;

@@ -241,12 +241,12 @@ def test_bucket_sorts_with_packed_entries(G, pack):
             if fused:
                 g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, fuse_records=0, **opts)
                 assert g2.stat("fused_records") == 0 and g2.stat("unresolved_after_initial") == g.stat("unresolved_after_initial")
-            # several bucket groups: one sweep over the text per group writes its records (records_sweep.h) where the lane-wise
+            # one sweep over the text per bucket group writes the group's records (records_sweep.h) where the lane-wise
             # record arithmetic applies (base <= 255, <= 10 symbols behind the bucket symbol); sweep_records = 0 is partition + gather
-            swept = pack == 1 and group_limit > 0 and g.stat("alphabet") <= 254 and g.stat("key_symbols") <= 11
+            swept = pack == 1 and g.stat("alphabet") <= 254 and g.stat("key_symbols") <= 11
             assert g.stat("sweep_records") == int(swept), (seed, g.stat("alphabet"), g.stat("key_symbols"))
             if swept:
-                assert g.stat("bucket_groups") > 1
+                assert (g.stat("bucket_groups") > 1) == (group_limit > 0)
                 g2, _ = _check_parity(G, blob, ds, patterns=pats, bucket_group_limit=group_limit, sweep_records=0, **opts)
                 assert g2.stat("sweep_records") == 0 and g2.stat("unresolved_after_initial") == g.stat("unresolved_after_initial")
                 assert np.array_equal(g.sa(), g2.sa())
@@ -758,12 +758,17 @@ def test_records_generators_at_the_alphabet_edge(G):
         blob = W.random_bytes(int(ds[-1]), 22 + lo, lo, hi)
         pats = W.sample_patterns(blob, ds, 120, 1, 5, seed=4, miss_frac=0.1)
         for ks in (0, 2, 3, 4, 7, 10, 12):
-            for striped in (1, 0):
-                opts = dict(force_big_path=1, records_lane_striped=striped)
+            # (striped = 2: the sweep kernel of records_sweep.h, which writes the fused form's records where its arithmetic applies —
+            #  the same condition as the lane-striped generator, which it replaced as the default; documents of 0..5 bytes: thousands
+            #  per tile, so the tile's document starts do not fit the LDS and the records look their documents up in global memory)
+            for striped in (2, 1, 0):
+                opts = dict(force_big_path=1, records_lane_striped=int(striped > 0), sweep_records=int(striped == 2))
                 if ks:
                     opts["key_symbols"] = ks
                 g, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
                 assert g.stat("fused_records") == 1, (lo, hi, opts)
+                if striped == 2:
+                    assert g.stat("sweep_records") == int(g.stat("alphabet") <= 254 and g.stat("key_symbols") <= 11), (lo, hi, opts)
 
 
 def test_full_self_check_finds_what_a_sample_can_miss(G, tmp_path):
