@@ -22,7 +22,7 @@
 namespace cdb {
 
 constexpr int RS_SWEEP_TILE = RS_GEN8_TILE;  // 512 threads x 16 positions: two workgroups per CU
-constexpr uint32_t RS_SWEEP_DOCS = 1024;     // document starts of a tile kept in LDS (more: binary searches in global memory)
+constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept in LDS (more: binary searches in global memory)
 
 // gen: text, doc_start, bits, base, nsym, rec_low_bits, padded, tile_doc (per RS_SWEEP_TILE), tile_base ([tiles][256]: array-wide
 // output slot of the tile's first suffix of every bucket slot); codeslot[byte] = symbol code | bucket slot << 8.
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
     __shared__ uint16_t s_cs[256];
     __shared__ uint64_t s_docs[RS_SWEEP_DOCS];
-    __shared__ uint32_t s_whist[NW][256];
+    constexpr int WH = 256 + 64;  // a wave's counters: one per bucket slot + one per lane for the positions it does not keep
+    __shared__ uint32_t s_whist[NW][WH];
+    __shared__ uint16_t s_pdoc[TILE / 32 + 2];  // document (tile-local) of every 32nd position
     __shared__ uint32_t s_tstart[256];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_wsum[4];
@@ -64,15 +66,22 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     if (okb) tb = *reinterpret_cast<const uint4*>(gen.text + gb);
     uint64_t my_base = 0;
     if ((uint32_t)tid >= g0 && (uint32_t)tid < g1) my_base = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)tid];
-    if (tid < 256) s_cs[tid] = codeslot[tid];
+    if (tid < 256) {  // (a byte outside the group: slot 0xFF — alphabets of <= 254 symbols, rs_sweep_records_ok)
+        const uint32_t e = codeslot[tid];
+        s_cs[tid] = (uint16_t)(((e >> 8) >= g0 && (e >> 8) < g1) ? e : (e | 0xFF00u));
+    }
     const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
-    for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
-    // (the document starts are wanted in phase B only: their loads have the staging and the ranking to land)
+    for (int i = tid; i < NW * WH; i += NT) (&s_whist[0][0])[i] = 0;
+    // (the document starts are wanted in phase B only: they stay in registers until the ranking is done — a store to the LDS in
+    //  front of the first barrier would make that barrier wait for two dependent global round trips)
+    const uint32_t ndl = (uint32_t)(dhi - dlo);  // (meaningful when docs_in_lds)
     const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)RS_SWEEP_DOCS;
-    if (docs_in_lds)
-        for (uint32_t i = tid; i < (uint32_t)(dhi - dlo + 2); i += NT) s_docs[i] = gen.doc_start[dlo + i];
+    uint64_t dreg0 = 0, dreg1 = 0;
+    if (docs_in_lds) {
+        if ((uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
+        if ((uint32_t)tid + NT < ndl + 2) dreg1 = gen.doc_start[dlo + tid + NT];
+    }
     __syncthreads();
-
     // ---- staging: one table lookup per byte gives the symbol code (kept for phase B) and the bucket slot; both go to the LDS as
     // the 16-byte vectors the thread loaded
     auto fetch = [&](uint64_t g, bool ok, uint4 w, uint32_t* c) {
@@ -98,6 +107,11 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
             codes[q] = (e[4 * q] & 0xFFu) | ((e[4 * q + 1] & 0xFFu) << 8) | ((e[4 * q + 2] & 0xFFu) << 16) | ((e[4 * q + 3] & 0xFFu) << 24);
             slots[q] = (e[4 * q] >> 8) | ((e[4 * q + 1] >> 8) << 8) | ((e[4 * q + 2] >> 8) << 16) | ((e[4 * q + 3] >> 8) << 24);
         }
+        if (valid < (uint32_t)TILE) {  // (uniform: the last tile) positions behind the text are kept by nobody
+#pragma unroll
+            for (int k = 0; k < IPT; ++k)
+                if ((uint32_t)tid * 16 + k >= valid) slots[k >> 2] |= 0xFFu << (8 * (k & 3));
+        }
         *reinterpret_cast<uint4*>(&s_text[(uint32_t)tid * 16]) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
         *reinterpret_cast<uint4*>(&s_dig[(uint32_t)tid * 16]) = make_uint4(slots[0], slots[1], slots[2], slots[3]);
         if (has_b) {  // the look-ahead behind the tile: codes only
@@ -117,20 +131,25 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     // behind them hand on to suffixes with equal keys.  No dependent chain between positions: 16 reads, then 16 atomics.
     constexpr int WCHUNK = IPT * 64;
     const uint32_t wbase = wave * WCHUNK + lane;
-    uint32_t info[IPT];  // rank | slot << 16, ~0 = not kept
+    uint32_t info[IPT];  // rank | slot << 16; slot 0xFF = not kept
     {
         uint32_t sl[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) sl[j] = s_dig[wbase + j * 64];
+        // (no branch, no execution mask: a position that is not kept counts on its lane's own counter behind the 256 slots)
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const bool keep = wbase + j * 64 < valid && sl[j] >= g0 && sl[j] < g1;
-            uint32_t inf = ~0u;
-            if (keep) inf = atomicAdd(&s_whist[wave][sl[j]], 1u) | (sl[j] << 16);
-            info[j] = inf;
+            uint32_t col = sl[j] == 0xFFu ? 256u + (uint32_t)lane : sl[j];
+            if (abl & 16) col = (col + (uint32_t)lane) & 0xFFu;  // (timing only: no two lanes on one counter)
+            info[j] = atomicAdd(&s_whist[wave][col], 1u) | (sl[j] << 16);
         }
     }
+    if (docs_in_lds) {
+        if ((uint32_t)tid < ndl + 2) s_docs[tid] = dreg0;
+        if ((uint32_t)tid + NT < ndl + 2) s_docs[tid + NT] = dreg1;
+    }
     __syncthreads();
+    if (abl & 32) return;  // (timing only: staging + ranking)
     // ---- per-slot totals of the tile: exclusive prefix across the waves, then across the slots
     uint32_t cnt = 0, incl = 0;
     if (tid < 256) {
@@ -147,8 +166,20 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
             if (lane >= off) incl += v;
         }
         if (lane == 63) s_wsum[wave] = incl;
+    } else if (docs_in_lds) {
+        // (the other four waves meanwhile: the document of every 32nd position, so that phase B searches between two of them)
+        for (uint32_t b = (uint32_t)tid - 256u; b < (uint32_t)TILE / 32 + 1; b += 256u) {
+            const uint64_t pos = base + (uint64_t)b * 32;
+            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
+            }
+            s_pdoc[b] = (uint16_t)lo;
+        }
     }
     __syncthreads();
+    if (abl & 64) return;  // (timing only: ... + first half of the scan)
     const uint32_t kept = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     if (tid < 256) {
         uint32_t wpre = 0;
@@ -162,8 +193,8 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        if (info[k] != ~0u) {
-            const uint32_t sl = (info[k] >> 16) & 0xFFu;
+        const uint32_t sl = info[k] >> 16;
+        if (sl != 0xFFu) {
             const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
             s_idx[pos] = (uint16_t)(wbase + k * 64);
             s_dig[pos] = (uint8_t)sl;  // (the staged slots are dead since the barrier behind phase A)
@@ -178,7 +209,6 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
     const int ns1 = gen.nsym - 1;
     const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
-    const uint32_t ndl = (uint32_t)(dhi - dlo);
 #pragma unroll 2
     for (uint32_t p = tid; p < kept; p += NT) {
         const uint32_t li = s_idx[p], sl = s_dig[p];
@@ -189,8 +219,8 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
             ds = s_docs[0];
             de = ds + (1ull << 40);
         } else if (docs_in_lds) {
-            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
-            while (lo < hi) {
+            uint32_t lo = s_pdoc[li >> 5], hi = s_pdoc[(li >> 5) + 1];  // largest d in [lo, hi] with s_docs[d] <= pos
+            while (lo < hi) {  // (documents longer than 32 bytes: rarely entered)
                 const uint32_t mid = lo + (hi - lo + 1) / 2;
                 if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
             }
