@@ -1,1 +1,4 @@
-python -m pytest tests -m gpu -q -x > /tmp/t.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR|Error|assert " /tmp/t.log | head -30 > gpurun_out/r04_gputests3.log; tail -c 1500 gpurun_out/r04_gputests3.log
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+for w in utf8_4g c2 c4shard; do
+CDB_TOP=6 timeout 600 python tools/keywidth_ab.py $w 0 2 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], d['kernels_ms'], d['verify'])"
+done
