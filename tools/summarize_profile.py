@@ -50,6 +50,9 @@ def family(name):
         if m.group(5) == "TextGen":
             return f"rs_onesweep_textgen{'_split' if aux else ''}_t{tile}"
         return f"rs_onesweep_{k}{v}{aux}_t{tile}"
+    m = re.search(r"rs_sweep_records_kernel<(unsigned char|unsigned short|unsigned int)>", name)
+    if m:
+        return "rs_sweep_records" + {"unsigned char": "_w8", "unsigned short": "_w16", "unsigned int": "_w32"}[m.group(1)] + "_t8192"
     m = re.search(r"(?:cdb::(?:\(anonymous namespace\)::)?)(\w+?)(?:_kernel)?[<(]", name)
     return m.group(1) if m and "cdb::" in name else name.split("(")[0][:48]
 
