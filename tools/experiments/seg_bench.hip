@@ -67,7 +67,9 @@ int main(int argc, char** argv) {
     unsigned long long* d_out;
     CDB_HIP(hipMalloc(&d_out, 4 * 8));
     if (!rs_atomic_rank_ok(s)) std::printf("one-atomic ranking self-test FAILED on this device\n");
-#ifdef SEG_IPT       // other tile sizes (keys and values share the staging buffer)
+#ifdef SEG_NT        // smaller workgroups: 16 keys per thread, keys and values staged at once — two or more workgroups per CU
+    using CfgG = RsCfg<16, false, true, SEG_NT, false, 1, 0, SEG_LB, false, true, true, 1, RS_GROUP>;
+#elif defined(SEG_IPT)       // other tile sizes (keys and values share the staging buffer)
     using CfgG = RsCfg<SEG_IPT, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
 #elif defined(SEG_NOREUSE)   // keys and values both staged at once (128 KB): one write-out phase instead of two
     using CfgG = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
@@ -195,7 +197,7 @@ int main(int argc, char** argv) {
             for (int p = 0; p < 4; ++p) {
                 const uint32_t e = ws.next_epoch(s);
                 int t = prof.begin(s);
-                hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, NoGen, NoVal, SegArgs>), dim3(grid), dim3(1024), 0, s,
+                hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, NoGen, NoVal, SegArgs>), dim3(grid), dim3(CfgG::NT), 0, s,
                                    (const uint32_t*)k[cur], k[cur ^ 1], (const uint32_t*)v[cur], v[cur ^ 1], n, 8 * p, 0xFFu,
                                    (const unsigned long long*)(d_starts + (size_t)p * 256), ws.status.as<uint64_t>(), ws.xticket_ptr(e), e,
                                    ws.err_ptr(), NoGen(), (const NoVal*)nullptr, (NoVal*)nullptr, -1, sa);
