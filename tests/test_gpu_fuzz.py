@@ -134,6 +134,10 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     if rng.random() < 0.2: opts["reference_compat"] = 0
     if rng.random() < 0.3: opts["initial_passes"] = int(rng.integers(1, 8))
     if rng.random() < 0.3: opts["pack_sa"] = 0          # (plain 8-byte storage; default: packed 5-byte storage)
+    # (drawn last, so that the seeds of earlier rounds keep their corpora and options) records by sweeps over the text — the default —
+    # against the generated records pass / partition + gather; counted tile bases against the chained scan
+    if rng.random() < 0.3: opts["sweep_records"] = 0
+    if rng.random() < 0.2: opts["gen_prebased"] = 0
     g = capi.GpuStringIndex()
     for k, v in opts.items():
         g.set_option(k, v)

@@ -1,2 +1,1 @@
-cd tools/experiments
-for b in seg_bench_nr seg_bench_nt512_lb4 seg_bench_nt512_lb8 seg_bench_nt256_lb4; do echo "== $b"; timeout 120 ./$b 30 256 3 2>&1 | tail -4; done
+CDB_FUZZ_N=200 CDB_FUZZ_SEG_N=400 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert|seed" | head -12
