@@ -2101,6 +2101,10 @@ inline const unsigned long long* rs_tile_bases(hipStream_t s, TileBaseWorkspace&
     return tb.base.as<unsigned long long>();
 }
 
+// (records_sweep.h) the generated pass of radix_sort_msd in two phases: rank on the staged top digits, generate in output order
+__global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
+                                                              uint32_t* __restrict__ vout);
+
 struct MsdWorkspace {
     DevBuf segs, tile_seg, hist, starts;
     void release() { segs.release(); tile_seg.release(); hist.release(); starts.release(); }
@@ -2112,7 +2116,7 @@ struct MsdWorkspace {
 inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, Profiler& prof, uint32_t* k0, uint32_t* k1,
                            uint32_t* v0, uint32_t* v1, uint8_t* wout, uint64_t n, const uint64_t* h_top, const TextGen& gen_in,
                            unsigned long long msd_m, const SegFinalKeepArgs& keep_in, SortStats* stats,
-                           const uint32_t* d_tile_counts = nullptr, TileBaseWorkspace* tbw = nullptr) {
+                           const uint32_t* d_tile_counts = nullptr, TileBaseWorkspace* tbw = nullptr, bool sweep_form = true) {
     // gen_in says how the generated pass splits a key into (top digit, u32 rest): msd_shift = 32 (msd_m = 2^32) or the pair
     // form (msd_m = span * base^4); the last pass puts the full key together again as top * msd_m + rest
     if (!rs_atomic_rank_ok(s)) throw Error("radix_sort_msd: needs the one-atomic ranking (internal)");
@@ -2170,7 +2174,10 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
         const uint32_t e = ws.next_epoch(s);
         const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles8, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles8;
         int t = prof.begin(s);
-        if (grouped)
+        if (sweep_form)  // (no record crosses the LDS, three workgroups per CU; static XCD-aware tile map)
+            hipLaunchKernelGGL(rs_sweep_msd_kernel, dim3((uint32_t)(ceil_div(gen_tiles8, 8u * RS_GROUP) * 8u * RS_GROUP)), dim3(512), 0, s,
+                               static_cast<const TextGen&>(gp), n, gen_tiles8, k1, v1);
+        else if (grouped)
             hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG8, TextGenPair, uint8_t>), dim3(grid), dim3(512), 0, s, (const uint32_t*)nullptr,
                                k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                                ws.xticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
@@ -2178,7 +2185,7 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
             hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP8, TextGenPair, uint8_t>), dim3(grid), dim3(512), 0, s, (const uint32_t*)nullptr,
                                k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                                ws.ticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
-        prof.end(t, "rs_onesweep_textgen_msd_t8192", n * 9, s);
+        prof.end(t, sweep_form ? "rs_sweep_msd_t8192" : "rs_onesweep_textgen_msd_t8192", n * 9, s);
         if (stats) stats->passes_run++;
     } else {
         TextGen g2 = gen_in;

@@ -320,6 +320,270 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     else phase_b(std::integral_constant<int, 1>{});
 }
 
+// The same two-phase form for the generated pass of the MSD-first sort below 2^32 (radix_sort.h: radix_sort_msd, pair form): digit
+// = top digit of the 6-symbol key, a function of the first two symbols; records (u32 key - top * M, u32 entry).  Every position
+// is kept.  gen: text, doc_start, symmap, bits, base, pair_span / pair_r / pair_s, padded, tile_doc, tile_base.
+// The digit of a document's LAST position counts its second symbol as 0 — exactly what the per-tile counts the tile bases
+// come from did (sa_build.hip: sa_tile_docend_fix_kernel): the tile marks those positions in a bit map before it stages.
+__global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
+                                                              uint32_t* __restrict__ vout) {
+    constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
+    constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
+    __shared__ uint8_t s_code[256];
+    __shared__ uint64_t s_docs[RS_SWEEP_DOCS];
+    __shared__ uint32_t s_whist[NW][256];
+    __shared__ uint16_t s_pdoc[TILE / 32 + 2];
+    __shared__ uint32_t s_endbits[TILE / 32];  // bit p: position p is the last one of its document
+    __shared__ uint32_t s_tstart[256];
+    __shared__ uint64_t s_gbase[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint16_t s_idx[TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_dig[TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint64_t tile = (uint64_t)((slot / RS_GROUP) * 8u + x) * RS_GROUP + slot % RS_GROUP;
+    if (tile >= (uint64_t)tiles) return;
+    const uint64_t base = tile * TILE;
+    const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
+
+    const uint64_t ga = base + (uint64_t)tid * 16, gb = base + (uint64_t)TILE + (uint64_t)tid * 16;
+    const bool has_b = (uint32_t)tid * 16 < TEXTB - (uint32_t)TILE;
+    const bool oka = gen.padded ? (ga < n + RS_GEN_LOOK) : (ga + 16 <= n);
+    const bool okb = has_b && (gen.padded ? (gb < n + RS_GEN_LOOK) : (gb + 16 <= n));
+    uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
+    if (oka) ta = *reinterpret_cast<const uint4*>(gen.text + ga);
+    if (okb) tb = *reinterpret_cast<const uint4*>(gen.text + gb);
+    const uint32_t tnext = ga + 16 < n ? (uint32_t)gen.text[ga + 16] : 0u;  // the byte behind the thread's 16: second symbol of its last pair
+    uint64_t my_base = 0;
+    if (tid < 256) {
+        my_base = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)tid];
+        s_code[tid] = (uint8_t)gen.symmap[tid];
+    }
+    const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
+    for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
+    if (tid < TILE / 32) s_endbits[tid] = 0;
+    const uint32_t ndl = (uint32_t)(dhi - dlo);
+    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)RS_SWEEP_DOCS;
+    uint64_t dreg0 = 0, dreg1 = 0;
+    if (docs_in_lds) {
+        if ((uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
+        if ((uint32_t)tid + NT < ndl + 2) dreg1 = gen.doc_start[dlo + tid + NT];
+    }
+    __syncthreads();  // (the zeroes)
+    if (docs_in_lds) {
+        // a document that starts at s > base ends its predecessor at s - 1 (empty documents repeat a start: the bit is set twice)
+        if ((uint32_t)tid < ndl + 2) {
+            s_docs[tid] = dreg0;
+            if (dreg0 > base && dreg0 - 1 - base < (uint64_t)valid) atomicOr(&s_endbits[(uint32_t)(dreg0 - 1 - base) >> 5], 1u << ((uint32_t)(dreg0 - 1 - base) & 31u));
+        }
+        if ((uint32_t)tid + NT < ndl + 2) {
+            s_docs[tid + NT] = dreg1;
+            if (dreg1 > base && dreg1 - 1 - base < (uint64_t)valid) atomicOr(&s_endbits[(uint32_t)(dreg1 - 1 - base) >> 5], 1u << ((uint32_t)(dreg1 - 1 - base) & 31u));
+        }
+    }
+    __syncthreads();
+
+    // ---- staging: bytes -> codes (kept for phase B) and, thread-consecutively, the top digit of every position's first pair
+    auto fetch = [&](uint64_t g, bool ok, uint4 w, uint32_t* c) {
+        c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = w.w;
+        if (!ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) c[q] |= (uint32_t)((g + 4 * q + b < n) ? gen.text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+            }
+        }
+    };
+    const uint32_t B = gen.base, B2 = B * B;
+    {
+        uint32_t c[4];
+        fetch(ga, oka, ta, c);
+        uint32_t e[IPT + 1];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) e[k] = s_code[(c[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+        e[IPT] = s_code[tnext];
+        uint32_t ends;  // bit k: position k of this thread is the last one of its document
+        if (docs_in_lds) {
+            ends = (s_endbits[(uint32_t)tid >> 1] >> (16 * ((uint32_t)tid & 1u))) & 0xFFFFu;
+        } else {  // (thousands of documents in the tile) the documents that start in (ga, ga + 16]
+            ends = 0;
+            const uint64_t d = rs_doc_upper(gen.doc_start, dlo, dhi, ga < n ? ga : n - 1);  // document of the thread's first position
+            for (uint64_t q = d + 1; q <= gen.ndocs; ++q) {
+                const uint64_t st = gen.doc_start[q];
+                if (st > ga + 16) break;
+                if (st > ga) ends |= 1u << (uint32_t)(st - 1 - ga);
+            }
+        }
+        uint32_t codes[4], digs[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) codes[q] = e[4 * q] | (e[4 * q + 1] << 8) | (e[4 * q + 2] << 16) | (e[4 * q + 3] << 24);
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const uint32_t c1 = (ends >> k) & 1u ? 0u : e[k + 1];
+            const uint32_t a = __umul24(e[k], B) + c1;
+            digs[k >> 2] |= (__umul24(a, gen.pair_r) >> gen.pair_s) << (8 * (k & 3));
+        }
+        *reinterpret_cast<uint4*>(&s_text[(uint32_t)tid * 16]) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
+        *reinterpret_cast<uint4*>(&s_dig[(uint32_t)tid * 16]) = make_uint4(digs[0], digs[1], digs[2], digs[3]);
+        if (has_b) {  // the look-ahead behind the tile: codes only
+            fetch(gb, okb, tb, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                c[q] = (uint32_t)s_code[c[q] & 0xFF] | ((uint32_t)s_code[(c[q] >> 8) & 0xFF] << 8) | ((uint32_t)s_code[(c[q] >> 16) & 0xFF] << 16) |
+                       ((uint32_t)s_code[c[q] >> 24] << 24);
+            *reinterpret_cast<uint4*>(&s_text[(uint32_t)TILE + (uint32_t)tid * 16]) = make_uint4(c[0], c[1], c[2], c[3]);
+        }
+    }
+    __syncthreads();
+    // ---- phase A: ranks, lane-striped (text order inside every bucket, see rs_sweep_records_kernel)
+    constexpr int WCHUNK = IPT * 64;
+    const uint32_t wbase = wave * WCHUNK + lane;
+    uint32_t info[IPT];  // rank | digit << 16; ~0 behind the text
+    {
+        uint32_t sl[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) sl[j] = s_dig[wbase + j * 64];
+        if (valid == (uint32_t)TILE) {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) info[j] = atomicAdd(&s_whist[wave][sl[j]], 1u) | (sl[j] << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                uint32_t inf = ~0u;
+                if (wbase + j * 64 < valid) inf = atomicAdd(&s_whist[wave][sl[j]], 1u) | (sl[j] << 16);
+                info[j] = inf;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t cnt = 0, incl = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t t = s_whist[w][tid];
+            s_whist[w][tid] = cnt;
+            cnt += t;
+        }
+        incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+    } else if (docs_in_lds) {
+        for (uint32_t b = (uint32_t)tid - 256u; b < (uint32_t)TILE / 32 + 1; b += 256u) {
+            const uint64_t pos = base + (uint64_t)b * 32;
+            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
+            }
+            s_pdoc[b] = (uint16_t)lo;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t wpre = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            if (w < wave) wpre += s_wsum[w];
+        const uint32_t tstart = wpre + incl - cnt;
+        s_tstart[tid] = tstart;
+        s_gbase[tid] = my_base - (uint64_t)tstart;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        if (info[k] != ~0u) {
+            const uint32_t sl = info[k] >> 16;
+            const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
+            s_idx[pos] = (uint16_t)(wbase + k * 64);
+            s_dig[pos] = (uint8_t)sl;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: output order; key - top M = ((a - top span) B^2 + m) B^2 + r with a, m, r = the three symbol pairs (one
+    // v_dot4_u32_u8 each; products below 2^24, rs_pair_setup), entry = (offset << bits) | document
+    const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
+    const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);
+    constexpr int U = 2;
+    for (uint32_t p0 = tid; p0 < valid; p0 += U * NT) {
+        uint32_t li[U], sl[U], lo[U], hi[U];
+        bool act[U];
+        uint64_t dd[U], ds[U], de[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = p0 + u * NT;
+            act[u] = p < valid;
+            const uint32_t q = act[u] ? p : p0;
+            li[u] = s_idx[q];
+            sl[u] = s_dig[q];
+        }
+        if (docs_in_lds) {
+            bool deep = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                lo[u] = s_pdoc[li[u] >> 5];
+                hi[u] = s_pdoc[(li[u] >> 5) + 1];
+                deep |= hi[u] > lo[u] + 1;
+            }
+            if (__builtin_amdgcn_ballot_w64(deep) != 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    while (lo[u] < hi[u]) {
+                        const uint32_t mid = lo[u] + (hi[u] - lo[u] + 1) / 2;
+                        if (s_docs[mid] <= base + li[u]) lo[u] = mid; else hi[u] = mid - 1;
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) lo[u] = s_docs[hi[u]] <= base + li[u] ? hi[u] : lo[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                dd[u] = dlo + lo[u];
+                ds[u] = s_docs[lo[u]];
+                de[u] = s_docs[lo[u] + 1];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                dd[u] = rs_doc_upper(gen.doc_start, dlo, dhi, base + li[u]);
+                ds[u] = gen.doc_start[dd[u]];
+                de[u] = gen.doc_start[dd[u] + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t pos = base + li[u];
+            const uint32_t ent = (uint32_t)(((pos - ds[u]) << gen.bits) + dd[u]);
+            const uint64_t left = de[u] - pos;  // symbols left in the document (>= 1)
+            const uint32_t rem = left < 64ull ? (uint32_t)left : 64u;
+            const uint32_t wi = li[u] >> 2, sel = li[u] & 3u;
+            const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+            uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
+            uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
+            if (rem < 6u) {  // (rare) the symbols behind the document end count as 0
+                x0 = rem >= 4u ? x0 : (x0 & ((1u << (8u * rem)) - 1u));
+                x1 = rem <= 4u ? 0u : (x1 & 0xFFu);
+            }
+            const uint32_t a = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
+            const uint32_t m = __builtin_amdgcn_udot4(x0, whi, 0u, false);
+            const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
+            const uint32_t a2 = a - __umul24(sl[u], gen.pair_span);  // (the digit IS top = floor(a / span))
+            const uint64_t dst = s_gbase[sl[u]] + (uint64_t)(p0 + u * NT);
+            if (act[u]) {
+                kout[dst] = __umul24(__umul24(a2, B2) + m, B2) + r;
+                vout[dst] = ent;
+            }
+        }
+    }
+}
+
 // whether the sweep's arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the key's nsym - 1 symbols come
 // from three code windows (<= 10 symbols after the first 4 + 4 ... see TextGenRecL)
 inline bool rs_sweep_records_ok(uint32_t base, int nsym) { return base <= 255u && nsym >= 2 && nsym - 1 <= 10; }

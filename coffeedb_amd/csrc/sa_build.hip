@@ -2147,8 +2147,9 @@ void build_typed(Index& ix, bool big) {
                 const bool prebased = tc_spec && msd_span != 0;  // (the counts were made with this span: same rule, same alphabet)
                 radix_sort_msd(s, ix.rws, ix.msd_ws, ix.prof, k32[0].as<uint32_t>(), k32[1].as<uint32_t>(), vals[0].as<uint32_t>(),
                                vals[1].as<uint32_t>(), low[1].as<uint8_t>(), n, h_top.data(), gen, msd_m, keep, &ss,
-                               prebased ? (const uint32_t*)d_tc.as<uint32_t>() : nullptr, prebased ? &ix.tbw : nullptr);
+                               prebased ? (const uint32_t*)d_tc.as<uint32_t>() : nullptr, prebased ? &ix.tbw : nullptr, ix.sweep_records);
                 st.gen_prebased = prebased ? 1 : 0;
+                st.sweep_records = prebased && ix.sweep_records && gen.msd_pair ? 1 : 0;
                 d_tc.release();
                 ix.tbw.base.release();
                 sel = 1;

@@ -1057,6 +1057,14 @@ def test_msd_first_split_sort(G, variant):
                 g1, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=variant, force_doubling=fd, key_coding=2, key_symbols=ksym,
                                       msd_pair=0)
                 assert g1.stat("msd_first") == 1 and g1.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial")
+                if ksym == 6:
+                    # the pair form's generated pass in two phases (records_sweep.h: rs_sweep_msd_kernel — ranks on the staged top
+                    # digits, records generated in output order) against the one-phase generated pass it replaced as the default
+                    assert g.stat("sweep_records") == 1 and g.stat("gen_prebased") == 1
+                    g2, _ = _check_parity(G, blob, ds, patterns=pats, sort_variant=variant, force_doubling=fd, key_coding=2, key_symbols=ksym,
+                                          sweep_records=0)
+                    assert g2.stat("msd_first") == 2 and g2.stat("sweep_records") == 0
+                    assert g2.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial") and np.array_equal(g.sa(), g2.sa())
                 seen += 1
             assert g.stat("unresolved_after_initial") == g0.stat("unresolved_after_initial")
             assert g.stat("rounds") == g0.stat("rounds")

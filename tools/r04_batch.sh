@@ -1,1 +1,1 @@
-CDB_FUZZ_N=200 CDB_FUZZ_SEG_N=400 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert|seed" | head -12
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -x -q -k "not 8gib and not shard" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
