@@ -501,8 +501,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
         if (info[k] != ~0u) {
             const uint32_t sl = info[k] >> 16;
             const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
-            s_idx[pos] = (uint16_t)(wbase + k * 64);
-            s_dig[pos] = (uint8_t)sl;
+            s_idx[pos] = (uint16_t)(wbase + k * 64);  // (the digit is not carried along: phase B has it back from the first pair)
         }
     }
     __syncthreads();
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);
     constexpr int U = 2;
     for (uint32_t p0 = tid; p0 < valid; p0 += U * NT) {
-        uint32_t li[U], sl[U], lo[U], hi[U];
+        uint32_t li[U], lo[U], hi[U];
         bool act[U];
         uint64_t dd[U], ds[U], de[U];
 #pragma unroll
@@ -522,7 +521,6 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
             act[u] = p < valid;
             const uint32_t q = act[u] ? p : p0;
             li[u] = s_idx[q];
-            sl[u] = s_dig[q];
         }
         if (docs_in_lds) {
             bool deep = false;
@@ -574,8 +572,9 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
             const uint32_t a = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
             const uint32_t m = __builtin_amdgcn_udot4(x0, whi, 0u, false);
             const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
-            const uint32_t a2 = a - __umul24(sl[u], gen.pair_span);  // (the digit IS top = floor(a / span))
-            const uint64_t dst = s_gbase[sl[u]] + (uint64_t)(p0 + u * NT);
+            const uint32_t top = __umul24(a, gen.pair_r) >> gen.pair_s;  // floor(a / span): the digit the position was ranked on
+            const uint32_t a2 = a - __umul24(top, gen.pair_span);
+            const uint64_t dst = s_gbase[top] + (uint64_t)(p0 + u * NT);
             if (act[u]) {
                 kout[dst] = __umul24(__umul24(a2, B2) + m, B2) + r;
                 vout[dst] = ent;
