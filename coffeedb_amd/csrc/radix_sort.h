@@ -2185,7 +2185,7 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
             hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP8, TextGenPair, uint8_t>), dim3(grid), dim3(512), 0, s, (const uint32_t*)nullptr,
                                k1, (const uint32_t*)nullptr, v1, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
                                ws.ticket_ptr(e), e, ws.err_ptr(), gp, (const uint8_t*)nullptr, (uint8_t*)nullptr, 0);
-        prof.end(t, sweep_form ? "rs_sweep_msd_t8192" : "rs_onesweep_textgen_msd_t8192", n * 9, s);
+        prof.end(t, sweep_form ? "rs_sweep_msd" : "rs_onesweep_textgen_msd_t8192", n * 9, s);
         if (stats) stats->passes_run++;
     } else {
         TextGen g2 = gen_in;
