@@ -2102,7 +2102,7 @@ inline const unsigned long long* rs_tile_bases(hipStream_t s, TileBaseWorkspace&
 }
 
 // (records_sweep.h) the generated pass of radix_sort_msd in two phases: rank on the staged top digits, generate in output order
-__global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
+__global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
                                                               uint32_t* __restrict__ vout);
 
 struct MsdWorkspace {

@@ -325,21 +325,22 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
 // is kept.  gen: text, doc_start, symmap, bits, base, pair_span / pair_r / pair_s, padded, tile_doc, tile_base.
 // The digit of a document's LAST position counts its second symbol as 0 — exactly what the per-tile counts the tile bases
 // come from did (sa_build.hip: sa_tile_docend_fix_kernel): the tile marks those positions in a bit map before it stages.
-__global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
+__global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
                                                               uint32_t* __restrict__ vout) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
     __shared__ uint8_t s_code[256];
-    __shared__ uint64_t s_docs[RS_SWEEP_DOCS];
+    constexpr uint32_t DOCS = 384;  // (40 KB of LDS in all: four workgroups per CU)
+    __shared__ uint64_t s_docs[DOCS];
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint16_t s_pdoc[TILE / 32 + 2];
     __shared__ uint32_t s_endbits[TILE / 32];  // bit p: position p is the last one of its document
     __shared__ uint32_t s_tstart[256];
-    __shared__ uint64_t s_gbase[256];
+    __shared__ uint32_t s_gbase[256];  // (below 2^32 suffixes: output slots are 32-bit, differences modulo 2^32)
     __shared__ uint32_t s_wsum[4];
-    __shared__ uint16_t s_idx[TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_dig[TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
+    uint8_t* const s_dig = reinterpret_cast<uint8_t*>(s_idx);  // (its first half, until the ranking is done: the staged top digits)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
     if (tid < TILE / 32) s_endbits[tid] = 0;
     const uint32_t ndl = (uint32_t)(dhi - dlo);
-    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)RS_SWEEP_DOCS;
+    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOCS;
     uint64_t dreg0 = 0, dreg1 = 0;
     if (docs_in_lds) {
         if ((uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
             if (w < wave) wpre += s_wsum[w];
         const uint32_t tstart = wpre + incl - cnt;
         s_tstart[tid] = tstart;
-        s_gbase[tid] = my_base - (uint64_t)tstart;
+        s_gbase[tid] = (uint32_t)my_base - tstart;
     }
     __syncthreads();
 #pragma unroll
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_msd_kernel(TextGen gen, uint6
             const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
             const uint32_t top = __umul24(a, gen.pair_r) >> gen.pair_s;  // floor(a / span): the digit the position was ranked on
             const uint32_t a2 = a - __umul24(top, gen.pair_span);
-            const uint64_t dst = s_gbase[top] + (uint64_t)(p0 + u * NT);
+            const uint32_t dst = s_gbase[top] + (p0 + u * NT);
             if (act[u]) {
                 kout[dst] = __umul24(__umul24(a2, B2) + m, B2) + r;
                 vout[dst] = ent;

@@ -1,2 +1,2 @@
-python -m pytest tests -m gpu -q -x > /tmp/t.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR|Error|assert " /tmp/t.log | head -30 > gpurun_out/r04_gputests4.log; tail -c 1500 gpurun_out/r04_gputests4.log
-bash tools/profile_round.sh r04d d025989 2>&1 | grep -E "^===|rs_sweep|textgen|GiB" | head -40
+python -m pytest tests/test_gpu_parity.py -x -q -k "msd or variant or xcd" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+CDB_TOP=8 timeout 300 python tools/keywidth_ab.py c1 0 3 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], d['kernels_ms'], d['verify'])"
