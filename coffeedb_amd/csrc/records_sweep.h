@@ -28,7 +28,7 @@ constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept i
 // output slot of the tile's first suffix of every bucket slot); codeslot[byte] = symbol code | bucket slot << 8.
 // Keeps the suffixes whose bucket slot is in [g0, g1); record r of the group lands at index tile_base - gstart.
 template <typename W>
-__global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
+__global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
                                                                   uint32_t g0, uint32_t g1, uint64_t gstart, uint32_t* __restrict__ kout,
                                                                   uint32_t* __restrict__ vout, W* __restrict__ wout, int abl) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
@@ -36,15 +36,17 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
     __shared__ uint16_t s_cs[256];
-    __shared__ uint64_t s_docs[RS_SWEEP_DOCS];
-    constexpr int WH = 256 + 64;  // a wave's counters: one per bucket slot + one per lane for the positions it does not keep
+    constexpr uint32_t DOCS = 384;  // (40 KB of LDS in all: four workgroups per CU)
+    __shared__ uint64_t s_docs[DOCS];
+    __shared__ uint8_t s_slotc[256];  // symbol code -> bucket slot (phase B has a record's slot back from its first symbol)
+    constexpr int WH = 256;
     __shared__ uint32_t s_whist[NW][WH];
     __shared__ uint16_t s_pdoc[TILE / 32 + 2];  // document (tile-local) of every 32nd position
     __shared__ uint32_t s_tstart[256];
     __shared__ uint64_t s_gbase[256];
     __shared__ uint32_t s_wsum[4];
-    __shared__ uint16_t s_idx[TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t s_dig[TILE];  // staged bucket slots by position, then by output slot
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
+    uint8_t* const s_dig = reinterpret_cast<uint8_t*>(s_idx);  // (its first half, until the ranking is done: the staged bucket slots)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware static tile map (no look-back, so no order between tiles is needed for progress): workgroup b runs on XCD b % 8,
@@ -69,13 +71,14 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
     if (tid < 256) {  // (a byte outside the group: slot 0xFF — alphabets of <= 254 symbols, rs_sweep_records_ok)
         const uint32_t e = codeslot[tid];
         s_cs[tid] = (uint16_t)(((e >> 8) >= g0 && (e >> 8) < g1) ? e : (e | 0xFF00u));
+        s_slotc[tid] = gen.slotmap[tid];
     }
     const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
     for (int i = tid; i < NW * WH; i += NT) (&s_whist[0][0])[i] = 0;
     // (the document starts are wanted in phase B only: they stay in registers until the ranking is done — a store to the LDS in
     //  front of the first barrier would make that barrier wait for two dependent global round trips)
     const uint32_t ndl = (uint32_t)(dhi - dlo);  // (meaningful when docs_in_lds)
-    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)RS_SWEEP_DOCS;
+    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOCS;
     uint64_t dreg0 = 0, dreg1 = 0;
     if (docs_in_lds) {
         if ((uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
@@ -136,12 +139,15 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
         uint32_t sl[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) sl[j] = s_dig[wbase + j * 64];
-        // (no branch, no execution mask: a position that is not kept counts on its lane's own counter behind the 256 slots)
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            uint32_t col = sl[j] == 0xFFu ? 256u + (uint32_t)lane : sl[j];
-            if (abl & 16) col = (col + (uint32_t)lane) & 0xFFu;  // (timing only: no two lanes on one counter)
-            info[j] = atomicAdd(&s_whist[wave][col], 1u) | (sl[j] << 16);
+            uint32_t inf = 0xFFu << 16;  // (scalars inside the branch: element writes under divergent control turn the array into a 16-wide tuple)
+            if (sl[j] != 0xFFu) {
+                uint32_t col = sl[j];
+                if (abl & 16) col = (col + (uint32_t)lane) & 0xFFu;  // (timing only: no two lanes on one counter)
+                inf = atomicAdd(&s_whist[wave][col], 1u) | (sl[j] << 16);
+            }
+            info[j] = inf;
         }
     }
     if (docs_in_lds) {
@@ -196,8 +202,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
         const uint32_t sl = info[k] >> 16;
         if (sl != 0xFFu) {
             const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
-            s_idx[pos] = (uint16_t)(wbase + k * 64);
-            s_dig[pos] = (uint8_t)sl;  // (the staged slots are dead since the barrier behind phase A)
+            s_idx[pos] = (uint16_t)(wbase + k * 64);  // (the slot is not carried along: phase B has it back from the position's first symbol)
         }
     }
     __syncthreads();
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 6) void rs_sweep_records_kernel(TextGen gen, c
             act[u] = p < kept;
             const uint32_t q = act[u] ? p : p0;
             li[u] = s_idx[q];
-            sl[u] = s_dig[q];
+            sl[u] = s_slotc[s_text[li[u]]];
         }
         if (abl & 4) {  // (timing only: no document search)
 #pragma unroll
@@ -596,7 +601,7 @@ void radix_sweep_records(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v
                          uint32_t g0, uint32_t g1,
                          uint64_t gstart, uint64_t gelems, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles,
                          int lead, int npass, unsigned long long* d_hist_out, SortStats* stats) {
-    if (!gen_in.tile_base || !gen_in.tile_doc || !d_codeslot) throw Error("radix_sweep_records: tile bases / documents / slots missing (internal)");
+    if (!gen_in.tile_base || !gen_in.tile_doc || !d_codeslot || !gen_in.slotmap) throw Error("radix_sweep_records: tile bases / documents / slots missing (internal)");
     if (!rs_sweep_records_ok(gen_in.base, gen_in.nsym)) throw Error("radix_sweep_records: key shape (internal)");
     const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_SWEEP_TILE);
     const uint32_t grid = (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP);

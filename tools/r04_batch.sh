@@ -1,2 +1,4 @@
-python -m pytest tests/test_gpu_parity.py -x -q -k "msd or variant or xcd" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
-CDB_TOP=8 timeout 300 python tools/keywidth_ab.py c1 0 3 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], d['kernels_ms'], d['verify'])"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+for w in utf8_4g c2 c4shard; do
+CDB_TOP=6 timeout 600 python tools/keywidth_ab.py $w 0 2 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], d['kernels_ms'], d['verify'])"
+done
