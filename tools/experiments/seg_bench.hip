@@ -69,8 +69,14 @@ int main(int argc, char** argv) {
     if (!rs_atomic_rank_ok(s)) std::printf("one-atomic ranking self-test FAILED on this device\n");
 #ifdef SEG_NT        // smaller workgroups: 16 keys per thread, keys and values staged at once — two or more workgroups per CU
     using CfgG = RsCfg<16, false, true, SEG_NT, false, 1, 0, SEG_LB, false, true, true, 1, RS_GROUP>;
-#elif defined(SEG_IPT)       // other tile sizes (keys and values share the staging buffer)
-    using CfgG = RsCfg<SEG_IPT, true, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
+#elif defined(SEG_IPT)       // other tile sizes (keys and values share the staging buffer); SEG_MINW = 8: two 1024-thread workgroups per CU
+#ifndef SEG_MINW
+#define SEG_MINW 1
+#endif
+#ifndef SEG_EARLYV
+#define SEG_EARLYV true
+#endif
+    using CfgG = RsCfg<SEG_IPT, true, SEG_EARLYV, 1024, false, SEG_MINW, 0, 4, false, true, true, 1, RS_GROUP>;
 #elif defined(SEG_NOREUSE)   // keys and values both staged at once (128 KB): one write-out phase instead of two
     using CfgG = RsCfg<16, false, true, 1024, false, 1, 0, 4, false, true, true, 1, RS_GROUP>;
 #else

@@ -1,4 +1,2 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -8
-for w in utf8_4g c2 c4shard; do
-CDB_TOP=6 timeout 600 python tools/keywidth_ab.py $w 0 2 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], d['kernels_ms'], d['verify'])"
-done
+cd tools/experiments
+for b in seg_bench_nr seg_bench_i15_w8_true seg_bench_i15_w8_false seg_bench_i14_w8_true seg_bench_i12_w8_true seg_bench_i15_w1_true; do echo "== $b"; timeout 120 ./$b 30 256 3 2>&1 | sed -n 2p; done
