@@ -2040,21 +2040,63 @@ static __global__ __launch_bounds__(256) void rs_tilecol_sum_kernel(const uint32
         for (uint32_t r = r0; r < r1; ++r) sum += counts[(size_t)r * 256 + c];
     partial[(size_t)b * 256 + d] = sum;
 }
-// totals[d] = column sums over all blocks (what the host wants as the digit histogram)
-static __global__ __launch_bounds__(256) void rs_tilecol_total_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
-                                                                      unsigned long long* __restrict__ totals) {
-    const uint32_t d = threadIdx.x;
+// totals[d] = column sums over all blocks (what the host wants as the digit histogram).  ONE workgroup (the result is 256 numbers),
+// but 1024 threads: four quarters of the blocks side by side, eight loads in flight per thread — a 256-thread loop with one load
+// per trip took 2.9 ms for the 8192 blocks of a 16 GiB text, all of it latency
+static __global__ __launch_bounds__(1024) void rs_tilecol_total_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
+                                                                       unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long s_q[4][256];
+    const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const uint32_t per = (blocks + 3u) / 4u;
+    const uint32_t b0 = g * per, b1 = b0 + per < blocks ? b0 + per : blocks;
     unsigned long long sum = 0;
-    for (uint32_t b = 0; b < blocks; ++b) sum += partial[(size_t)b * 256 + d];
-    totals[d] = sum;
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = partial[(size_t)(b + i) * 256 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    for (; b < b1; ++b) sum += partial[(size_t)b * 256 + d];
+    s_q[g][d] = sum;
+    __syncthreads();
+    if (g == 0) totals[d] = s_q[0][d] + s_q[1][d] + s_q[2][d] + s_q[3][d];
 }
-// blockbase[b][d] = digit_start[d] + sum of partial[b'][d], b' < b
-static __global__ __launch_bounds__(256) void rs_tilecol_scan_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
-                                                                     const unsigned long long* __restrict__ digit_start,
-                                                                     unsigned long long* __restrict__ blockbase) {
-    const uint32_t d = threadIdx.x;
+// blockbase[b][d] = digit_start[d] + sum of partial[b'][d], b' < b (same shape: quarter sums first, then every quarter's running sums)
+static __global__ __launch_bounds__(1024) void rs_tilecol_scan_kernel(const unsigned long long* __restrict__ partial, uint32_t blocks,
+                                                                      const unsigned long long* __restrict__ digit_start,
+                                                                      unsigned long long* __restrict__ blockbase) {
+    __shared__ unsigned long long s_q[4][256];
+    const uint32_t d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const uint32_t per = (blocks + 3u) / 4u;
+    const uint32_t b0 = g * per < blocks ? g * per : blocks, b1 = b0 + per < blocks ? b0 + per : blocks;
+    unsigned long long sum = 0;
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = partial[(size_t)(b + i) * 256 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[i];
+    }
+    for (; b < b1; ++b) sum += partial[(size_t)b * 256 + d];
+    s_q[g][d] = sum;
+    __syncthreads();
     unsigned long long run = digit_start[d];
-    for (uint32_t b = 0; b < blocks; ++b) {
+    for (uint32_t q = 0; q < g; ++q) run += s_q[q][d];
+    b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = partial[(size_t)(b + i) * 256 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            blockbase[(size_t)(b + i) * 256 + d] = run;
+            run += v[i];
+        }
+    }
+    for (; b < b1; ++b) {
         blockbase[(size_t)b * 256 + d] = run;
         run += partial[(size_t)b * 256 + d];
     }
@@ -2081,7 +2123,7 @@ inline const unsigned long long* rs_tile_totals(hipStream_t s, TileBaseWorkspace
     tb.partial.ensure((size_t)blocks * 256 * sizeof(uint64_t));
     tb.totals.ensure(256 * sizeof(uint64_t));
     hipLaunchKernelGGL(rs_tilecol_sum_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col, tb.partial.as<unsigned long long>());
-    hipLaunchKernelGGL(rs_tilecol_total_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
+    hipLaunchKernelGGL(rs_tilecol_total_kernel, dim3(1), dim3(1024), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
                        tb.totals.as<unsigned long long>());
     return tb.totals.as<unsigned long long>();
 }
@@ -2094,7 +2136,7 @@ inline const unsigned long long* rs_tile_bases(hipStream_t s, TileBaseWorkspace&
     tb.blockbase.ensure((size_t)blocks * 256 * sizeof(uint64_t));
     tb.base.ensure((size_t)rows * 256 * sizeof(uint64_t));
     hipLaunchKernelGGL(rs_tilecol_sum_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col, tb.partial.as<unsigned long long>());
-    hipLaunchKernelGGL(rs_tilecol_scan_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
+    hipLaunchKernelGGL(rs_tilecol_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned long long*)tb.partial.as<unsigned long long>(), blocks,
                        d_digit_start, tb.blockbase.as<unsigned long long>());
     hipLaunchKernelGGL(rs_tilecol_apply_kernel, dim3(blocks), dim3(256), 0, s, d_counts, rows, d_src_col,
                        (const unsigned long long*)tb.blockbase.as<unsigned long long>(), tb.base.as<unsigned long long>());

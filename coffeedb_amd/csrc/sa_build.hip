@@ -78,15 +78,19 @@ __global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __rest
 // are the byte histogram.  Wave-autonomous like sa_tile_paircount_kernel below.
 constexpr uint32_t TBC_TILES_PER_WAVE = 8;
 __global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t tiles, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t s_cnt[4][4][256];
+    // (four copies of a wave's counters, by lane — and 8 banks apart: text is skewed, a copy stride of 256 words would leave the
+    //  four counters of a frequent byte on ONE bank, where their atomics serialise just as on one address)
+    constexpr int CS = 256 + 8;
+    __shared__ uint32_t s_cnt[4][4 * CS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint32_t* cnt = s_cnt[wave][lane & 3];
-    uint32_t* call = &s_cnt[wave][0][0];
+    uint32_t* cnt = &s_cnt[wave][(lane & 3) * CS];
+    uint32_t* call = &s_cnt[wave][0];
     for (uint32_t k = 0; k < TBC_TILES_PER_WAVE; ++k) {
         const uint32_t tile = (blockIdx.x * 4u + (uint32_t)wave) * TBC_TILES_PER_WAVE + k;
         if (tile >= tiles) break;  // (uniform per wavefront)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) call[q * 64 + lane] = 0;
+        for (int q = 0; q < (4 * CS + 63) / 64; ++q)
+            if (q * 64 + lane < 4 * CS) call[q * 64 + lane] = 0;
         const uint64_t b0 = (uint64_t)tile * RS_GEN8_TILE;
         constexpr int VEC = RS_GEN8_TILE / 16 / 64;
 #pragma unroll 2
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int dgt = q * 64 + lane;
-            counts[(size_t)tile * 256 + dgt] = call[dgt] + call[256 + dgt] + call[512 + dgt] + call[768 + dgt];
+            counts[(size_t)tile * 256 + dgt] = call[dgt] + call[CS + dgt] + call[2 * CS + dgt] + call[3 * CS + dgt];
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -1,2 +1,4 @@
-cd tools/experiments
-for b in seg_bench_nr seg_bench_i15_w8_true seg_bench_i15_w8_false seg_bench_i14_w8_true seg_bench_i12_w8_true seg_bench_i15_w1_true; do echo "== $b"; timeout 120 ./$b 30 256 3 2>&1 | sed -n 2p; done
+python -m pytest tests/test_gpu_parity.py -x -q -k "bucket or packed or records_generators or msd or variant" 2>&1 | grep -E "passed|failed|Error|assert" | head -8
+for w in c1 utf8_4g c4shard; do
+CDB_TOP=14 timeout 600 python tools/keywidth_ab.py $w 0 3 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], {k:v for k,v in d['kernels_ms'].items() if 'tile' in k or 'sweep' in k}, d['verify'])"
+done
