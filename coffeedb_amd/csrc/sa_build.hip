@@ -1214,57 +1214,99 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
     skey[j] |= key2;
 }
 
-// Compaction of the unresolved entries, specialised for the byte-flag array (the generic scan spends
-// most of its time carrying 16 (u64, u64) pairs per thread for entries that are almost all resolved):
-// one 16-byte load per thread, SWAR popcounts, a workgroup scan of one packed u32 (both tile-local counts
-// stay below 2^16), and the consumer functor only runs for threads that own unresolved entries.
-// Uses the tile partials produced by scan_totals<U2>(FlagIn) — same tile geometry (SC_TILE = 256 x 16).
-template <typename Out>
-__global__ __launch_bounds__(SC_NT) void sa_flag_compact_kernel(const uint8_t* __restrict__ flags, uint64_t n,
-                                                               const U2* __restrict__ partials, Out out) {
-    static_assert(SC_IPT == 16 && SC_NT == 256, "flag compaction assumes 256 x 16 tiles");
-    __shared__ uint32_t s_w[4];
-    const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
-    uint32_t x[4] = {0, 0, 0, 0};
+// Compaction of the unresolved entries, specialised for the byte-flag array (the generic scan spends most of its time carrying
+// 16 (u64, u64) pairs per thread for entries that are almost all resolved).  Round 4: WAVE-autonomous — a wavefront owns whole
+// tiles of the scan geometry (SC_TILE = 4096 flags = four 1 KiB chunks of 16 bytes per lane), counts with SWAR popcounts, scans
+// with wave shuffles and takes its tiles one after the other: no LDS, no workgroup barrier, millions of 4 KiB workgroups less
+// (16 GiB shard: 10.9 -> see DESIGN §4.2).  sa_flag_count_kernel leaves the raw tile sums (unresolved entries, unresolved group
+// heads) in the partials of scan.h's layout; sa_flag_compact_kernel uses their exclusive scan.
+constexpr uint32_t FC_TILES_PER_WAVE = 4;
+__device__ __forceinline__ void fc_load(const uint8_t* __restrict__ flags, uint64_t n, uint64_t base, uint32_t (&x)[4]) {
+    x[0] = x[1] = x[2] = x[3] = 0;
     if (base + 16 <= n) {
         const uint4 w = *reinterpret_cast<const uint4*>(flags + base);
         x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
     } else if (base < n) {
         for (int k = 0; k < 16 && base + k < n; ++k) x[k >> 2] |= (uint32_t)flags[base + k] << (8 * (k & 3));
     }
-    uint32_t cu = 0, ch = 0;  // unresolved entries / unresolved group heads owned by this thread
+}
+__device__ __forceinline__ uint32_t fc_count(const uint32_t (&x)[4]) {  // unresolved entries | unresolved group heads << 16
+    uint32_t cu = 0, ch = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t u = (x[q] >> 1) & 0x01010101u;
         cu += __popc(u);
         ch += __popc(u & x[q] & 0x01010101u);
     }
-    uint32_t v = cu | (ch << 16);
+    return cu | (ch << 16);
+}
+__global__ __launch_bounds__(256) void sa_flag_count_kernel(const uint8_t* __restrict__ flags, uint64_t n, uint64_t tiles, U2* __restrict__ partials) {
+    static_assert(SC_TILE == 4096, "flag compaction assumes 4096-flag tiles");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * 4 + wave) * FC_TILES_PER_WAVE;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(incl, off);
-        if (lane >= off) incl += y;
+    for (uint32_t k = 0; k < FC_TILES_PER_WAVE; ++k) {
+        const uint64_t tile = t0 + k;
+        if (tile >= tiles) break;  // (uniform per wavefront)
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t x[4];
+            fc_load(flags, n, tile * SC_TILE + (uint64_t)c * 1024 + (uint64_t)lane * 16, x);
+            v += fc_count(x);  // (both halves stay below 2^16: at most 4096 per tile)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) partials[tile] = U2{(uint64_t)(v & 0xFFFFu), (uint64_t)(v >> 16)};
     }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t pre = 0;
+}
+template <typename Out>
+__global__ __launch_bounds__(256) void sa_flag_compact_kernel(const uint8_t* __restrict__ flags, uint64_t n, uint64_t tiles,
+                                                              const U2* __restrict__ partials, Out out) {
+    static_assert(SC_TILE == 4096, "flag compaction assumes 4096-flag tiles");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * 4 + wave) * FC_TILES_PER_WAVE;
+    for (uint32_t k = 0; k < FC_TILES_PER_WAVE; ++k) {
+        const uint64_t tile = t0 + k;
+        if (tile >= tiles) break;  // (uniform per wavefront)
+        uint32_t x[4][4], v[4], incl[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (w < wave) pre += s_w[w];
-    if (cu == 0) return;
-    const uint32_t excl = pre + incl - v;
-    U2 run = partials[blockIdx.x];
-    run.a += excl & 0xFFFFu;
-    run.b += excl >> 16;
+        for (int c = 0; c < 4; ++c) fc_load(flags, n, tile * SC_TILE + (uint64_t)c * 1024 + (uint64_t)lane * 16, x[c]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t f = (x[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        const uint64_t u = (f >> 1) & 1u;
-        const U2 nxt{run.a + u, run.b + (u & (f & 1u))};
-        if (u) out(base + k, run, nxt);
-        run = nxt;
+        for (int c = 0; c < 4; ++c) incl[c] = v[c] = fc_count(x[c]);
+        // element order inside the tile = (chunk, lane, byte): one wave scan per chunk (independent: their shuffles interleave)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t y = __shfl_up(incl[c], off);
+                if (lane >= off) incl[c] += y;
+            }
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) any |= v[c];
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) continue;  // (nothing unresolved in the tile)
+        const U2 tile_run = partials[tile];
+        uint32_t cpre = 0;  // packed counts of the chunks in front
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t ctot = __shfl(incl[c], 63);
+            if (v[c] & 0xFFFFu) {
+                const uint32_t excl = cpre + incl[c] - v[c];
+                U2 run{tile_run.a + (excl & 0xFFFFu), tile_run.b + (excl >> 16)};
+                const uint64_t base = tile * SC_TILE + (uint64_t)c * 1024 + (uint64_t)lane * 16;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t f = (x[c][q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                    const uint64_t u = (f >> 1) & 1u;
+                    const U2 nxt{run.a + u, run.b + (u & (f & 1u))};
+                    if (u) out(base + q, run, nxt);
+                    run = nxt;
+                }
+            }
+            cpre += ctot;
+        }
     }
 }
 
@@ -2973,7 +3015,6 @@ void build_typed(Index& ix, bool big) {
     auto refine = [&](auto sa) {
     using SAW = decltype(sa);
     for (;;) {
-        FlagIn fin{flags.as<uint8_t>()};
         if (st.rounds > 0) {
             uint64_t still = 0;
             CDB_HIP(hipMemcpyAsync(&still, d_open.p, sizeof(still), hipMemcpyDeviceToHost, s));
@@ -2981,8 +3022,16 @@ void build_typed(Index& ix, bool big) {
             if (still == 0) break;
         }
         CDB_HIP(hipMemsetAsync(d_open.p, 0, sizeof(uint64_t), s));
-        const U2 tot = tile_sums_ready ? scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0})
-                                       : scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+        auto flag_tile_sums = [&]() {  // raw tile sums of the flag array into the scan's partials (wave-autonomous sweep)
+            const uint64_t nb = ceil_div(n, SC_TILE);
+            ix.scan_partials.ensure(scan_partials_slots(nb) * sizeof(U2));
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL(sa_flag_count_kernel, dim3((unsigned)ceil_div(nb, (uint64_t)(4 * FC_TILES_PER_WAVE))), dim3(256), 0, s,
+                               (const uint8_t*)flags.as<uint8_t>(), n, nb, ix.scan_partials.as<U2>());
+            ix.prof.end(t, "sa_flag_count", n, s);
+        };
+        if (!tile_sums_ready) flag_tile_sums();
+        const U2 tot = scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0});
         tile_sums_ready = false;
         const uint64_t m = tot.a, G = tot.b;
         if (st.rounds == 0) st.unresolved_initial = m;
@@ -3011,7 +3060,8 @@ void build_typed(Index& ix, bool big) {
                 isa = true;
                 st.isa_built = 1;
                 // the partials buffer now belongs to the max-scan: redo the compaction totals
-                (void)scan_totals<U2>(s, ix.scan_partials, fin, n, OpAdd{}, U2{0, 0});
+                flag_tile_sums();
+                (void)scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0});
             }
         }
         const int kbits = isa ? bit_width64(n) : nsym2 * symbits;
@@ -3028,8 +3078,9 @@ void build_typed(Index& ix, bool big) {
         {
             int t = ix.prof.begin(s);
             CompactOut<SAW, I> co{sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
-            hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(n, SC_TILE)), dim3(SC_NT), 0, s,
-                               (const uint8_t*)flags.as<uint8_t>(), n, (const U2*)ix.scan_partials.as<U2>(), co);
+            hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(ceil_div(n, SC_TILE), (uint64_t)(4 * FC_TILES_PER_WAVE))),
+                               dim3(256), 0, s, (const uint8_t*)flags.as<uint8_t>(), n, (uint64_t)ceil_div(n, SC_TILE),
+                               (const U2*)ix.scan_partials.as<U2>(), co);
             if (isa)
                 hipLaunchKernelGGL((sa_round_keys_kernel<V, R, true>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
