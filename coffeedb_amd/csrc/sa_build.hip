@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
                                                             const uint8_t* __restrict__ text,
                                                             const uint16_t* __restrict__ symmap,
                                                             const R* __restrict__ rank, int bits, uint64_t mask, uint64_t h,
-                                                            int nsym2, int symbits, uint64_t* __restrict__ skey) {
+                                                            int nsym2, int symbits, uint64_t* __restrict__ skey, uint64_t n_text) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     const V v = sval[j];
@@ -1206,9 +1206,27 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
     } else {
         const uint64_t rem = doc_start[d + 1] - ds - off - h;  // >= 0: unresolved => length >= h
         const uint8_t* p = text + ds + off + h;
-        for (int k = 0; k < nsym2; ++k) {
-            const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[p[k]] : 0ull;
-            key2 = (key2 << symbits) | sym;
+        if (nsym2 <= 9 && rem > 0) {
+            // the next symbols by TWO aligned 8-byte loads instead of one load per byte: the entries arrive in suffix order, every
+            // load instruction of a wave touches 64 different lines, and with thousands of gathers in flight per CU a line does not
+            // survive in the L1 from one byte to the next (16 GiB shard: 310 B of fabric traffic per entry with byte loads).  The
+            // second word is read only where it holds a byte of the text (an aligned word never crosses a page)
+            const uint64_t pa = (uint64_t)p & ~7ull;
+            const uint32_t sh = (uint32_t)((uint64_t)p & 7ull) * 8u;
+            const uint64_t w0 = *reinterpret_cast<const uint64_t*>(pa);
+            const uint64_t w1 = pa + 8 < (uint64_t)(text + n_text) ? *reinterpret_cast<const uint64_t*>(pa + 8) : 0ull;
+            const uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;  // bytes p[0] .. p[7]
+            const uint32_t b8 = (uint32_t)(w1 >> sh) & 0xFFu;                 // byte p[8]
+            for (int k = 0; k < nsym2; ++k) {
+                const uint32_t byte = k < 8 ? (uint32_t)(lo >> (8 * k)) & 0xFFu : b8;
+                const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[byte] : 0ull;
+                key2 = (key2 << symbits) | sym;
+            }
+        } else {
+            for (int k = 0; k < nsym2; ++k) {
+                const uint64_t sym = (uint64_t)k < rem ? (uint64_t)symmap[p[k]] : 0ull;
+                key2 = (key2 << symbits) | sym;
+            }
         }
     }
     skey[j] |= key2;
@@ -1218,7 +1236,7 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
 // 16 (u64, u64) pairs per thread for entries that are almost all resolved).  Round 4: WAVE-autonomous — a wavefront owns whole
 // tiles of the scan geometry (SC_TILE = 4096 flags = four 1 KiB chunks of 16 bytes per lane), counts with SWAR popcounts, scans
 // with wave shuffles and takes its tiles one after the other: no LDS, no workgroup barrier, millions of 4 KiB workgroups less
-// (16 GiB shard: 10.9 -> see DESIGN §4.2).  sa_flag_count_kernel leaves the raw tile sums (unresolved entries, unresolved group
+// (the compaction itself stays bound by its gather of the unresolved entries).  sa_flag_count_kernel leaves the raw tile sums (unresolved entries, unresolved group
 // heads) in the partials of scan.h's layout; sa_flag_compact_kernel uses their exclusive scan.
 constexpr uint32_t FC_TILES_PER_WAVE = 4;
 __device__ __forceinline__ void fc_load(const uint8_t* __restrict__ flags, uint64_t n, uint64_t base, uint32_t (&x)[4]) {
@@ -3084,11 +3102,11 @@ void build_typed(Index& ix, bool big) {
             if (isa)
                 hipLaunchKernelGGL((sa_round_keys_kernel<V, R, true>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
-                                   (const R*)rank.as<R>(), (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>());
+                                   (const R*)rank.as<R>(), (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>(), n);
             else
                 hipLaunchKernelGGL((sa_round_keys_kernel<V, R, false>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
-                                   (const R*)nullptr, (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>());
+                                   (const R*)nullptr, (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>(), n);
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
         const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
