@@ -1,4 +1,3 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | head -8
-for w in c1 utf8_4g c2 c4shard; do
-CDB_TOP=30 timeout 600 python tools/keywidth_ab.py $w 0 3 2>&1 | grep workload | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['workload'], d['build_ms'], {k:v for k,v in d['kernels_ms'].items() if 'flag' in k or 'compact' in k or 'update' in k}, d['verify'])"
-done
+python -m pytest tests -m gpu -q -x > /tmp/t.log 2>&1; grep -E "passed|failed|^FAILED|^ERROR|Error|assert " /tmp/t.log | head -30 > gpurun_out/r04_gputests6.log; tail -c 1500 gpurun_out/r04_gputests6.log
+bash tools/profile_round.sh r04d 622374e 2>&1 | grep -E "^===|rs_sweep|sa_round|GiB" | head -40
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
