@@ -12,7 +12,7 @@
 // generates afterwards: phase A looks at one staged symbol per position (bucket slot -> LDS counter -> rank), phase B walks the
 // tile's KEPT positions in output order, evaluates their records (the arithmetic of TextGenRecL: nsym - 1 <= 10 codes behind the
 // bucket symbol as a number in base B <= 255, pairs by v_dot4_u32_u8, Horner in base B^2) and writes them lane-consecutively —
-// no record ever crosses the LDS, only a 16-bit position, its bucket slot and its document do.
+// no record ever crosses the LDS, only a 16-bit position does (40 KB of LDS: four workgroups per CU).
 //
 // reference: the records are the sort keys of src/index.h:66-101 (radix_sort on the suffixes' leading bytes), restated as dense
 // numbers per first-symbol bucket; DESIGN.md §4.2.
