@@ -516,7 +516,10 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
     // v_dot4_u32_u8 each; products below 2^24, rs_pair_setup), entry = (offset << bits) | document
     const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);
-    constexpr int U = 2;
+#ifndef RS_MSD_U
+#define RS_MSD_U 2
+#endif
+    constexpr int U = RS_MSD_U;
     for (uint32_t p0 = tid; p0 < valid; p0 += U * NT) {
         uint32_t li[U], lo[U], hi[U];
         bool act[U];
