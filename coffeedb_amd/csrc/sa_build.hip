@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restr
     nh[j] = (uint8_t)(oldhead || j == 0 || skey[j] != skey[j - 1]);
 }
 
-template <typename SAW, typename I>
+template <typename SAW, typename I, bool WANT_POS = true>
 __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename SAW::val* sval, const I* U, const uint8_t* nh,
                                          const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, SAW sa,
                                          uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open) {
@@ -1347,9 +1347,14 @@ __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename 
     const bool head = nh[j];
     const bool last = j + 1 == m || nh[j + 1];
     const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
-    const uint64_t ds = doc_start[d];
-    const uint64_t rem = doc_start[d + 1] - ds - off;
-    const bool exhausted = rem < hnew;
+    // (a group of one is settled whatever is left of its document: most entries of a round, and their two random loads from the
+    //  document table are the kernel's only gathers — skipped unless the caller wants the entry's text position)
+    uint64_t ds = 0;
+    bool exhausted = false;
+    if (WANT_POS || !(head && last)) {
+        ds = doc_start[d];
+        exhausted = doc_start[d + 1] - ds - off < hnew;
+    }
     const bool open = !(head && last) && !exhausted;
     sa.store(i, v);
     flags[i] = (uint8_t)((head ? 1 : 0) | (open ? 2 : 0));
@@ -1367,7 +1372,7 @@ __global__ __launch_bounds__(256) void sa_update_kernel(const typename SAW::val*
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     uint64_t q;
-    sa_place<SAW, I>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
+    sa_place<SAW, I, false>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
 }
 
 template <typename I>
