@@ -358,7 +358,7 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
     return out
 
 
-def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0):
+def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_check=None):
     """CPU restatement of the reference (oracle/cpu_ref.cpp, kind "port") on this host, as BASELINE.md §3 plans:
     C0 in full with the build's thread count swept (the reference spawns hardware_concurrency() spinning workers,
     index.cpp:225 — oversubscription is visible in the sweep), then the largest prefix of the bench corpus that
@@ -438,6 +438,28 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0):
         o.build(best_th)
         tbf = time.perf_counter() - t
         tq1, tqa = query_leg(o, host_text[: full_docs * doclen], ds)
+        if gpu_check is not None:
+            # BASELINE config 1's "bit-exact SA check" taken literally (index.cpp:209-231 vs cdb_sa_copy): the oracle's complete array,
+            # ties in the canonical order of SURVEY §8(c), against the array the GPU built in the timed region — and the rows of the
+            # whole pattern batch.  The oracle is the checker here, outside the timed region.
+            try:
+                t = time.perf_counter()
+                o.canonicalize(cores)
+                gs = gpu_check["sa"]
+                osa = o.sa_view()
+                same = bool(osa.dtype == gs.dtype and osa.shape == gs.shape and np.array_equal(osa, gs))
+                orp, oi, oc, ohits = o.query_batch(gpu_check["pb"], gpu_check["po"], nthreads=cores)
+                grp, gi, gc, ghits = gpu_check["rows"]
+                rows_same = bool(ohits == ghits and np.array_equal(orp, grp) and np.array_equal(oi, gi) and np.array_equal(oc, gc))
+                out["c1_sa_bit_exact"] = same
+                out["c1_rows_bit_exact"] = rows_same
+                out["c1_bit_exact_check"] = {"entries": int(len(gs)), "entry_bytes": int(gs.dtype.itemsize), "patterns": int(len(orp) - 1),
+                                             "rows": int(len(oi)), "hits": int(ohits), "seconds": round(time.perf_counter() - t, 2),
+                                             "note": "oracle array (ties canonicalised) == cdb_sa_copy of the GPU build, element for element; "
+                                                     "oracle rows == cdb_query_batch rows for the whole batch"}
+            except Exception as e:  # noqa: BLE001
+                out["c1_sa_bit_exact"] = None
+                out["c1_bit_exact_check"] = {"error": repr(e)[:300]}
         out.update({
             "value": round(full_docs * doclen / 2**30 / tbf, 6),
             "sample": f"the WHOLE bench corpus ({full_docs} docs, {full_docs * doclen / 2**20:.0f} MiB), SA build with {best_th} threads (the "
@@ -509,6 +531,70 @@ def pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat, reps=3):
            "query_split_ms": {"upload": round(g.stat("query_upload_ms"), 3), "device": round(g.stat("query_device_ms"), 3),
                               "download": round(g.stat("query_download_ms"), 3)}}
     g.close()
+    return out
+
+
+def mg_selfcheck(torch, dist, capi, g, merger, rank, world, local_rank, device, coll_device, args, build, d_blob, d_offs, npat):
+    """The N > 1 plumbing checked before anything is timed: communicator size, one device per rank, and a small merge whose
+    merged row_ptr[-1] equals the all-reduced sum of the ranks' local row counts.  Every rank returns the same verdict
+    (`ok` is all-reduced), so a failure ends ALL ranks with a non-zero exit instead of a hang in the timed region."""
+    out = {"world": world, "transport": merger.comm.transport if merger.comm is not None else f"torch.distributed/{args.backend}",
+           "cdb_comm_world": int(merger.comm.world) if merger.comm is not None else None, "patterns": int(npat)}
+    ok = True
+    try:
+        if merger.comm is not None and int(merger.comm.world) != world:
+            ok = False
+            out["error"] = f"cdb_comm_world {merger.comm.world} != {world}"
+        # one device per rank (PCI bus ids; --share-gpu is the one-GPU stand-in and says so)
+        prop = torch.cuda.get_device_properties(device)
+        bus = int(getattr(prop, "pci_bus_id", local_rank)) * 256 + int(getattr(prop, "pci_device_id", 0))
+        mine = torch.tensor([bus if not args.share_gpu else rank], dtype=torch.int64, device=coll_device)
+        alld = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(alld, mine)
+        else:
+            alld = [mine]
+        devs = [int(x.item()) for x in alld]
+        out["devices_distinct"] = len(set(devs)) == world
+        out["share_gpu"] = bool(args.share_gpu)
+        if not out["devices_distinct"]:
+            ok = False
+            out["error"] = f"ranks share a device: {devs}"
+        r = None
+        try:
+            build()
+            nb = int(d_offs[npat].item())
+            r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nb)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            out["error"] = repr(e)[:300]
+        ready = torch.tensor([1 if (ok and r is not None) else 0], dtype=torch.int32, device=coll_device)
+        if world > 1:  # (the merge is collective: nobody enters it unless everybody can)
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if not bool(ready.item()):
+            raise RuntimeError(out.get("error", "another rank failed before the merge"))
+        local_rows = int(r.nrows)
+        m = merger.merge(r, npat)
+        if merger.comm is not None:
+            merged_rows = int(m.nrows_total) if merger.mode == "counts" else int(m.nrows)
+        else:
+            merged_rows = int(m[0][-1].item())
+        t = torch.tensor([local_rows], dtype=torch.int64, device=coll_device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out["local_rows"] = local_rows
+        out["sum_of_local_rows"] = int(t.item())
+        out["merged_rows"] = merged_rows
+        if merged_rows != int(t.item()):
+            ok = False
+            out["error"] = f"merged row_ptr[-1] {merged_rows} != sum of local rows {int(t.item())}"
+    except Exception as e:  # noqa: BLE001 - a rank that throws must still reach the all-reduce below
+        ok = False
+        out["error"] = repr(e)[:300]
+    v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
+    if world > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+    out["ok"] = bool(v.item())
     return out
 
 
@@ -684,6 +770,16 @@ def main():
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
     trace("inputs ready")
+    selfcheck = None
+    if merger is not None:
+        # first contact with several GPUs is the driver's run: fail loudly and cheaply BEFORE the timed region
+        selfcheck = mg_selfcheck(torch, dist, capi, g, merger, rank, world, local_rank, device, coll_device, args,
+                                 lambda: g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), ndocs),
+                                 d_blob, d_offs, min(npat, 1000))
+        if rank == 0:
+            print(json.dumps({"mg_selfcheck": selfcheck}), file=sys.stderr, flush=True)
+        if not selfcheck["ok"]:
+            raise SystemExit(f"mg_selfcheck failed on rank {rank}: {selfcheck}")
     for _ in range(args.warmup):
         step()
     g.profile_reset()
@@ -752,6 +848,7 @@ def main():
             "merge": merger.note if merger is not None else None,
             "rccl_ranks": int(merger.comm.world) if (merger is not None and merger.comm is not None) else None,
             "rows_per_rank": rows_per_rank,
+            "mg_selfcheck": selfcheck,
             "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),
             "query_hits_per_batch": hits,
@@ -793,15 +890,18 @@ def main():
                                                   "p90": round(float(c_us[(len(c_us) * 9) // 10]), 2),
                                                   "note": "the same calls timed inside the library (cdb_debug_query_latency): what a C++ caller "
                                                           "such as database.cpp:392 sees; median over 32 calls per keyword"}
-            # the same with the opt-in resident workgroup (resident_query = 1: no launch per query, host-mapped mailbox)
-            g.set_option("resident_query", 1)
-            for kw in kws[:8]:
-                g.query(kw)
-            r_us = np.sort(g.query_latency_us(kws, reps=32))
-            g.set_option("resident_query", 0)
-            out["single_query_us"]["resident"] = {"median": round(float(r_us[len(r_us) // 2]), 2), "p10": round(float(r_us[len(r_us) // 10]), 2),
-                                                  "p90": round(float(r_us[(len(r_us) * 9) // 10]), 2),
-                                                  "note": "option resident_query = 1, timed inside the library like c_caller"}
+            out["single_query_us"]["c_caller"]["note"] += ("; DEFAULT options: resident_query = 2 (automatic) hands keywords that arrive back "
+                                                           "to back to the resident workgroup after 6 calls less than 1 ms apart")
+            # the same with the resident workgroup forced on (resident_query = 1) and off (0: one launch per keyword)
+            for mode, key in ((1, "resident"), (0, "launched")):
+                g.set_option("resident_query", mode)
+                for kw in kws[:8]:
+                    g.query(kw)
+                r_us = np.sort(g.query_latency_us(kws, reps=32))
+                out["single_query_us"][key] = {"median": round(float(r_us[len(r_us) // 2]), 2), "p10": round(float(r_us[len(r_us) // 10]), 2),
+                                               "p90": round(float(r_us[(len(r_us) * 9) // 10]), 2),
+                                               "note": f"option resident_query = {mode}, timed inside the library like c_caller"}
+            g.set_option("resident_query", 2)
         except Exception as e:  # noqa: BLE001
             out["single_query_us"] = {"error": repr(e)[:200]}
     extra = args.configs
@@ -818,6 +918,12 @@ def main():
             out["pcie_inclusive_query_patterns_per_s"] = out["pcie_inclusive"]["query_patterns_per_s"]
         except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
             out["pcie_inclusive"] = {"error": repr(e)[:300]}
+    gpu_check = None
+    if rank == 0 and world == 1 and small and not args.no_cpu_baseline and args.cpu_full_budget > 0:
+        try:  # the array and rows of the index the timed region built, for the literal bit-exact check in the CPU-baseline leg
+            gpu_check = {"sa": g.sa(), "rows": g.query_batch(pb, po), "pb": pb, "po": po}
+        except Exception as e:  # noqa: BLE001
+            out["c1_bit_exact_check"] = {"error": "fetching the GPU array: " + repr(e)[:200]}
     g.close()
     if rank == 0 and world == 1 and small and not args.no_pcie and isinstance(out.get("pcie_inclusive"), dict):
         # what the SHIM's build() really calls (shim/index.cpp: cdb_build_views over one std::string per document,
@@ -867,7 +973,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(W, host_text, cfg.get("doclen", 1024), full_budget_s=args.cpu_full_budget)
+                out["cpu_baseline"] = cpu_baseline(W, host_text, cfg.get("doclen", 1024), full_budget_s=args.cpu_full_budget, gpu_check=gpu_check)
+                for k in ("c1_sa_bit_exact", "c1_rows_bit_exact", "c1_bit_exact_check"):  # (top level of the line: BASELINE config 1's check)
+                    if k in out["cpu_baseline"]:
+                        out[k] = out["cpu_baseline"].pop(k)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)[:300]}
         else:

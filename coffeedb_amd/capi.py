@@ -26,7 +26,7 @@ EXPORTS = [
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_shards_build_views", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
-    "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge", "cdb_comm_merge_counts",
+    "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_create_group", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge", "cdb_comm_merge_counts",
     "cdb_comm_world", "cdb_comm_transport",
 ]
 
@@ -174,6 +174,7 @@ def load_library():
     lib.cdb_shards_transport.restype = cp
     lib.cdb_comm_unique_id.argtypes = [vp]
     lib.cdb_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int]
+    lib.cdb_comm_create_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     lib.cdb_comm_destroy.argtypes = [vp]
     lib.cdb_comm_destroy.restype = None
     lib.cdb_comm_last_error.argtypes = [vp]
@@ -210,6 +211,11 @@ class GpuStringIndex:
         if rc != 0:
             raise RuntimeError(f"cdb_create failed (code {rc}): no usable gfx950 device — there is no CPU fallback")
         self._h = h
+        # measurement plumbing of THIS binding (tools/, bench.py A/B runs): CDB_OPTIONS="name=value,..." is applied through
+        # cdb_set_option; the library itself reads no option from the environment
+        for kv in filter(None, os.environ.get("CDB_OPTIONS", "").split(",")):
+            name, _, val = kv.partition("=")
+            self._lib.cdb_set_option(self._h, name.strip().encode(), int(val))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -625,6 +631,23 @@ class ShardComm:
         if rc != 0:
             raise RuntimeError(f"cdb_comm_create failed (code {rc})")
         self._h = h
+
+    @classmethod
+    def group(cls, devices):
+        """The ranks of ONE process (cdb_comm_create_group): one ShardComm per entry of `devices`; a host thread per rank
+        calls the collectives.  Ranks sharing a device exchange through device copies."""
+        lib = load_library()
+        devs = (C.c_int * len(devices))(*devices)
+        hs = (C.c_void_p * len(devices))()
+        rc = lib.cdb_comm_create_group(hs, len(devices), devs)
+        if rc != 0:
+            raise RuntimeError(f"cdb_comm_create_group failed (code {rc})")
+        out = []
+        for h in hs:
+            c = cls.__new__(cls)
+            c._lib, c._h = lib, C.c_void_p(h)
+            out.append(c)
+        return out
 
     def merge(self, local: "CdbDeviceResult"):
         out = CdbDeviceResult()

@@ -353,18 +353,6 @@ int cdb_create(cdb_index** out, int device) {
         return CDB_E_DEVICE;
     }
     *out = h;
-    if (const char* e = std::getenv("CDB_OPTIONS")) {  // test / measurement hook: "name=value,name=value" applied to every new handle
-        std::string all(e);
-        size_t at = 0;
-        while (at < all.size()) {
-            size_t end = all.find(',', at);
-            if (end == std::string::npos) end = all.size();
-            const std::string kv = all.substr(at, end - at);
-            const size_t eq = kv.find('=');
-            if (eq != std::string::npos) (void)cdb_set_option(h, kv.substr(0, eq).c_str(), std::atoll(kv.c_str() + eq + 1));
-            at = end + 1;
-        }
-    }
     return CDB_OK;
 }
 
@@ -646,10 +634,18 @@ int cdb_load(cdb_index* h, const char* path) {
         const Layout L = layout_of(doc_start, hd.ndocs);  // (also: doc_start non-decreasing)
         if (L.size != hd.size || L.bits != hd.bits || L.mask != hd.mask || (uint64_t)L.width != hd.width)
             throw Error(std::string("Corrupt index file (entry layout): ") + path);
-        DevBuf text, sa, d_start, d_ids;
+        DevBuf text, sa, sa_hi, d_start, d_ids;
         text.alloc(hd.size + TEXT_PAD);
         CDB_HIP(hipMemsetAsync((uint8_t*)text.p + hd.size, 0, TEXT_PAD, ix.stream));
-        sa.alloc(std::max<uint64_t>(hd.size * hd.width, 16));
+        // 8-byte entries below 2^40 are stored packed (the storage a build of this column would leave): they are packed chunk by
+        // chunk while the file is read, so the plain array never exists on the device and nothing can fail after the commit
+        const bool pack = ix.pack_sa && hd.width == 8 && (int)L.bits + L.off_bits <= 40 && hd.size > 0;
+        if (pack) {
+            sa.alloc(hd.size * sizeof(uint32_t));
+            sa_hi.alloc(hd.size);
+        } else {
+            sa.alloc(std::max<uint64_t>(hd.size * hd.width, 16));
+        }
         std::vector<char> buf(std::min<uint64_t>(std::max<uint64_t>(hd.size * hd.width, 1), 256ull << 20));
         auto fill = [&](void* dptr, uint64_t bytes) {
             for (uint64_t o = 0; o < bytes; o += buf.size()) {
@@ -660,11 +656,27 @@ int cdb_load(cdb_index* h, const char* path) {
             }
         };
         fill(text.p, hd.size);
-        fill(sa.p, hd.size * hd.width);
         upload_tables(ix, doc_start, ids, hd.ndocs, d_start, d_ids);
         // every entry must name a real (document, offset): queries decode entries without further checks
-        if (count_invalid_entries(ix.stream, sa.p, (int)hd.width, hd.size, d_start.as<uint64_t>(), hd.ndocs, (int)L.bits, L.mask) != 0)
-            throw Error(std::string("Corrupt index file (suffix array): ") + path);
+        const char* bad_sa = "Corrupt index file (suffix array): ";
+        if (pack) {
+            DevBuf chunk;
+            const uint64_t per = buf.size() / 8;
+            chunk.alloc(std::max<uint64_t>(per * 8, 16));
+            for (uint64_t first = 0; first < hd.size; first += per) {
+                const uint64_t cnt = std::min<uint64_t>(per, hd.size - first);
+                if (std::fread(buf.data(), 8, cnt, fp) != cnt) throw Error(std::string("Truncated index file: ") + path);
+                CDB_HIP(hipMemcpyAsync(chunk.p, buf.data(), cnt * 8, hipMemcpyHostToDevice, ix.stream));
+                if (count_invalid_entries(ix.stream, chunk.p, 8, cnt, d_start.as<uint64_t>(), hd.ndocs, (int)L.bits, L.mask) != 0)
+                    throw Error(std::string(bad_sa) + path);
+                sa_pack_chunk(ix.stream, chunk.as<uint64_t>(), cnt, sa.as<uint32_t>(), sa_hi.as<uint8_t>(), first);
+                CDB_HIP(hipStreamSynchronize(ix.stream));  // (buf and chunk are reused)
+            }
+        } else {
+            fill(sa.p, hd.size * hd.width);
+            if (count_invalid_entries(ix.stream, sa.p, (int)hd.width, hd.size, d_start.as<uint64_t>(), hd.ndocs, (int)L.bits, L.mask) != 0)
+                throw Error(std::string(bad_sa) + path);
+        }
         CDB_HIP(hipStreamSynchronize(ix.stream));
         // ---- commit
         reset_unbuilt(ix);
@@ -681,9 +693,12 @@ int cdb_load(cdb_index* h, const char* path) {
         ix.d_text = ix.d_text_owned.as<uint8_t>();
         ix.text_padded = true;
         ix.d_sa = std::move(sa);
+        if (pack) {
+            ix.d_sa_hi = std::move(sa_hi);
+            ix.sa_packed = true;
+        }
         ix.d_doc_start = std::move(d_start);
         ix.d_ids = std::move(d_ids);
-        if (sa_packable(ix)) sa_pack_inplace(ix);  // (the same storage a build of this column would leave)
     });
 }
 
@@ -796,6 +811,19 @@ int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uin
         // A column that fails validation is simply dropped after the copy.
         const uint64_t n_claimed = ndocs ? doc_start[ndocs] - first : 0;
         if (ndocs && (doc_start[ndocs] < first || n_claimed >= (1ull << 48))) throw Error("doc_start must be non-decreasing");
+        // O(1) checks BEFORE anything is allocated or uploaded: the longest document has at least n / ndocs bytes, so a
+        // column the width rule refuses for that length gets the reference's capacity error (index.cpp:195-200), not a hipMalloc
+        // error after the block cache was trimmed; and a text that does not fit the device is refused without trimming it
+        if (ndocs) (void)layout_from(ndocs, n_claimed, (n_claimed + ndocs - 1) / ndocs);
+        {
+            size_t fre = 0, tot = 0;
+            if (hipMemGetInfo(&fre, &tot) == hipSuccess) {
+                if ((double)n_claimed + (double)TEXT_PAD > (double)fre + (double)cdb_cached_memory_bytes())
+                    throw Error("HIP error: the column does not fit the device memory that is free");
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         DevBuf text;
         text.alloc(n_claimed + TEXT_PAD);
         CDB_HIP(hipMemsetAsync((uint8_t*)text.p + n_claimed, 0, TEXT_PAD, ix.stream));
@@ -822,7 +850,6 @@ int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uin
             hstart[d + 1] = doc_start[d + 1] - first;
         }
         const Layout L = layout_of(hstart, ndocs);  // (throws the reference's capacity errors: nothing changed yet)
-        const uint64_t n = L.size;
         bool committed = false;
         try {
             DevBuf d_start, d_ids;
@@ -1493,6 +1520,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "fuse_keygen")) ix.fuse_keygen = value != 0;
     else if (!std::strcmp(name, "force_big_path")) ix.force_big_path = value != 0;
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
+    else if (!std::strcmp(name, "debug_no_segcap")) ix.debug_no_segcap = value != 0;  // test hook: "a bucket does not fit the record memory"
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = (int)value;  // 1 = reported after the sorts, 2 = error flag up before the initial sort
     else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 2 ? 2 : (int)value;  // 0 off, 1 sample, 2 every pair
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
@@ -1502,8 +1530,10 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "single_query")) ix.use_single_query = value != 0;
     else if (!std::strcmp(name, "resident_query")) {
         std::lock_guard<std::mutex> g(ix.mu);
-        if (!value) query_resident_stop(ix);
-        ix.resident_query = value != 0;
+        if (value != 1) query_resident_stop(ix);
+        ix.resident_mode = value <= 0 ? 0 : value == 1 ? 1 : 2;  // 0 never, 1 always, 2 automatic (default)
+        ix.resident_query = ix.resident_mode == 1;
+        ix.single_streak = 0;
     }
     else if (!std::strcmp(name, "bucket_group_limit")) ix.bucket_group_limit = (uint64_t)value;
     else if (!std::strcmp(name, "query_hit_budget"))  // <= 2^31: one kernel launch addresses < 2^32 threads
@@ -1532,6 +1562,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
         {"host_upload_ms", h->ix.host_upload_ms}, {"host_free_ms", h->ix.host_free_ms},
+        {"resident_answers", (double)h->ix.res_answers}, {"launched_answers", (double)h->ix.launched_answers}, {"resident_mode", (double)h->ix.resident_mode},
         {"query_ms", q.query_ms}, {"query_upload_ms", q.upload_ms}, {"query_device_ms", q.device_ms}, {"query_download_ms", q.download_ms}, {"query_hits", (double)q.nhits}, {"query_rows", (double)q.nrows},
     };
     for (auto& e : tab)

@@ -116,7 +116,15 @@ struct Index {
     void* h_single = nullptr;     // host-mapped result block of that kernel (+ its device address)
     void* d_single = nullptr;
     // resident_query: one workgroup stays on the device and answers lone keywords from a host-mapped mailbox (query.hip)
+    // resident_mode (option resident_query): 0 = never, 1 = always, 2 = automatic (default) — a caller that sends lone keywords back
+    // to back (interface.cpp:79-113 loops over a query's keywords; RESIDENT_AUTO_STREAK calls less than RESIDENT_AUTO_GAP_US apart)
+    // gets the resident workgroup without asking for it; it idles out by itself ~3 ms after the last keyword.  resident_query is
+    // what the call in progress uses (decided in query_single_launch under ix.mu).
+    int resident_mode = 2;
     bool resident_query = false;
+    uint32_t single_streak = 0;
+    int64_t last_single_ns = 0;
+    uint64_t res_answers = 0, launched_answers = 0;  // lone keywords answered by the resident workgroup / by a launched kernel (stats)
     void* h_res = nullptr;        // the mailbox (+ its device address)
     void* d_res = nullptr;
     hipStream_t res_stream = nullptr;
@@ -231,6 +239,7 @@ struct Index {
                                       // the build fall back to the ballot ranking once, then fail
     int self_check_fallbacks = 0;
     bool debug_fail_self_check = false;  // test hook: the first spot check of a build reports a failure
+    bool debug_no_segcap = false;   // test hook: the bucket-wise build takes its per-bucket fallback ("a bucket does not fit the record memory")
     int debug_starve_group = 0;     // test hook: a build in XCD-aware tile order reports a look-back timeout once
     bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
     bool force_big_path = false;  // test hook: use the >= 2^32 code path (u64 ranks, bucket-wise sort) at any size
@@ -263,6 +272,7 @@ void build_suffix_array(Index& ix);
 void verify_suffix_array(Index& ix, uint64_t out[5]);
 void sa_expand(Index& ix, uint64_t first, uint64_t cnt, uint64_t* d_out);  // verify.hip: packed entries -> u64 (on ix.stream)
 void sa_pack_inplace(Index& ix);                                           // verify.hip: u64 entries in d_sa -> packed storage
+void sa_pack_chunk(hipStream_t s, const uint64_t* d_in, uint64_t cnt, uint32_t* lo, uint8_t* hi, uint64_t first);  // verify.hip
 inline bool sa_packable(const Index& ix) { return ix.pack_sa && ix.width == 8 && (int)ix.bits + ix.off_bits <= 40; }
 void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // verify.hip: the check behind every build
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:

@@ -11,6 +11,8 @@
 //   a12     run-length encoding into CSR rows (ids[doc], count), ascending document index.
 #include <cstring>
 
+#include <chrono>
+
 #include "index_impl.h"
 #include "scan.h"
 
@@ -1436,6 +1438,8 @@ __global__ __launch_bounds__(256) void q_single_kernel(typename SaOf<V>::ptr sa,
 constexpr int RES_WORDS = 22;       // 154 payload bytes: len u32, decisive u8, ranged u8, pad, klo u64, khi u64, lo0 u32, hi0 u32,
                                     // keyword <= 120 bytes
 constexpr uint32_t RES_IDLE_POLLS = 2500;
+constexpr int64_t RESIDENT_AUTO_GAP_US = 1000;   // resident_query = 2 (automatic): lone keywords closer together than this ...
+constexpr uint32_t RESIDENT_AUTO_STREAK = 6;     // ... this many times in a row go to the resident workgroup
 constexpr uint32_t RES_MAX_SERVED = 4096;  // it also leaves after this many answers (~30 ms of back-to-back queries): a
                                            // device-wide synchronisation elsewhere in the process is never starved by traffic
 struct ResidentBox {
@@ -1648,6 +1652,18 @@ SingleLaunch query_single_launch(Index& ix, const char* kw, size_t len) {
         }
     }
     out->nrows = ~0ull;
+    if (ix.resident_mode == 2) {
+        // automatic: lone keywords arriving back to back (the reference's caller resolves a query keyword by keyword,
+        // interface.cpp:79-113) switch to the resident workgroup; a pause sends the next keyword through a launch again while the
+        // workgroup idles out on its own
+        const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const bool close = now - ix.last_single_ns < RESIDENT_AUTO_GAP_US * 1000;
+        ix.last_single_ns = now;
+        ix.single_streak = close ? ix.single_streak + 1u : 0u;
+        ix.resident_query = ix.single_streak >= RESIDENT_AUTO_STREAK;
+    } else {
+        ix.resident_query = ix.resident_mode == 1;
+    }
     if (ix.resident_query) {
         // ---- post the request to the resident workgroup (started now if it is not there)
         if (!ix.res_stream) CDB_HIP(hipStreamCreateWithFlags(&ix.res_stream, hipStreamNonBlocking));
@@ -1712,7 +1728,9 @@ bool query_single_collect(Index& ix, int64_t** ids_out, int64_t** counts_out, si
             __builtin_ia32_pause();
         }
         if (v == ~0ull) throw Error("HIP error: the resident query kernel did not answer");
+        ix.res_answers++;
     } else {
+        ix.launched_answers++;
         volatile uint64_t* flag = &out->nrows;
         uint64_t v = ~0ull;
         for (uint32_t spin = 0; spin < (1u << 22); ++spin) {

@@ -30,8 +30,13 @@ namespace cdb {
 constexpr int RS_MAX_PASSES = 16;
 
 constexpr uint64_t RS_VAL_MASK = (1ull << 54) - 1;
-constexpr uint32_t RS_SPIN_LIMIT = 1u << 18;  // bounded look-back spin (~0.3-0.5 s of polling): a predecessor that has not answered by
-                                              // then is not coming (starved XCD-ordered pass); 2^22 held a starved build for ~8 s per wait
+// bounded look-back spins.  XCD-ordered (grouped) passes reserve tiles for workgroups that have not started: a predecessor that has
+// not answered after ~0.3-0.5 s of polling is not coming (starved pass; the build retries in plain ticket order), and 2^22 held a
+// starved build for ~8 s per wait.  In plain ticket order a tile only waits for tiles that already RUN, so a long wait means the
+// predecessor was descheduled (two processes on one GPU, CWSR preemption, a profiler): that pass keeps the patient bound — nothing
+// retries it.
+constexpr uint32_t RS_SPIN_LIMIT_GROUPED = 1u << 18;
+constexpr uint32_t RS_SPIN_LIMIT_PLAIN = 1u << 22;
 // XCD-aware tile order of the big-tile configurations: groups of RS_GROUP consecutive tiles go to one XCD (RsCfg::GROUP).
 // Tiles are reserved for workgroups that have not started yet, so up to 7 * RS_GROUP resident workgroups can wait for
 // one that is still to be dispatched: the pass needs more than that many resident at a time (it has 256 when it runs
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
             p -= used;  // the chain's first tile always publishes an inclusive prefix, so p never underflows
             if (used == 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > RS_SPIN_LIMIT) {
+                if (++spins > (Cfg::GROUP > 0 ? RS_SPIN_LIMIT_GROUPED : RS_SPIN_LIMIT_PLAIN)) {
                     atomicExch(err, 1u);
                     break;
                 }

@@ -14,13 +14,18 @@
 // bucket symbol as a number in base B <= 255, pairs by v_dot4_u32_u8, Horner in base B^2) and writes them lane-consecutively —
 // no record ever crosses the LDS, only a 16-bit position does (40 KB of LDS: four workgroups per CU).
 //
-// reference: the records are the sort keys of src/index.h:66-101 (radix_sort on the suffixes' leading bytes), restated as dense
-// numbers per first-symbol bucket; DESIGN.md §4.2.
+// reference: the records are the sort keys of the radix nodes, src/index.cpp:96-126 (257-way buckets on character(), src/index.h:66-73),
+// restated as dense numbers per first-symbol bucket; DESIGN.md §4.2.
 #pragma once
 #include "radix_sort.h"
 
 namespace cdb {
 
+// Timing-only ablations of the sweep kernel (WRONG records) exist only in a library compiled with -DRS_SWEEP_ABL=<bits> and loaded
+// through CDB_LIB_PATH by the measuring script — never in the product build, and never chosen at run time.
+#ifndef RS_SWEEP_ABL
+#define RS_SWEEP_ABL 0
+#endif
 constexpr int RS_SWEEP_TILE = RS_GEN8_TILE;  // 512 threads x 16 positions: two workgroups per CU
 constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept in LDS (more: binary searches in global memory)
 
@@ -30,8 +35,9 @@ constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept i
 template <typename W>
 __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
                                                                   uint32_t g0, uint32_t g1, uint64_t gstart, uint32_t* __restrict__ kout,
-                                                                  uint32_t* __restrict__ vout, W* __restrict__ wout, int abl) {
+                                                                  uint32_t* __restrict__ vout, W* __restrict__ wout) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
+    constexpr int abl = RS_SWEEP_ABL;  // (0 in every product build; timing-only ablations are a COMPILE-time choice, see the top of the file)
     static_assert(NT * IPT == TILE, "tile shape");
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
@@ -609,9 +615,8 @@ void radix_sweep_records(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v
     const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_SWEEP_TILE);
     const uint32_t grid = (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP);
     CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
-    static const int abl = getenv("CDB_SWEEP_ABL") ? std::atoi(getenv("CDB_SWEEP_ABL")) : 0;  // timing-only ablations (WRONG results)
     int t = prof.begin(s);
-    hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w, abl);
+    hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w);
     prof.end(t, (std::string("rs_sweep_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t8192").c_str(),
              n + gelems * (8 + sizeof(W)), s);
     if (stats) stats->passes_run++;

@@ -39,6 +39,12 @@
 #include "records_sweep.h"
 #include "scan.h"
 
+// Timing-only ablations of the record gather (WRONG records): compile-time only (-DRS_GATHER_ABL=<bits>, a library of its own loaded
+// through CDB_LIB_PATH by tools/big_ablate.sh), never a run-time switch of the product build.
+#ifndef RS_GATHER_ABL
+#define RS_GATHER_ABL 0
+#endif
+
 namespace cdb {
 namespace {
 
@@ -1051,8 +1057,8 @@ __global__ __launch_bounds__(256) void sa_bucket_records_lists_kernel(typename S
                                                                       const uint16_t* __restrict__ symmap, int bits, uint64_t mask, int nsym,
                                                                       uint32_t kbase, int low_bits, int npass, uint64_t gstart,
                                                                       uint32_t bucket0, uint32_t* __restrict__ k32, W* __restrict__ low,
-                                                                      uint32_t* __restrict__ elo, unsigned long long* __restrict__ hist,
-                                                                      int abl) {
+                                                                      uint32_t* __restrict__ elo, unsigned long long* __restrict__ hist) {
+    constexpr int abl = RS_GATHER_ABL;  // (0 in every product build: timing-only ablations are compiled in with -DRS_GATHER_ABL=<bits>)
     __shared__ uint16_t s_map[256];
     __shared__ uint32_t s_hist[8][256];
     __shared__ uint32_t s_slot;
@@ -2431,7 +2437,15 @@ void build_typed(Index& ix, bool big) {
                                           &ss, ix.sort_variant, fbits, first_digit.data(), &gen);
             radix_check_error(s, ix.rws);  // (the gathers below read the text through these entries)
         };
-        if (!fuse_rec && !sweep_rec) partition_entries();
+        if (!fuse_rec && !sweep_rec) {
+            // partition + gather reads no per-tile byte counts: they (1 KiB per 8 Ki positions: 2 GiB at 16 GiB of text) and the
+            // tile-base workspace go back to the pool BEFORE the record memory of the groups is sized
+            d_tbc.release();
+            ix.tbw.partial.release();
+            ix.tbw.blockbase.release();
+            ix.tbw.base.release();
+            partition_entries();
+        }
         if (root_folded) {
             uint64_t at = 0;
             for (int k = 0; k < sigma; ++k) {
@@ -2550,7 +2564,7 @@ void build_typed(Index& ix, bool big) {
                 }
                 if (fuse_rec) seg_cap = n;  // (decided with the same bound before the entries were NOT partitioned)
             }
-            if (!fuse_rec && getenv("CDB_DEBUG_NO_SEGCAP")) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
+            if (!fuse_rec && ix.debug_no_segcap) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
             if (sweep_rec && !seg_cap) {  // (a bucket larger than the record memory: partition + gather, bucket by bucket)
                 sweep_rec = false;
@@ -2703,20 +2717,18 @@ void build_typed(Index& ix, bool big) {
                                            d_items2.as<BucketItem>());
                         ix.prof.end(t, "sa_gather_plan", (uint64_t)g.cells * 24 + (g.elems / BR_ITEM) * sizeof(BucketItem), s);
                         t = ix.prof.begin(s);
-                        static const unsigned gather_wgs = getenv("CDB_GATHER_WGS") ? (unsigned)std::atoi(getenv("CDB_GATHER_WGS")) : 256u * 8u;
+                        constexpr unsigned gather_wgs = 256u * 8u;
                         if (pack_seg)
                         hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W, Packed40>), dim3(gather_wgs), dim3(256), 0, s,
                                            Sa40{E.as<uint32_t>(), sa_hi_buf.as<uint8_t>()},
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
-                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>(),
-                                           getenv("CDB_GATHER_ABL") ? std::atoi(getenv("CDB_GATHER_ABL")) : 0);
+                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>());
                         else
                         hipLaunchKernelGGL((sa_bucket_records_lists_kernel<W>), dim3(gather_wgs), dim3(256), 0, s, (const uint64_t*)E.as<uint64_t>(),
                                            (const BucketItem*)d_items2.as<BucketItem>(), (const uint32_t*)list_len, tickets, text, n, doc_start,
                                            (const uint16_t*)d_symmap.as<uint16_t>(), (int)ix.bits, ix.mask, nsym, bbase, blow, bpass, g.gstart,
-                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>(),
-                                           getenv("CDB_GATHER_ABL") ? std::atoi(getenv("CDB_GATHER_ABL")) : 0);
+                                           g.b0, kbp[0], wb[0].as<W>(), ebp[0], d_bh2.as<unsigned long long>());
                         ix.prof.end(t, "sa_bucket_records", g.elems * ((uint64_t)nsym + recb + sizeof(V)), s);
                         st.gather_items += g.elems / BR_ITEM;
                         hipLaunchKernelGGL(rs_seg_tilemap_kernel, dim3((unsigned)ceil_div(g.tiles, 256)), dim3(256), 0, s,

@@ -459,6 +459,49 @@ int cdb_comm_create(cdb_comm** out, const void* id128, int rank, int world, int 
     return CDB_OK;
 }
 
+// the ranks of ONE process (a host thread per rank calls the collectives): RCCL over distinct devices, device-to-device copies when
+// ranks share a device — e.g. BASELINE config 3's four 8 GiB shards co-resident on one MI355X (tests/test_gpu_fullsize.py)
+int cdb_comm_create_group(cdb_comm** out, int world, const int* devices) {
+    if (!out || !devices || world < 1) return CDB_E_INVALID;
+    for (int i = 0; i < world; ++i) out[i] = nullptr;
+    try {
+        bool distinct = true;
+        for (int i = 0; i < world; ++i)
+            for (int j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) distinct = false;
+        const char* force = std::getenv("CDB_SHARD_TRANSPORT");
+        std::shared_ptr<Transport> tr;
+        if (world > 1 && distinct && RcclApi::get().ok() && !(force && std::string(force) == "copy")) {
+            auto r = std::make_shared<RcclTransport>(world);
+            r->comms.assign(world, nullptr);
+            CDB_NCCL(RcclApi::get().CommInitAll(r->comms.data(), world, devices));
+            for (int i = 0; i < world; ++i) r->local_rank.push_back(i);
+            tr = r;
+        } else {
+            tr = std::make_shared<LocalTransport>(world);
+        }
+        for (int i = 0; i < world; ++i) {
+            cdb_comm* c = new cdb_comm();
+            out[i] = c;
+            c->mr.rank = i;
+            c->mr.world = world;
+            c->mr.device = devices[i];
+            c->mr.tr = tr;
+            CDB_HIP(hipSetDevice(devices[i]));
+            CDB_HIP(hipStreamCreateWithFlags(&c->mr.stream, hipStreamNonBlocking));
+            c->mr.own_stream = true;
+        }
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "cdb_comm_create_group: %s\n", e.what());
+        for (int i = 0; i < world; ++i) {
+            delete out[i];
+            out[i] = nullptr;
+        }
+        return CDB_E_DEVICE;
+    }
+    return CDB_OK;
+}
+
 void cdb_comm_destroy(cdb_comm* c) { delete c; }
 
 const char* cdb_comm_last_error(const cdb_comm* c) {

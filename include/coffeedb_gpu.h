@@ -291,6 +291,11 @@ const char* cdb_shards_transport(const cdb_shards* h);
 typedef struct cdb_comm cdb_comm;
 int cdb_comm_unique_id(void* id128);
 int cdb_comm_create(cdb_comm** out, const void* id128, int rank, int world, int device);
+/* The same communicator for ranks that live in ONE process (a host thread per rank calls the collectives): out[world]
+ * receives one handle per rank, rank i on devices[i].  Distinct devices exchange over RCCL (ncclCommInitAll); ranks that
+ * share a device — e.g. BASELINE config 3's four 8 GiB shards co-resident on one MI355X — through device-to-device copies
+ * (cdb_comm_transport says which).  Destroy every handle with cdb_comm_destroy. */
+int cdb_comm_create_group(cdb_comm** out, int world, const int* devices);
 void cdb_comm_destroy(cdb_comm* c);
 const char* cdb_comm_last_error(const cdb_comm* c);
 int cdb_comm_merge(cdb_comm* c, const cdb_device_result* local, cdb_device_result* merged);

@@ -257,6 +257,48 @@ uint64_t canonicalize_typed(Oracle& ix, T* sa) {
     return runs;
 }
 
+// the same over [i0, i1) of the array on `nthreads` threads: a thread owns the runs that START in its chunk (a run is found by
+// comparing neighbours, so a thread first skips the entries that continue a run of the chunk in front) — what bench.py's
+// full-size bit-exact check uses on 2^30 entries, where the single-threaded walk takes minutes
+template <typename T>
+uint64_t canonicalize_mt_typed(Oracle& ix, T* sa, unsigned nthreads) {
+    if (nthreads <= 1 || ix.size < (1u << 20)) return canonicalize_typed(ix, sa);
+    // phase 1 (read-only): every thread lists the runs of two and more that start in its chunk; phase 2: the runs are sorted
+    // (they are disjoint, so nobody reads what another thread writes)
+    std::vector<std::vector<std::pair<uint64_t, uint64_t>>> found(nthreads);
+    const uint64_t n = ix.size;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t] {
+                View<T> v{ix, sa};
+                auto same = [&](uint64_t a, uint64_t b) { return !v.less(sa[a], sa[b], 0) && !v.less(sa[b], sa[a], 0); };
+                uint64_t i = n * t / nthreads;
+                const uint64_t end = n * (t + 1) / nthreads;
+                while (i > 0 && i < end && same(i - 1, i)) ++i;
+                while (i < end) {
+                    uint64_t j = i + 1;
+                    while (j < n && same(i, j)) ++j;
+                    if (j - i > 1) found[t].push_back({i, j});
+                    i = j;
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    uint64_t total = 0;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t] {
+                for (auto& r : found[t])
+                    std::sort(sa + r.first, sa + r.second, [&](T x, T y) { return ((uint64_t)x & ix.mask) < ((uint64_t)y & ix.mask); });
+            });
+        for (auto& x : th) x.join();
+    }
+    for (auto& f : found) total += f.size();
+    return total;
+}
+
 template <typename T>
 uint64_t inversions_typed(const Oracle& ix, const T* sa) {
     View<T> v{ix, const_cast<T*>(sa)};
@@ -530,6 +572,13 @@ uint64_t orc_canonicalize(void* h) {
     if (!ix.built) return 0;
     return ix.width == 4 ? canonicalize_typed<uint32_t>(ix, ix.sa32.data())
                          : canonicalize_typed<uint64_t>(ix, ix.sa64.data());
+}
+
+uint64_t orc_canonicalize_mt(void* h, unsigned nthreads) {
+    Oracle& ix = *(Oracle*)h;
+    if (!ix.built) return 0;
+    return ix.width == 4 ? canonicalize_mt_typed<uint32_t>(ix, ix.sa32.data(), nthreads)
+                         : canonicalize_mt_typed<uint64_t>(ix, ix.sa64.data(), nthreads);
 }
 
 // number of adjacent pairs out of unsigned-lexicographic order (0 for pure-ASCII text; >0 exposes

@@ -33,6 +33,8 @@ def _lib():
         for f in ("orc_size", "orc_bits", "orc_mask", "orc_canonicalize", "orc_inversions"):
             getattr(lib, f).restype = u64
             getattr(lib, f).argtypes = [vp]
+        lib.orc_canonicalize_mt.restype = u64
+        lib.orc_canonicalize_mt.argtypes = [vp, C.c_uint]
         lib.orc_sa_width.restype = C.c_int
         lib.orc_sa_width.argtypes = [vp]
         lib.orc_sa_data.restype = vp
@@ -92,8 +94,16 @@ class OracleIndex:
         buf = (C.c_char * (n * w)).from_address(_lib().orc_sa_data(self._h))
         return np.frombuffer(buf, dtype=dt).copy()
 
-    def canonicalize(self):
-        return _lib().orc_canonicalize(self._h)
+    def canonicalize(self, nthreads=1):
+        return _lib().orc_canonicalize_mt(self._h, nthreads) if nthreads > 1 else _lib().orc_canonicalize(self._h)
+
+    def sa_view(self):
+        """The oracle's own array without a copy (valid while the index lives)."""
+        n, w = self.size, self.sa_width
+        dt = np.uint32 if w == 4 else np.uint64
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.frombuffer((C.c_char * (n * w)).from_address(_lib().orc_sa_data(self._h)), dtype=dt)
 
     def inversions(self):
         return _lib().orc_inversions(self._h)

@@ -111,3 +111,24 @@ def test_layout_rule_and_capacity_limit_messages(lib):
         capi.layout_rule((1 << 32) + 1, 4)
     with pytest.raises(RuntimeError, match="The amount of data exceeds the maximum range that CoffeeDB can handle"):
         capi.layout_rule(1 << 31, 1 << 33)                        # 32 + 34 bits
+
+
+def test_no_result_changing_switch_in_the_product_library(lib):
+    """timing ablations that produce WRONG indexes must be a compile-time choice of a separate library
+    (-DRS_SWEEP_ABL / -DRS_GATHER_ABL / -DRS_SEG_ABL / -DRS_GEN_ABL, loaded through CDB_LIB_PATH by the measuring script), never a
+    run-time switch of the shipped one: no environment variable with ABL in its name, no CDB_OPTIONS back door inside the library,
+    no kernel with an ablation parameter."""
+    so = os.path.join(ROOT, "coffeedb_amd", "csrc", "libcoffeedb_gpu.so")
+    blob = open(so, "rb").read()
+    for needle in (b"_ABL", b"CDB_OPTIONS", b"CDB_DEBUG_NO_SEGCAP", b"CDB_GATHER_WGS"):
+        assert needle not in blob, needle
+    csrc = os.path.join(ROOT, "coffeedb_amd", "csrc")
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h")):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        # ablation masks are constexpr copies of a compile-time macro that defaults to 0; never a function parameter
+        assert not re.search(r"\bint\s+abl\s*[,)]", txt), f
+        assert not re.search(r'getenv\("[A-Z_]*ABL', txt), f
+        for m in re.finditer(r"#define\s+(RS_[A-Z]+_ABL)\s+(\S+)", txt):
+            assert m.group(2) == "0", (f, m.group(0))

@@ -502,3 +502,153 @@ def test_rebuild_8gib_column_beside_the_serving_index():
     r = new.query_batch_device(pb_blob.data_ptr(), pb_offs.data_ptr(), 20_000, pb_bytes)
     assert int(r.nhits) >= 18_000
     new.close()
+
+
+def test_c3_32gib_as_four_co_resident_shards_merged_on_one_gpu():
+    """BASELINE.json configs[3] AS WORDED except for the xGMI hop: 2^25 docs x 1024 B of printable ASCII = 32 GiB, cut by
+    byte range into four doc-aligned 8 GiB shards (index.h:61-65: suffixes never cross documents; index.cpp:317-321: a row
+    belongs to one document), every shard with its own suffix array — all four CO-RESIDENT on one MI355X (packed 5-byte
+    entries: ~44.5 GB of index per shard beside its 8 GiB of text).  The later shards build beside the resident ones, so
+    their bucket groups adapt to what is free.  Global object ids are rank * ndocs + i; every shard answers the whole
+    100 k-pattern batch; the per-shard results meet through cdb_comm (one host thread per rank, ranks sharing the device
+    exchange by device copies) in BOTH forms: the counts-only merge and the full all-gatherv merge.  Checked: every
+    shard's array by the GPU verifier, merged row_ptr = sum of the shards' counts, merged rows = shard rows in shard
+    order, and brute-force scans over the whole 32 GiB for sampled patterns incl. short ones whose rows lie in all four
+    shards."""
+    import json
+    import os
+    import threading
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    free, total = torch.cuda.mem_get_info()
+    if free < (270 << 30):
+        pytest.skip("needs a whole 288 GB MI355X")
+    G, nd, dl, npat = 4, 1 << 23, 1024, 100_000
+    n = nd * dl
+    ds = W.uniform_docs(nd, dl)
+    d_ds = torch.from_numpy(ds.astype(np.int64)).cuda()
+    capi.load_library().cdb_release_cached_memory()
+    capi.memory_reset_peak()
+    texts, shards, report = [], [], []
+    blobs, offs, base = [], [], 0
+    for r in range(G):
+        text = W.random_bytes_torch(n, 12345, 0x20, 0x7E, stream=20 + r, device="cuda")
+        # a quarter of the batch is drawn from every shard's documents (so every shard owns guaranteed hits)
+        b_, o_, nb = W.sample_patterns_torch(text, d_ds, npat // G, 4, 16, seed=99 + r, miss_byte=0x7F)
+        blobs.append(b_[:nb].clone())
+        offs.append(o_[:-1] + base)
+        base += nb
+        del b_, o_
+        d_ids = torch.arange(nd, dtype=torch.int64, device="cuda") + r * nd          # global object ids
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        g = capi.GpuStringIndex()
+        g.build_resident(text.data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), nd)
+        assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1
+        assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
+        in_use, peak, cached = capi.memory_stats()
+        report.append({"shard": r, "build_ms": round(g.stat("build_ms"), 1), "bucket_groups": int(g.stat("bucket_groups")),
+                       "fused_records": int(g.stat("fused_records")), "library_in_use_bytes": in_use, "library_peak_bytes": peak,
+                       "device_free_bytes_after": int(torch.cuda.mem_get_info()[0])})
+        capi.load_library().cdb_release_cached_memory()       # the next shard sizes its groups from what is really free
+        texts.append((text, d_ids))
+        shards.append(g)
+    for g in shards:
+        v = g.verify()
+        assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+        assert v["entry_sum"] == v["expected_entry_sum"]
+    d_blob = torch.cat(blobs + [torch.zeros(16, dtype=torch.uint8, device="cuda")])
+    d_offs = torch.cat(offs + [torch.tensor([base], dtype=torch.int64, device="cuda")])
+    del blobs, offs
+    torch.cuda.synchronize()
+    local = [g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, base) for g in shards]
+    comms = capi.ShardComm.group([0] * G)
+    assert all(c.world == G and c.transport == "device copies" for c in comms)
+
+    def collective(fn):
+        out, err = [None] * G, []
+
+        def run(r):
+            try:
+                out[r] = fn(r)
+            except Exception as e:  # noqa: BLE001
+                err.append(repr(e))
+        th = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not err, err[:2]
+        return out
+
+    def dev(ptr, cnt):
+        if cnt == 0:
+            return torch.zeros(0, dtype=torch.int64, device="cuda")
+        return torch.as_tensor(_Dev(ptr, cnt), device="cuda")
+
+    lrp = [dev(r.d_row_ptr, npat + 1) for r in local]
+    lrows = [int(r.nrows) for r in local]
+    assert all(int(r.nhits) >= int(r.nrows) > 0 for r in local)
+    want_rp = torch.zeros(npat + 1, dtype=torch.int64, device="cuda")
+    for p in lrp:
+        want_rp += p                                           # merged row_ptr = sum of the shards' row_ptrs
+    # ---- counts-only merge: merged row_ptr + every rank's row bases
+    slices = collective(lambda r: comms[r].merge_counts(local[r]))
+    for r, sl in enumerate(slices):
+        assert int(sl.nrows_total) == sum(lrows) and int(sl.nrows_local) == lrows[r]
+        assert torch.equal(dev(sl.d_row_ptr, npat + 1), want_rp)
+        want_base = want_rp[:-1].clone()
+        for q in range(r):
+            want_base += lrp[q][1:] - lrp[q][:-1]
+        assert torch.equal(dev(sl.d_row_base, npat), want_base)
+    # ---- full merge: every rank holds the merged CSR (shard rows in shard order = ascending global document)
+    merged = collective(lambda r: comms[r].merge(local[r]))
+    total_rows = sum(lrows)
+    m0 = merged[0]
+    assert int(m0.nrows) == total_rows and torch.equal(dev(m0.d_row_ptr, npat + 1), want_rp)
+    m_ids, m_cnt = dev(m0.d_ids, total_rows), dev(m0.d_counts, total_rows)
+    for r in (1, G - 1):
+        assert torch.equal(dev(merged[r].d_ids, total_rows), m_ids) and torch.equal(dev(merged[r].d_counts, total_rows), m_cnt)
+    assert int(m_cnt.sum()) == sum(int(r.nhits) for r in local)
+    rows = (want_rp[1:] - want_rp[:-1])
+    inner = torch.ones(total_rows, dtype=torch.bool, device="cuda")
+    inner[want_rp[:-1][rows > 0]] = False
+    assert bool(((m_ids[1:] - m_ids[:-1])[inner[1:]] > 0).all())     # ids ascend inside every pattern, across the shard seams
+    assert float((rows > 0).float().mean()) > 0.88
+    # ---- brute force over the whole 32 GiB
+    ho = d_offs.cpu().numpy()
+    hb = d_blob.cpu().numpy()
+    lens = np.diff(ho)
+    rng = np.random.default_rng(8)
+    short = np.nonzero(lens == 4)[0]
+    picks = rng.choice(npat, 16, replace=False).tolist() + rng.choice(short, 5, replace=False).tolist() + [int(np.argmax(rows.cpu().numpy()))]
+    straddle = 0
+    hrp = want_rp.cpu().numpy()
+    for j in picks:
+        kw = hb[int(ho[j]):int(ho[j + 1])]
+        d_kw = torch.from_numpy(kw.copy()).cuda()
+        wd, wc = [], []
+        for r in range(G):
+            pos = _scan_occurrences(torch, texts[r][0], d_kw)
+            pos = pos[(pos % dl) + len(kw) <= dl]
+            d, c = torch.unique(pos // dl, return_counts=True)
+            wd.append(d + r * nd)
+            wc.append(c)
+        straddle += int(sum(1 for d in wd if d.numel()) > 1)
+        a, b = int(hrp[j]), int(hrp[j + 1])
+        assert torch.equal(m_ids[a:b], torch.cat(wd)) and torch.equal(m_cnt[a:b], torch.cat(wc)), (j, bytes(kw))
+    assert straddle >= 5                                              # patterns whose rows lie on both sides of a shard boundary
+    free_end = int(torch.cuda.mem_get_info()[0])
+    summary = {"config": "C3: 2^25 docs x 1024 B = 32 GiB as 4 doc-aligned shards on ONE MI355X", "shards": report,
+               "merged_rows": total_rows, "patterns": npat, "patterns_checked_by_brute_force": len(picks), "straddling": straddle,
+               "device_total_bytes": int(total), "device_free_bytes_all_resident": free_end, "transport": comms[0].transport}
+    print("\n" + json.dumps(summary))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/c3_one_gpu.json", "w") as f:
+            json.dump(summary, f, indent=1)
+    except OSError:
+        pass
+    for c in comms:
+        c.close()
+    for g in shards:
+        g.close()
+    capi.load_library().cdb_release_cached_memory()

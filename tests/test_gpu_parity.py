@@ -725,11 +725,7 @@ def test_packed_suffix_array_storage(G, tmp_path):
         if opts.get("fuse_records") == 0:
             # a bucket that does not fit the record memory sends the partitioned (packed) entries back to plain 8-byte form
             # for the per-bucket sorts (test hook); the array is packed at the end of the build instead
-            os.environ["CDB_DEBUG_NO_SEGCAP"] = "1"
-            try:
-                g4, _ = _check_parity(G, blob, ds, ids=ids, patterns=pats, **opts)
-            finally:
-                del os.environ["CDB_DEBUG_NO_SEGCAP"]
+            g4, _ = _check_parity(G, blob, ds, ids=ids, patterns=pats, debug_no_segcap=1, **opts)
             assert g4.stat("sa_packed") == 1 and g4.stat("segmented") == 0 and np.array_equal(g4.sa(), g1.sa())
         if "fuse_records" in opts or "fold_root" in opts:
             continue                                                     # (save / load once per storage path is enough)
@@ -1169,6 +1165,23 @@ def test_resident_query_workgroup(G):
     g.set_option("resident_query", 0)
     lat_off = np.median(g.query_latency_us(kws[20:52], reps=16))
     print(f"lone keyword: resident {lat_on:.1f} us, launched {lat_off:.1f} us")
+    # DEFAULT options (resident_query = 2, automatic): keywords that arrive back to back — what interface.cpp:79-113 does with the
+    # keywords of one query — move to the resident workgroup by themselves after a few calls; a pause sends the next one through a
+    # launch again.  Same answers either way.
+    ga = _gpu(G, blob, ds, ids)
+    o3 = _oracle(blob, ds, ids)
+    assert ga.stat("resident_mode") == 2 and ga.stat("resident_answers") == 0
+    for kw in kws[20:120]:
+        assert ga.query(kw) == o3.query(kw), kw
+    # (the Python binding adds ~10 us per call: the 1 ms gap rule holds easily)
+    assert ga.stat("resident_answers") >= 60 and ga.stat("launched_answers") >= 1, (ga.stat("resident_answers"), ga.stat("launched_answers"))
+    time.sleep(0.02)
+    before = ga.stat("launched_answers")
+    assert ga.query(kws[25]) == o3.query(kws[25])     # after the pause: a launch (the streak starts over)
+    assert ga.stat("launched_answers") == before + 1
+    lat_auto = np.median(ga.query_latency_us(kws[20:52], reps=16))
+    print(f"lone keyword, default options (automatic): {lat_auto:.1f} us")
+    assert ga.stat("resident_answers") > 400
     # reference-compat ordering (not globally sorted): the resident workgroup walks the reference's bisections too
     blob2, ds2 = W.utf8_corpus(300, 120, seed=4)
     ids2 = np.arange(len(ds2) - 1, dtype=np.int64)
