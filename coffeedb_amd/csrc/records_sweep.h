@@ -26,6 +26,23 @@ namespace cdb {
 #ifndef RS_SWEEP_ABL
 #define RS_SWEEP_ABL 0
 #endif
+#ifndef RS_SWEEP_UNALIGNED
+#define RS_SWEEP_UNALIGNED 0   // (measured: unaligned 8-byte LDS reads of the code windows, see rs_sweep_msd_kernel)
+#endif
+// inclusive prefix sum over the 64 lanes of a wavefront by DPP adds (row shifts inside 16 lanes, then the row totals broadcast to
+// the rows behind them): seven vector instructions, no LDS — __shfl_up costs a ds_bpermute and three vector instructions per step
+__device__ __forceinline__ uint32_t rs_wave_incl_scan(uint32_t x) {
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);  // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);  // row_shr:4, lanes 4-15 of every row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);  // row_shr:8, lanes 8-15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 constexpr int RS_SWEEP_TILE = RS_GEN8_TILE;  // 512 threads x 16 positions: two workgroups per CU
 constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept in LDS (more: binary searches in global memory)
 
@@ -335,21 +352,33 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
 // = top digit of the 6-symbol key, a function of the first two symbols; records (u32 key - top * M, u32 entry).  Every position
 // is kept.  gen: text, doc_start, symmap, bits, base, pair_span / pair_r / pair_s, padded, tile_doc, tile_base.
 // The digit of a document's LAST position counts its second symbol as 0 — exactly what the per-tile counts the tile bases
-// come from did (sa_build.hip: sa_tile_docend_fix_kernel): the tile marks those positions in a bit map before it stages.
+// come from did (sa_build.hip: sa_tile_docend_fix_kernel).
+//
+// Round 5: SQ counters (profiles/r05a_sq_counters.txt) showed the round-4 form issue-bound, not latency-bound: 84 vector and 15 LDS
+// instructions per position kept the vector units ~78 % and the LDS ~77 % busy (half of the LDS cycles bank conflicts).  Most of
+// them were 64-bit document arithmetic in phase B (position -> document by three table reads and a 64-bit compare, offset, entry,
+// symbols left: ~30 instructions per record).  Now the tile keeps, per document, a 32-bit start RELATIVE to the tile and an entry
+// bias ((tile base - document start) << bits) + document, and per 32 positions the bit map of document starts with the number of
+// starts in front of it: document = count + popcount(bits & mask) — exact for any number of documents in a block, no search —,
+// entry = bias + (position << bits), symbols left = next start - position: 9 instructions and two LDS reads.  The code windows
+// are ONE unaligned 8-byte LDS read (gfx950 reads the LDS at any byte address), the per-slot tile starts are folded into the
+// waves' counters (one read less per position in the scatter), the top digits of the staging thread ignore document ends
+// (the few ends are patched afterwards by the lanes that hold one), and the byte behind a thread's 16 comes from its neighbour
+// lane instead of a global load.
 __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint64_t n, uint32_t tiles, uint32_t* __restrict__ kout,
                                                               uint32_t* __restrict__ vout) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
+    constexpr uint32_t DOCS = 384;         // documents of a tile kept in the LDS (more: the generic path searches global memory)
+    constexpr uint32_t NBLK = TILE / 32;
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
     __shared__ uint8_t s_code[256];
-    constexpr uint32_t DOCS = 384;  // (40 KB of LDS in all: four workgroups per CU)
-    __shared__ uint64_t s_docs[DOCS];
+    __shared__ __attribute__((aligned(8))) uint32_t s_doc[2 * DOCS + 2];      // document d of the tile: [2d] = entry bias, [2d + 1] = start of document d + 1 - tile base (clamped)
     __shared__ uint32_t s_whist[NW][256];
-    __shared__ uint16_t s_pdoc[TILE / 32 + 2];
-    __shared__ uint32_t s_endbits[TILE / 32];  // bit p: position p is the last one of its document
-    __shared__ uint32_t s_tstart[256];
+    __shared__ __attribute__((aligned(8))) uint32_t s_blk[2 * (NBLK + 1)];    // block b of 32 positions: [2b] = bit p: a document starts at 32 b + p, [2b + 1] = 8 x (starts in front of the block)
     __shared__ uint32_t s_gbase[256];  // (below 2^32 suffixes: output slots are 32-bit, differences modulo 2^32)
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[8];
+    __shared__ uint32_t s_flag;        // a document of the tile is empty (two starts on one position): the generic path
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
     uint8_t* const s_dig = reinterpret_cast<uint8_t*>(s_idx);  // (its first half, until the ranking is done: the staged top digits)
 
@@ -367,7 +396,8 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
     uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
     if (oka) ta = *reinterpret_cast<const uint4*>(gen.text + ga);
     if (okb) tb = *reinterpret_cast<const uint4*>(gen.text + gb);
-    const uint32_t tnext = ga + 16 < n ? (uint32_t)gen.text[ga + 16] : 0u;  // the byte behind the thread's 16: second symbol of its last pair
+    uint32_t tnext = 0;  // the byte behind the wave's 1024: second symbol of its last pair (the other lanes ask their neighbour)
+    if (lane == 63 && ga + 16 < n) tnext = (uint32_t)gen.text[ga + 16];
     uint64_t my_base = 0;
     if (tid < 256) {
         my_base = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)tid];
@@ -375,7 +405,8 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
     }
     const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
     for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
-    if (tid < TILE / 32) s_endbits[tid] = 0;
+    if ((uint32_t)tid <= NBLK) s_blk[2 * tid] = 0;
+    if (tid == 0) s_flag = 0;
     const uint32_t ndl = (uint32_t)(dhi - dlo);
     const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOCS;
     uint64_t dreg0 = 0, dreg1 = 0;
@@ -385,15 +416,19 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
     }
     __syncthreads();  // (the zeroes)
     if (docs_in_lds) {
-        // a document that starts at s > base ends its predecessor at s - 1 (empty documents repeat a start: the bit is set twice)
-        if ((uint32_t)tid < ndl + 2) {
-            s_docs[tid] = dreg0;
-            if (dreg0 > base && dreg0 - 1 - base < (uint64_t)valid) atomicOr(&s_endbits[(uint32_t)(dreg0 - 1 - base) >> 5], 1u << ((uint32_t)(dreg0 - 1 - base) & 31u));
-        }
-        if ((uint32_t)tid + NT < ndl + 2) {
-            s_docs[tid + NT] = dreg1;
-            if (dreg1 > base && dreg1 - 1 - base < (uint64_t)valid) atomicOr(&s_endbits[(uint32_t)(dreg1 - 1 - base) >> 5], 1u << ((uint32_t)(dreg1 - 1 - base) & 31u));
-        }
+        auto put = [&](uint32_t d, uint64_t ds) {
+            const int64_t diff = (int64_t)(ds - base);
+            const int32_t rel = diff < -(1ll << 30) ? -(1 << 30) : (diff > (1ll << 30) ? (1 << 30) : (int32_t)diff);
+            s_doc[2 * d] = (uint32_t)(((base - ds) << gen.bits) + dlo + d);
+            if (d >= 1) s_doc[2 * d - 1] = (uint32_t)rel;  // (beside the entry bias of the document in front: one aligned 8-byte read)
+            // a document that starts at s > base ends its predecessor at s - 1; two starts on one position = an empty document
+            if (d >= 1 && rel <= (int32_t)TILE) {
+                const uint32_t bit = 1u << ((uint32_t)rel & 31u);
+                if (atomicOr(&s_blk[2 * ((uint32_t)rel >> 5)], bit) & bit) s_flag = 1;
+            }
+        };
+        if ((uint32_t)tid < ndl + 2) put((uint32_t)tid, dreg0);
+        if ((uint32_t)tid + NT < ndl + 2) put((uint32_t)tid + NT, dreg1);
     }
     __syncthreads();
 
@@ -413,13 +448,15 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
     {
         uint32_t c[4];
         fetch(ga, oka, ta, c);
+        const uint32_t nb = __shfl_down(c[0] & 0xFFu, 1);  // the neighbour thread's first byte
         uint32_t e[IPT + 1];
 #pragma unroll
         for (int k = 0; k < IPT; ++k) e[k] = s_code[(c[k >> 2] >> (8 * (k & 3))) & 0xFFu];
-        e[IPT] = s_code[tnext];
-        uint32_t ends;  // bit k: position k of this thread is the last one of its document
+        e[IPT] = s_code[lane == 63 ? tnext : nb];
+        uint32_t ends;  // bit k: position k of this thread is the last one of its document (position k + 1 starts one)
         if (docs_in_lds) {
-            ends = (s_endbits[(uint32_t)tid >> 1] >> (16 * ((uint32_t)tid & 1u))) & 0xFFFFu;
+            const uint32_t w0 = s_blk[2 * ((uint32_t)tid >> 1)], w1 = s_blk[2 * ((uint32_t)tid >> 1) + 2];
+            ends = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (16u * ((uint32_t)tid & 1u) + 1u)) & 0xFFFFu;
         } else {  // (thousands of documents in the tile) the documents that start in (ga, ga + 16]
             ends = 0;
             const uint64_t d = rs_doc_upper(gen.doc_start, dlo, dhi, ga < n ? ga : n - 1);  // document of the thread's first position
@@ -433,13 +470,16 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
 #pragma unroll
         for (int q = 0; q < 4; ++q) codes[q] = e[4 * q] | (e[4 * q + 1] << 8) | (e[4 * q + 2] << 16) | (e[4 * q + 3] << 24);
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const uint32_t c1 = (ends >> k) & 1u ? 0u : e[k + 1];
-            const uint32_t a = __umul24(e[k], B) + c1;
-            digs[k >> 2] |= (__umul24(a, gen.pair_r) >> gen.pair_s) << (8 * (k & 3));
-        }
+        for (int k = 0; k < IPT; ++k)  // (document ends ignored here: patched below by the few lanes that hold one)
+            digs[k >> 2] |= (__umul24(__umul24(e[k], B) + e[k + 1], gen.pair_r) >> gen.pair_s) << (8 * (k & 3));
         *reinterpret_cast<uint4*>(&s_text[(uint32_t)tid * 16]) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
         *reinterpret_cast<uint4*>(&s_dig[(uint32_t)tid * 16]) = make_uint4(digs[0], digs[1], digs[2], digs[3]);
+        while (ends) {  // a document's last position: its second symbol counts as 0
+            const uint32_t k = (uint32_t)__builtin_ctz(ends);
+            ends &= ends - 1u;
+            const uint32_t cc = s_text[(uint32_t)tid * 16 + k];
+            s_dig[(uint32_t)tid * 16 + k] = (uint8_t)(__umul24(__umul24(cc, B), gen.pair_r) >> gen.pair_s);
+        }
         if (has_b) {  // the look-ahead behind the tile: codes only
             fetch(gb, okb, tb, c);
 #pragma unroll
@@ -471,48 +511,45 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
         }
     }
     __syncthreads();
-    uint32_t cnt = 0, incl = 0;
+    // ---- per-digit totals of the tile (waves 0-3), and meanwhile (waves 4-7) the number of document starts in front of every block
+    uint32_t wc[NW], cnt = 0, incl = 0;
     if (tid < 256) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const uint32_t t = s_whist[w][tid];
-            s_whist[w][tid] = cnt;
-            cnt += t;
+            wc[w] = s_whist[w][tid];
+            cnt += wc[w];
         }
         incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-    } else if (docs_in_lds) {
-        for (uint32_t b = (uint32_t)tid - 256u; b < (uint32_t)TILE / 32 + 1; b += 256u) {
-            const uint64_t pos = base + (uint64_t)b * 32;
-            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
-            while (lo < hi) {
-                const uint32_t mid = lo + (hi - lo + 1) / 2;
-                if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
-            }
-            s_pdoc[b] = (uint16_t)lo;
-        }
+    } else {
+        incl = cnt = (uint32_t)__builtin_popcount(s_blk[2 * (tid - 256)]);
     }
+    incl = rs_wave_incl_scan(incl);
+    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    if (tid < 256) {
+    {
         uint32_t wpre = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-            if (w < wave) wpre += s_wsum[w];
-        const uint32_t tstart = wpre + incl - cnt;
-        s_tstart[tid] = tstart;
-        s_gbase[tid] = (uint32_t)my_base - tstart;
+            if (w < (wave & 3)) wpre += s_wsum[(wave & 4) + w];
+        const uint32_t excl = wpre + incl - cnt;
+        if (tid < 256) {  // every wave's counter of the digit becomes its first slot in the tile's sorted order
+            uint32_t run = excl;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s_whist[w][tid] = run;
+                run += wc[w];
+            }
+            s_gbase[tid] = (uint32_t)my_base - excl;
+        } else {
+            s_blk[2 * (tid - 256) + 1] = excl * 8u;
+            if (tid == 511) s_blk[2 * NBLK + 1] = (excl + cnt) * 8u;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         if (info[k] != ~0u) {
-            const uint32_t sl = info[k] >> 16;
-            const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
+            const uint32_t pos = s_whist[wave][info[k] >> 16] + (info[k] & 0xFFFFu);
             s_idx[pos] = (uint16_t)(wbase + k * 64);  // (the digit is not carried along: phase B has it back from the first pair)
         }
     }
@@ -520,80 +557,64 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
 
     // ---- phase B: output order; key - top M = ((a - top span) B^2 + m) B^2 + r with a, m, r = the three symbol pairs (one
     // v_dot4_u32_u8 each; products below 2^24, rs_pair_setup), entry = (offset << bits) | document
-    const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);
-#ifndef RS_MSD_U
-#define RS_MSD_U 2
+    const int nspan = -(int)gen.pair_span;
+    auto emit = [&](uint32_t p, uint32_t li, uint32_t ent, uint32_t rem) {
+#if RS_SWEEP_UNALIGNED
+        uint2 xw;
+        __builtin_memcpy(&xw, &s_text[li], 8);  // codes of li .. li + 7: one LDS read at a byte address
+        uint32_t x0 = xw.x, x1 = xw.y;
+#else
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
+        const uint32_t wi = li >> 2, sel = li & 3u;
+        const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+        uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
+        uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
 #endif
-    constexpr int U = RS_MSD_U;
-    for (uint32_t p0 = tid; p0 < valid; p0 += U * NT) {
-        uint32_t li[U], lo[U], hi[U];
-        bool act[U];
-        uint64_t dd[U], ds[U], de[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = p0 + u * NT;
-            act[u] = p < valid;
-            const uint32_t q = act[u] ? p : p0;
-            li[u] = s_idx[q];
-        }
-        if (docs_in_lds) {
-            bool deep = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                lo[u] = s_pdoc[li[u] >> 5];
-                hi[u] = s_pdoc[(li[u] >> 5) + 1];
-                deep |= hi[u] > lo[u] + 1;
-            }
-            if (__builtin_amdgcn_ballot_w64(deep) != 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    while (lo[u] < hi[u]) {
-                        const uint32_t mid = lo[u] + (hi[u] - lo[u] + 1) / 2;
-                        if (s_docs[mid] <= base + li[u]) lo[u] = mid; else hi[u] = mid - 1;
-                    }
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u) lo[u] = s_docs[hi[u]] <= base + li[u] ? hi[u] : lo[u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                dd[u] = dlo + lo[u];
-                ds[u] = s_docs[lo[u]];
-                de[u] = s_docs[lo[u] + 1];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                dd[u] = rs_doc_upper(gen.doc_start, dlo, dhi, base + li[u]);
-                ds[u] = gen.doc_start[dd[u]];
-                de[u] = gen.doc_start[dd[u] + 1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t pos = base + li[u];
-            const uint32_t ent = (uint32_t)(((pos - ds[u]) << gen.bits) + dd[u]);
-            const uint64_t left = de[u] - pos;  // symbols left in the document (>= 1)
-            const uint32_t rem = left < 64ull ? (uint32_t)left : 64u;
-            const uint32_t wi = li[u] >> 2, sel = li[u] & 3u;
-            const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-            uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li .. li + 3
-            uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 4 .. li + 7
-            if (rem < 6u) {  // (rare) the symbols behind the document end count as 0
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(rem < 6u) != 0)) != 0, 0)) {  // (wave-uniform; a quarter of the waves at 1 KiB documents)
+            if (rem < 6u) {  // the symbols behind the document end count as 0
                 x0 = rem >= 4u ? x0 : (x0 & ((1u << (8u * rem)) - 1u));
                 x1 = rem <= 4u ? 0u : (x1 & 0xFFu);
             }
-            const uint32_t a = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
-            const uint32_t m = __builtin_amdgcn_udot4(x0, whi, 0u, false);
-            const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
-            const uint32_t top = __umul24(a, gen.pair_r) >> gen.pair_s;  // floor(a / span): the digit the position was ranked on
-            const uint32_t a2 = a - __umul24(top, gen.pair_span);
-            const uint32_t dst = s_gbase[top] + (p0 + u * NT);
-            if (act[u]) {
-                kout[dst] = __umul24(__umul24(a2, B2) + m, B2) + r;
-                vout[dst] = ent;
+        }
+        const uint32_t a = __builtin_amdgcn_udot4(x0, wlo, 0u, false);
+        const uint32_t m = __builtin_amdgcn_udot4(x0, whi, 0u, false);
+        const uint32_t r = __builtin_amdgcn_udot4(x1, wlo, 0u, false);
+        const uint32_t top = (uint32_t)__umul24(a, gen.pair_r) >> gen.pair_s;  // floor(a / span): the digit the position was ranked on
+        const uint32_t a2 = (uint32_t)(__mul24((int)top, nspan) + (int)a);
+        const uint32_t dst = s_gbase[top] + p;
+        kout[dst] = (uint32_t)__umul24((uint32_t)__umul24(a2, B2) + m, B2) + r;
+        vout[dst] = ent;
+    };
+    if (docs_in_lds && s_flag == 0 && valid == (uint32_t)TILE) {
+        constexpr int U = 2;  // (two records per trip: their loads stage by stage in flight together)
+        const int bits = gen.bits;
+#pragma nounroll
+        for (uint32_t p0 = tid; p0 < (uint32_t)TILE; p0 += U * NT) {
+            uint32_t li[U];
+            uint2 bk[U], dc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) li[u] = s_idx[p0 + u * NT];
+#pragma unroll
+            for (int u = 0; u < U; ++u) bk[u] = *reinterpret_cast<const uint2*>(&s_blk[2 * (li[u] >> 5)]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // document = starts in front of the block + starts inside it up to the position
+                const uint32_t doff = bk[u].y + 8u * (uint32_t)__builtin_popcount(bk[u].x & ~(0xFFFFFFFEu << (li[u] & 31u)));
+                dc[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(s_doc) + doff);  // entry bias, next start
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) emit(p0 + u * NT, li[u], dc[u].x + (li[u] << bits), dc[u].y - li[u]);
+        }
+    } else {
+        // (the ragged last tile, tiles with hundreds of documents or empty ones: searches in global memory)
+        for (uint32_t p = tid; p < valid; p += NT) {
+            const uint32_t li = s_idx[p];
+            const uint64_t pos = base + li;
+            const uint64_t dd = rs_doc_upper(gen.doc_start, dlo, dhi, pos);
+            const uint64_t ds = gen.doc_start[dd], de = gen.doc_start[dd + 1];
+            const uint64_t left = de - pos;
+            emit(p, li, (uint32_t)(((pos - ds) << gen.bits) + dd), left < 64ull ? (uint32_t)left : 64u);
         }
     }
 }
