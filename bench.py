@@ -675,7 +675,10 @@ def main():
         # server.cpp:44: the start-up build of a fresh process — measured FIRST, while this process has not touched the GPU
         # (VRAM a process released just before is scrubbed by the driver on re-allocation: the recycled case the configs
         # blocks measure)
-        cold = host_caller("cold", 4 << 30)
+        cold = host_caller("cold", 4 << 30)  # (with string_index::reserve running beside the "ingest": the product path)
+        if isinstance(cold, dict) and "error" not in cold:
+            # the same start-up without the reservation, for the record (SECOND: its pages are recycled ones)
+            cold["without_reserve"] = host_caller("cold", 4 << 30, "noreserve")
 
     import torch
     import torch.distributed as dist
@@ -929,6 +932,8 @@ def main():
         # what the SHIM's build() really calls (shim/index.cpp: cdb_build_views over one std::string per document,
         # database.cpp:262-264): the C++ caller of tests/cpp at this workload's shape, in a process of its own
         out["pcie_inclusive"]["build_views"] = host_caller("views", ndocs, cfg.get("doclen", 1024), 3)
+        # ... and at the north-star size: 4 M separately allocated strings of valid UTF-8 (4 GiB), warm (repetitions 1-2)
+        out["pcie_inclusive"]["build_views_4g"] = host_caller("views", 4 << 20, 1024, 2, "utf8")
     if cold is not None:
         out["cold_start"] = cold
     del text, d_blob, d_offs

@@ -27,7 +27,7 @@ EXPORTS = [
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_shards_build_views", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
     "cdb_comm_unique_id", "cdb_comm_create", "cdb_comm_create_group", "cdb_comm_destroy", "cdb_comm_last_error", "cdb_comm_merge", "cdb_comm_merge_counts",
-    "cdb_comm_world", "cdb_comm_transport",
+    "cdb_comm_world", "cdb_comm_transport", "cdb_reserve", "cdb_reserve_wait",
 ]
 
 
@@ -174,6 +174,8 @@ def load_library():
     lib.cdb_shards_transport.restype = cp
     lib.cdb_comm_unique_id.argtypes = [vp]
     lib.cdb_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int]
+    lib.cdb_reserve.argtypes = [C.c_int, u64, u64, C.c_char_p, C.c_size_t]
+    lib.cdb_reserve_wait.restype = None
     lib.cdb_comm_create_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     lib.cdb_comm_destroy.argtypes = [vp]
     lib.cdb_comm_destroy.restype = None

@@ -331,6 +331,42 @@ void ensure_host_staging(Index& ix) {
 }
 }  // namespace cdb
 
+namespace {
+struct ReserveJob {
+    std::mutex mu;
+    std::thread th;
+    ~ReserveJob() {
+        if (th.joinable()) th.join();
+    }
+};
+ReserveJob& reserve_job() {
+    static ReserveJob j;
+    return j;
+}
+thread_local bool t_in_reserve = false;
+void reserve_join() {
+    if (t_in_reserve) return;
+    ReserveJob& j = reserve_job();
+    std::lock_guard<std::mutex> g(j.mu);
+    if (j.th.joinable()) j.th.join();
+}
+// text[i] = table[hash(i) >> 52]: 4096 slots filled in proportion to the sample's byte histogram
+__global__ __launch_bounds__(256) void reserve_fill_kernel(uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ table,
+                                                           uint64_t* __restrict__ doc_start, int64_t* __restrict__ ids, uint64_t ndocs) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        uint64_t x = i + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        text[i] = table[(x ^ (x >> 31)) >> 52];
+    }
+    for (uint64_t d = (uint64_t)blockIdx.x * 256 + threadIdx.x; d <= ndocs; d += stride) {
+        doc_start[d] = d == ndocs ? n : (unsigned __int128)n * d / ndocs;
+        if (d < ndocs) ids[d] = (int64_t)d;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int cdb_create(cdb_index** out, int device) {
@@ -607,6 +643,7 @@ int cdb_save(cdb_index* h, const char* path) {
 }
 
 int cdb_load(cdb_index* h, const char* path) {
+    reserve_join();
     if (!h || !path) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
@@ -702,8 +739,89 @@ int cdb_load(cdb_index* h, const char* path) {
     });
 }
 
+// ---- cdb_reserve: the working set of the first build, mapped BEFORE the build is asked for --------------------------------
+// The first build of a fresh process pays for VRAM the driver maps (and, for pages another process released, scrubs) on first
+// use: 0.3-2.6 s for a 4 GiB column by the state of the box against 0.13 s warm.  server.cpp:43-44 loads the data
+// from disk and only then builds, so that time can hide behind the ingest: cdb_reserve starts a helper thread that builds a
+// throw-away index over SYNTHETIC text of the announced size (independent bytes drawn from the sample's byte histogram, so the
+// alphabet — and with it record widths and block sizes — resembles the real column) and destroys it again.  Its blocks stay in
+// the process-wide block cache (DevPool), which hands them to the real build.  Best effort: any failure just leaves the cache
+// as it was.  Every cdb_build* / cdb_load first waits for a reservation still in flight.
+int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sample, size_t sample_len) {
+    if (text_bytes == 0 || text_bytes >= (1ull << 40)) return CDB_E_INVALID;
+    // 4 % and 64 MiB over the announced size: a cached block serves a request only when it is at least as large (DevPool keeps up
+    // to a quarter of slack), so the synthetic column must not come out smaller than the real one
+    text_bytes = (text_bytes + text_bytes / 25 + (64ull << 20) + 15) & ~15ull;
+    if (ndocs == 0) ndocs = std::max<uint64_t>(1, text_bytes / 1024);
+    else ndocs += ndocs / 25;
+    if (ndocs > text_bytes) ndocs = text_bytes;
+    std::vector<uint8_t> table(4096);
+    {
+        uint64_t hist[256] = {0};
+        if (sample && sample_len) {
+            for (size_t i = 0; i < sample_len; ++i) hist[(uint8_t)sample[i]]++;
+        } else {
+            for (int b = 0x20; b <= 0x7E; ++b) hist[b] = 1;  // (no sample: printable ASCII)
+        }
+        uint64_t total = 0;
+        for (uint64_t v : hist) total += v;
+        size_t at = 0;
+        uint64_t run = 0;
+        for (int b = 0; b < 256; ++b) {
+            run += hist[b];
+            const size_t end = (size_t)((unsigned __int128)run * 4096 / total);
+            const size_t stop = hist[b] ? std::max(end, std::min<size_t>(at + 1, 4096)) : end;  // (every byte of the sample keeps a slot)
+            while (at < stop && at < 4096) table[at++] = (uint8_t)b;
+        }
+        for (; at < 4096; ++at) table[at] = at ? table[at - 1] : (uint8_t)0x20;
+    }
+    reserve_join();
+    ReserveJob& j = reserve_job();
+    std::lock_guard<std::mutex> g(j.mu);
+    try {
+        j.th = std::thread([device, text_bytes, ndocs, table] {
+            t_in_reserve = true;
+            const double t_start = wall_ms();
+            cdb_index* h = nullptr;
+            try {
+                if (cdb_create(&h, device) != CDB_OK) return;
+                Index& ix = h->ix;
+                CDB_HIP(hipSetDevice(ix.device));
+                DevBuf text, d_table, d_start, d_ids;
+                text.alloc(text_bytes + TEXT_PAD);
+                d_table.alloc(4096);
+                d_start.alloc((ndocs + 1) * sizeof(uint64_t));
+                d_ids.alloc(ndocs * sizeof(int64_t));
+                CDB_HIP(hipMemcpyAsync(d_table.p, table.data(), 4096, hipMemcpyHostToDevice, ix.stream));
+                CDB_HIP(hipMemsetAsync((uint8_t*)text.p + text_bytes, 0, TEXT_PAD, ix.stream));
+                hipLaunchKernelGGL(reserve_fill_kernel, dim3(4096), dim3(256), 0, ix.stream, text.as<uint8_t>(), text_bytes,
+                                   (const uint8_t*)d_table.as<uint8_t>(), d_start.as<uint64_t>(), d_ids.as<int64_t>(), ndocs);
+                CDB_HIP(hipStreamSynchronize(ix.stream));
+                {   // the pinned staging chunks of the first upload (upload_views / upload_pageable: two 16 MiB blocks per copy thread)
+                    std::vector<void*> pins;
+                    for (int k = 0; k < 24; ++k)
+                        if (void* q = HostPool::get().alloc(16u << 20)) pins.push_back(q);
+                    for (void* q : pins) (void)HostPool::get().release(q);
+                }
+                const int rc = cdb_build_resident(h, text.p, d_start.as<uint64_t>(), d_ids.as<int64_t>(), ndocs);
+                if (getenv("CDB_BUILD_TRACE"))
+                    std::fprintf(stderr, "[reserve] %llu bytes, %llu documents: throw-away build rc %d, %.1f ms in all\n", (unsigned long long)text_bytes,
+                                 (unsigned long long)ndocs, rc, wall_ms() - t_start);
+            } catch (...) {
+            }
+            if (h) cdb_destroy(h);  // (its arrays and the build's scratch go back to the block cache: that is the reservation)
+        });
+    } catch (...) {
+        return CDB_E_DEVICE;
+    }
+    return CDB_OK;
+}
+
+void cdb_reserve_wait(void) { reserve_join(); }
+
 int cdb_build(cdb_index* h) {
     if (!h) return CDB_E_INVALID;
+    reserve_join();
     return guarded(h, [&] {
         Index& ix = h->ix;
         ensure_host_staging(ix);  // (a rebuild after cdb_load / a device build: the staging copy is fetched back)
@@ -752,6 +870,7 @@ int cdb_build(cdb_index* h) {
 }
 
 int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start, const int64_t* ids, uint64_t ndocs) {
+    reserve_join();
     if (!h || (ndocs && (!doc_start || !ids))) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
@@ -800,6 +919,7 @@ int cdb_build_device(cdb_index* h, const void* d_text, const uint64_t* doc_start
  * (a memcpy into fresh pages: 180 ms per GiB, 3x the build it feeds).  The column goes to the device through the
  * chunked pinned upload; afterwards the handle owns device copies only (cdb_add* fetch them back when needed). */
 int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uint64_t* doc_start, uint64_t ndocs) {
+    reserve_join();
     if (!h || (ndocs && (!ids || !doc_start || (!blob && doc_start[ndocs] > doc_start[0])))) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
@@ -884,6 +1004,7 @@ int cdb_build_view(cdb_index* h, const int64_t* ids, const char* blob, const uin
 /* cdb_build_views: the same for documents that are separate strings on the host (ptrs[d], lens[d]) — exactly what
  * string_index::add collects (index.cpp:174-177: ids.push_back(id); data.push_back(view)).  The shim's build() is this call. */
 int cdb_build_views(cdb_index* h, const int64_t* ids, const char* const* ptrs, const uint64_t* lens, uint64_t ndocs) {
+    reserve_join();
     if (!h || (ndocs && (!ids || !ptrs || !lens))) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
@@ -931,6 +1052,7 @@ int cdb_build_views(cdb_index* h, const int64_t* ids, const char* const* ptrs, c
 
 int cdb_build_resident(cdb_index* h, const void* d_text, const uint64_t* d_doc_start, const int64_t* d_ids,
                        uint64_t ndocs) {
+    reserve_join();
     if (!h || !d_doc_start || (ndocs && !d_ids)) return CDB_E_INVALID;
     return guarded(h, [&] {
         Index& ix = h->ix;
@@ -1723,6 +1845,7 @@ int cdb_layout_rule(uint64_t ndocs, uint64_t longest, uint64_t* bits, uint64_t* 
 }
 
 void cdb_release_cached_memory(void) {
+    reserve_join();
     DevPool::get().trim();
     HostPool::get().trim();
 }

@@ -114,6 +114,10 @@ string_index::string_index() {
     // (7.6-8.2 us instead of 12 us per call; INTEGRATION.md says what it costs)
     if (const char* r = std::getenv("COFFEEDB_RESIDENT_QUERY"); r && *r == '1') (void)cdb_set_option(handle, "resident_query", 1);
 }
+void string_index::reserve(uint64_t bytes, std::string_view sample) {
+    if (!shard_devices().empty()) return;  // (several GPUs: every shard maps its own share when it builds)
+    (void)cdb_reserve(-1, bytes, 0, sample.data(), sample.size());
+}
 string_index::~string_index() {
     cdb_destroy(handle);
     cdb_shards_destroy(shards);

@@ -94,6 +94,11 @@ public:
     // Render with cdb_shim::render_spans (highlight.h).
     std::vector<std::pair<int64_t, std::vector<std::pair<uint64_t, uint64_t>>>> highlight_spans(
         const std::vector<std::string>& keywords) const;
+    // NEW (no counterpart in the reference): announce a string column of roughly `bytes` bytes BEFORE the data is loaded —
+    // start_server() calls init() and then build() (server.cpp:43-44); called at the start of init() with the size of the raw
+    // directory (and any document as a sample of the alphabet) it lets the GPU map the first build's working set on a helper
+    // thread while init() reads the files.  Returns at once; build() waits for it.  Purely an optimisation (cdb_reserve).
+    static void reserve(uint64_t bytes, std::string_view sample = {});
 
 private:
     std::vector<int64_t> ids;        // index.h:58-59: ids and (non-owning) views of the documents, in add() order

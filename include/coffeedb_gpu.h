@@ -341,6 +341,16 @@ int cdb_profile_get(cdb_index* h, const char* kernel, double* total_ms, uint64_t
 int cdb_profile_dump(cdb_index* h, char* buf, size_t cap);
 void cdb_profile_reset(cdb_index* h);
 
+/* The first build of a fresh process pays for device memory the driver maps (and scrubs) on first use: 0.3-2.6 s for a 4 GiB
+ * column against 0.13 s warm.  The reference loads its data and only then builds (server.cpp:43-44: init(); build();), so
+ * that cost can hide behind the ingest: cdb_reserve — called as soon as the size of the column is roughly known, e.g. with
+ * the size of the raw directory at the start of init() — builds and destroys a throw-away index over synthetic text of that
+ * size on a helper thread (bytes drawn from the byte histogram of `sample`, e.g. the first document; NULL = printable ASCII;
+ * ndocs = 0: 1 KiB documents), which leaves the build's working set in the block cache below.  Returns at once;
+ * cdb_build* / cdb_load wait for a reservation in flight, cdb_reserve_wait() does so explicitly.  Best effort. */
+int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sample, size_t sample_len);
+void cdb_reserve_wait(void);
+
 /* Device blocks released by builds/queries are cached process-wide for the next build (hipMalloc of the
  * ~30 GiB working set of a 1 GiB build costs ~1 s on MI355X — the driver maps and clears VRAM).  This
  * returns every cached block to the driver; cdb_cached_memory_bytes reports the cache size.  Result

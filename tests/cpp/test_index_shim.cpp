@@ -2,8 +2,9 @@
 // (make_unique<string_index>, dynamic_cast, add, build through index*, query through index*).
 // usage: test_index_shim numeric   — CPU-only parts (no GPU needed)
 //        test_index_shim all       — also the GPU string index (README known answers)
-//        test_index_shim views [docs] [doclen] [reps]  — timing: string_index::build() over separately allocated strings (JSON)
-//        test_index_shim cold [bytes]                  — timing: a fresh process builds one large UTF-8 column once (JSON)
+//        test_index_shim views [docs] [doclen] [reps] [utf8]  — timing: string_index::build() over separately allocated strings (JSON)
+//        test_index_shim cold [bytes] [noreserve]      — timing: a fresh process builds one large UTF-8 column once (JSON); unless
+//                                                        "noreserve", string_index::reserve() runs while the strings are made
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -156,7 +157,16 @@ static void fill_utf8(std::string& s, size_t want, uint64_t seed) {
         }
     }
 }
-static int bench_views(size_t docs, size_t doclen, int reps) {
+// a keyword of `want` ASCII bytes that occurs in `v` (UTF-8 text: the first run of that many bytes below 0x80)
+static std::string ascii_keyword(const std::string& v, size_t want) {
+    size_t run = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        run = ((unsigned char)v[i] < 0x80) ? run + 1 : 0;
+        if (run == want) return v.substr(i + 1 - want, want);
+    }
+    return v.substr(0, std::min(want, v.size()));
+}
+static int bench_views(size_t docs, size_t doclen, int reps, bool utf8 = false) {
     // one heap block per value, like the map<string, var> values of database.cpp:22 (allocated in shuffled order so that
     // neighbouring documents are not neighbours in memory)
     std::vector<std::string> values(docs);
@@ -169,6 +179,10 @@ static int bench_views(size_t docs, size_t doclen, int reps) {
         th.emplace_back([&, t] {
             for (size_t k = t; k < docs; k += T) {
                 std::string& v = values[order[k]];
+                if (utf8) {
+                    fill_utf8(v, doclen, order[k]);
+                    continue;
+                }
                 v.resize(doclen);
                 uint64_t x = mix64(order[k]);
                 for (size_t b = 0; b < doclen; ++b) {
@@ -188,25 +202,44 @@ static int bench_views(size_t docs, size_t doclen, int reps) {
         t = now_ms();
         static_cast<index*>(ix.get())->build();
         build_ms.push_back(now_ms() - t);
-        hits += static_cast<index*>(ix.get())->query(values[docs / 2].substr(3, 8)).size();
+        // (on text with bytes >= 0x80 the reference's own bisection misses keywords that occur — index.h:66-73, SURVEY Q2 —,
+        //  and the default reference_compat reproduces that: ask until a keyword answers)
+        for (size_t k = 0; k < 64 && (k == 0 || (utf8 && !hits)); ++k)
+            hits += static_cast<index*>(ix.get())->query(ascii_keyword(values[(docs / 2 + 7919 * k) % docs], utf8 ? 3 : 8)).size();
     }
-    if (!hits) { std::printf("{\"error\": \"the built index did not answer\"}\n"); return 1; }
-    std::printf("{\"docs\": %zu, \"doclen\": %zu, \"bytes\": %zu, \"first_build_ms\": %.2f, \"build_ms\": [", docs, doclen, docs * doclen, build_ms[0]);
+    size_t total = 0;
+    for (auto& v : values) total += v.size();
+    // (UTF-8 text: zero rows IS the reference's answer — its bisection compares unsigned bytes on an array whose root radix node
+    //  lays the bytes 0x80..0xFF out first, index.h:66-73, so it walks away from every ASCII keyword; reference_compat = 1, the
+    //  default, reproduces that bit for bit)
+    if (!hits && !utf8) { std::printf("{\"error\": \"the built index did not answer\"}\n"); return 1; }
+    std::printf("{\"docs\": %zu, \"doclen\": %zu, \"bytes\": %zu, \"utf8\": %s, \"first_build_ms\": %.2f, \"build_ms\": [", docs, doclen, total, utf8 ? "true" : "false", build_ms[0]);
     double best = 1e30;
     for (int r = 1; r <= reps; ++r) {
         std::printf("%s%.2f", r > 1 ? ", " : "", build_ms[r]);
         best = std::min(best, build_ms[r]);
     }
-    std::printf("], \"add_ms\": %.2f, \"build_views_GiB_per_s\": %.3f, \"note\": \"string_index::add of %zu separately allocated std::strings + "
+    std::printf("], \"add_ms\": %.2f, \"build_views_GiB_per_s\": %.3f, \"rows_of_the_probe_keywords\": %zu, \"note\": \"string_index::add of %zu separately allocated std::strings + "
                 "string_index::build() = cdb_build_views (gather into pinned chunks + upload + device build), C++ caller, fresh object per build\"}\n",
-                add_ms.back(), (double)(docs * doclen) / (1ull << 30) / (best * 1e-3), docs);
+                add_ms.back(), (double)total / (1ull << 30) / (best * 1e-3), hits, docs);
     return 0;
 }
-static int bench_cold(size_t bytes) {
+static int bench_cold(size_t bytes, bool reserve) {
     const size_t doclen = 1024, docs = bytes / doclen;
     std::vector<std::string> values(docs);
     const unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     std::vector<std::thread> th;
+    double reserve_call_ms = 0;
+    if (reserve) {
+        // what a CoffeeDB start-up does with the shim: the size of the raw directory is known before init() reads it
+        // (server.cpp:43-44), so the first build's device memory is mapped on a helper thread WHILE the data is loaded
+        // (here: while the strings are generated)
+        std::string sample;
+        fill_utf8(sample, 4096, 12345);
+        const double tr = now_ms();
+        string_index::reserve(bytes, sample);
+        reserve_call_ms = now_ms() - tr;
+    }
     const double tg = now_ms();
     for (unsigned t = 0; t < T; ++t)
         th.emplace_back([&, t] { for (size_t k = t; k < docs; k += T) fill_utf8(values[k], doclen, k); });
@@ -221,19 +254,22 @@ static int bench_cold(size_t bytes) {
     const double t2 = now_ms();
     static_cast<index*>(ix.get())->build();
     const double t3 = now_ms();
-    const size_t rows = static_cast<index*>(ix.get())->query(values[docs / 2].substr(0, 2)).size();
+    size_t rows = 0, asked = 0;  // (reference_compat reproduces the reference's misses on bytes >= 0x80: ask until a keyword answers)
+    for (; asked < 64 && !rows; ++asked) rows = static_cast<index*>(ix.get())->query(ascii_keyword(values[(docs / 2 + 7919 * asked) % docs], 3)).size();
     const double t4 = now_ms();
     auto again = std::make_unique<string_index>();
     for (size_t i = 0; i < docs; ++i) again->add((int64_t)i, values[i]);
     const double t5 = now_ms();
     static_cast<index*>(again.get())->build();
     const double t6 = now_ms();
-    std::printf("{\"bytes\": %zu, \"docs\": %zu, \"generate_ms\": %.0f, \"create_ms\": %.1f, \"add_ms\": %.1f, \"first_build_ms\": %.1f, "
-                "\"first_query_ms\": %.2f, \"first_query_rows\": %zu, \"second_build_ms\": %.1f, \"cold_over_warm\": %.2f, "
+    std::printf("{\"bytes\": %zu, \"docs\": %zu, \"reserve\": %s, \"reserve_call_ms\": %.2f, \"generate_ms\": %.0f, \"create_ms\": %.1f, \"add_ms\": %.1f, \"first_build_ms\": %.1f, "
+                "\"first_query_ms\": %.2f, \"first_query_rows\": %zu, \"first_query_keywords_asked\": %zu, \"second_build_ms\": %.1f, \"cold_over_warm\": %.2f, "
                 "\"first_build_GiB_per_s\": %.3f, \"note\": \"fresh process, no torch, no warm block cache: string_index over %zu separately "
                 "allocated strings of valid UTF-8, build() = gather + upload + device build incl. every first-use allocation (server.cpp:44); "
-                "second_build = a new object beside the first (database.cpp:276-280), blocks partly from the cache\"}\n",
-                total, docs, gen_ms, t1 - t0, t2 - t1, t3 - t2, t4 - t3, rows, t6 - t5, (t3 - t2) / (t6 - t5),
+                "second_build = a new object beside the first (database.cpp:276-280), blocks partly from the cache; first_query_rows = 0 is the "
+                "reference's own answer on text with bytes >= 0x80 (its bisection misses ASCII keywords there, SURVEY Q2; reproduced by the default "
+                "reference_compat = 1)\"}\n",
+                total, docs, reserve ? "true" : "false", reserve_call_ms, gen_ms, t1 - t0, t2 - t1, t3 - t2, t4 - t3, rows, asked, t6 - t5, (t3 - t2) / (t6 - t5),
                 (double)total / (1ull << 30) / ((t3 - t2) * 1e-3), docs);
     (void)rows;  // (under reference_compat a UTF-8 keyword may find nothing: the reference's own behaviour on bytes >= 0x80)
     return 0;
@@ -242,8 +278,9 @@ static int bench_cold(size_t bytes) {
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "views")
         return bench_views(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (1u << 20), argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1024,
-                           argc > 4 ? std::atoi(argv[4]) : 3);
-    if (argc > 1 && std::string(argv[1]) == "cold") return bench_cold(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (4ull << 30));
+                           argc > 4 ? std::atoi(argv[4]) : 3, argc > 5 && std::string(argv[5]) == "utf8");
+    if (argc > 1 && std::string(argv[1]) == "cold")
+        return bench_cold(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : (4ull << 30), !(argc > 3 && std::string(argv[3]) == "noreserve"));
     const bool all = argc > 1 && std::string(argv[1]) == "all";
     numeric();
     if (all) gpu_string();

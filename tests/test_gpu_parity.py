@@ -1479,3 +1479,26 @@ def test_and_merge_across_keys_matches_reference_loop(G):
     assert capi.query_and([(gs[0], [b"ab"])]) == sorted(ref_or(os_[0], [b"ab"]).items())   # one key: its own OR list
     with pytest.raises(RuntimeError, match="Empty keywords"):
         capi.query_and([(gs[0], [b"ab"]), (gs[1], [b""])])
+
+
+def test_reserve_maps_the_first_builds_working_set_in_the_background(G):
+    # cdb_reserve (round 5): server.cpp:43-44 loads the data and only then builds; announcing the size of the column first lets a
+    # helper thread build and drop a throw-away index over synthetic text of that size, which leaves the build's blocks in the
+    # process-wide cache.  The real build then waits for it, takes the blocks from the cache, and is unaffected otherwise.
+    from coffeedb_amd import capi
+    lib = capi.load_library()
+    blob, ds = W.ascii_corpus(60000, 300, seed=77)
+    ids = np.arange(60000, dtype=np.int64)
+    lib.cdb_release_cached_memory()
+    assert lib.cdb_cached_memory_bytes() == 0
+    assert lib.cdb_reserve(0, len(blob), 60000, bytes(blob[:4096]), 4096) == 0
+    lib.cdb_reserve_wait()
+    cached = lib.cdb_cached_memory_bytes()
+    assert cached > 8 * len(blob), cached                       # text + suffix array + sort records of an 18 MB column
+    g, o = _check_parity(G, blob, ds, ids=ids, patterns=W.sample_patterns(blob, ds, 200, 2, 9, seed=1))
+    assert lib.cdb_cached_memory_bytes() < cached              # the build took blocks from the reservation
+    # a build that starts while the reservation is still running waits for it (no two working sets side by side)
+    assert lib.cdb_reserve(0, len(blob), 0, None, 0) == 0
+    g2 = _gpu(G, blob, ds, ids)
+    assert np.array_equal(g2.sa(), o.sa())
+    assert lib.cdb_reserve(0, 0, 0, None, 0) != 0              # nothing to reserve: refused
