@@ -34,6 +34,8 @@ struct BuildStats {
     int gen_prebased = 0;        // ... generated pass without look-back (counted tile bases)
     int fused_records = 0;       // ... bucket records written by the generated pass itself (one bucket group): no partition + gather
     int sweep_records = 0;       // ... bucket records of every bucket group written by a sweep over the text (records_sweep.h): no partition + gather
+    int vl_key_bits = 0;         // ... keys = the first vl_key_bits - 1 bits of the alphabetic code stream + a "continues" bit (vl_code.h); 0 = dense keys
+    double vl_avg_len = 0, vl_rate = 0, vl_est_unresolved = 0, fixed_est_unresolved = 0;
     int segmented = 0;           // ... sorted by segmented passes: one launch per pass for all buckets of a group
     uint64_t gather_items = 0;
     int key_symbols = 0, symbol_bits = 0, alphabet = 0, digit_bits = 8;
@@ -225,6 +227,8 @@ struct Index {
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)
     bool fuse_records = true;  // bucket-wise build with ONE bucket group: the generated pass writes the records (0 = partition + gather)
+    int vl_keys = 2;           // bucket-wise build, variable-length keys (vl_code.h): 0 off, 2 when the cost model says so, 1 always, 16..56 always with that many key bits
+    bool vl_off_once = false;  // (this build only: the sweep form turned out not to apply — dense keys after all)
     bool sweep_records = true; // bucket-wise build with several bucket groups: one sweep over the text per group writes its records (0 = partition + gather)
     bool pack_entries = true;  // bucket-wise build: 8-byte entries below 2^40 travel through the bucket sorts as u32 + u8
     bool msd_first = true;    // keys of 33..40 bits below 2^32 suffixes: top digit first, then every bucket on its own with

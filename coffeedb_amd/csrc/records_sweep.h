@@ -348,6 +348,300 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     else phase_b(std::integral_constant<int, 1>{});
 }
 
+// ---- variable-length keys (round 5, vl_code.h) ------------------------------------------------------------------------------------
+// The same sweep for keys that are the first B - 1 bits of the suffix's ALPHABETIC CODE STREAM behind its bucket symbol (+ one bit
+// "the suffix continues behind the key").  Every position's key is a window into ONE bit stream, so the tile concatenates the
+// code words of its symbols once (staging thread: 16 consecutive symbols -> two pieces of <= 56 bits, OR-ed into the LDS at the
+// thread's bit offset, which a scan of the threads' bit counts provides) and keeps every position's 16-bit bit offset; phase B
+// then reads 64 stream bits at the offset of its position: the first code word names the bucket slot and its own length
+// (s_dec: the next 7 bits -> slot, length), the B - 1 bits behind it are the key.  Bits behind the end of the document are
+// cleared: END is the all-zero word, so a short suffix is its code words, END, and zeros — in front of every continuation.
+// The key's lowest bit says whether anything was cut off: keys with it clear are whole suffixes (equal keys = equal suffixes,
+// final; the last pass tests "key mod 2 == 0" exactly like "key mod base == 0" of the dense coding).
+// LDS: 52.5 KB — three workgroups per CU (the bit offsets are 16 KB).  Alphabets of <= 127 symbols (7-bit words, 128 slots).
+struct VlTables {
+    const uint16_t* sym = nullptr;  // [256] symbol code -> code word | length << 8 (code 0 = END)
+    const uint16_t* dec = nullptr;  // [128] the next 7 stream bits -> bucket slot | length << 8 of the code word that starts there
+    int key_bits = 0;               // B (whole key incl. the "continues" bit)
+    int end_len = 0;                // length of END's (all-zero) word
+};
+constexpr uint32_t RS_VL_BITW = ((RS_GEN8_TILE + RS_GEN_LOOK) * 7 + 31) / 32 + 4;  // words of the tile's bit stream
+
+template <typename W>
+__global__ __launch_bounds__(512, 6) void rs_sweep_records_vl_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, VlTables vl, uint64_t n,
+                                                                     uint32_t tiles, uint32_t g0, uint32_t g1, uint64_t gstart,
+                                                                     uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, W* __restrict__ wout) {
+    constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
+    constexpr uint32_t LOOK = RS_GEN_LOOK, NBLK = TILE / 32, DOCS = 256, SL = 128;
+    static_assert(LOOK == 64, "four staging threads cover the look-ahead");
+    __shared__ uint32_t s_bits[RS_VL_BITW];                                   // the code stream, most significant bit first
+    __shared__ __attribute__((aligned(16))) uint16_t s_boff[TILE + LOOK + 8];  // bit offset of every position's code word (+ the end)
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
+    __shared__ uint32_t s_whist[NW][SL];
+    __shared__ uint16_t s_cs[256];
+    __shared__ uint16_t s_vl[SL];
+    __shared__ uint16_t s_dec[128];
+    __shared__ __attribute__((aligned(16))) uint32_t s_doc[4 * DOCS + 4];      // document d: entry bias (64 bit), start of d + 1 - tile base, -
+    __shared__ __attribute__((aligned(8))) uint32_t s_blk[2 * (NBLK + 1)];
+    __shared__ uint64_t s_gbase[SL];
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_flag;
+    uint8_t* const s_dig = reinterpret_cast<uint8_t*>(s_idx);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint64_t tile = (uint64_t)((slot / RS_GROUP) * 8u + x) * RS_GROUP + slot % RS_GROUP;
+    if (tile >= (uint64_t)tiles) return;
+    const uint64_t base = tile * TILE;
+    const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
+
+    const uint64_t ga = base + (uint64_t)tid * 16, gb = base + (uint64_t)TILE + (uint64_t)tid * 16;
+    const bool has_b = (uint32_t)tid * 16 < LOOK;
+    const bool oka = gen.padded ? (ga < n + LOOK) : (ga + 16 <= n);
+    const bool okb = has_b && (gen.padded ? (gb < n + LOOK) : (gb + 16 <= n));
+    uint4 ta = make_uint4(0, 0, 0, 0), tb = make_uint4(0, 0, 0, 0);
+    if (oka) ta = *reinterpret_cast<const uint4*>(gen.text + ga);
+    if (okb) tb = *reinterpret_cast<const uint4*>(gen.text + gb);
+    uint64_t my_base = 0;
+    if ((uint32_t)tid >= g0 && (uint32_t)tid < g1) my_base = (uint64_t)gen.tile_base[tile * 256 + (uint64_t)tid];
+    if (tid < 256) {  // (a byte outside the group: slot 0xFF)
+        const uint32_t e = codeslot[tid];
+        s_cs[tid] = (uint16_t)(((e >> 8) >= g0 && (e >> 8) < g1) ? e : (e | 0xFF00u));
+    }
+    if (tid < (int)SL) {
+        s_vl[tid] = vl.sym[tid];
+        s_dec[tid] = vl.dec[tid];
+    }
+    const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
+    for (int i = tid; i < NW * (int)SL; i += NT) (&s_whist[0][0])[i] = 0;
+    for (uint32_t i = tid; i < RS_VL_BITW; i += NT) s_bits[i] = 0;
+    if ((uint32_t)tid <= NBLK) s_blk[2 * tid] = 0;
+    if (tid == 0) s_flag = 0;
+    const uint32_t ndl = (uint32_t)(dhi - dlo);
+    const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOCS;
+    uint64_t dreg0 = 0;
+    if (docs_in_lds && (uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
+    __syncthreads();  // (the zeroes, the tables)
+    if (docs_in_lds && (uint32_t)tid < ndl + 2) {
+        const uint32_t d = (uint32_t)tid;
+        const int64_t diff = (int64_t)(dreg0 - base);
+        const int32_t rel = diff < -(1ll << 30) ? -(1 << 30) : (diff > (1ll << 30) ? (1 << 30) : (int32_t)diff);
+        const uint64_t eb = ((base - dreg0) << gen.bits) + dlo + d;
+        s_doc[4 * d] = (uint32_t)eb;
+        s_doc[4 * d + 1] = (uint32_t)(eb >> 32);
+        if (d >= 1) s_doc[4 * d - 2] = (uint32_t)rel;  // (the start of d beside the bias of d - 1: one 16-byte read in phase B)
+        if (d >= 1 && rel <= (int32_t)TILE) {
+            const uint32_t bit = 1u << ((uint32_t)rel & 31u);
+            if (atomicOr(&s_blk[2 * ((uint32_t)rel >> 5)], bit) & bit) s_flag = 1;  // two starts on one position: an empty document
+        }
+    }
+    // ---- staging, first half: bytes -> symbol code and bucket slot (one lookup), symbol code -> code word (a second one); the
+    // thread's 16 code words as two left-aligned pieces of <= 56 bits and its bit count
+    auto fetch = [&](uint64_t g, bool ok, uint4 w, uint32_t* c) {
+        c[0] = w.x; c[1] = w.y; c[2] = w.z; c[3] = w.w;
+        if (!ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c[q] = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) c[q] |= (uint32_t)((g + 4 * q + b < n) ? gen.text[g + 4 * q + b] : (uint8_t)0) << (8 * b);
+            }
+        }
+    };
+    // four code words -> one word of <= 28 bits (right-aligned) and its length; lens4: the four lengths as nibbles
+    auto pack4 = [&](const uint32_t* v, uint32_t& word, uint32_t& wlen, uint32_t& lens4) {
+        const uint32_t l0 = v[0] >> 8, l1 = v[1] >> 8, l2 = v[2] >> 8, l3 = v[3] >> 8;
+        word = ((((((v[0] & 0xFFu) << l1) | (v[1] & 0xFFu)) << l2) | (v[2] & 0xFFu)) << l3) | (v[3] & 0xFFu);
+        wlen = l0 + l1 + l2 + l3;
+        lens4 = l0 | (l1 << 4) | (l2 << 8) | (l3 << 12);
+    };
+    uint64_t pieceA[2] = {0, 0}, pieceB[2] = {0, 0};  // [0]: symbols 0-7, [1]: symbols 8-15 (A: the tile, B: the look-ahead)
+    uint32_t plenA[2] = {0, 0}, plenB[2] = {0, 0}, lensA[2] = {0, 0}, lensB[2] = {0, 0};
+    auto stage = [&](const uint32_t* c, uint64_t* piece, uint32_t* plen, uint32_t* lens, bool with_slots) {
+        uint32_t e[IPT], v[IPT];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) e[k] = s_cs[(c[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) v[k] = s_vl[e[k] & 0x7Fu];
+        if (with_slots) {
+            uint32_t slots[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slots[q] = (e[4 * q] >> 8) | ((e[4 * q + 1] >> 8) << 8) | ((e[4 * q + 2] >> 8) << 16) | ((e[4 * q + 3] >> 8) << 24);
+            if (valid < (uint32_t)TILE) {  // (uniform: the last tile) positions behind the text are kept by nobody
+#pragma unroll
+                for (int k = 0; k < IPT; ++k)
+                    if ((uint32_t)tid * 16 + k >= valid) slots[k >> 2] |= 0xFFu << (8 * (k & 3));
+            }
+            *reinterpret_cast<uint4*>(&s_dig[(uint32_t)tid * 16]) = make_uint4(slots[0], slots[1], slots[2], slots[3]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t w0, n0, q0, w1, n1, q1;
+            pack4(v + 8 * h, w0, n0, q0);
+            pack4(v + 8 * h + 4, w1, n1, q1);
+            plen[h] = n0 + n1;                                                   // <= 56
+            piece[h] = (((uint64_t)w0 << n1) | (uint64_t)w1) << (64u - plen[h]);  // left-aligned (plen >= 8)
+            lens[h] = q0 | (q1 << 16);
+        }
+    };
+    {
+        uint32_t c[4];
+        fetch(ga, oka, ta, c);
+        stage(c, pieceA, plenA, lensA, true);
+        if (has_b) {
+            fetch(gb, okb, tb, c);
+            stage(c, pieceB, plenB, lensB, false);
+        }
+    }
+    const uint32_t totA = plenA[0] + plenA[1], totB = has_b ? plenB[0] + plenB[1] : 0u;
+    const uint32_t inclA = rs_wave_incl_scan(totA), inclB = rs_wave_incl_scan(totB);  // (look-ahead: lanes 0-3 of wave 0)
+    if (lane == 63) s_wsum[wave] = inclA;
+    __syncthreads();
+    // ---- staging, second half: every position's bit offset, the pieces into the stream
+    {
+        uint32_t wpre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t t = s_wsum[w];
+            if (w < wave) wpre += t;
+            all += t;
+        }
+        auto emit_bits = [&](uint32_t at, const uint64_t* piece, const uint32_t* plen, const uint32_t* lens, uint32_t pos0) {
+            uint32_t o = at, packed[8];
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                if (k & 1) packed[k >> 1] |= o << 16; else packed[k >> 1] = o;
+                o += (lens[k >> 3] >> (4 * (k & 7))) & 0xFu;
+            }
+            *reinterpret_cast<uint4*>(&s_boff[pos0]) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            *reinterpret_cast<uint4*>(&s_boff[pos0 + 8]) = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+            uint32_t bo = at;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t wi = bo >> 5, sh = bo & 31u;
+                const uint32_t xh = (uint32_t)(piece[h] >> 32), xl = (uint32_t)piece[h];
+                atomicOr(&s_bits[wi], __builtin_amdgcn_alignbit(0u, xh, sh));
+                atomicOr(&s_bits[wi + 1], __builtin_amdgcn_alignbit(xh, xl, sh));
+                atomicOr(&s_bits[wi + 2], __builtin_amdgcn_alignbit(xl, 0u, sh));
+                bo += plen[h];
+            }
+            return o;
+        };
+        (void)emit_bits(wpre + inclA - totA, pieceA, plenA, lensA, (uint32_t)tid * 16);
+        if (has_b) {
+            const uint32_t end = emit_bits(all + inclB - totB, pieceB, plenB, lensB, (uint32_t)TILE + (uint32_t)tid * 16);
+            if ((uint32_t)tid * 16 + 16 == LOOK) s_boff[TILE + LOOK] = (uint16_t)end;
+        }
+    }
+    __syncthreads();
+    // ---- phase A: rank the kept positions, lane-striped (see rs_sweep_records_kernel)
+    constexpr int WCHUNK = IPT * 64;
+    const uint32_t wbase = wave * WCHUNK + lane;
+    uint32_t info[IPT];  // rank | slot << 16; slot 0xFF = not kept
+    {
+        uint32_t sl[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) sl[j] = s_dig[wbase + j * 64];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            uint32_t inf = 0xFFu << 16;
+            if (sl[j] != 0xFFu) inf = atomicAdd(&s_whist[wave][sl[j]], 1u) | (sl[j] << 16);
+            info[j] = inf;
+        }
+    }
+    __syncthreads();
+    // ---- per-slot totals (waves 0-1) and, meanwhile (waves 4-7), the document starts in front of every block of 32 positions
+    uint32_t wc[NW], cnt = 0, incl = 0;
+    if (tid < (int)SL) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            wc[w] = s_whist[w][tid];
+            cnt += wc[w];
+        }
+        incl = cnt;
+    } else if (tid >= 256) {
+        incl = cnt = (uint32_t)__builtin_popcount(s_blk[2 * (tid - 256)]);
+    }
+    incl = rs_wave_incl_scan(incl);
+    if (lane == 63) s_wsum[8 + wave] = incl;
+    __syncthreads();
+    const uint32_t kept = s_wsum[8] + s_wsum[9];
+    {
+        uint32_t wpre = 0;
+        if (tid < (int)SL) {
+            if (wave == 1) wpre = s_wsum[8];
+            const uint32_t excl = wpre + incl - cnt;
+            uint32_t run = excl;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s_whist[w][tid] = run;
+                run += wc[w];
+            }
+            s_gbase[tid] = my_base - gstart - (uint64_t)excl;
+        } else if (tid >= 256) {
+#pragma unroll
+            for (int w = 4; w < NW; ++w)
+                if (w < wave) wpre += s_wsum[8 + w];
+            const uint32_t excl = wpre + incl - cnt;
+            s_blk[2 * (tid - 256) + 1] = excl * 16u;
+            if (tid == 511) s_blk[2 * NBLK + 1] = (excl + cnt) * 16u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const uint32_t sl = info[k] >> 16;
+        if (sl != 0xFFu) s_idx[s_whist[wave][sl] + (info[k] & 0xFFFFu)] = (uint16_t)(wbase + k * 64);
+    }
+    __syncthreads();
+
+    // ---- phase B: the kept positions in output order
+    const int KB1 = vl.key_bits - 1;  // code bits of a key
+    const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
+    auto emit = [&](uint32_t p, uint32_t li, uint64_t e64, uint32_t endbit) {
+        // 64 stream bits at the position's offset: its own code word (<= 7 bits: slot and length from the table), then the key
+        const uint32_t o0 = s_boff[li];
+        const uint32_t wi = o0 >> 5, sh = o0 & 31u;
+        const uint32_t w0 = s_bits[wi], w1 = s_bits[wi + 1], w2 = s_bits[wi + 2];
+        const uint32_t hi = __builtin_amdgcn_alignbit(w0, w1, 32u - sh), lo = __builtin_amdgcn_alignbit(w1, w2, 32u - sh);
+        const uint64_t top = sh ? (((uint64_t)hi << 32) | lo) : (((uint64_t)w0 << 32) | w1);
+        const uint32_t dv = s_dec[(uint32_t)(top >> 57)];
+        const uint32_t sl = dv & 0xFFu, len = dv >> 8;
+        const uint32_t avail = endbit - (o0 + len);  // code bits between the bucket symbol and the end of the document
+        const uint32_t take = avail < (uint32_t)KB1 ? avail : (uint32_t)KB1;
+        uint64_t kb = (top << len) >> (64 - KB1);                   // the next KB1 stream bits
+        kb &= ~0ull << ((uint32_t)KB1 - take);                      // ... of which the document holds `take`: zeros behind its end
+        const uint64_t key = (kb << 1) | (uint64_t)(avail + (uint32_t)vl.end_len > (uint32_t)KB1 ? 1u : 0u);
+        const uint64_t dst = s_gbase[sl] + (uint64_t)p;
+        kout[dst] = (uint32_t)(key >> gen.rec_low_bits);
+        vout[dst] = (uint32_t)e64;
+        wout[dst] = (W)((key & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+    };
+    if (docs_in_lds && s_flag == 0 && valid == (uint32_t)TILE) {
+        const int bits = gen.bits;
+        for (uint32_t p = tid; p < kept; p += NT) {
+            const uint32_t li = s_idx[p];
+            const uint2 bk = *reinterpret_cast<const uint2*>(&s_blk[2 * (li >> 5)]);
+            const uint32_t doff = bk.y + 16u * (uint32_t)__builtin_popcount(bk.x & ~(0xFFFFFFFEu << (li & 31u)));
+            const uint4 dc = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_doc) + doff);  // bias lo, hi, next start
+            const int32_t rn = (int32_t)dc.z;
+            const uint32_t relend = rn < (int32_t)(TILE + LOOK) ? (uint32_t)rn : (uint32_t)(TILE + LOOK);
+            emit(p, li, (((uint64_t)dc.y << 32) | dc.x) + ((uint64_t)li << bits), (uint32_t)s_boff[relend]);
+        }
+    } else {
+        // (the ragged last tile, tiles with hundreds of documents or empty ones: searches in global memory)
+        for (uint32_t p = tid; p < kept; p += NT) {
+            const uint32_t li = s_idx[p];
+            const uint64_t pos = base + li;
+            const uint64_t dd = rs_doc_upper(gen.doc_start, dlo, dhi, pos);
+            const uint64_t ds = gen.doc_start[dd], de = gen.doc_start[dd + 1];
+            const uint64_t rel = de - base;
+            const uint32_t relend = rel < (uint64_t)(TILE + LOOK) ? (uint32_t)rel : (uint32_t)(TILE + LOOK);
+            emit(p, li, ((pos - ds) << gen.bits) + dd, (uint32_t)s_boff[relend]);
+        }
+    }
+}
+
 // The same two-phase form for the generated pass of the MSD-first sort below 2^32 (radix_sort.h: radix_sort_msd, pair form): digit
 // = top digit of the 6-symbol key, a function of the first two symbols; records (u32 key - top * M, u32 entry).  Every position
 // is kept.  gen: text, doc_start, symmap, bits, base, pair_span / pair_r / pair_s, padded, tile_doc, tile_base.
@@ -639,6 +933,29 @@ void radix_sweep_records(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v
     int t = prof.begin(s);
     hipLaunchKernelGGL((rs_sweep_records_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, n, tiles8, g0, g1, gstart, k, v, w);
     prof.end(t, (std::string("rs_sweep_records") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t8192").c_str(),
+             n + gelems * (8 + sizeof(W)), s);
+    if (stats) stats->passes_run++;
+    t = prof.begin(s);
+    hipLaunchKernelGGL((rs_seg_hist_kernel<W>), dim3((unsigned)ceil_div(seg_tiles, (uint32_t)RS_MSD_HIST_TILES)), dim3(1024), 0, s, (const uint32_t*)k,
+                       (const W*)w, lead, npass, d_tile_seg, d_segs, seg_tiles, d_hist_out);
+    prof.end(t, "rs_seg_hist", gelems * (4 + (lead > 0 ? sizeof(W) : 0)), s);
+    CDB_HIP(hipGetLastError());
+}
+
+// the same with variable-length keys (rs_sweep_records_vl_kernel): gen_in.base / nsym are not used, gen_in.rec_low_bits and the passes as above
+template <typename W>
+void radix_sweep_records_vl(hipStream_t s, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const TextGen& gen_in, const uint16_t* d_codeslot,
+                            const VlTables& vl, uint32_t g0, uint32_t g1, uint64_t gstart, uint64_t gelems, const uint32_t* d_tile_seg,
+                            const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles, int lead, int npass, unsigned long long* d_hist_out,
+                            SortStats* stats) {
+    if (!gen_in.tile_base || !gen_in.tile_doc || !d_codeslot || !vl.sym || !vl.dec) throw Error("radix_sweep_records_vl: tables missing (internal)");
+    if (vl.key_bits < 16 || vl.key_bits > 56) throw Error("radix_sweep_records_vl: key width (internal)");
+    const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_SWEEP_TILE);
+    const uint32_t grid = (uint32_t)(ceil_div(tiles8, 8u * RS_GROUP) * 8u * RS_GROUP);
+    CDB_HIP(hipMemsetAsync(d_hist_out, 0, (size_t)nseg * 8 * 256 * sizeof(uint64_t), s));
+    int t = prof.begin(s);
+    hipLaunchKernelGGL((rs_sweep_records_vl_kernel<W>), dim3(grid), dim3(512), 0, s, gen_in, d_codeslot, vl, n, tiles8, g0, g1, gstart, k, v, w);
+    prof.end(t, (std::string("rs_sweep_records_vl") + (sizeof(W) == 1 ? "_w8" : (sizeof(W) == 2 ? "_w16" : "_w32")) + "_t8192").c_str(),
              n + gelems * (8 + sizeof(W)), s);
     if (stats) stats->passes_run++;
     t = prof.begin(s);

@@ -37,6 +37,7 @@
 
 #include "index_impl.h"
 #include "records_sweep.h"
+#include "vl_code.h"
 #include "scan.h"
 
 // Timing-only ablations of the record gather (WRONG records): compile-time only (-DRS_GATHER_ABL=<bits>, a library of its own loaded
@@ -1874,6 +1875,9 @@ void build_typed(Index& ix, bool big) {
     // ~ n * c_k of all suffixes share their k-prefix with another one.  (An order-0 symbol model is far
     // too optimistic for correlated text such as multi-byte UTF-8.)  Small corpora use the order-0 model.
     int nsym;
+    double est_unres = -1.0;  // expected share of the suffixes the initial sort leaves unresolved (from the sample; -1: not estimated)
+    int est_nsym = 0;         // ... with a key of this many symbols
+    uint64_t refine_depth0 = 0;  // symbols every key of the initial sort covers for certain (0: nsym; variable-length keys: fewer)
     const int kmax = std::min(64 / symbits, 16);
     if (ix.initial_passes > 0) {
         const int passes = std::min(ix.initial_passes, 8);
@@ -1926,6 +1930,8 @@ void build_typed(Index& ix, bool big) {
             const double u0 = (double)n * ((double)h_eq[nsym] / pairs), u1 = (double)n * ((double)h_eq[k1] / pairs);
             if (u1 <= 1.0 / 40.0 && plan_bytes(k1) + u1 * refine_bytes < plan_bytes(nsym) + u0 * refine_bytes) nsym = k1;
         }
+        est_unres = (double)n * ((double)h_eq[nsym] / pairs);
+        est_nsym = nsym;
     } else {
         double pc = 0;
         for (int b = 0; b < 256; ++b) {
@@ -2346,6 +2352,68 @@ void build_typed(Index& ix, bool big) {
             }
             if (bbits != 999) bbits = bit_width64((uint64_t)(v - 1));
         }
+        // ---- variable-length keys (vl_code.h): the first B - 1 bits of the suffix's alphabetic code stream + a "continues" bit instead
+        // of the dense number, when the model of key_cost_model says they are cheaper — skewed text, where equal prefixes are made of
+        // frequent symbols with short code words (8 GiB of Zipf-64 text: 40 key bits = 5 passes over 10-byte records instead of 54 bits
+        // = 7 passes over 12-byte records).  Needs the sweep form (the key of a position is a window into the tile's bit stream).
+        VlCode vlc;
+        int vl_bits = 0;
+        DevBuf d_vl_sym, d_vl_dec;
+        if (sizeof(V) == 8 && ix.vl_keys != 0 && !ix.vl_off_once && tile_bytes && ix.sweep_records && ix.segmented_sort && ix.pack_entries &&
+            ix.narrow_keys && (int)ix.bits + ix.off_bits <= 40 && sigma >= 2 && sigma <= 127 && nsym > 1 && rs_atomic_rank_ok(s) &&
+            (ix.vl_keys != 2 || (ix.initial_passes == 0 && ix.key_symbols == 0))) {
+            uint64_t cnts[257] = {0};
+            cnts[0] = D;
+            for (int c = 1; c <= sigma; ++c) cnts[c] = h_first[c];
+            if (vl_build(cnts, sigma, vlc)) {
+                auto rec_bytes = [](int b) { return 8.0 + (b <= 32 ? 1.0 : (b <= 40 ? 2.0 : 4.0)); };
+                const double refine_bytes = 2000.0;  // (what a text-extension round costs per unresolved suffix: key_cost_model above)
+                // the sample measured the dense key's unresolved share; the order-0 model q^k says what it "should" be — their ratio
+                // carries the text's correlation over to the estimate for the code stream: share(B) = ratio n q 2^(-rate (B - 1))
+                const double model_fixed = std::min(1.0, (double)n * std::pow(vlc.q, (double)(est_nsym > 0 ? est_nsym : nsym)));
+                const double ratio = est_unres >= 0 ? std::min(1e6, std::max(0.05, est_unres / std::max(model_fixed, 1e-300))) : 1.0;
+                const double u_fixed = std::min(1.0, ratio * (double)n * std::pow(vlc.q, (double)nsym));
+                const double cost_fixed = bbits != 999 ? std::ceil(bbits / 8.0) * 2.0 * rec_bytes(bbits) + u_fixed * refine_bytes : 1e9;
+                auto share = [&](int B) { return std::min(1.0, ratio * (double)n * vlc.q * std::pow(2.0, -vlc.rate * (double)(B - 1))); };
+                int best_b = 0;
+                double best = 1e18;
+                for (int B : {32, 40, 48, 56}) {
+                    const double u = share(B);
+                    if (u > 1.0 / 32.0) continue;  // (text extension wants few open suffixes)
+                    const double c = (double)(B / 8) * 2.0 * rec_bytes(B) + u * refine_bytes + 6.0;  // (+ the slower sweep: three workgroups per CU)
+                    if (c < best) {
+                        best = c;
+                        best_b = B;
+                    }
+                }
+                if (ix.vl_keys >= 16) best_b = std::min(56, (ix.vl_keys + 7) / 8 * 8);
+                else if (ix.vl_keys == 1 && !best_b) best_b = 56;
+                if (best_b && (ix.vl_keys != 2 || best < 0.93 * cost_fixed)) {
+                    vl_bits = best_b;
+                    bbits = vl_bits;
+                    std::vector<uint16_t> sym(256, 0), dec(128, (uint16_t)(0xFFu | ((unsigned)vlc.end_len << 8)));
+                    for (int c = 0; c <= sigma; ++c) {
+                        sym[c] = (uint16_t)(vlc.bits[c] | ((unsigned)vlc.len[c] << 8));
+                        if (c == 0) continue;
+                        const int l = vlc.len[c];
+                        for (unsigned x = 0; x < (1u << (VL_MAX_LEN - l)); ++x)
+                            dec[((unsigned)vlc.bits[c] << (VL_MAX_LEN - l)) | x] = (uint16_t)(h_slotmap[c] | ((unsigned)l << 8));
+                    }
+                    d_vl_sym.alloc(256 * sizeof(uint16_t));
+                    d_vl_dec.alloc(128 * sizeof(uint16_t));
+                    CDB_HIP(hipMemcpyAsync(d_vl_sym.p, sym.data(), 256 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipMemcpyAsync(d_vl_dec.p, dec.data(), 128 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipStreamSynchronize(s));  // (sym, dec)
+                    st.vl_key_bits = vl_bits;
+                    st.vl_avg_len = vlc.avg_len;
+                    st.vl_rate = vlc.rate;
+                    st.vl_est_unresolved = share(vl_bits);
+                    st.fixed_est_unresolved = u_fixed;
+                    // every key covers at least this many whole symbols behind the bucket symbol: where the refinement starts
+                    refine_depth0 = 1 + (uint64_t)((vl_bits - 1) / vlc.max_len);
+                }
+            }
+        }
         // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
         //  symbols, the grouped gather and no separate histogram pass)
         // packed entries (sa_bucket_records_packed_kernel): 8-byte entries below 2^40 travel as u32 + one byte on top of the
@@ -2406,10 +2474,13 @@ void build_typed(Index& ix, bool big) {
         // SWEEP form (records_sweep.h): the records do not fit at once, but with counted tile bases a sweep over the text can write
         // the records of any bucket group in place — the entries are not partitioned and no gather re-reads them and the text
         bool sweep_rec = !fuse_rec && tile_bytes && ix.sweep_records && brecords && packed && sigma <= 255 && ix.segmented_sort &&
-                         sizeof(V) == 8 && rs_atomic_rank_ok(s) && rs_sweep_records_ok(bbase, nsym);
+                         sizeof(V) == 8 && rs_atomic_rank_ok(s) && (vl_bits || rs_sweep_records_ok(bbase, nsym));
         // (the fused form writes its records with the same kernel where it applies: one sweep that keeps every bucket — it beats the
         //  generated pass of radix_gen_records, which carries whole records through the LDS: 4 GiB UTF-8 18.8 against 21.4 ms)
-        const bool sweep_fused = fuse_rec && tile_bytes && ix.sweep_records && rs_sweep_records_ok(bbase, nsym);
+        const bool sweep_fused = fuse_rec && tile_bytes && ix.sweep_records && (vl_bits || rs_sweep_records_ok(bbase, nsym));
+        // (variable-length keys exist in the sweep kernels only: build_suffix_array redoes the build with dense keys)
+        const char* vl_retry = "variable-length keys: the sweep form does not apply (retry with dense keys)";
+        if (vl_bits && !sweep_rec && !sweep_fused) throw Error(vl_retry);
         // partition + gather with packed output: the partitioned entries ARE stored packed from the start (E = low words,
         // sa_hi_buf = bits 32..39): the gather reads them through Sa40, the last pass of every group writes the finished
         // entries back in that form — 16 GiB of text: 80 instead of 128 GiB of suffix array, during the build and after it
@@ -2491,7 +2562,9 @@ void build_typed(Index& ix, bool big) {
         st.bucket_low_digits = brecords && blow > 0 ? blow / 8 : 0;
         st.key_layout = brecords ? (packed ? 5 : (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3)))) : 0;
         if (brecords) {
-            const uint64_t bmagic = (bbase & (bbase - 1u)) ? (uint64_t)(~0ull / bbase) + 1ull : 0ull;
+            // "the key ends inside the document" = key mod base == 0 (dense number) / its lowest bit clear (variable-length keys)
+            const uint32_t fbase = vl_bits ? 2u : bbase;
+            const uint64_t bmagic = (fbase & (fbase - 1u)) ? (uint64_t)(~0ull / fbase) + 1ull : 0ull;
             const int bpass = (int)ceil_div(bbits, 8);
             const int lowb = blow / 8;
             const int keyb = bwide ? 8 : 4;  // bytes of the key part of a record
@@ -2566,6 +2639,7 @@ void build_typed(Index& ix, bool big) {
             }
             if (!fuse_rec && ix.debug_no_segcap) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
+            if (vl_bits && !seg_cap) throw Error(vl_retry);
             if (sweep_rec && !seg_cap) {  // (a bucket larger than the record memory: partition + gather, bucket by bucket)
                 sweep_rec = false;
                 sweep_doc.release();
@@ -2701,6 +2775,17 @@ void build_typed(Index& ix, bool big) {
                             rg.rec_low_bits = blow;
                             rg.tile_doc = sweep_doc.as<uint64_t>();
                             rg.tile_base = sweep_base;
+                            if (vl_bits) {
+                                VlTables vt;
+                                vt.sym = d_vl_sym.as<uint16_t>();
+                                vt.dec = d_vl_dec.as<uint16_t>();
+                                vt.key_bits = vl_bits;
+                                vt.end_len = vlc.end_len;
+                                radix_sweep_records_vl<W>(s, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n, rg, (const uint16_t*)d_codeslot.as<uint16_t>(), vt,
+                                                          g.b0, g.b1, g.gstart, g.elems, (const uint32_t*)tile_seg.as<uint32_t>(),
+                                                          (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
+                                                          d_bh2.as<unsigned long long>(), &ss);
+                            } else
                             radix_sweep_records<W>(s, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n, rg, (const uint16_t*)d_codeslot.as<uint16_t>(), g.b0, g.b1,
                                                    g.gstart, g.elems,
                                                    (const uint32_t*)tile_seg.as<uint32_t>(), (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb,
@@ -2748,7 +2833,7 @@ void build_typed(Index& ix, bool big) {
                         fin.edges = edges.as<SegEdge>();
                         fin.hi_shift = blow;
                         fin.low_bits = blow;
-                        fin.kbase = bbase;
+                        fin.kbase = fbase;
                         fin.kmagic = bmagic;
                         radix_sort_segmented<W>(s, ix.rws, ix.prof, kbp[0], kbp[1], ebp[0], ebp[1], wb[0].as<W>(), wb[1].as<W>(), g.elems,
                                                 (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), (const uint32_t*)tile_seg.as<uint32_t>(), gb,
@@ -3041,7 +3126,7 @@ void build_typed(Index& ix, bool big) {
         order.nseg = (uint32_t)blks.size();
     }
     DevBuf U, skey[2], sval[2], nh, rank;
-    uint64_t h = (uint64_t)nsym;
+    uint64_t h = refine_depth0 ? refine_depth0 : (uint64_t)nsym;
     bool isa = false;
     uint64_t cap = 0;
     DevBuf d_open;  // entries still unresolved after the last round (saves a full flag scan to learn "none")
@@ -3232,9 +3317,23 @@ void build_suffix_array(Index& ix) {
             else build_typed<uint64_t, uint64_t, uint64_t>(ix, true);
         }
     };
-    try {
+    ix.vl_off_once = false;
+    auto run_dense_after_vl = [&]() {
         try {
             run();
+        } catch (const Error& e) {
+            if (std::strstr(e.what(), "variable-length keys: the sweep form does not apply") == nullptr) throw;
+            (void)hipStreamSynchronize(ix.stream);
+            ix.prof.resolve();
+            ix.release_sa();
+            ix.drop_keys();
+            ix.vl_off_once = true;
+            run();
+        }
+    };
+    try {
+        try {
+            run_dense_after_vl();
         } catch (const Error& e) {
             // A pass in XCD-aware tile order needs a few dozen workgroups resident at once (radix_sort.h: RS_GROUP);
             // other kernels on the device can starve it, which ends in the (bounded) look-back timeout.  The plain
@@ -3247,7 +3346,7 @@ void build_suffix_array(Index& ix) {
             ix.rws.plain_order = true;
             if (!ix.debug_starve_group) rs_group_order_disable(ix.device);  // (the test hook leaves the device alone)
             ix.group_fallbacks += 1;
-            run();
+            run_dense_after_vl();
         }
     } catch (...) {
         // (the scratch buffers went back to the block cache while the stack unwound; they carry an event of this
@@ -3297,7 +3396,7 @@ void build_suffix_array(Index& ix) {
             ix.release_sa();  // (the failed array and its keys go first: the rebuild needs their memory on large corpora)
             ix.drop_keys();
             try {
-                run();
+                run_dense_after_vl();
                 CDB_HIP(hipStreamSynchronize(ix.stream));
                 ix.prof.resolve();
                 pack_now();

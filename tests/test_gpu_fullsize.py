@@ -652,3 +652,98 @@ def test_c3_32gib_as_four_co_resident_shards_merged_on_one_gpu():
     for g in shards:
         g.close()
     capi.load_library().cdb_release_cached_memory()
+
+
+def test_rebuild_16gib_utf8_shard_beside_the_serving_index_and_with_8gb_held():
+    """database.cpp:276-280 at C4's per-GPU share: the serving index of a 16 GiB UTF-8 shard keeps answering while the next
+    generation is built beside it.  Two packed generations (5-byte entries) + both texts are ~212 GB; the build sizes its bucket
+    groups from what is left (records come from one text sweep per group, so no partitioned entry array exists).  The FIRST
+    build runs with 8 GB of device memory held by somebody else — the torch context + RCCL buffers a rank carries at N = 8 —
+    and must complete as well.  Memory figures go to stdout and gpurun_out/rebuild_16g.json."""
+    import json
+    import os
+    import threading
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    free, total = torch.cuda.mem_get_info()
+    if free < (270 << 30):
+        pytest.skip("needs a whole 288 GB MI355X")
+    capi.load_library().cdb_release_cached_memory()
+    capi.memory_reset_peak()
+    report = {}
+    held = torch.empty(8 << 30, dtype=torch.uint8, device="cuda")          # (somebody else's 8 GB)
+    text_a, ds_a = W.utf8_bytes_torch(16 << 30, seed=5, device="cuda")
+    nd_a = len(ds_a) - 1
+    d_ds_a = torch.from_numpy(ds_a.astype(np.int64)).cuda()
+    d_ids_a = torch.arange(nd_a, dtype=torch.int64, device="cuda")
+    pa_blob, pa_offs, pa_bytes = W.sample_patterns_torch(text_a, d_ds_a, 20_000, 6, 14, seed=5, miss_byte=0xFF, utf8=True)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    old = capi.GpuStringIndex()
+    old.build_resident(text_a.data_ptr(), d_ds_a.data_ptr(), d_ids_a.data_ptr(), nd_a)
+    assert old.sa_width == 8 and old.stat("self_check_fallbacks") == 0 and old.stat("group_fallbacks") == 0
+    v = old.verify()
+    assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
+    report["first_build_with_8GB_held"] = dict(zip(("in_use", "peak", "cached"), capi.memory_stats()), groups=int(old.stat("bucket_groups")),
+                                               build_ms=round(old.stat("build_ms"), 1), device_free=int(torch.cuda.mem_get_info()[0]))
+    del held
+    want = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)
+    want_rows, want_hits = int(want.nrows), int(want.nhits)
+    capi.load_library().cdb_release_cached_memory()
+    torch.cuda.empty_cache()
+    capi.memory_reset_peak()
+
+    stop, errors, served = threading.Event(), [], [0]
+
+    def serve():
+        try:
+            while not stop.is_set():
+                r = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)
+                assert (int(r.nrows), int(r.nhits)) == (want_rows, want_hits)
+                served[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = threading.Thread(target=serve)
+    th.start()
+    outcome = "built"
+    try:
+        text_b, ds_b = W.utf8_bytes_torch(16 << 30, seed=6, device="cuda")   # the next generation of the column
+        nd_b = len(ds_b) - 1
+        d_ds_b = torch.from_numpy(ds_b.astype(np.int64)).cuda()
+        d_ids_b = torch.arange(nd_b, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        report["device_free_before_rebuild"] = int(torch.cuda.mem_get_info()[0])
+        new = capi.GpuStringIndex()
+        try:
+            new.build_resident(text_b.data_ptr(), d_ds_b.data_ptr(), d_ids_b.data_ptr(), nd_b)
+        except RuntimeError as e:
+            outcome = "cannot: " + str(e)[:300]
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors[:2]
+    report["outcome"] = outcome
+    report["served_batches_meanwhile"] = served[0]
+    if outcome == "built":
+        assert new.stat("self_check_fallbacks") == 0 and new.stat("group_fallbacks") == 0
+        v = new.verify()
+        assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
+        r = new.verify_reference()
+        assert r["violations"] == 0, r
+        report["rebuild"] = dict(zip(("in_use", "peak", "cached"), capi.memory_stats()), groups=int(new.stat("bucket_groups")),
+                                 build_ms=round(new.stat("build_ms"), 1), device_free=int(torch.cuda.mem_get_info()[0]))
+        r = old.query_batch_device(pa_blob.data_ptr(), pa_offs.data_ptr(), 20_000, pa_bytes)      # both generations answer
+        assert int(r.nrows) == want_rows
+        new.close()
+    print("\n" + json.dumps(report))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/rebuild_16g.json", "w") as f:
+            json.dump(report, f, indent=1)
+    except OSError:
+        pass
+    old.close()
+    capi.load_library().cdb_release_cached_memory()
+    assert outcome == "built", outcome

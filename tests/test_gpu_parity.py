@@ -1502,3 +1502,72 @@ def test_reserve_maps_the_first_builds_working_set_in_the_background(G):
     g2 = _gpu(G, blob, ds, ids)
     assert np.array_equal(g2.sa(), o.sa())
     assert lib.cdb_reserve(0, 0, 0, None, 0) != 0              # nothing to reserve: refused
+
+
+@pytest.mark.parametrize("bits", [1, 16, 24, 32, 40, 48, 56])
+def test_variable_length_keys(G, bits):
+    # vl_code.h / rs_sweep_records_vl_kernel (round 5): the bucket keys are the first B - 1 bits of the suffix's alphabetic code
+    # stream (Garsia-Wachs code words in symbol order, END = zeros) + a "continues" bit instead of the dense base-(alphabet + 1)
+    # number.  Same suffix array and rows as the oracle for every key width, alphabet shape and document shape — skewed (Zipf)
+    # text is what the coding is for, but it must be right on anything: uniform alphabets, two symbols, duplicated documents
+    # (keys that end inside the document: the "continues" bit clear), deep repeats, documents of 0..5 bytes (thousands per tile:
+    # the generic path), bytes on both sides of 0x80 (reference order), one and several bucket groups.
+    # (8-byte entries — what the bucket-wise path of >= 2^32 suffixes has — need document + offset bits > 32: many small
+    #  documents and one long one, _wide_entry_docs)
+    def wide(text, nsmall, small_len, big_len):
+        ds = _wide_entry_docs(nsmall, small_len, big_len)
+        assert int(ds[-1]) <= len(text)
+        return text[: int(ds[-1])].copy(), ds
+    cases = []
+    z64 = W.zipf_corpus(1, 400000, seed=2, nsym=64)[0]
+    cases.append((wide(z64, 40000, 8, 70000), {}))
+    z20 = W.zipf_corpus(1, 400000, seed=3, nsym=20)[0]
+    cases.append((wide(z20, 40000, 7, 70000), dict(bucket_group_limit=100000)))
+    az = W.random_bytes(400000, 5, 0x61, 0x7A)
+    cases.append((wide(az, 70000, 3, 80000), {}))                                            # tiny documents: thousands per tile
+    ds = _wide_entry_docs(70000, 4, 70000)
+    ds[1000:30000:3] = ds[999:29999:3]                                                        # ... and empty ones
+    ds = np.maximum.accumulate(ds)
+    cases.append(((W.random_bytes(int(ds[-1]), 6, 0x61, 0x64), ds), dict(bucket_group_limit=90000)))
+    half = W.random_bytes(150000, 9, 0x61, 0x62)
+    dsh = _wide_entry_docs(36000, 2, 78000)
+    cases.append(((np.concatenate([half, half]), np.concatenate([dsh, dsh[1:] + dsh[-1]])), {}))   # every document twice: ties
+    dsa = _wide_entry_docs(262145, 1, 16385)    # (the oracle's std::sort leaf is quadratic in the length of a run of one letter)
+    cases.append(((np.full(int(dsa[-1]), 0x61, dtype=np.uint8), dsa), {}))                       # aaaa...: one symbol, nothing to code
+    cases.append((wide(W.random_bytes(400000, 12, 0x61, 0x62) , 40000, 3, 70000), dict(force_doubling=1)))   # two symbols, doubling
+    cases.append((wide(W.random_bytes(400000, 11, 0x70, 0x90), 40000, 5, 70000), {}))               # bytes on both sides of 0x80
+    ran = 0
+    for (blob, ds), extra in cases:
+        nd = len(ds) - 1
+        pats = W.sample_patterns(blob, ds, 120, 1, 9, seed=3, miss_frac=0.1)
+        ids = np.arange(nd, dtype=np.int64) * (1 << 33) + 3
+        g, o = _check_parity(G, blob, ds, ids=ids, patterns=pats, force_big_path=1, vl_keys=bits, **extra)
+        assert g.sa_width == 8
+        sigma = len(np.unique(blob))
+        if sigma >= 2:
+            want_bits = (32, 40, 48, 56) if bits == 1 else (bits,)    # (1: the width the cost model likes best)
+            assert g.stat("vl_key_bits") in want_bits and g.stat("sweep_records") == 1, (sigma, g.stat("vl_key_bits"))
+            assert 1.0 <= g.stat("vl_avg_len") <= 7.0 and 0 < g.stat("vl_rate") <= 1.001
+            ran += 1
+            if bits in (1, 32):    # the dense keys leave the same array behind (and usually more unresolved suffixes per key bit)
+                g0, _ = _check_parity(G, blob, ds, ids=ids, force_big_path=1, vl_keys=0, **extra)
+                assert g0.stat("vl_key_bits") == 0 and np.array_equal(g0.sa(), g.sa())
+        else:
+            assert g.stat("vl_key_bits") == 0      # one symbol: nothing to code
+    assert ran >= 7
+
+
+def test_variable_length_keys_are_chosen_for_skewed_text_only(G):
+    # automatic mode (vl_keys = 2, the default): the cost model takes the code stream for skewed text and keeps the dense number
+    # for flat alphabets (printable ASCII, UTF-8), where an alphabetic code cannot beat log2(alphabet + 1) bits per symbol
+    ds = _wide_entry_docs(40000, 40, 70000)
+    n = int(ds[-1])
+    blob = W.zipf_corpus(1, n, seed=2, nsym=64)[0]
+    g, _ = _check_parity(G, blob, ds, force_big_path=1)
+    assert g.sa_width == 8 and g.stat("vl_key_bits") in (32, 40, 48, 56), g.stat("vl_key_bits")
+    assert g.stat("vl_avg_len") < 5.6 and g.stat("vl_est_unresolved") <= 1 / 32
+    g, _ = _check_parity(G, W.random_bytes(n, 3), ds, force_big_path=1)
+    assert g.stat("vl_key_bits") == 0
+    u8 = W.utf8_corpus(2200, 900, seed=4)[0]
+    g, _ = _check_parity(G, u8[:n].copy(), ds, force_big_path=1)
+    assert g.stat("vl_key_bits") == 0
