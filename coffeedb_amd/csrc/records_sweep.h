@@ -49,25 +49,31 @@ constexpr uint32_t RS_SWEEP_DOCS = 768;      // document starts of a tile kept i
 // gen: text, doc_start, bits, base, nsym, rec_low_bits, padded, tile_doc (per RS_SWEEP_TILE), tile_base ([tiles][256]: array-wide
 // output slot of the tile's first suffix of every bucket slot); codeslot[byte] = symbol code | bucket slot << 8.
 // Keeps the suffixes whose bucket slot is in [g0, g1); record r of the group lands at index tile_base - gstart.
+// Round 5 (profiles/r05a_sq_counters.txt: 105 vector and 17 LDS instructions per position, vector units and LDS ~78 % busy): the
+// document of a kept position comes from a per-tile table instead of searches — per document a 64-bit entry bias
+// ((tile base - start) << bits) + document and the start of the NEXT document relative to the tile, per 32 positions the bit map
+// of document starts with the number of starts in front of it: document = count + popcount(bits & mask), entry = bias +
+// (position << bits), symbols left = next start - position — no 64-bit compares, no dependent table walk; the per-slot tile
+// starts are folded into the waves' counters, the scans are DPP adds.  Tiles with more documents than the table holds, with
+// empty documents, and the ragged last tile take the generic path (searches in global memory).
 template <typename W>
 __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, const uint16_t* __restrict__ codeslot, uint64_t n, uint32_t tiles,
                                                                   uint32_t g0, uint32_t g1, uint64_t gstart, uint32_t* __restrict__ kout,
                                                                   uint32_t* __restrict__ vout, W* __restrict__ wout) {
     constexpr int NT = 512, IPT = 16, TILE = RS_SWEEP_TILE, NW = NT / 64;
-    constexpr int abl = RS_SWEEP_ABL;  // (0 in every product build; timing-only ablations are a COMPILE-time choice, see the top of the file)
     static_assert(NT * IPT == TILE, "tile shape");
+    constexpr int abl = RS_SWEEP_ABL;  // (0 in every product build; timing-only ablations are a COMPILE-time choice, see the top of the file)
     constexpr uint32_t TEXTB = ((TILE + RS_GEN_LOOK + 15) / 16) * 16;
+    constexpr uint32_t NBLK = TILE / 32, DOCS = 184;  // (40 KB of LDS in all: four workgroups per CU)
     __shared__ __attribute__((aligned(16))) uint8_t s_text[TEXTB];
     __shared__ uint16_t s_cs[256];
-    constexpr uint32_t DOCS = 384;  // (40 KB of LDS in all: four workgroups per CU)
-    __shared__ uint64_t s_docs[DOCS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_doc[4 * DOCS];          // document d: entry bias (64 bit), start of d + 1 - tile base, -
     __shared__ uint8_t s_slotc[256];  // symbol code -> bucket slot (phase B has a record's slot back from its first symbol)
-    constexpr int WH = 256;
-    __shared__ uint32_t s_whist[NW][WH];
-    __shared__ uint16_t s_pdoc[TILE / 32 + 2];  // document (tile-local) of every 32nd position
-    __shared__ uint32_t s_tstart[256];
+    __shared__ uint32_t s_whist[NW][256];
+    __shared__ __attribute__((aligned(8))) uint32_t s_blk[2 * (NBLK + 1)];     // block of 32 positions: start bits, 16 x (starts in front of it)
     __shared__ uint64_t s_gbase[256];
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[8];
+    __shared__ uint32_t s_flag;
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
     uint8_t* const s_dig = reinterpret_cast<uint8_t*>(s_idx);  // (its first half, until the ranking is done: the staged bucket slots)
 
@@ -80,8 +86,7 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     const uint64_t base = tile * TILE;
     const uint32_t valid = (uint32_t)((n - base) < (uint64_t)TILE ? (n - base) : (uint64_t)TILE);
 
-    // ---- everything the tile needs from global memory is requested up front, in ONE round trip where possible: its text (16 B
-    // per thread), the byte table, its tile bases (one per thread and bucket slot of the group), its document range
+    // ---- everything the tile needs from global memory is requested up front, in ONE round trip where possible
     const uint64_t ga = base + (uint64_t)tid * 16, gb = base + (uint64_t)TILE + (uint64_t)tid * 16;
     const bool has_b = (uint32_t)tid * 16 < TEXTB - (uint32_t)TILE;
     const bool oka = gen.padded ? (ga < n + RS_GEN_LOOK) : (ga + 16 <= n);
@@ -97,17 +102,27 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
         s_slotc[tid] = gen.slotmap[tid];
     }
     const uint64_t dlo = gen.tile_doc[tile], dhi = gen.tile_doc[tile + 1];
-    for (int i = tid; i < NW * WH; i += NT) (&s_whist[0][0])[i] = 0;
-    // (the document starts are wanted in phase B only: they stay in registers until the ranking is done — a store to the LDS in
-    //  front of the first barrier would make that barrier wait for two dependent global round trips)
-    const uint32_t ndl = (uint32_t)(dhi - dlo);  // (meaningful when docs_in_lds)
+    for (int i = tid; i < NW * 256; i += NT) (&s_whist[0][0])[i] = 0;
+    if ((uint32_t)tid <= NBLK) s_blk[2 * tid] = 0;
+    if (tid == 0) s_flag = 0;
+    const uint32_t ndl = (uint32_t)(dhi - dlo);
     const bool docs_in_lds = dhi - dlo + 2 <= (uint64_t)DOCS;
-    uint64_t dreg0 = 0, dreg1 = 0;
-    if (docs_in_lds) {
-        if ((uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
-        if ((uint32_t)tid + NT < ndl + 2) dreg1 = gen.doc_start[dlo + tid + NT];
-    }
+    uint64_t dreg0 = 0;
+    if (docs_in_lds && (uint32_t)tid < ndl + 2) dreg0 = gen.doc_start[dlo + tid];
     __syncthreads();
+    if (docs_in_lds && (uint32_t)tid < ndl + 2) {
+        const uint32_t d = (uint32_t)tid;
+        const int64_t diff = (int64_t)(dreg0 - base);
+        const int32_t rel = diff < -(1ll << 30) ? -(1 << 30) : (diff > (1ll << 30) ? (1 << 30) : (int32_t)diff);
+        const uint64_t eb = ((base - dreg0) << gen.bits) + dlo + d;
+        s_doc[4 * d] = (uint32_t)eb;
+        s_doc[4 * d + 1] = (uint32_t)(eb >> 32);
+        if (d >= 1) s_doc[4 * d - 2] = (uint32_t)rel;  // (the start of d beside the bias of d - 1: one 16-byte read in phase B)
+        if (d >= 1 && rel <= (int32_t)TILE) {
+            const uint32_t bit = 1u << ((uint32_t)rel & 31u);
+            if (atomicOr(&s_blk[2 * ((uint32_t)rel >> 5)], bit) & bit) s_flag = 1;  // two starts on one position: an empty document
+        }
+    }
     // ---- staging: one table lookup per byte gives the symbol code (kept for phase B) and the bucket slot; both go to the LDS as
     // the 16-byte vectors the thread loaded
     auto fetch = [&](uint64_t g, bool ok, uint4 w, uint32_t* c) {
@@ -173,60 +188,49 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
             info[j] = inf;
         }
     }
-    if (docs_in_lds) {
-        if ((uint32_t)tid < ndl + 2) s_docs[tid] = dreg0;
-        if ((uint32_t)tid + NT < ndl + 2) s_docs[tid + NT] = dreg1;
-    }
     __syncthreads();
     if (abl & 32) return;  // (timing only: staging + ranking)
-    // ---- per-slot totals of the tile: exclusive prefix across the waves, then across the slots
-    uint32_t cnt = 0, incl = 0;
+    // ---- per-slot totals of the tile (waves 0-3) and, meanwhile (waves 4-7), the document starts in front of every block
+    uint32_t wc[NW], cnt = 0, incl = 0;
     if (tid < 256) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const uint32_t t = s_whist[w][tid];
-            s_whist[w][tid] = cnt;
-            cnt += t;
+            wc[w] = s_whist[w][tid];
+            cnt += wc[w];
         }
         incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-    } else if (docs_in_lds) {
-        // (the other four waves meanwhile: the document of every 32nd position, so that phase B searches between two of them)
-        for (uint32_t b = (uint32_t)tid - 256u; b < (uint32_t)TILE / 32 + 1; b += 256u) {
-            const uint64_t pos = base + (uint64_t)b * 32;
-            uint32_t lo = 0, hi = ndl;  // largest d in [0, ndl] with s_docs[d] <= pos
-            while (lo < hi) {
-                const uint32_t mid = lo + (hi - lo + 1) / 2;
-                if (s_docs[mid] <= pos) lo = mid; else hi = mid - 1;
-            }
-            s_pdoc[b] = (uint16_t)lo;
-        }
+    } else {
+        incl = cnt = (uint32_t)__builtin_popcount(s_blk[2 * (tid - 256)]);
     }
+    incl = rs_wave_incl_scan(incl);
+    if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     if (abl & 64) return;  // (timing only: ... + first half of the scan)
     const uint32_t kept = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    if (tid < 256) {
+    {
         uint32_t wpre = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-            if (w < wave) wpre += s_wsum[w];
-        const uint32_t tstart = wpre + incl - cnt;
-        s_tstart[tid] = tstart;
-        s_gbase[tid] = my_base - gstart - (uint64_t)tstart;
+            if (w < (wave & 3)) wpre += s_wsum[(wave & 4) + w];
+        const uint32_t excl = wpre + incl - cnt;
+        if (tid < 256) {  // every wave's counter of the slot becomes its first index in the tile's sorted order
+            uint32_t run = excl;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                s_whist[w][tid] = run;
+                run += wc[w];
+            }
+            s_gbase[tid] = my_base - gstart - (uint64_t)excl;
+        } else {
+            s_blk[2 * (tid - 256) + 1] = excl * 16u;
+            if (tid == 511) s_blk[2 * NBLK + 1] = (excl + cnt) * 16u;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const uint32_t sl = info[k] >> 16;
-        if (sl != 0xFFu) {
-            const uint32_t pos = s_tstart[sl] + s_whist[wave][sl] + (info[k] & 0xFFFFu);
-            s_idx[pos] = (uint16_t)(wbase + k * 64);  // (the slot is not carried along: phase B has it back from the position's first symbol)
-        }
+        if (sl != 0xFFu) s_idx[s_whist[wave][sl] + (info[k] & 0xFFFFu)] = (uint16_t)(wbase + k * 64);  // (the slot is not carried along)
     }
     __syncthreads();
 
@@ -237,115 +241,84 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
     const int ns1 = gen.nsym - 1;
     const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
-    // (U positions per trip, stage by stage: the loads of one stage are in flight together — the trip's dependent chain
-    //  position -> document -> code windows -> key is walked once for U records)
-    auto phase_b = [&](auto uc) {
-    constexpr int U = decltype(uc)::value;
-    for (uint32_t p0 = tid; p0 < kept; p0 += U * NT) {
-        uint32_t li[U], sl[U];
-        bool act[U];
-        uint64_t dd[U], ds[U], de[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t p = p0 + u * NT;
-            act[u] = p < kept;
-            const uint32_t q = act[u] ? p : p0;
-            li[u] = s_idx[q];
-            sl[u] = s_slotc[s_text[li[u]]];
-        }
-        if (abl & 4) {  // (timing only: no document search)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                dd[u] = dlo;
-                ds[u] = s_docs[0];
-                de[u] = ds[u] + (1ull << 40);
-            }
-        } else if (docs_in_lds) {
-            uint32_t lo[U], hi[U];  // largest d in [lo, hi] with s_docs[d] <= position
-            bool deep = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                lo[u] = s_pdoc[li[u] >> 5];
-                hi[u] = s_pdoc[(li[u] >> 5) + 1];
-                deep |= hi[u] > lo[u] + 1;
-            }
-            if (__builtin_amdgcn_ballot_w64(deep) != 0) {  // (wave-uniform, rare: several documents start inside 32 positions)
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    while (lo[u] < hi[u]) {
-                        const uint32_t mid = lo[u] + (hi[u] - lo[u] + 1) / 2;
-                        if (s_docs[mid] <= base + li[u]) lo[u] = mid; else hi[u] = mid - 1;
-                    }
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u) lo[u] = s_docs[hi[u]] <= base + li[u] ? hi[u] : lo[u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                dd[u] = dlo + lo[u];
-                ds[u] = s_docs[lo[u]];
-                de[u] = s_docs[lo[u] + 1];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                dd[u] = rs_doc_upper(gen.doc_start, dlo, dhi, base + li[u]);
-                ds[u] = gen.doc_start[dd[u]];
-                de[u] = gen.doc_start[dd[u] + 1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t pos = base + li[u];
-            const uint64_t e64 = ((pos - ds[u]) << gen.bits) + dd[u];
-            const uint64_t left = de[u] - pos - 1ull;  // key symbols left in the document
-            const uint32_t rem1 = left < 64ull ? (uint32_t)left : 64u;
-            const uint32_t l1 = li[u] + 1u, wi = l1 >> 2, sel = l1 & 3u;
-            const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-            uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li + 1 .. li + 4
-            uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 5 .. li + 8
-            uint32_t x2 = 0;
-            if (ns1 > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
-            if (rem1 < (uint32_t)ns1) {  // (rare) the symbols behind the document end count as 0
+    auto emit = [&](uint32_t p, uint32_t li, uint64_t e64, uint32_t rem1) {  // rem1: key symbols left in the document
+        const uint32_t sl = s_slotc[s_text[li]];
+        const uint32_t l1 = li + 1u, wi = l1 >> 2, sel = l1 & 3u;
+        const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
+        uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li + 1 .. li + 4
+        uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 5 .. li + 8
+        uint32_t x2 = 0;
+        if (ns1 > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(rem1 < (uint32_t)ns1) != 0)) != 0, 0)) {
+            if (rem1 < (uint32_t)ns1) {  // the symbols behind the document end count as 0
                 x0 = rem1 >= 4u ? x0 : (rem1 == 0u ? 0u : (x0 & ((1u << (8u * rem1)) - 1u)));
                 x1 = rem1 >= 8u ? x1 : (rem1 <= 4u ? 0u : (x1 & ((1u << (8u * (rem1 - 4u))) - 1u)));
                 x2 = rem1 >= 12u ? x2 : (rem1 <= 8u ? 0u : (x2 & ((1u << (8u * (rem1 - 8u))) - 1u)));
             }
-            uint64_t acc = 0;
+        }
+        uint64_t acc = 0;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                if (2 * q < ns1) {  // (uniform)
-                    const uint32_t xw = q < 2 ? x0 : (q < 4 ? x1 : x2);
-                    uint32_t pv, mult;
-                    if (2 * q + 1 < ns1) {
-                        pv = __builtin_amdgcn_udot4(xw, (q & 1) ? whi : wlo, 0u, false);
-                        mult = B2;
-                    } else {  // an odd number of symbols: the last one stands alone
-                        pv = (q & 1) ? ((xw >> 16) & 0xFFu) : (xw & 0xFFu);
-                        mult = B;
-                    }
-                    if (q == 0) acc = pv;
-                    else if (q == 1) acc = (uint64_t)(uint32_t)acc * mult + pv;  // (below 2^16 x 2^16: one v_mad_u64_u32)
-                    else acc = acc * (uint64_t)mult + pv;
+        for (int q = 0; q < 5; ++q) {
+            if (2 * q < ns1) {  // (uniform)
+                const uint32_t xw = q < 2 ? x0 : (q < 4 ? x1 : x2);
+                uint32_t pv, mult;
+                if (2 * q + 1 < ns1) {
+                    pv = __builtin_amdgcn_udot4(xw, (q & 1) ? whi : wlo, 0u, false);
+                    mult = B2;
+                } else {  // an odd number of symbols: the last one stands alone
+                    pv = (q & 1) ? ((xw >> 16) & 0xFFu) : (xw & 0xFFu);
+                    mult = B;
                 }
-            }
-            const uint64_t dst = s_gbase[sl[u]] + (uint64_t)(p0 + u * NT);
-            if (abl & 8) {  // (timing only: no stores)
-                if (acc == 0x123456789ull && e64 == 77) kout[dst] = 1;
-                continue;
-            }
-            if (act[u]) {
-                kout[dst] = (uint32_t)(acc >> gen.rec_low_bits);
-                vout[dst] = (uint32_t)e64;
-                wout[dst] = (W)((acc & lmask) | ((e64 >> 32) << gen.rec_low_bits));
+                if (q == 0) acc = pv;
+                else if (q == 1) acc = (uint64_t)(uint32_t)acc * mult + pv;  // (below 2^16 x 2^16: one v_mad_u64_u32)
+                else acc = acc * (uint64_t)mult + pv;
             }
         }
-    }
+        const uint64_t dst = s_gbase[sl] + (uint64_t)p;
+        if (abl & 8) {  // (timing only: no stores)
+            if (acc == 0x123456789ull && e64 == 77) kout[dst] = 1;
+            return;
+        }
+        kout[dst] = (uint32_t)(acc >> gen.rec_low_bits);
+        vout[dst] = (uint32_t)e64;
+        wout[dst] = (W)((acc & lmask) | ((e64 >> 32) << gen.rec_low_bits));
     };
-    // (two records per trip pay when most of the tile is kept — 4 GiB UTF-8, one group: 17.7 -> 16.5 ms; a sweep that keeps a third
-    //  of its positions is 2 % faster with one: 16 GiB shard, three groups: 98.9 against 96.5 ms)
-    if (kept >= (uint32_t)TILE / 2) phase_b(std::integral_constant<int, 2>{});
-    else phase_b(std::integral_constant<int, 1>{});
+    if (docs_in_lds && s_flag == 0 && valid == (uint32_t)TILE && !(abl & 4)) {
+        const int bits = gen.bits;
+        // (two records per trip pay when most of the tile is kept — one group: their loads are in flight together; a sweep that
+        //  keeps a third of its positions is faster with one)
+        auto rec = [&](uint32_t p) {
+            const uint32_t li = s_idx[p];
+            const uint2 bk = *reinterpret_cast<const uint2*>(&s_blk[2 * (li >> 5)]);
+            const uint32_t doff = bk.y + 16u * (uint32_t)__builtin_popcount(bk.x & ~(0xFFFFFFFEu << (li & 31u)));
+            const uint4 dc = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_doc) + doff);  // bias lo, hi, next start
+            emit(p, li, (((uint64_t)dc.y << 32) | dc.x) + ((uint64_t)li << bits), (uint32_t)((int32_t)dc.z - (int32_t)li - 1));
+        };
+        if (kept >= (uint32_t)TILE / 2) {
+            uint32_t p = tid;
+            for (; p + NT < kept; p += 2 * NT) {
+                rec(p);
+                rec(p + NT);
+            }
+            if (p < kept) rec(p);
+        } else {
+            for (uint32_t p = tid; p < kept; p += NT) rec(p);
+        }
+    } else {
+        // (the ragged last tile, tiles with more documents than the table holds or with empty ones: searches in global memory)
+        for (uint32_t p = tid; p < kept; p += NT) {
+            const uint32_t li = s_idx[p];
+            const uint64_t pos = base + li;
+            uint64_t dd = dlo, ds = 0, de = 1ull << 40;
+            if (!(abl & 4)) {
+                dd = rs_doc_upper(gen.doc_start, dlo, dhi, pos);
+                ds = gen.doc_start[dd];
+                de = gen.doc_start[dd + 1];
+            }
+            const uint64_t left = de - pos - 1ull;
+            emit(p, li, ((pos - ds) << gen.bits) + dd, left < 64ull ? (uint32_t)left : 64u);
+        }
+    }
 }
 
 // ---- variable-length keys (round 5, vl_code.h) ------------------------------------------------------------------------------------
