@@ -1631,7 +1631,6 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "vl_keys")) ix.vl_keys = value < 0 ? 0 : (value > 56 ? 56 : (int)value);
     else if (!std::strcmp(name, "pack_sa")) ix.pack_sa = value != 0;
     else if (!std::strcmp(name, "key_cost_model")) ix.key_cost_model = value != 0;
-    else if (!std::strcmp(name, "records_lane_striped")) ix.records_lane_striped = value != 0;
     else if (!std::strcmp(name, "gen_prebased")) ix.gen_prebased = value != 0;
     else if (!std::strcmp(name, "pack_entries")) ix.pack_entries = value != 0;
     else if (!std::strcmp(name, "segmented_sort")) ix.segmented_sort = value != 0;

@@ -165,7 +165,6 @@ struct Index {
     bool gen_prebased = true;         // option: generated passes take their tile bases from counted per-tile digits (no look-back, two
                                       // 8 Ki-key workgroups per CU; radix_sort.h: TextGen::tile_base)
     TileBaseWorkspace tbw;
-    bool records_lane_striped = true; // option: the fused records pass generates lane-striped (TextGenRecL) where it can (0 = rolling keys)
     bool key_cost_model = true;       // option: bucket-wise builds weigh one key symbol fewer (a pass saved) against the refinement it costs
     bool pack_sa = true;              // option: builds with 8-byte entries below 2^40 store them packed
     void release_sa() {

@@ -190,7 +190,6 @@ struct TextGen {
 // (tools/experiments/gen_bench.hip, -DRS_GEN_MODES: 5.55 vs 5.31 ms).  TextGen itself = the rolling-key form.
 struct TextGenPair : TextGen {};  // MSD-first sort, pair form (msd_pair)
 struct TextGenRec : TextGen {};   // bucket records (rec_mode), thread-consecutive rolling keys
-struct TextGenRecL : TextGen {};  // bucket records, lane-striped: every record straight from the staged codes (base <= 255, <= 10 key symbols)
 constexpr int RS_GEN_LOOK = 64;
 // timing-only ablations of the generated pass (tools/experiments/gen_bench.hip; WRONG results): 1 = no key arithmetic,
 // 2 = no transposition through LDS, 4 = no text staging
@@ -472,9 +471,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
     WS aux[HAS_W ? IPT : 1] = {};
     constexpr bool GM_PAIR = std::is_same<Gen, TextGenPair>::value;
     constexpr bool GM_REC = std::is_same<Gen, TextGenRec>::value;
-    constexpr bool GM_RECL = std::is_same<Gen, TextGenRecL>::value;
-    static_assert(!(GM_PAIR || GM_REC || GM_RECL) || (BLK && HAS_W), "pair / records generators: 16 Ki tiles with an auxiliary word");
-    constexpr bool recs = GM_REC || GM_RECL;
+    static_assert(!(GM_PAIR || GM_REC) || (BLK && HAS_W), "pair / records generators: 16 Ki tiles with an auxiliary word");
+    constexpr bool recs = GM_REC;
     uint32_t gdig[recs ? IPT / 4 : 1] = {};  // records generators: the elements' sort digits, four per register
     auto digit_of = [&](K k, WS a) -> uint32_t {
         if constexpr (HAS_W) {
@@ -606,79 +604,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
                     aux[j] = (WS)top;
                     val[j] = (VS)((((uint32_t)base + li) << gen.bits) + (uint32_t)ebase);
                 }
-            }
-        } else if constexpr (GM_RECL) {
-            // Lane-striped bucket records (round 4): every element straight from the staged codes, in the order the ranking wants
-            // them — no rolling key and none of the three transpositions (keys, auxiliary words, entries) through the staging
-            // buffer with their all-wave barriers (a barrier between two phases whose duration varies per wave costs ~0.14 ms
-            // per 2^30 suffixes).  The key is the nsym - 1 <= 10 codes behind the bucket symbol as a number in base B <= 255:
-            // pairs c B + c' by one v_dot4_u32_u8 each, combined by Horner steps in base B^2 (the first two stay below 2^32).
-            const uint32_t B = gen.base, B2 = B * B;
-            const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
-            const int ns1 = nsym - 1;
-            const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
-            const uint8_t* s_slot = gbuf + GEN_TEXTB + 512 + GEN_DOCS * 8;
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const uint32_t li = wbase + j * 64;
-                key[j] = (K)~(K)0;
-                val[j] = VS(0);
-                aux[j] = WS(0);
-                uint32_t dg = 0;
-                if (li < valid) {
-                    if (li >= dend_l) {  // (also the first element: dend_l = 0)
-                        const uint64_t p = base + li;
-                        uint64_t ds, de;
-                        if (docs_in_lds) {
-                            d = dlo + rs_doc_upper(s_docs, d - dlo, dhi - dlo, p);
-                            ds = s_docs[d - dlo];
-                            de = s_docs[d - dlo + 1];
-                        } else {
-                            d = rs_doc_upper(gen.doc_start, d, dhi, p);
-                            ds = gen.doc_start[d];
-                            de = gen.doc_start[d + 1];
-                        }
-                        const uint64_t rel = de - base;
-                        dend_l = rel < (1ull << 30) ? (uint32_t)rel : (1u << 30);
-                        ebase = d - (ds << gen.bits);
-                    }
-                    const uint32_t l1 = li + 1u, wi = l1 >> 2, sel = l1 & 3u;
-                    const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
-                    uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li + 1 .. li + 4
-                    uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 5 .. li + 8
-                    uint32_t x2 = 0;
-                    if (ns1 > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
-                    const uint32_t rem1 = dend_l - li - 1u;  // key symbols left in the document
-                    if (rem1 < (uint32_t)ns1) {  // (rare) the symbols behind the document end count as 0
-                        x0 = rem1 >= 4u ? x0 : (rem1 == 0u ? 0u : (x0 & ((1u << (8u * rem1)) - 1u)));
-                        x1 = rem1 >= 8u ? x1 : (rem1 <= 4u ? 0u : (x1 & ((1u << (8u * (rem1 - 4u))) - 1u)));
-                        x2 = rem1 >= 12u ? x2 : (rem1 <= 8u ? 0u : (x2 & ((1u << (8u * (rem1 - 8u))) - 1u)));
-                    }
-                    uint64_t acc = 0;
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        if (2 * q < ns1) {  // (uniform)
-                            const uint32_t xw = q < 2 ? x0 : (q < 4 ? x1 : x2);
-                            uint32_t pv, mult;
-                            if (2 * q + 1 < ns1) {
-                                pv = __builtin_amdgcn_udot4(xw, (q & 1) ? whi : wlo, 0u, false);
-                                mult = B2;
-                            } else {  // an odd number of symbols: the last one stands alone
-                                pv = (q & 1) ? ((xw >> 16) & 0xFFu) : (xw & 0xFFu);
-                                mult = B;
-                            }
-                            if (q == 0) acc = pv;
-                            else if (q == 1) acc = (uint64_t)(uint32_t)acc * mult + pv;  // (below 2^16 x 2^16: one v_mad_u64_u32)
-                            else acc = acc * (uint64_t)mult + pv;
-                        }
-                    }
-                    const uint64_t e64 = ((base + li) << gen.bits) + ebase;
-                    key[j] = (K)(acc >> gen.rec_low_bits);
-                    aux[j] = (WS)((acc & lmask) | ((e64 >> 32) << gen.rec_low_bits));
-                    val[j] = (VS)(uint32_t)e64;
-                    dg = (uint32_t)s_slot[s_text[li]];
-                }
-                gdig[j >> 2] |= dg << (8 * (j & 3));
             }
         } else if constexpr (BLK) {
             // Thread-consecutive generation: a thread owns IPT consecutive positions, so inside a document
@@ -861,7 +786,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void rs_onesweep_kernel(
         }
         // the staging buffer is reused for the sorted keys below (the pair generator never touched it: its codes, code table and
         // document table live in s_gen, which nothing writes before the next barrier)
-        if constexpr (!GM_PAIR && !GM_RECL) __syncthreads();
+        if constexpr (!GM_PAIR) __syncthreads();
     } else if constexpr (Cfg::DMA && HAS_V && EARLYV && sizeof(K) == 8 && (IPT % 4) == 0) {
         // Keys and values travel global -> LDS by 16-byte-per-lane DMA (global_load_lds: full-rate 1 KiB
         // per wave instruction, no staging registers) into this wave's slice of the still unused
@@ -2335,7 +2260,7 @@ inline void radix_sort_msd(hipStream_t s, RadixWorkspace& ws, MsdWorkspace& mw, 
 template <typename W>
 void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32_t* k, uint32_t* v, W* w, uint64_t n, const uint64_t* h_first,
                        const TextGen& gen_in, const uint32_t* d_tile_seg, const SegInfo* d_segs, uint32_t nseg, uint32_t seg_tiles, int lead,
-                       int npass, unsigned long long* d_hist_out, SortStats* stats, bool lane_striped = true,
+                       int npass, unsigned long long* d_hist_out, SortStats* stats,
                        const uint32_t* d_tile_counts = nullptr, const uint16_t* d_src_col = nullptr, TileBaseWorkspace* tbw = nullptr) {
     if (!rs_atomic_rank_ok(s)) throw Error("radix_gen_records: needs the one-atomic ranking (internal)");
     constexpr int TILE = RS_SEG_TILE;
@@ -2359,9 +2284,6 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
     const uint32_t e = ws.next_epoch(s);
     const uint32_t grid = grouped ? (uint32_t)(ceil_div(gen_tiles, 8u * RS_GROUP) * 8u * RS_GROUP) : gen_tiles;
     int t = prof.begin(s);
-    // lane-striped generator (TextGenRecL) where its arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the
-    // key's nsym - 1 symbols come from three code windows (<= 10 symbols); otherwise the rolling form
-    const bool striped = lane_striped && g2.base <= 255u && g2.nsym - 1 <= 10 && g2.nsym >= 2;
     if (d_tile_counts && tbw) {
         // look-back-free form (TextGen::tile_base): per-tile byte counts (sa_build.hip: sa_tile_bytecount_kernel), columns mapped
         // byte -> bucket slot, scanned over the tiles; 8 Ki-key tiles, two workgroups per CU
@@ -2380,27 +2302,9 @@ void radix_gen_records(hipStream_t s, RadixWorkspace& ws, Profiler& prof, uint32
     hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CFG, GENT, W>), dim3(grid8), dim3(512), 0, s, (const uint32_t*)nullptr, k, \
                        (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(), tk, e,    \
                        ws.err_ptr(), GENV, (const W*)nullptr, w, -1)
-        if (striped) {
-            TextGenRecL g3;
-            static_cast<TextGen&>(g3) = g2;
-            if (grouped) CDB_REC8(CfgG8, TextGenRecL, g3);
-            else CDB_REC8(CfgP8, TextGenRecL, g3);
-        } else {
-            if (grouped) CDB_REC8(CfgG8, TextGenRec, g2);
-            else CDB_REC8(CfgP8, TextGenRec, g2);
-        }
+        if (grouped) CDB_REC8(CfgG8, TextGenRec, g2);
+        else CDB_REC8(CfgP8, TextGenRec, g2);
 #undef CDB_REC8
-    } else if (striped) {
-        TextGenRecL g3;
-        static_cast<TextGen&>(g3) = g2;
-        if (grouped)
-            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGenRecL, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
-                               (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
-                               ws.xticket_ptr(e), e, ws.err_ptr(), g3, (const W*)nullptr, w, -1);
-        else
-            hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgP, TextGenRecL, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
-                               (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),
-                               ws.ticket_ptr(e), e, ws.err_ptr(), g3, (const W*)nullptr, w, -1);
     } else if (grouped)
         hipLaunchKernelGGL((rs_onesweep_kernel<uint32_t, uint32_t, CfgG, TextGenRec, W>), dim3(grid), dim3(1024), 0, s, (const uint32_t*)nullptr, k,
                            (const uint32_t*)nullptr, v, n, 0, 0xFFu, (const unsigned long long*)d_start, ws.status.as<uint64_t>(),

@@ -10,7 +10,7 @@
 //
 // A sweep must be cheap for the suffixes it does NOT keep (two thirds of them with three groups), so the kernel ranks first and
 // generates afterwards: phase A looks at one staged symbol per position (bucket slot -> LDS counter -> rank), phase B walks the
-// tile's KEPT positions in output order, evaluates their records (the arithmetic of TextGenRecL: nsym - 1 <= 10 codes behind the
+// tile's KEPT positions in output order, evaluates their records (nsym - 1 <= 10 codes behind the
 // bucket symbol as a number in base B <= 255, pairs by v_dot4_u32_u8, Horner in base B^2) and writes them lane-consecutively —
 // no record ever crosses the LDS, only a 16-bit position does (40 KB of LDS: four workgroups per CU).
 //
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
 }
 
 // whether the sweep's arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the key's nsym - 1 symbols come
-// from three code windows (<= 10 symbols after the first 4 + 4 ... see TextGenRecL)
+// from three code windows (<= 10 symbols: two or three 4-byte windows)
 inline bool rs_sweep_records_ok(uint32_t base, int nsym) { return base <= 255u && nsym >= 2 && nsym - 1 <= 10; }
 
 // One group: records of the buckets [g0, g1) into (k, v, w) at group-local indices, then the digit histograms of every bucket's

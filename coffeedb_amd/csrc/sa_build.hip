@@ -2762,7 +2762,7 @@ void build_typed(Index& ix, bool big) {
                                 radix_gen_records<W>(s, ix.rws, ix.prof, kbp[0], ebp[0], wb[0].as<W>(), n,
                                                      first_digit.data(), rg, (const uint32_t*)tile_seg.as<uint32_t>(),
                                                      (const SegInfo*)(d_segs.as<SegInfo>() + g.b0), gb, g.tiles, lowb, bpass,
-                                                     d_bh2.as<unsigned long long>(), &ss, ix.records_lane_striped,
+                                                     d_bh2.as<unsigned long long>(), &ss,
                                                      tile_bytes ? (const uint32_t*)d_tbc.as<uint32_t>() : nullptr,
                                                      tile_bytes ? (const uint16_t*)d_src_col.as<uint16_t>() : nullptr, tile_bytes ? &ix.tbw : nullptr);
                                 st.gen_prebased = tile_bytes ? 1 : 0;

@@ -744,9 +744,10 @@ def test_packed_suffix_array_storage(G, tmp_path):
 
 
 def test_records_generators_at_the_alphabet_edge(G):
-    # the fused records pass generates lane-striped (TextGenRecL: symbol codes weighted by B in a v_dot4_u32_u8) while the base
-    # alphabet + 1 fits a byte weight (<= 255) and the key has <= 10 symbols behind the bucket symbol; 255 symbols (base 256) and
-    # longer keys take the rolling form.  Both forms, both sides of the edge, odd and even key lengths, against the oracle.
+    # the sweep kernel of records_sweep.h writes the fused form's records while the base alphabet + 1 fits a byte weight of its
+    # v_dot4_u32_u8 arithmetic (<= 255) and the key has <= 10 symbols behind the bucket symbol; 255 symbols (base 256) and longer
+    # keys fall back to the generated records pass with rolling keys (TextGenRec).  Both forms, both sides of the edge, odd and
+    # even key lengths, against the oracle.  (Round 4's lane-striped generated pass, which the sweep superseded, is gone.)
     lens = (W.random_bytes(40000, 21, 0, 5)).astype(np.uint64)
     lens[99] = 70000
     ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -754,16 +755,15 @@ def test_records_generators_at_the_alphabet_edge(G):
         blob = W.random_bytes(int(ds[-1]), 22 + lo, lo, hi)
         pats = W.sample_patterns(blob, ds, 120, 1, 5, seed=4, miss_frac=0.1)
         for ks in (0, 2, 3, 4, 7, 10, 12):
-            # (striped = 2: the sweep kernel of records_sweep.h, which writes the fused form's records where its arithmetic applies —
-            #  the same condition as the lane-striped generator, which it replaced as the default; documents of 0..5 bytes: thousands
-            #  per tile, so the tile's document starts do not fit the LDS and the records look their documents up in global memory)
-            for striped in (2, 1, 0):
-                opts = dict(force_big_path=1, records_lane_striped=int(striped > 0), sweep_records=int(striped == 2))
+            # (documents of 0..5 bytes: thousands per tile, so the tile's document starts do not fit the LDS and the records look
+            #  their documents up in global memory)
+            for swept in (1, 0):
+                opts = dict(force_big_path=1, sweep_records=swept, vl_keys=0)
                 if ks:
                     opts["key_symbols"] = ks
                 g, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
                 assert g.stat("fused_records") == 1, (lo, hi, opts)
-                if striped == 2:
+                if swept:
                     assert g.stat("sweep_records") == int(g.stat("alphabet") <= 254 and g.stat("key_symbols") <= 11), (lo, hi, opts)
 
 
