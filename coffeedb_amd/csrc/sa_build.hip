@@ -1201,12 +1201,28 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
                                                             const uint8_t* __restrict__ text,
                                                             const uint16_t* __restrict__ symmap,
                                                             const R* __restrict__ rank, int bits, uint64_t mask, uint64_t h,
-                                                            int nsym2, int symbits, uint64_t* __restrict__ skey, uint64_t n_text) {
+                                                            int nsym2, int symbits, uint64_t* __restrict__ skey, uint64_t n_text,
+                                                            const uint8_t* __restrict__ vl_len = nullptr, uint32_t vl_kb1 = 0,
+                                                            uint32_t h_extra = 0, uint8_t* __restrict__ hcov = nullptr) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     const V v = sval[j];
     const uint64_t d = (uint64_t)v & mask, off = (uint64_t)v >> bits;
     const uint64_t ds = doc_start[d];
+    if (!USE_ISA && vl_len) {
+        // variable-length keys (vl_code.h): the symbols the initial key covered IN FULL — the bucket symbol + the code words that fit
+        // its vl_kb1 bits — are equal throughout the entry's group (equal keys decode alike), so the round may start behind them
+        const uint64_t len = doc_start[d + 1] - ds - off;
+        const uint8_t* q = text + ds + off;
+        uint32_t used = 0, cov = 1;
+        while ((uint64_t)cov < len && cov < 200u) {
+            used += vl_len[q[cov]];
+            if (used > vl_kb1) break;
+            ++cov;
+        }
+        hcov[j] = (uint8_t)cov;
+        h = (uint64_t)cov + h_extra;
+    }
     uint64_t key2 = 0;
     if constexpr (USE_ISA) {
         key2 = (uint64_t)rank[ds + d + off + h];  // extended position: one end slot per document
@@ -1348,7 +1364,9 @@ __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restr
 template <typename SAW, typename I, bool WANT_POS = true>
 __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename SAW::val* sval, const I* U, const uint8_t* nh,
                                          const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, SAW sa,
-                                         uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open) {
+                                         uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open,
+                                         const uint8_t* hcov = nullptr, uint32_t h_add = 0) {
+    if (hcov) hnew = (uint64_t)hcov[j] + h_add;  // (variable-length keys: the group's own depth; slot j stays inside its group through the sort)
     const typename SAW::val v = sval[j];
     const uint64_t i = U[j];
     const bool head = nh[j];
@@ -1375,11 +1393,12 @@ __global__ __launch_bounds__(256) void sa_update_kernel(const typename SAW::val*
                                                         const uint64_t* __restrict__ doc_start, int bits,
                                                         uint64_t mask, uint64_t hnew, SAW sa,
                                                         uint8_t* __restrict__ flags,
-                                                        unsigned long long* __restrict__ still_open) {
+                                                        unsigned long long* __restrict__ still_open,
+                                                        const uint8_t* __restrict__ hcov = nullptr, uint32_t h_add = 0) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     uint64_t q;
-    sa_place<SAW, I, false>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open);
+    sa_place<SAW, I, false>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open, hcov, h_add);
 }
 
 template <typename I>
@@ -1878,6 +1897,8 @@ void build_typed(Index& ix, bool big) {
     double est_unres = -1.0;  // expected share of the suffixes the initial sort leaves unresolved (from the sample; -1: not estimated)
     int est_nsym = 0;         // ... with a key of this many symbols
     uint64_t refine_depth0 = 0;  // symbols every key of the initial sort covers for certain (0: nsym; variable-length keys: fewer)
+    DevBuf d_vl_bytelen;         // variable-length keys: text byte -> code-word length (the refinement recovers every group's exact depth)
+    uint32_t vl_kb1 = 0;
     const int kmax = std::min(64 / symbits, 16);
     if (ix.initial_passes > 0) {
         const int passes = std::min(ix.initial_passes, 8);
@@ -2411,6 +2432,13 @@ void build_typed(Index& ix, bool big) {
                     st.fixed_est_unresolved = u_fixed;
                     // every key covers at least this many whole symbols behind the bucket symbol: where the refinement starts
                     refine_depth0 = 1 + (uint64_t)((vl_bits - 1) / vlc.max_len);
+                    // (the text-extension rounds start every group at the depth its key really covered: code-word length per text byte)
+                    std::vector<uint8_t> blen(256, 0);
+                    for (int b = 0; b < 256; ++b) blen[b] = h_map[b] ? vlc.len[h_map[b]] : (uint8_t)0;
+                    d_vl_bytelen.alloc(256);
+                    CDB_HIP(hipMemcpyAsync(d_vl_bytelen.p, blen.data(), 256, hipMemcpyHostToDevice, s));
+                    CDB_HIP(hipStreamSynchronize(s));  // (blen)
+                    vl_kb1 = (uint32_t)(vl_bits - 1);
                 }
             }
         }
@@ -3125,7 +3153,8 @@ void build_typed(Index& ix, bool big) {
         order.u_start = d_order.as<unsigned long long>() + blks.size();
         order.nseg = (uint32_t)blks.size();
     }
-    DevBuf U, skey[2], sval[2], nh, rank;
+    DevBuf U, skey[2], sval[2], nh, rank, hcov;
+    uint32_t h_acc = 0;  // symbols the text-extension rounds so far added behind every group's own depth (variable-length keys)
     uint64_t h = refine_depth0 ? refine_depth0 : (uint64_t)nsym;
     bool isa = false;
     uint64_t cap = 0;
@@ -3194,6 +3223,7 @@ void build_typed(Index& ix, bool big) {
             sval[0].alloc(m * sizeof(V));
             sval[1].alloc(m * sizeof(V));
             nh.alloc(m);
+            if (vl_kb1) hcov.alloc(m);
         }
         {
             int t = ix.prof.begin(s);
@@ -3208,7 +3238,8 @@ void build_typed(Index& ix, bool big) {
             else
                 hipLaunchKernelGGL((sa_round_keys_kernel<V, R, false>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
-                                   (const R*)nullptr, (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>(), n);
+                                   (const R*)nullptr, (int)ix.bits, ix.mask, h, nsym2, symbits, skey[0].as<uint64_t>(), n,
+                                   vl_kb1 ? (const uint8_t*)d_vl_bytelen.as<uint8_t>() : nullptr, vl_kb1, h_acc, vl_kb1 ? hcov.as<uint8_t>() : nullptr);
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
         const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
@@ -3230,7 +3261,9 @@ void build_typed(Index& ix, bool big) {
             } else {
                 hipLaunchKernelGGL((sa_update_kernel<SAW, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[rs].as<V>(), (const I*)U.as<I>(), (const uint8_t*)nh.as<uint8_t>(), m,
-                                   doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>(), d_open.as<unsigned long long>());
+                                   doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>(), d_open.as<unsigned long long>(),
+                                   vl_kb1 ? (const uint8_t*)hcov.as<uint8_t>() : nullptr, h_acc + (uint32_t)nsym2);
+                h_acc += (uint32_t)nsym2;
                 st.ext_rounds++;
             }
             ix.prof.end(t, "sa_update", m * (2 * sizeof(V) + sizeof(I) + 2 + (isa ? sizeof(R) : 0)), s);

@@ -28,9 +28,15 @@ python3 - $O "$WORKLOADS" > gpurun_out/sq_$TAG.txt <<'PY'
 import csv, glob, collections, sys, re
 O, wl = sys.argv[1], sys.argv[2].split()
 def fam(n):
-    n = n.split('(')[0]
-    m = re.match(r'(?:void )?(?:cdb::)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+)', n.strip())
-    return m.group(1) if m else n[:40]
+    head = n.split('(')[0]
+    m = re.match(r'(?:void )?(?:cdb::)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+)', head.strip())
+    k = m.group(1) if m else head[:40]
+    if k == 'rs_onesweep_kernel':   # the pass's role is in its template arguments
+        for tag, name in (('SegFinalKeepMsdArgs', 'rs_seg_final_keepmsd'), ('SegFinalKeepArgs', 'rs_final_keep'), ('SegFinalArgs', 'rs_seg_final'),
+                          ('TextGenPair', 'rs_gen_pair'), ('TextGenRec', 'rs_gen_records'), ('TextGen', 'rs_gen'), ('SegArgs', 'rs_seg')):
+            if tag in n:
+                return name
+    return k
 for W in wl:
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in sorted(glob.glob(f'{O}/{W}/p*/**/*counter_collection.csv', recursive=True)):
