@@ -1214,9 +1214,19 @@ __global__ __launch_bounds__(256) void sa_round_keys_kernel(const V* __restrict_
         // its vl_kb1 bits — are equal throughout the entry's group (equal keys decode alike), so the round may start behind them
         const uint64_t len = doc_start[d + 1] - ds - off;
         const uint8_t* q = text + ds + off;
+        // (the first symbols by aligned 8-byte loads, like the keys below: byte loads in suffix order cost a line each)
+        const uint64_t pa = (uint64_t)q & ~7ull;
+        const uint32_t sh = (uint32_t)((uint64_t)q & 7ull) * 8u;
+        const uint64_t tend = (uint64_t)(text + n_text);
+        const uint64_t w0 = *reinterpret_cast<const uint64_t*>(pa);
+        const uint64_t w1 = pa + 8 < tend ? *reinterpret_cast<const uint64_t*>(pa + 8) : 0ull;
+        const uint64_t w2 = pa + 16 < tend ? *reinterpret_cast<const uint64_t*>(pa + 16) : 0ull;
+        const uint64_t b0 = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;  // bytes q[0] .. q[7]
+        const uint64_t b1 = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;  // bytes q[8] .. q[15]
         uint32_t used = 0, cov = 1;
         while ((uint64_t)cov < len && cov < 200u) {
-            used += vl_len[q[cov]];
+            const uint32_t byte = cov < 8u ? (uint32_t)(b0 >> (8u * cov)) & 0xFFu : (cov < 16u ? (uint32_t)(b1 >> (8u * (cov - 8u))) & 0xFFu : (uint32_t)q[cov]);
+            used += vl_len[byte];
             if (used > vl_kb1) break;
             ++cov;
         }
@@ -2398,10 +2408,13 @@ void build_typed(Index& ix, bool big) {
                 auto share = [&](int B) { return std::min(1.0, ratio * (double)n * vlc.q * std::pow(2.0, -vlc.rate * (double)(B - 1))); };
                 int best_b = 0;
                 double best = 1e18;
+                // (with these keys the text-extension rounds start every group at the depth its key really covered, so the open
+                //  suffixes are settled in one or two rounds: ~1000 B each — 8 GiB of Zipf text, B = 40: 46 ms for 206 M of them)
+                const double refine_bytes_vl = 1000.0;
                 for (int B : {32, 40, 48, 56}) {
                     const double u = share(B);
-                    if (u > 1.0 / 32.0) continue;  // (text extension wants few open suffixes)
-                    const double c = (double)(B / 8) * 2.0 * rec_bytes(B) + u * refine_bytes + 6.0;  // (+ the slower sweep: three workgroups per CU)
+                    if (u > 1.0 / 24.0) continue;  // (text extension wants few open suffixes; the estimate errs on the high side)
+                    const double c = (double)(B / 8) * 2.0 * rec_bytes(B) + u * refine_bytes_vl + 6.0;  // (+ 6: the tile's bit offsets)
                     if (c < best) {
                         best = c;
                         best_b = B;
