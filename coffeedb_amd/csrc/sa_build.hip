@@ -1906,6 +1906,8 @@ void build_typed(Index& ix, bool big) {
     int nsym;
     double est_unres = -1.0;  // expected share of the suffixes the initial sort leaves unresolved (from the sample; -1: not estimated)
     int est_nsym = 0;         // ... with a key of this many symbols
+    double est_k0 = 0;        // the sample's measured pair-collision probability at est_k0n symbols (>= 50 colliding pairs: meaningful)
+    int est_k0n = 0;
     uint64_t refine_depth0 = 0;  // symbols every key of the initial sort covers for certain (0: nsym; variable-length keys: fewer)
     DevBuf d_vl_bytelen;         // variable-length keys: text byte -> code-word length (the refinement recovers every group's exact depth)
     uint32_t vl_kb1 = 0;
@@ -1963,6 +1965,11 @@ void build_typed(Index& ix, bool big) {
         }
         est_unres = (double)n * ((double)h_eq[nsym] / pairs);
         est_nsym = nsym;
+        for (int k = 1; k <= kmax; ++k)  // the longest prefix the sample still sees often enough to measure
+            if (h_eq[k] >= 50) {
+                est_k0n = k;
+                est_k0 = (double)h_eq[k] / pairs;
+            }
     } else {
         double pc = 0;
         for (int b = 0; b < 256; ++b) {
@@ -2401,8 +2408,10 @@ void build_typed(Index& ix, bool big) {
                 const double refine_bytes = 2000.0;  // (what a text-extension round costs per unresolved suffix: key_cost_model above)
                 // the sample measured the dense key's unresolved share; the order-0 model q^k says what it "should" be — their ratio
                 // carries the text's correlation over to the estimate for the code stream: share(B) = ratio n q 2^(-rate (B - 1))
-                const double model_fixed = std::min(1.0, (double)n * std::pow(vlc.q, (double)(est_nsym > 0 ? est_nsym : nsym)));
-                const double ratio = est_unres >= 0 ? std::min(1e6, std::max(0.05, est_unres / std::max(model_fixed, 1e-300))) : 1.0;
+                // (measured where the sample SEES collisions — the longest prefix with >= 50 colliding sample pairs; at the key width
+                //  that was chosen it sees none by construction, and "none" is no measurement: a first version divided 0 by the model
+                //  and took 32-bit code-stream keys for 16 GiB of printable ASCII, 12 % unresolved)
+                const double ratio = est_k0n > 0 ? std::min(1e3, std::max(0.2, est_k0 / std::max(std::pow(vlc.q, (double)est_k0n), 1e-300))) : 1.0;
                 const double u_fixed = std::min(1.0, ratio * (double)n * std::pow(vlc.q, (double)nsym));
                 const double cost_fixed = bbits != 999 ? std::ceil(bbits / 8.0) * 2.0 * rec_bytes(bbits) + u_fixed * refine_bytes : 1e9;
                 auto share = [&](int B) { return std::min(1.0, ratio * (double)n * vlc.q * std::pow(2.0, -vlc.rate * (double)(B - 1))); };
@@ -2422,7 +2431,10 @@ void build_typed(Index& ix, bool big) {
                 }
                 if (ix.vl_keys >= 16) best_b = std::min(56, (ix.vl_keys + 7) / 8 * 8);
                 else if (ix.vl_keys == 1 && !best_b) best_b = 56;
-                if (best_b && (ix.vl_keys != 2 || best < 0.93 * cost_fixed)) {
+                // (automatic mode also wants a code that really is shorter than the dense number's log2(alphabet + 1) bits per symbol:
+                //  on a flat alphabet the code stream can only lose)
+                const bool shorter = vlc.avg_len <= 0.93 * std::log2((double)sigma + 1.0);
+                if (best_b && (ix.vl_keys != 2 || (shorter && best < 0.93 * cost_fixed))) {
                     vl_bits = best_b;
                     bbits = vl_bits;
                     std::vector<uint16_t> sym(256, 0), dec(128, (uint16_t)(0xFFu | ((unsigned)vlc.end_len << 8)));

@@ -160,6 +160,8 @@ def test_c2_full_size_zipf_one_million_patterns_with_offsets():
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1       # 24 + 11 bits -> u64 entries
     assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
+    # skewed text: variable-length keys (vl_code.h), and their unresolved share as the cost model promised
+    assert g.stat("vl_key_bits") in (40, 48) and g.stat("unresolved_after_initial") < n / 24
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
@@ -305,6 +307,7 @@ def test_c4_shard_16gib_utf8_ten_million_patterns():
     g.build_device(text.data_ptr(), ds, ids)
     assert g.size == n and g.sa_width == 8 and g.stat("bucketed") == 1
     assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
+    assert g.stat("vl_key_bits") == 0 and g.stat("unresolved_after_initial") < n / 24
     v = g.verify()
     assert v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"] and v["tie_violations"] == 0
     r = g.verify_reference()
@@ -418,6 +421,8 @@ def test_c3_shard_8gib_ascii():
     g.build_device(text.data_ptr(), ds, ids)
     assert (g.size, g.bits, g.sa_width) == (n, 24, 8) and g.stat("bucketed") == 1
     assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
+    # a flat alphabet keeps the dense keys (an alphabetic code cannot beat log2(96) bits per symbol), and few suffixes stay open
+    assert g.stat("vl_key_bits") == 0 and g.stat("unresolved_after_initial") < n / 64
     v = g.verify()
     assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
     assert v["entry_sum"] == v["expected_entry_sum"]
