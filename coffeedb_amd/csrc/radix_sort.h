@@ -171,6 +171,10 @@ struct TextGen {
     // them, value = entry bits 0..31.  16 Ki-key tiles only (thread-consecutive rolling keys); kernels of type TextGenRec.
     const uint8_t* slotmap = nullptr;  // [257] symbol code -> bucket slot
     int rec_low_bits = 0;
+    // Leftover key bits (round 5, sweep form only): a key of nsym - 1 symbols in whole 8-bit passes leaves room for part_m >= 2 more
+    // values below it — they hold the NEXT symbol quantised to part_m levels, floor(code * part_m / base) = (code * part_r) >>
+    // part_s (monotone in the code, so the key stays order-preserving): key = dense * part_m + level.  part_m = 1: none.
+    uint32_t part_m = 1, part_r = 0, part_s = 0;
     // MSD-first sort, pair form (6-symbol keys; kernels of type TextGenPair): top digit = (first two symbols as a number A) /
     // span, i.e. key / M with M = span * base^4 <= 2^32 — a function of two symbols, so its histogram comes from a pair count
     // of the text instead of a sweep that evaluates every key.  The generated pass works in 32-bit part arithmetic (G = three

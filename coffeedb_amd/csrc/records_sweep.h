@@ -240,6 +240,7 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     const uint32_t B = gen.base, B2 = B * B;
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
     const int ns1 = gen.nsym - 1;
+    const int nsx = ns1 + (gen.part_m > 1 ? 1 : 0);  // symbols the key looks at (incl. the quantised one in its leftover bits)
     const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
     auto emit = [&](uint32_t p, uint32_t li, uint64_t e64, uint32_t rem1) {  // rem1: key symbols left in the document
         const uint32_t sl = s_slotc[s_text[li]];
@@ -248,9 +249,9 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
         uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sel);  // codes of li + 1 .. li + 4
         uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, sel);  // codes of li + 5 .. li + 8
         uint32_t x2 = 0;
-        if (ns1 > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
-        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(rem1 < (uint32_t)ns1) != 0)) != 0, 0)) {
-            if (rem1 < (uint32_t)ns1) {  // the symbols behind the document end count as 0
+        if (nsx > 8) x2 = __builtin_amdgcn_alignbyte(s_words[wi + 3], w2, sel);  // (uniform) codes of li + 9 .. li + 12
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(rem1 < (uint32_t)nsx) != 0)) != 0, 0)) {
+            if (rem1 < (uint32_t)nsx) {  // the symbols behind the document end count as 0
                 x0 = rem1 >= 4u ? x0 : (rem1 == 0u ? 0u : (x0 & ((1u << (8u * rem1)) - 1u)));
                 x1 = rem1 >= 8u ? x1 : (rem1 <= 4u ? 0u : (x1 & ((1u << (8u * (rem1 - 4u))) - 1u)));
                 x2 = rem1 >= 12u ? x2 : (rem1 <= 8u ? 0u : (x2 & ((1u << (8u * (rem1 - 8u))) - 1u)));
@@ -273,6 +274,11 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
                 else if (q == 1) acc = (uint64_t)(uint32_t)acc * mult + pv;  // (below 2^16 x 2^16: one v_mad_u64_u32)
                 else acc = acc * (uint64_t)mult + pv;
             }
+        }
+        if (gen.part_m > 1) {  // (uniform) the leftover key bits: the next symbol, quantised (TextGen::part_m)
+            const uint32_t xq = ns1 < 4 ? x0 : (ns1 < 8 ? x1 : x2);
+            const uint32_t cq = (xq >> (8 * (ns1 & 3))) & 0xFFu;
+            acc = acc * (uint64_t)gen.part_m + (uint64_t)((cq * gen.part_r) >> gen.part_s);
         }
         const uint64_t dst = s_gbase[sl] + (uint64_t)p;
         if (abl & 8) {  // (timing only: no stores)
@@ -889,6 +895,26 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_msd_kernel(TextGen gen, uint6
 // whether the sweep's arithmetic applies: codes are bytes weighted by B in a dot4 (B <= 255), the key's nsym - 1 symbols come
 // from three code windows (<= 10 symbols: two or three 4-byte windows)
 inline bool rs_sweep_records_ok(uint32_t base, int nsym) { return base <= 255u && nsym >= 2 && nsym - 1 <= 10; }
+// constants of the quantiser floor(code * m / base) = (code * r) >> s for every code < base; false: none found (m stays 1)
+template <typename G>
+inline bool rs_part_setup(G& gen, uint32_t base, uint32_t m) {
+    gen.part_m = 1;
+    gen.part_r = gen.part_s = 0;
+    if (m < 2 || base < 2 || base > 256) return false;
+    for (uint32_t sh = 0; sh < 24; ++sh) {
+        const uint64_t r = (((uint64_t)m << sh) + base - 1) / base;
+        if (r >= (1u << 24)) break;
+        bool ok = true;
+        for (uint64_t c = 0; c < base && ok; ++c) ok = ((c * r) >> sh) == c * m / base;
+        if (ok) {
+            gen.part_m = m;
+            gen.part_r = (uint32_t)r;
+            gen.part_s = sh;
+            return true;
+        }
+    }
+    return false;
+}
 
 // One group: records of the buckets [g0, g1) into (k, v, w) at group-local indices, then the digit histograms of every bucket's
 // passes from the records (d_hist_out: [nseg][8][256], zeroed here).  d_tile_doc: [tiles8 + 1] (rs_tiledoc_kernel over

@@ -2467,6 +2467,27 @@ void build_typed(Index& ix, bool big) {
                 }
             }
         }
+        // ---- leftover key bits (sweep form): the dense number of nsym - 1 symbols is sorted in whole 8-bit passes; when its range
+        // leaves a factor part_m >= 2 of room, the NEXT symbol quantised to part_m levels rides along below it — order-preserving
+        // (monotone in the symbol), no extra pass or byte, fewer unresolved suffixes (16 GiB of UTF-8: 206^5 = 2^38.4 in 40 bits ->
+        // part_m = 2).  "The key ends inside the document" = key mod (base * part_m) == 0.  Like the variable-length keys it exists
+        // in the sweep kernels only; should the build fall back to another records form it is redone without.
+        TextGen part_gen{};
+        uint32_t part_m = 1;
+        if (!vl_bits && sizeof(V) == 8 && ix.partial_symbol && !ix.vl_off_once && tile_bytes && ix.sweep_records && ix.segmented_sort &&
+            ix.pack_entries && ix.narrow_keys && (int)ix.bits + ix.off_bits <= 40 && sigma <= 254 && nsym > 1 && nsym - 1 <= 10 &&
+            bbits != 999 && bbits <= 56 && rs_atomic_rank_ok(s) && rs_sweep_records_ok(bbase, nsym) && true) {
+            const int pbits = 8 * (int)ceil_div(bbits, 8);
+            unsigned __int128 range = 1;
+            for (int i = 0; i + 1 < nsym; ++i) range *= bbase;
+            const uint64_t room = (uint64_t)((((unsigned __int128)1) << pbits) / range);
+            const uint32_t m = (uint32_t)std::min<uint64_t>(room, bbase - 1);
+            if (m >= 2 && rs_part_setup(part_gen, bbase, m)) {
+                part_m = m;
+                bbits = bit_width64((uint64_t)(range * m - 1));
+                st.partial_levels = (int)m;
+            }
+        }
         // (wider keys, up to 56 bits: dense u64 keys without low digits — still fewer passes than bit-aligned
         //  symbols, the grouped gather and no separate histogram pass)
         // packed entries (sa_bucket_records_packed_kernel): 8-byte entries below 2^40 travel as u32 + one byte on top of the
@@ -2533,7 +2554,7 @@ void build_typed(Index& ix, bool big) {
         const bool sweep_fused = fuse_rec && tile_bytes && ix.sweep_records && (vl_bits || rs_sweep_records_ok(bbase, nsym));
         // (variable-length keys exist in the sweep kernels only: build_suffix_array redoes the build with dense keys)
         const char* vl_retry = "variable-length keys: the sweep form does not apply (retry with dense keys)";
-        if (vl_bits && !sweep_rec && !sweep_fused) throw Error(vl_retry);
+        if ((vl_bits || part_m > 1) && !sweep_rec && !sweep_fused) throw Error(vl_retry);
         // partition + gather with packed output: the partitioned entries ARE stored packed from the start (E = low words,
         // sa_hi_buf = bits 32..39): the gather reads them through Sa40, the last pass of every group writes the finished
         // entries back in that form — 16 GiB of text: 80 instead of 128 GiB of suffix array, during the build and after it
@@ -2616,7 +2637,7 @@ void build_typed(Index& ix, bool big) {
         st.key_layout = brecords ? (packed ? 5 : (bwide ? 4 : (blow == 0 ? 1 : (blow == 8 ? 2 : 3)))) : 0;
         if (brecords) {
             // "the key ends inside the document" = key mod base == 0 (dense number) / its lowest bit clear (variable-length keys)
-            const uint32_t fbase = vl_bits ? 2u : bbase;
+            const uint32_t fbase = vl_bits ? 2u : bbase * part_m;
             const uint64_t bmagic = (fbase & (fbase - 1u)) ? (uint64_t)(~0ull / fbase) + 1ull : 0ull;
             const int bpass = (int)ceil_div(bbits, 8);
             const int lowb = blow / 8;
@@ -2692,7 +2713,7 @@ void build_typed(Index& ix, bool big) {
             }
             if (!fuse_rec && ix.debug_no_segcap) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
-            if (vl_bits && !seg_cap) throw Error(vl_retry);
+            if ((vl_bits || part_m > 1) && !seg_cap) throw Error(vl_retry);
             if (sweep_rec && !seg_cap) {  // (a bucket larger than the record memory: partition + gather, bucket by bucket)
                 sweep_rec = false;
                 sweep_doc.release();
@@ -2826,6 +2847,9 @@ void build_typed(Index& ix, bool big) {
                             TextGen rg{text, doc_start, d_symmap.as<uint16_t>(), D, (int)ix.bits, bbase, nsym, 0, ix.text_padded};
                             rg.slotmap = d_slotmap.as<uint8_t>();
                             rg.rec_low_bits = blow;
+                            rg.part_m = part_m;
+                            rg.part_r = part_gen.part_r;
+                            rg.part_s = part_gen.part_s;
                             rg.tile_doc = sweep_doc.as<uint64_t>();
                             rg.tile_base = sweep_base;
                             if (vl_bits) {

@@ -1571,3 +1571,31 @@ def test_variable_length_keys_are_chosen_for_skewed_text_only(G):
     u8 = W.utf8_corpus(2200, 900, seed=4)[0]
     g, _ = _check_parity(G, u8[:n].copy(), ds, force_big_path=1)
     assert g.stat("vl_key_bits") == 0
+
+
+def test_leftover_key_bits_hold_a_quantised_symbol(G):
+    # sweep form, dense keys: the number of nsym - 1 symbols is sorted in whole 8-bit passes; a factor >= 2 of leftover range holds
+    # the NEXT symbol quantised to that many levels (TextGen::part_m) — same array as without, never more unresolved suffixes, and
+    # "the key ends inside the document" still exact (documents of a few bytes, duplicated tails).
+    lens = (W.random_bytes(40000, 31, 0, 6)).astype(np.uint64)
+    lens[123] = 70000
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    levels = set()
+    for lo, hi in ((0x30, 0x39), (0x61, 0x7A), (0x20, 0xE7), (0x41, 0x42)):
+        blob = W.random_bytes(int(ds[-1]), 40 + lo, lo, hi)
+        blob[5000:9000] = blob[1000:5000]                                   # repeated stretch: equal tails across documents
+        pats = W.sample_patterns(blob, ds, 100, 1, 6, seed=5, miss_frac=0.1)
+        for ks in (0, 2, 3, 4, 5, 7):
+            for group_limit in (0, 60000):
+                opts = dict(force_big_path=1, vl_keys=0, bucket_group_limit=group_limit)
+                if ks:
+                    opts["key_symbols"] = ks
+                g, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
+                g0, _ = _check_parity(G, blob, ds, partial_symbol=0, **opts)
+                assert g0.stat("partial_levels") == 0 and np.array_equal(g.sa(), g0.sa())
+                lv = int(g.stat("partial_levels"))
+                levels.add(lv)
+                if lv >= 2:
+                    assert g.stat("sweep_records") == 1
+                    assert g.stat("unresolved_after_initial") <= g0.stat("unresolved_after_initial"), (lo, hi, ks, lv)
+    assert max(levels) >= 4 and 0 in levels, levels
