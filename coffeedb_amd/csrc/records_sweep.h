@@ -291,8 +291,11 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     };
     if (docs_in_lds && s_flag == 0 && valid == (uint32_t)TILE && !(abl & 4)) {
         const int bits = gen.bits;
-        // (two records per trip pay when most of the tile is kept — one group: their loads are in flight together; a sweep that
-        //  keeps a third of its positions is faster with one)
+        // (two records per trip pay when the whole tile is kept — one group: their loads are in flight together; a sweep that keeps
+        //  a part of its positions takes one.  A first version paired records whenever half the tile was kept and came out WRONG
+        //  for tiles with more than 4608 kept positions: the pair iteration in which only some lanes of a wave still have a second
+        //  record — emit()'s wave-uniform branch on a ballot sits inside it — is the one shape the all-kept and the one-record
+        //  loops never produce; found at full size by the C3 test, now covered by test_sweep_groups_that_keep_most_of_a_tile)
         auto rec = [&](uint32_t p) {
             const uint32_t li = s_idx[p];
             const uint2 bk = *reinterpret_cast<const uint2*>(&s_blk[2 * (li >> 5)]);
@@ -300,13 +303,11 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
             const uint4 dc = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(s_doc) + doff);  // bias lo, hi, next start
             emit(p, li, (((uint64_t)dc.y << 32) | dc.x) + ((uint64_t)li << bits), (uint32_t)((int32_t)dc.z - (int32_t)li - 1));
         };
-        if (kept >= (uint32_t)TILE / 2) {
-            uint32_t p = tid;
-            for (; p + NT < kept; p += 2 * NT) {
+        if (kept == (uint32_t)TILE) {  // (everything kept — one group: a fixed trip count, no lane leaves early)
+            for (uint32_t p = tid; p < (uint32_t)TILE; p += 2 * NT) {
                 rec(p);
                 rec(p + NT);
             }
-            if (p < kept) rec(p);
         } else {
             for (uint32_t p = tid; p < kept; p += NT) rec(p);
         }

@@ -558,10 +558,11 @@ def test_c3_32gib_as_four_co_resident_shards_merged_on_one_gpu():
         capi.load_library().cdb_release_cached_memory()       # the next shard sizes its groups from what is really free
         texts.append((text, d_ids))
         shards.append(g)
-    for g in shards:
+    for r, g in enumerate(shards):
         v = g.verify()
-        assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
-        assert v["entry_sum"] == v["expected_entry_sum"]
+        what = (r, v, report[r], {k: g.stat(k) for k in ("key_symbols", "partial_levels", "vl_key_bits", "unresolved_after_initial", "rounds", "sweep_records", "segmented", "fused_records", "bucket_groups", "gen_prebased", "sort_passes")})
+        assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0, what
+        assert v["entry_sum"] == v["expected_entry_sum"], what
     d_blob = torch.cat(blobs + [torch.zeros(16, dtype=torch.uint8, device="cuda")])
     d_offs = torch.cat(offs + [torch.tensor([base], dtype=torch.int64, device="cuda")])
     del blobs, offs
