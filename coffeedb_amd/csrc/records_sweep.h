@@ -292,10 +292,14 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     if (docs_in_lds && s_flag == 0 && valid == (uint32_t)TILE && !(abl & 4)) {
         const int bits = gen.bits;
         // (two records per trip pay when the whole tile is kept — one group: their loads are in flight together; a sweep that keeps
-        //  a part of its positions takes one.  A first version paired records whenever half the tile was kept and came out WRONG
-        //  for tiles with more than 4608 kept positions: the pair iteration in which only some lanes of a wave still have a second
-        //  record — emit()'s wave-uniform branch on a ballot sits inside it — is the one shape the all-kept and the one-record
-        //  loops never produce; found at full size by the C3 test, now covered by test_sweep_groups_that_keep_most_of_a_tile)
+        //  a part of its positions takes one.  A first version paired records whenever half the tile was kept
+        //  ("for (; p + NT < kept; p += 2 NT) { rec(p); rec(p + NT); }  if (p < kept) rec(p);") and came out WRONG for tiles with
+        //  more than 9 NT = 4608 kept positions, i.e. when the last pair iteration runs with only SOME lanes of a wave — about one
+        //  wave's worth of records per such tile.  The cause was not isolated: a build with emit()'s ballot branch replaced by
+        //  unconditional masking fails identically, and a reduced kernel of the same loop shape compiles correctly; the all-kept
+        //  and the one-record loops below never leave a wave half-way through a pair.  Found at full size by the C3 test (a shard
+        //  whose first group held 52 of 95 buckets), covered since by test_sweep_groups_that_keep_most_of_a_tile, which fails on
+        //  the old loop.)
         auto rec = [&](uint32_t p) {
             const uint32_t li = s_idx[p];
             const uint2 bk = *reinterpret_cast<const uint2*>(&s_blk[2 * (li >> 5)]);

@@ -1904,8 +1904,6 @@ void build_typed(Index& ix, bool big) {
     // ~ n * c_k of all suffixes share their k-prefix with another one.  (An order-0 symbol model is far
     // too optimistic for correlated text such as multi-byte UTF-8.)  Small corpora use the order-0 model.
     int nsym;
-    double est_unres = -1.0;  // expected share of the suffixes the initial sort leaves unresolved (from the sample; -1: not estimated)
-    int est_nsym = 0;         // ... with a key of this many symbols
     double est_k0 = 0;        // the sample's measured pair-collision probability at est_k0n symbols (>= 50 colliding pairs: meaningful)
     int est_k0n = 0;
     uint64_t refine_depth0 = 0;  // symbols every key of the initial sort covers for certain (0: nsym; variable-length keys: fewer)
@@ -1963,8 +1961,6 @@ void build_typed(Index& ix, bool big) {
             const double u0 = (double)n * ((double)h_eq[nsym] / pairs), u1 = (double)n * ((double)h_eq[k1] / pairs);
             if (u1 <= 1.0 / 40.0 && plan_bytes(k1) + u1 * refine_bytes < plan_bytes(nsym) + u0 * refine_bytes) nsym = k1;
         }
-        est_unres = (double)n * ((double)h_eq[nsym] / pairs);
-        est_nsym = nsym;
         for (int k = 1; k <= kmax; ++k)  // the longest prefix the sample still sees often enough to measure
             if (h_eq[k] >= 50) {
                 est_k0n = k;
