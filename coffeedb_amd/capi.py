@@ -239,6 +239,8 @@ class GpuStringIndex:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
         assert len(doc_start) == len(ids) + 1
+        if len(doc_start) and int(doc_start[-1]) > len(blob):   # (the C ABI takes plain pointers: a short blob would be read past its end)
+            raise ValueError(f"blob holds {len(blob)} bytes, doc_start[-1] = {int(doc_start[-1])}")
         self._check(self._lib.cdb_add_bulk(self._h, _ptr(ids), _ptr(blob), _ptr(doc_start), len(ids)))
 
     def build(self):
@@ -250,6 +252,8 @@ class GpuStringIndex:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
         assert len(doc_start) == len(ids) + 1
+        if len(doc_start) and int(doc_start[-1]) > len(blob):   # (the C ABI takes plain pointers: a short blob would be read past its end)
+            raise ValueError(f"blob holds {len(blob)} bytes, doc_start[-1] = {int(doc_start[-1])}")
         self._check(self._lib.cdb_build_view(self._h, _ptr(ids), _ptr(blob) if len(blob) else None, _ptr(doc_start), len(ids)))
 
     def build_views(self, ids, docs):
@@ -513,6 +517,9 @@ class GpuShards:
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
+        assert len(doc_start) == len(ids) + 1
+        if len(doc_start) and int(doc_start[-1]) > len(blob):   # (the C ABI takes plain pointers: a short blob would be read past its end)
+            raise ValueError(f"blob holds {len(blob)} bytes, doc_start[-1] = {int(doc_start[-1])}")
         self._check(self._lib.cdb_shards_add_bulk(self._h, _ptr(ids), _ptr(blob), _ptr(doc_start), len(ids)))
 
     def set_option(self, name, value):

@@ -293,13 +293,17 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
         const int bits = gen.bits;
         // (two records per trip pay when the whole tile is kept — one group: their loads are in flight together; a sweep that keeps
         //  a part of its positions takes one.  A first version paired records whenever half the tile was kept
-        //  ("for (; p + NT < kept; p += 2 NT) { rec(p); rec(p + NT); }  if (p < kept) rec(p);") and came out WRONG for tiles with
-        //  more than 9 NT = 4608 kept positions, i.e. when the last pair iteration runs with only SOME lanes of a wave — about one
-        //  wave's worth of records per such tile.  The cause was not isolated: a build with emit()'s ballot branch replaced by
-        //  unconditional masking fails identically, and a reduced kernel of the same loop shape compiles correctly; the all-kept
-        //  and the one-record loops below never leave a wave half-way through a pair.  Found at full size by the C3 test (a shard
-        //  whose first group held 52 of 95 buckets), covered since by test_sweep_groups_that_keep_most_of_a_tile, which fails on
-        //  the old loop.)
+        //      for (; p + NT < kept; p += 2 * NT) { rec(p); rec(p + NT); }   if (p < kept) rec(p);
+        //  and came out with WRONG KEYS for the tail's lanes whenever other lanes of their wavefront ran one more pair
+        //  (kept mod 2 NT > NT).  Cause, read off the ISA: hipcc (ROCm 7.2) keeps emit()'s wave-uniform switches (2 q < ns1,
+        //  part_m > 1, ...) as lane masks and re-materialises them INSIDE the loop with vector compares under the current exec
+        //  ("v_cndmask_b32 v, 0, 1, s[c]; v_cmp_ne_u32_e64 s[m], 1, v": bits only for the lanes still looping); the tail behind
+        //  the loop tests the same s[m] for lanes that had left the loop earlier and reads zeros — every switch "on" for them.
+        //  Nothing in the source is wrong; loops whose lanes leave together, or code that does not follow such a loop with a copy
+        //  of its body, never show it.  tools/isa_lanemask_scan.py finds the shape in the assembly (the old build: 4 uses; every
+        //  device object of the library is scanned by `make isa-scan` / tests/test_capi_cpu.py), and
+        //  test_sweep_groups_that_keep_most_of_a_tile + the mid-size fuzz cover the values of `kept` that the all-kept and the
+        //  one-third-kept configurations never produce.  Found at full size by the C3 test.)
         auto rec = [&](uint32_t p) {
             const uint32_t li = s_idx[p];
             const uint2 bk = *reinterpret_cast<const uint2*>(&s_blk[2 * (li >> 5)]);

@@ -75,6 +75,8 @@ class OracleIndex:
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_start = np.ascontiguousarray(doc_start, dtype=np.uint64)
         assert len(doc_start) == len(ids) + 1
+        if len(doc_start) and int(doc_start[-1]) > len(blob):
+            raise ValueError(f"blob holds {len(blob)} bytes, doc_start[-1] = {int(doc_start[-1])}")
         _lib().orc_add_bulk(self._h, _ptr(ids), _ptr(blob), _ptr(doc_start), len(ids))
 
     def build(self, nthreads=0):

@@ -132,3 +132,28 @@ def test_no_result_changing_switch_in_the_product_library(lib):
         assert not re.search(r'getenv\("[A-Z_]*ABL', txt), f
         for m in re.finditer(r"#define\s+(RS_[A-Z]+_ABL)\s+(\S+)", txt):
             assert m.group(2) == "0", (f, m.group(0))
+
+
+def test_device_code_is_free_of_the_lane_mask_miscompile(tmp_path):
+    """Round 5 shipped wrong sweep records for half a day because of a compiler artefact, not a source error: wave-uniform switches
+    re-materialised as lane masks INSIDE a loop that lanes leave at different times, then tested behind the loop for the lanes that
+    had left (records_sweep.h, at phase B's loops).  tools/isa_lanemask_scan.py recognises that shape in the assembly: every device
+    object of the library must scan clean, and the scanner must still recognise the shape (a minimal listing of it)."""
+    import shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scan = os.path.join(root, "tools", "isa_lanemask_scan.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("\n".join([
+        "_Z1kv:", "\ts_branch .LBB0_2",
+        ".LBB0_1:                                ;   in Loop: Header=BB0_2 Depth=1",
+        "\ts_andn2_b64 exec, exec, s[30:31]", "\ts_cbranch_execz .LBB0_3",
+        ".LBB0_2:                                ; =>This Inner Loop Header: Depth=1",
+        "\tv_cndmask_b32_e64 v2, 0, 1, s[46:47]", "\tv_cmp_ne_u32_e64 s[22:23], 1, v2", "\ts_branch .LBB0_1",
+        ".LBB0_3:", "\ts_or_b64 exec, exec, s[30:31]", "\ts_and_b64 vcc, exec, s[22:23]", "\ts_cbranch_vccnz .LBB0_4",
+        ".LBB0_4:", "\ts_endpgm", ".Lfunc_end0:", ""]))
+    r = subprocess.run([sys.executable, scan, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "suspicious uses: 1" in r.stdout, r.stdout
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc: the library's own assembly is scanned where it is built")
+    r = subprocess.run(["make", "-C", os.path.join(root, "coffeedb_amd", "csrc"), "isa-scan", f"ISA_DIR={tmp_path}"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "suspicious uses: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -160,3 +160,63 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
         v = g.verify()
         assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"], (seed, kind, opts)
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_MID_N", "20"))))
+def test_fuzz_bucket_wise_with_documents_of_real_size(seed):
+    """The >= 2^32 code path on corpora whose documents are hundreds of bytes long — what the full-size configurations look like
+    and what the tiny-document fuzz above never reaches: tiles whose document table fits the LDS take the FAST phase B of the
+    sweeps (records_sweep.h), and with several bucket groups a sweep keeps an arbitrary share of every tile.  (Round 5 shipped a
+    loop that was wrong for tiles with 56-99 % kept for half a day: only the 32 GiB test saw it.)  2-7 MB per corpus: seconds in
+    the oracle."""
+    from coffeedb_amd import capi
+    from oracle import OracleIndex
+    rng = np.random.default_rng(52000 + seed)
+    nd = int(rng.integers(3000, 20000))
+    mean = int(rng.integers(60, 900))
+    lens = rng.integers(mean // 2, mean * 3 // 2 + 2, size=nd).astype(np.uint64)
+    if rng.random() < 0.3: lens[rng.integers(0, nd, size=nd // 50)] = 0                       # some empty documents (generic path tiles)
+    if rng.random() < 0.6: lens[int(rng.integers(0, nd))] = int(rng.integers(1 << 20, 1 << 21))   # (mostly) 8-byte entries
+    while int(lens.sum()) > 7_000_000: lens = lens[: len(lens) * 3 // 4]
+    nd = len(lens)
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    n = int(ds[-1])
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        lo = int(rng.integers(0x20, 0x60)); hi = int(min(0x7E, lo + rng.integers(1, 95)))
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), lo, hi)
+    elif kind == 1:
+        blob = W.zipf_corpus(1, n, seed=int(rng.integers(1 << 30)), nsym=int(rng.integers(8, 90)))[0][:n]
+    elif kind == 2:    # valid UTF-8 (bytes on both sides of 0x80: the reference's signed child order)
+        blob = W.utf8_corpus(1, n + n // 8 + 64, seed=int(rng.integers(1 << 30)))[0][:n].copy()   # (about 1.7 bytes per code point: cut from a longer one)
+    elif kind == 3:
+        lo = int(rng.integers(0, 120)); hi = int(min(255, lo + rng.integers(20, 253)))
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), lo, hi)
+    else:              # long repeats: groups the key cannot resolve
+        blob = W.random_bytes(n, int(rng.integers(1 << 30)), 0x61, 0x7A)
+        q = n // 4
+        blob[2 * q:3 * q] = blob[:q]
+    ids = rng.permutation(nd).astype(np.int64) * 3 + 1
+    opts = {"force_big_path": 1}
+    if rng.random() < 0.8: opts["bucket_group_limit"] = max(1, int(n * rng.uniform(0.08, 1.0)))
+    if rng.random() < 0.3: opts["vl_keys"] = int(rng.choice([0, 1, 24, 32, 40]))
+    if rng.random() < 0.25: opts["partial_symbol"] = 0
+    if rng.random() < 0.2: opts["pack_sa"] = 0
+    if rng.random() < 0.15: opts["sweep_records"] = 0
+    if rng.random() < 0.15: opts["plain_tile_order"] = 1
+    if rng.random() < 0.15: opts["force_doubling"] = 1
+    if rng.random() < 0.2: opts["initial_passes"] = int(rng.integers(2, 8))
+    g = capi.GpuStringIndex()
+    for k, v in opts.items():
+        g.set_option(k, v)
+    g.add_bulk(ids, blob, ds)
+    g.build()
+    info = (seed, kind, nd, n, opts, g.sa_width, g.stat("bucket_groups"), g.stat("sweep_records"))
+    assert g.stat("bucketed") == 1, info
+    assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0, info
+    o = OracleIndex(); o.add_bulk(ids, blob, ds); o.build(4); o.canonicalize()
+    assert np.array_equal(g.sa(), o.sa()), info
+    pb, po = W.sample_patterns(blob, ds, 100, 1, 9, seed=seed, miss_frac=0.1, miss_byte=int(blob[0]) ^ 0x55)
+    got, want = g.query_batch(pb, po), o.query_batch(pb, po)
+    assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])), info
+    g.close()
