@@ -3456,11 +3456,14 @@ void build_suffix_array(Index& ix) {
     if (ix.self_check && ix.size >= 2) {
         uint64_t sc[2] = {0, 0};
         auto check = [&]() {
-            // self_check = 1: 2^15 random adjacent pairs (a sample: notices a ranking that went wrong, which scatters inversions
-            // over the whole array; proves nothing about one stray pair).  self_check = 2: EVERY adjacent pair — a proof of the
-            // order at the cost of one sweep over the array with a random text access per entry (DESIGN §4.4 has the times).
+            // self_check = 1: n / 4096 random adjacent pairs, at least 2^15 and at most 2^21 (a sample: notices a ranking that went
+            // wrong, which scatters inversions over the whole array, and local damage down to a few thousand bad pairs per 2^32
+            // entries; proves nothing about one stray pair — round 5's wrong sweep records, 1 295 inversions among 8.6 x 10^9
+            // pairs, passed the 2^15 pairs of earlier rounds).  self_check = 2: EVERY adjacent pair — a proof of the order at
+            // the cost of one sweep over the array with a random text access per entry (DESIGN §4.4 has the times).
             const double tc = now_ms();
-            const uint32_t samples = ix.self_check >= 2 ? 0u : (uint32_t)std::min<uint64_t>(1u << 15, ix.size - 1);
+            const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 15, ix.size >> 12), 1u << 21);
+            const uint32_t samples = ix.self_check >= 2 ? 0u : (uint32_t)std::min<uint64_t>(want, ix.size - 1);
             spot_check_suffix_array(ix, samples, sc);
             ix.self_check_pairs = samples ? samples : ix.size - 1;
             ix.self_check_ms = now_ms() - tc;
