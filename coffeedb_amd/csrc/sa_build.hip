@@ -1361,6 +1361,62 @@ __global__ __launch_bounds__(256) void sa_flag_compact_kernel(const uint8_t* __r
     }
 }
 
+// The refinement's sort, specialised for what it sorts: the compacted list is ALREADY ordered by group (the group id sits in the
+// key's high bits and ascends with the list), so "sort by (group, minor key)" only permutes entries INSIDE their group — runs of two
+// or three entries on every named configuration (8 GiB of Zipf text: 28 242 of 2.07 x 10^8 entries sit in groups of more than 49,
+// 6 in groups of more than 257).  One pass instead of the general sort's eight: an entry looks at the members of its group on both
+// sides (neighbouring list slots: cached lines) and takes the slot
+//     j - #{members in front with a greater key} + #{members behind with a smaller key}
+// — the stable order, slot for slot what the LSD passes produce.  The work is the sum of the SQUARED group sizes, so it is bounded:
+// an entry that walks more than GS_FREE members reports its walk to a global counter, and once the walks add up to more than
+// `budget` members (16 per entry of the list), or a group exceeds `cap` members on one side of an entry, `state[0]` is raised — every
+// thread gives up at its next look at it and the caller falls back to the general sort (duplicated documents: groups of thousands).
+constexpr uint32_t GS_FREE = 32;  // (walks this short cost no more than the general sort would: never reported)
+template <typename V>
+__global__ __launch_bounds__(256) void sa_group_sort_kernel(const uint64_t* __restrict__ kin, const V* __restrict__ vin, uint64_t m, int kbits, uint32_t cap,
+                                                            unsigned long long budget, uint64_t* __restrict__ kout, V* __restrict__ vout,
+                                                            unsigned long long* __restrict__ state /* [0] gave up, [1] members walked by long walks */) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const volatile unsigned long long* vstate = state;
+    if (vstate[0]) return;
+    const uint64_t k = kin[j];
+    const uint64_t g = kbits >= 64 ? 0ull : k >> kbits;
+    auto gid = [&](uint64_t x) { return kbits >= 64 ? 0ull : x >> kbits; };
+    uint64_t pos = j;
+    uint32_t walked = 0;
+    bool too = false;
+    {
+        uint32_t d = 1;
+        for (; d <= cap && j >= d; ++d) {
+            const uint64_t o = kin[j - d];
+            if (gid(o) != g) break;
+            pos -= (uint64_t)(o > k);
+            if ((d & 127u) == 0 && vstate[0]) return;
+        }
+        too = d > cap && j >= d && gid(kin[j - d]) == g;
+        walked += d - 1;
+    }
+    if (!too) {
+        uint32_t d = 1;
+        for (; d <= cap && j + d < m; ++d) {
+            const uint64_t o = kin[j + d];
+            if (gid(o) != g) break;
+            pos += (uint64_t)(o < k);
+            if ((d & 127u) == 0 && vstate[0]) return;
+        }
+        too = d > cap && j + d < m && gid(kin[j + d]) == g;
+        walked += d - 1;
+    }
+    if (walked > GS_FREE && !too) too = atomicAdd(&state[1], (unsigned long long)walked) + walked > budget;
+    if (too) {
+        atomicExch(&state[0], 1ull);
+        return;
+    }
+    kout[pos] = k;
+    vout[pos] = vin[j];
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void sa_newhead_kernel(const uint64_t* __restrict__ skey, const I* __restrict__ U,
                                                          const uint8_t* __restrict__ flags, uint64_t m,
@@ -3205,6 +3261,9 @@ void build_typed(Index& ix, bool big) {
     uint64_t cap = 0;
     DevBuf d_open;  // entries still unresolved after the last round (saves a full flag scan to learn "none")
     d_open.alloc(sizeof(uint64_t));
+    DevBuf d_gs_state;  // sa_group_sort_kernel: [0] it gave up (groups too long for it), [1] members walked by its long walks
+    d_gs_state.alloc(2 * sizeof(unsigned long long));
+    bool group_sort_on = ix.group_sort;
     // (generic over the array's storage: SaRW<V> = plain entries, Sa40RW = packed 5-byte entries, index_impl.h)
     auto refine = [&](auto sa) {
     using SAW = decltype(sa);
@@ -3287,9 +3346,30 @@ void build_typed(Index& ix, bool big) {
                                    vl_kb1 ? (const uint8_t*)d_vl_bytelen.as<uint8_t>() : nullptr, vl_kb1, h_acc, vl_kb1 ? hcov.as<uint8_t>() : nullptr);
             ix.prof.end(t, "sa_compact", n + m * (sizeof(I) + 8 + 2 * sizeof(V)), s);
         }
-        const int rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
-                                               sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss, ix.sort_variant);
-        radix_check_error(s, ix.rws);  // (sa_update scatters through the sorted values: never after a failed sort)
+        int rs = -1;
+        if (group_sort_on) {  // one pass inside the groups (sa_group_sort_kernel); groups too long for it: the general sort, from now on
+            CDB_HIP(hipMemsetAsync(d_gs_state.p, 0, 2 * sizeof(unsigned long long), s));
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL((sa_group_sort_kernel<V>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s, (const uint64_t*)skey[0].as<uint64_t>(),
+                               (const V*)sval[0].as<V>(), m, kbits, (uint32_t)ix.group_sort_cap, (unsigned long long)(16 * m + (1u << 20)),
+                               skey[1].as<uint64_t>(), sval[1].as<V>(), d_gs_state.as<unsigned long long>());
+            ix.prof.end(t, "sa_group_sort", m * 2 * (8 + sizeof(V)), s);
+            unsigned long long gave_up = 0;
+            CDB_HIP(hipMemcpyAsync(&gave_up, d_gs_state.p, sizeof(gave_up), hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            if (gave_up) {
+                group_sort_on = false;
+                st.group_sort_fallbacks++;
+            } else {
+                rs = 1;
+                st.group_sorts++;
+            }
+        }
+        if (rs < 0) {
+            rs = radix_sort<uint64_t, V>(s, ix.rws, ix.prof, skey[0].as<uint64_t>(), skey[1].as<uint64_t>(),
+                                         sval[0].as<V>(), sval[1].as<V>(), m, 0, kbits + gbits, &ss, ix.sort_variant);
+            radix_check_error(s, ix.rws);  // (sa_update scatters through the sorted values: never after a failed sort)
+        }
         hipLaunchKernelGGL((sa_newhead_kernel<I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                            (const uint64_t*)skey[rs].as<uint64_t>(), (const I*)U.as<I>(),
                            (const uint8_t*)flags.as<uint8_t>(), m, nh.as<uint8_t>());

@@ -1620,3 +1620,38 @@ def test_sweep_groups_that_keep_most_of_a_tile(G):
         for frac in (0.55, 0.62, 0.75, 0.9, 0.97):
             g, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, bucket_group_limit=int(n * frac), vl_keys=vl)
             assert g.stat("sweep_records") == 1 and g.stat("bucket_groups") >= 2, (lo, hi, frac, g.stat("bucket_groups"))
+
+
+def test_refinement_sorts_inside_its_groups_in_one_pass(G):
+    # the compacted list of a refinement round is ordered by group already: one pass that permutes entries inside their groups
+    # (sa_group_sort_kernel) replaces the general sort's eight; groups of more than 49 entries (duplicated documents) send the build
+    # back to the general sort.  Array against array with group_sort = 0, both paths (below and above 2^32), both refinements.
+    blob, ds = W.ascii_corpus(3000, 300, seed=5, lo=0x61, hi=0x64)              # 4 symbols: most suffixes need refinement rounds
+    pats = W.sample_patterns(blob, ds, 80, 2, 10, seed=2)
+    for opts in ({}, {"force_big_path": 1}, {"force_doubling": 1}, {"force_big_path": 1, "force_doubling": 1, "bucket_group_limit": 300000}):
+        g1, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
+        g0, _ = _check_parity(G, blob, ds, patterns=pats, group_sort=0, **opts)
+        assert g1.stat("group_sorts") >= 1 and g1.stat("group_sort_fallbacks") == 0, (opts, g1.stat("group_sorts"))
+        assert g0.stat("group_sorts") == 0 and np.array_equal(g0.sa(), g1.sa())
+        assert g1.stat("rounds") == g0.stat("rounds")
+    # 200 copies of one document: groups of 200 equal suffixes everywhere — the pass's work (the squared group sizes) runs over its
+    # budget of 16 walked members per entry, it gives up, and the general sort takes over for the rest of the build
+    doc = W.random_bytes(400, 3, 0x61, 0x7A)
+    blob = np.concatenate([doc] * 200 + [W.random_bytes(50000, 4, 0x61, 0x7A)])
+    ds = np.concatenate([np.arange(0, 201, dtype=np.uint64) * 400, [len(blob)]]).astype(np.uint64)
+    for opts in ({}, {"force_big_path": 1}):
+        g, _ = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 50, 3, 12, seed=1), **opts)
+        assert g.stat("group_sort_fallbacks") == 1 and g.stat("rounds") >= 2, (opts, g.stat("group_sorts"), g.stat("rounds"))
+    # ... 60 copies of a SHORT document among others: groups of 60 (walks beyond the free 32 members, reported) within the budget
+    doc = W.random_bytes(40, 9, 0x41, 0x5A)
+    blob = np.concatenate([doc] * 60 + [W.random_bytes(300_000, 8, 0x61, 0x7A)])
+    ds = np.concatenate([np.arange(0, 61, dtype=np.uint64) * 40, [len(blob)]]).astype(np.uint64)
+    g, _ = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 30, 3, 9, seed=1))
+    assert g.stat("group_sort_fallbacks") == 0 and g.stat("group_sorts") >= 1, (g.stat("group_sort_fallbacks"), g.stat("group_sorts"))
+    # the limit on a group's members on one side of an entry, set to 48 for the test: 49 copies pass, 50 do not
+    for copies, fb in ((49, 0), (50, 1)):
+        doc = W.random_bytes(40, 9, 0x41, 0x5A)
+        blob = np.concatenate([doc] * copies + [W.random_bytes(30000, 8, 0x61, 0x7A)])
+        ds = np.concatenate([np.arange(0, copies + 1, dtype=np.uint64) * 40, [len(blob)]]).astype(np.uint64)
+        g, _ = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 30, 3, 9, seed=1), group_sort_cap=48)
+        assert g.stat("group_sort_fallbacks") == fb, (copies, g.stat("group_sort_fallbacks"), g.stat("group_sorts"))
