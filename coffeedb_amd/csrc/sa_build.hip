@@ -1193,6 +1193,26 @@ struct CompactOut {
     }
 };
 
+// The same compaction from the PREVIOUS round's list (text-extension rounds behind the first): only entries of that list can still be
+// open, and sa_update left their new flag bytes in list order (`lf`), so the wave-autonomous flag sweeps run over m bytes instead of
+// the array's n, and the entries come from the sorted list instead of a gather through the suffix array.
+template <typename V, typename I>
+struct CompactListOut {
+    const I* Uo;
+    const V* svo;
+    I* U;
+    uint64_t* skey;
+    V* sval;
+    int kbits;
+    __device__ __forceinline__ void operator()(uint64_t j, const U2& ex, const U2& in) const {
+        if (in.a == ex.a) return;  // not an unresolved entry
+        const uint64_t jj = ex.a;
+        U[jj] = Uo[j];
+        skey[jj] = (in.b - 1) << kbits;  // group id
+        sval[jj] = svo[j];
+    }
+};
+
 // minor sort key of every compacted entry: the rank of the suffix h symbols further on (prefix
 // doubling) or the next nsym2 symbols read from the text (text extension)
 template <typename V, typename R, bool USE_ISA>
@@ -1431,7 +1451,7 @@ template <typename SAW, typename I, bool WANT_POS = true>
 __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename SAW::val* sval, const I* U, const uint8_t* nh,
                                          const uint64_t* doc_start, int bits, uint64_t mask, uint64_t hnew, SAW sa,
                                          uint8_t* flags, uint64_t& ext_pos, unsigned long long* still_open,
-                                         const uint8_t* hcov = nullptr, uint32_t h_add = 0) {
+                                         const uint8_t* hcov = nullptr, uint32_t h_add = 0, uint8_t* lf = nullptr) {
     if (hcov) hnew = (uint64_t)hcov[j] + h_add;  // (variable-length keys: the group's own depth; slot j stays inside its group through the sort)
     const typename SAW::val v = sval[j];
     const uint64_t i = U[j];
@@ -1449,6 +1469,7 @@ __device__ __forceinline__ void sa_place(uint64_t j, uint64_t m, const typename 
     const bool open = !(head && last) && !exhausted;
     sa.store(i, v);
     flags[i] = (uint8_t)((head ? 1 : 0) | (open ? 2 : 0));
+    if (lf) lf[j] = (uint8_t)((head ? 1 : 0) | (open ? 2 : 0));  // (the same byte in list order: the next round compacts from the list)
     if (open) atomicAdd(still_open, 1ull);  // the compiler folds this into one add per wave
     ext_pos = ds + d + off;
 }
@@ -1460,11 +1481,11 @@ __global__ __launch_bounds__(256) void sa_update_kernel(const typename SAW::val*
                                                         uint64_t mask, uint64_t hnew, SAW sa,
                                                         uint8_t* __restrict__ flags,
                                                         unsigned long long* __restrict__ still_open,
-                                                        const uint8_t* __restrict__ hcov = nullptr, uint32_t h_add = 0) {
+                                                        const uint8_t* __restrict__ hcov = nullptr, uint32_t h_add = 0, uint8_t* __restrict__ lf = nullptr) {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     uint64_t q;
-    sa_place<SAW, I, false>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open, hcov, h_add);
+    sa_place<SAW, I, false>(j, m, sval, U, nh, doc_start, bits, mask, hnew, sa, flags, q, still_open, hcov, h_add, lf);
 }
 
 template <typename I>
@@ -3261,6 +3282,10 @@ void build_typed(Index& ix, bool big) {
     uint64_t cap = 0;
     DevBuf d_open;  // entries still unresolved after the last round (saves a full flag scan to learn "none")
     d_open.alloc(sizeof(uint64_t));
+    DevBuf U2b, lf;       // list-based rounds: the other list of positions, the flag bytes of the current list in list order
+    bool have_list = false;  // the last round was a text-extension round: lf / U / sval[list_rs] describe its list
+    uint64_t m_list = 0;
+    int list_rs = 0;
     DevBuf d_gs_state;  // sa_group_sort_kernel: [0] it gave up (groups too long for it), [1] members walked by its long walks
     d_gs_state.alloc(2 * sizeof(unsigned long long));
     bool group_sort_on = ix.group_sort;
@@ -3283,10 +3308,21 @@ void build_typed(Index& ix, bool big) {
                                (const uint8_t*)flags.as<uint8_t>(), n, nb, ix.scan_partials.as<U2>());
             ix.prof.end(t, "sa_flag_count", n, s);
         };
-        if (!tile_sums_ready) flag_tile_sums();
-        const U2 tot = scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0});
+        bool from_list = have_list && ix.list_rounds;  // (this round's unresolved entries are a subset of the previous round's list)
+        have_list = false;
+        if (from_list) {
+            const uint64_t nb = ceil_div(m_list, SC_TILE);
+            ix.scan_partials.ensure(scan_partials_slots(nb) * sizeof(U2));
+            int t = ix.prof.begin(s);
+            hipLaunchKernelGGL(sa_flag_count_kernel, dim3((unsigned)ceil_div(nb, (uint64_t)(4 * FC_TILES_PER_WAVE))), dim3(256), 0, s,
+                               (const uint8_t*)lf.as<uint8_t>(), m_list, nb, ix.scan_partials.as<U2>());
+            ix.prof.end(t, "sa_flag_count", m_list, s);
+        } else if (!tile_sums_ready) {
+            flag_tile_sums();
+        }
+        U2 tot = scan_totals_from_partials<U2>(s, ix.scan_partials, from_list ? m_list : n, OpAdd{}, U2{0, 0});
         tile_sums_ready = false;
-        const uint64_t m = tot.a, G = tot.b;
+        uint64_t m = tot.a, G = tot.b;
         if (st.rounds == 0) st.unresolved_initial = m;
         st.unresolved_max = std::max(st.unresolved_max, m);
         if (m == 0) break;
@@ -3312,7 +3348,9 @@ void build_typed(Index& ix, bool big) {
                 ix.prof.end(t, "sa_isa_init", n * (1 + sizeof(V) + sizeof(R)), s);
                 isa = true;
                 st.isa_built = 1;
-                // the partials buffer now belongs to the max-scan: redo the compaction totals
+                // the partials buffer now belongs to the max-scan: redo the compaction totals (from the array: the doubling rounds
+                // do not keep a list)
+                from_list = false;
                 flag_tile_sums();
                 (void)scan_totals_from_partials<U2>(s, ix.scan_partials, n, OpAdd{}, U2{0, 0});
             }
@@ -3327,14 +3365,30 @@ void build_typed(Index& ix, bool big) {
             sval[0].alloc(m * sizeof(V));
             sval[1].alloc(m * sizeof(V));
             nh.alloc(m);
+            lf.alloc(m + 16);
             if (vl_kb1) hcov.alloc(m);
         }
         {
             int t = ix.prof.begin(s);
+            if (from_list) {
+                if (list_rs == 0) {  // the sorted list must not be the compaction's target
+                    std::swap(skey[0], skey[1]);
+                    std::swap(sval[0], sval[1]);
+                    list_rs = 1;
+                }
+                U2b.ensure(cap * sizeof(I));
+                CompactListOut<V, I> co{(const I*)U.as<I>(), (const V*)sval[1].as<V>(), U2b.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
+                hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(ceil_div(m_list, SC_TILE), (uint64_t)(4 * FC_TILES_PER_WAVE))),
+                                   dim3(256), 0, s, (const uint8_t*)lf.as<uint8_t>(), m_list, (uint64_t)ceil_div(m_list, SC_TILE),
+                                   (const U2*)ix.scan_partials.as<U2>(), co);
+                std::swap(U, U2b);
+                st.list_rounds++;
+            } else {
             CompactOut<SAW, I> co{sa, U.as<I>(), skey[0].as<uint64_t>(), sval[0].as<V>(), kbits};
             hipLaunchKernelGGL((sa_flag_compact_kernel<decltype(co)>), dim3((unsigned)ceil_div(ceil_div(n, SC_TILE), (uint64_t)(4 * FC_TILES_PER_WAVE))),
                                dim3(256), 0, s, (const uint8_t*)flags.as<uint8_t>(), n, (uint64_t)ceil_div(n, SC_TILE),
                                (const U2*)ix.scan_partials.as<U2>(), co);
+            }
             if (isa)
                 hipLaunchKernelGGL((sa_round_keys_kernel<V, R, true>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[0].as<V>(), m, doc_start, text, (const uint16_t*)d_symmap.as<uint16_t>(),
@@ -3387,9 +3441,12 @@ void build_typed(Index& ix, bool big) {
                 hipLaunchKernelGGL((sa_update_kernel<SAW, I>), dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, s,
                                    (const V*)sval[rs].as<V>(), (const I*)U.as<I>(), (const uint8_t*)nh.as<uint8_t>(), m,
                                    doc_start, (int)ix.bits, ix.mask, hnew, sa, flags.as<uint8_t>(), d_open.as<unsigned long long>(),
-                                   vl_kb1 ? (const uint8_t*)hcov.as<uint8_t>() : nullptr, h_acc + (uint32_t)nsym2);
+                                   vl_kb1 ? (const uint8_t*)hcov.as<uint8_t>() : nullptr, h_acc + (uint32_t)nsym2, lf.as<uint8_t>());
                 h_acc += (uint32_t)nsym2;
                 st.ext_rounds++;
+                have_list = true;
+                m_list = m;
+                list_rs = rs;
             }
             ix.prof.end(t, "sa_update", m * (2 * sizeof(V) + sizeof(I) + 2 + (isa ? sizeof(R) : 0)), s);
         }

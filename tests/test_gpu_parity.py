@@ -1655,3 +1655,22 @@ def test_refinement_sorts_inside_its_groups_in_one_pass(G):
         ds = np.concatenate([np.arange(0, copies + 1, dtype=np.uint64) * 40, [len(blob)]]).astype(np.uint64)
         g, _ = _check_parity(G, blob, ds, patterns=W.sample_patterns(blob, ds, 30, 3, 9, seed=1), group_sort_cap=48)
         assert g.stat("group_sort_fallbacks") == fb, (copies, g.stat("group_sort_fallbacks"), g.stat("group_sorts"))
+
+
+def test_later_refinement_rounds_compact_from_the_previous_list(G):
+    # text-extension rounds behind the first take their unresolved entries from the previous round's list (its flag bytes in list
+    # order, its sorted entries) instead of sweeping the whole flag array and gathering through the suffix array again
+    blob, ds = W.ascii_corpus(4000, 300, seed=11, lo=0x61, hi=0x7A)               # 1.2 MB of random letters ...
+    for d in range(20):                                                           # ... and 20 documents that occur twice: a small share
+        blob[int(ds[2000 + d]):int(ds[2001 + d])] = blob[int(ds[d]):int(ds[d + 1])]  # of suffixes with common prefixes of up to 300 symbols
+    pats = W.sample_patterns(blob, ds, 80, 2, 12, seed=2)
+    seen = 0
+    for opts in ({}, {"force_big_path": 1}, {"force_big_path": 1, "bucket_group_limit": 500000, "vl_keys": 1}, {"group_sort": 0}, {"initial_passes": 2}):
+        g1, _ = _check_parity(G, blob, ds, patterns=pats, **opts)
+        g0, _ = _check_parity(G, blob, ds, patterns=pats, list_rounds=0, **opts)
+        assert g0.stat("list_rounds") == 0 and np.array_equal(g0.sa(), g1.sa()), opts
+        assert g1.stat("rounds") == g0.stat("rounds") and g1.stat("ext_rounds") == g0.stat("ext_rounds"), opts
+        # every text-extension round behind the first comes from the list (the doubling rounds keep no list)
+        assert g1.stat("list_rounds") == max(0, g1.stat("ext_rounds") - 1), (opts, g1.stat("list_rounds"), g1.stat("ext_rounds"), g1.stat("rounds"))
+        seen += int(g1.stat("list_rounds"))
+    assert seen >= 3, seen
