@@ -1631,6 +1631,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "partial_symbol")) ix.partial_symbol = value != 0;
     else if (!std::strcmp(name, "group_sort")) ix.group_sort = value != 0;
     else if (!std::strcmp(name, "list_rounds")) ix.list_rounds = value != 0;
+    else if (!std::strcmp(name, "fuse_pairclass")) ix.fuse_pairclass = value != 0;
     else if (!std::strcmp(name, "group_sort_cap")) ix.group_sort_cap = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20));
     else if (!std::strcmp(name, "vl_keys")) ix.vl_keys = value < 0 ? 0 : (value > 56 ? 56 : (int)value);
     else if (!std::strcmp(name, "pack_sa")) ix.pack_sa = value != 0;
@@ -1683,7 +1684,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"sweep_records", (double)b.sweep_records}, {"vl_key_bits", (double)b.vl_key_bits}, {"partial_levels", (double)b.partial_levels}, {"list_rounds", (double)b.list_rounds}, {"group_sorts", (double)b.group_sorts}, {"group_sort_fallbacks", (double)b.group_sort_fallbacks}, {"vl_avg_len", b.vl_avg_len}, {"vl_rate", b.vl_rate}, {"vl_est_unresolved", b.vl_est_unresolved}, {"fixed_est_unresolved", b.fixed_est_unresolved}, {"gen_prebased", (double)b.gen_prebased}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"sweep_records", (double)b.sweep_records}, {"vl_key_bits", (double)b.vl_key_bits}, {"partial_levels", (double)b.partial_levels}, {"list_rounds", (double)b.list_rounds}, {"pairclass_fused", (double)b.pairclass_fused}, {"group_sorts", (double)b.group_sorts}, {"group_sort_fallbacks", (double)b.group_sort_fallbacks}, {"vl_avg_len", b.vl_avg_len}, {"vl_rate", b.vl_rate}, {"vl_est_unresolved", b.vl_est_unresolved}, {"fixed_est_unresolved", b.fixed_est_unresolved}, {"gen_prebased", (double)b.gen_prebased}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

@@ -34,6 +34,7 @@ struct BuildStats {
     int gen_prebased = 0;        // ... generated pass without look-back (counted tile bases)
     int fused_records = 0;       // ... bucket records written by the generated pass itself (one bucket group): no partition + gather
     int sweep_records = 0;       // ... bucket records of every bucket group written by a sweep over the text (records_sweep.h): no partition + gather
+    int pairclass_fused = 0;     // reference order, one level below the root: next-byte classes counted beside the bytes (no second sweep over the text)
     int list_rounds = 0;         // refinement rounds compacted from the previous round's list instead of the whole flag array
     int group_sorts = 0, group_sort_fallbacks = 0;  // refinement rounds sorted inside their groups in one pass / sent to the general sort
     int partial_levels = 0;      // ... leftover key bits hold the next symbol quantised to this many levels (sweep form; 0 / 1 = none)
@@ -229,6 +230,7 @@ struct Index {
     bool segmented_sort = true;  // bucket-wise build: one launch per radix pass for all buckets of a group, entries and flags
                                  // written by the last pass (0 = one sort per bucket + assemble + flag kernels: round 2)
     bool fuse_records = true;  // bucket-wise build with ONE bucket group: the generated pass writes the records (0 = partition + gather)
+    bool fuse_pairclass = true; // bucket-wise build of text with bytes >= 0x80: next-byte classes counted by the tile byte count (0 = separate sweep)
     bool list_rounds = true;    // text-extension rounds behind the first compact from the previous round's list (0 = from the flag array)
     int group_sort_cap = 4096;  // ... members of a group on one side of an entry beyond which the pass gives up (its work is also bounded, sa_build.hip)
     bool group_sort = true;     // refinement rounds: one pass inside the groups instead of the general sort (0 = always the general sort)

@@ -84,14 +84,22 @@ __global__ __launch_bounds__(256) void sa_bytecount_kernel(const uint8_t* __rest
 // their columns mapped byte -> bucket slot, are the per-tile digit counts of the records / partition pass, and their column sums
 // are the byte histogram.  Wave-autonomous like sa_tile_paircount_kernel below.
 constexpr uint32_t TBC_TILES_PER_WAVE = 8;
-__global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t tiles, uint32_t* __restrict__ counts) {
+// PAIR (round 5): the same sweep also counts, per byte value, the positions whose NEXT byte is >= 0x80 (sa_pairclass_kernel's
+// pair[b][1], document ends ignored as there): the counter index carries that bit (byte | next_high << 8, 512 counters per copy
+// instead of 256 — still one LDS atomic per position), a tile's row is the sum of both halves, the upper halves add up in four
+// registers per lane and reach `pair_hi[b]` once per wavefront.  Saves the reference-order build its second sweep over the text.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t tiles, uint32_t* __restrict__ counts,
+                                                                unsigned long long* __restrict__ pair_hi /*[256], PAIR only*/) {
     // (four copies of a wave's counters, by lane — and 8 banks apart: text is skewed, a copy stride of 256 words would leave the
     //  four counters of a frequent byte on ONE bank, where their atomics serialise just as on one address)
-    constexpr int CS = 256 + 8;
+    constexpr int NB = PAIR ? 512 : 256;
+    constexpr int CS = NB + 8;
     __shared__ uint32_t s_cnt[4][4 * CS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     uint32_t* cnt = &s_cnt[wave][(lane & 3) * CS];
     uint32_t* call = &s_cnt[wave][0];
+    uint32_t pc[4] = {0, 0, 0, 0};
     for (uint32_t k = 0; k < TBC_TILES_PER_WAVE; ++k) {
         const uint32_t tile = (blockIdx.x * 4u + (uint32_t)wave) * TBC_TILES_PER_WAVE + k;
         if (tile >= tiles) break;  // (uniform per wavefront)
@@ -103,20 +111,45 @@ __global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* _
 #pragma unroll 2
         for (int r = 0; r < VEC; ++r) {
             const uint64_t p = b0 + ((uint64_t)r * 64 + lane) * 16;
-            if (p >= n) continue;
-            if (p + 16 <= n) {
+            uint32_t x[4] = {0, 0, 0, 0};
+            const bool full = p + 16 <= n;
+            if (full) {
                 const uint4 v = *reinterpret_cast<const uint4*>(text + p);
-                const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            }
+            uint32_t follow = 0;  // PAIR: the byte behind this lane's sixteen (the neighbour lane's first; lane 63 reads it)
+            if constexpr (PAIR) {
+                follow = __shfl_down(x[0] & 0xFFu, 1);
+                if (lane == 63 || !full) follow = p + 16 < n ? (uint32_t)text[p + 16] : 0u;
+                // (a neighbour lane without a full vector handed over 0: only the last vectors of the text, whose own lanes take the
+                //  byte-wise path below — the lane in front of them reads its follower itself)
+                const uint64_t pn = p + 16;
+                if (full && lane != 63 && !(pn + 16 <= n)) follow = pn < n ? (uint32_t)text[pn] : 0u;
+            }
+            if (p >= n) continue;
+            if (full) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    atomicAdd(&cnt[x[q] & 0xFF], 1u);
-                    atomicAdd(&cnt[(x[q] >> 8) & 0xFF], 1u);
-                    atomicAdd(&cnt[(x[q] >> 16) & 0xFF], 1u);
-                    atomicAdd(&cnt[x[q] >> 24], 1u);
+                    if constexpr (PAIR) {
+                        const uint32_t nx = q < 3 ? x[q + 1] & 0xFFu : follow;  // the byte behind this dword
+                        atomicAdd(&cnt[(x[q] & 0xFF) | ((x[q] >> 7) & 0x100u)], 1u);
+                        atomicAdd(&cnt[((x[q] >> 8) & 0xFF) | ((x[q] >> 15) & 0x100u)], 1u);
+                        atomicAdd(&cnt[((x[q] >> 16) & 0xFF) | ((x[q] >> 23) & 0x100u)], 1u);
+                        atomicAdd(&cnt[(x[q] >> 24) | ((nx << 1) & 0x100u)], 1u);
+                    } else {
+                        atomicAdd(&cnt[x[q] & 0xFF], 1u);
+                        atomicAdd(&cnt[(x[q] >> 8) & 0xFF], 1u);
+                        atomicAdd(&cnt[(x[q] >> 16) & 0xFF], 1u);
+                        atomicAdd(&cnt[x[q] >> 24], 1u);
+                    }
                 }
             } else {
                 for (int q = 0; q < 16; ++q)
-                    if (p + q < n) atomicAdd(&cnt[text[p + q]], 1u);
+                    if (p + q < n) {
+                        uint32_t idx = text[p + q];
+                        if constexpr (PAIR) idx |= (p + q + 1 < n ? ((uint32_t)text[p + q + 1] << 1) & 0x100u : 0u);
+                        atomicAdd(&cnt[idx], 1u);
+                    }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -124,10 +157,31 @@ __global__ __launch_bounds__(256) void sa_tile_bytecount_kernel(const uint8_t* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int dgt = q * 64 + lane;
-            counts[(size_t)tile * 256 + dgt] = call[dgt] + call[CS + dgt] + call[2 * CS + dgt] + call[3 * CS + dgt];
+            uint32_t c = call[dgt] + call[CS + dgt] + call[2 * CS + dgt] + call[3 * CS + dgt];
+            if constexpr (PAIR) {
+                const uint32_t hi = call[256 + dgt] + call[CS + 256 + dgt] + call[2 * CS + 256 + dgt] + call[3 * CS + 256 + dgt];
+                c += hi;
+                pc[q] += hi;  // (a wavefront counts at most 8 x 8192 positions: no overflow)
+            }
+            counts[(size_t)tile * 256 + dgt] = c;
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (pc[q]) atomicAdd(&pair_hi[q * 64 + lane], (unsigned long long)pc[q]);
+    }
+}
+// any byte >= 0x80 among the first `len` bytes?  (decides whether the byte count is worth its PAIR form before anything is known
+// about the text; a text whose high bytes only start later pays sa_pairclass_kernel's separate sweep as before)
+__global__ __launch_bounds__(256) void sa_sample_high_kernel(const uint8_t* __restrict__ text, uint64_t len, uint32_t* __restrict__ flag) {
+    bool hi = false;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w * 16 + 16 <= len; w += (uint64_t)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + w * 16);
+        hi = hi || ((v.x | v.y | v.z | v.w) & 0x80808080u);
+    }
+    if (__builtin_amdgcn_ballot_w64(hi) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // MSD-first initial sort, pair form (radix_sort.h: TextGen::msd_pair): how often every pair of symbol CODES (c0, c1) starts
@@ -1886,11 +1940,27 @@ void build_typed(Index& ix, bool big) {
     const uint32_t tiles8 = (uint32_t)ceil_div(n, (uint64_t)RS_GEN8_TILE);
     const bool tile_bytes = big && sizeof(V) == 8 && ix.gen_prebased && ix.segmented_sort && rs_atomic_rank_ok(s);
     const unsigned long long* d_count_src = d_counts.as<unsigned long long>();
+    DevBuf d_pair_hi;      // per byte value: positions whose next byte is >= 0x80 (counted beside the bytes, PAIR form)
+    bool pair_hi_counted = false;
     if (tile_bytes) {
         d_tbc.alloc((size_t)tiles8 * 256 * sizeof(uint32_t));
+        if (ix.reference_compat && ix.fold_root && ix.fold_depth1 && ix.fuse_pairclass) {
+            // the reference-order build will want the next-byte classes if the text holds bytes >= 0x80: ask its first MiB
+            d_pair_hi.alloc(257 * sizeof(unsigned long long));
+            CDB_HIP(hipMemsetAsync(d_pair_hi.p, 0, 257 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(sa_sample_high_kernel, dim3(64), dim3(256), 0, s, text, std::min<uint64_t>(n, 1u << 20), reinterpret_cast<uint32_t*>(d_pair_hi.as<unsigned long long>() + 256));
+            uint32_t any = 0;
+            CDB_HIP(hipMemcpyAsync(&any, d_pair_hi.as<unsigned long long>() + 256, sizeof(any), hipMemcpyDeviceToHost, s));
+            CDB_HIP(hipStreamSynchronize(s));
+            pair_hi_counted = any != 0;
+        }
         int t = ix.prof.begin(s);
-        hipLaunchKernelGGL(sa_tile_bytecount_kernel, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TBC_TILES_PER_WAVE))), dim3(256), 0, s, text, n,
-                           tiles8, d_tbc.as<uint32_t>());
+        if (pair_hi_counted)
+            hipLaunchKernelGGL(sa_tile_bytecount_kernel<true>, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TBC_TILES_PER_WAVE))), dim3(256), 0, s, text, n,
+                               tiles8, d_tbc.as<uint32_t>(), d_pair_hi.as<unsigned long long>());
+        else
+        hipLaunchKernelGGL(sa_tile_bytecount_kernel<false>, dim3((unsigned)ceil_div((uint64_t)tiles8, (uint64_t)(4 * TBC_TILES_PER_WAVE))), dim3(256), 0, s, text, n,
+                           tiles8, d_tbc.as<uint32_t>(), (unsigned long long*)nullptr);
         d_count_src = rs_tile_totals(s, ix.tbw, d_tbc.as<uint32_t>(), tiles8, nullptr);
         ix.prof.end(t, "sa_tile_bytecount", n + (uint64_t)tiles8 * 2048, s);
     } else {
@@ -2681,6 +2751,7 @@ void build_typed(Index& ix, bool big) {
                 d_cls.alloc((512 + 768) * sizeof(uint64_t));
                 CDB_HIP(hipMemsetAsync(d_cls.p, 0, (512 + 768) * sizeof(uint64_t), s));
                 int t = ix.prof.begin(s);
+                if (!pair_hi_counted)  // (counted beside the bytes otherwise: sa_tile_bytecount_kernel<true>)
                 hipLaunchKernelGGL(sa_pairclass_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(n, 256 * 16 * 4), 2048))),
                                    dim3(256), 0, s, text, n, d_cls.as<unsigned long long>());
                 hipLaunchKernelGGL(sa_docend_class_kernel, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ceil_div(D, 256), 1024))),
@@ -2688,7 +2759,16 @@ void build_typed(Index& ix, bool big) {
                 ix.prof.end(t, "sa_pairclass", n + D * 18, s);
                 std::vector<uint64_t> cls(512 + 768);
                 CDB_HIP(hipMemcpyAsync(cls.data(), d_cls.p, cls.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+                uint64_t h_pair_hi[256];
+                if (pair_hi_counted) CDB_HIP(hipMemcpyAsync(h_pair_hi, d_pair_hi.p, sizeof(h_pair_hi), hipMemcpyDeviceToHost, s));
                 CDB_HIP(hipStreamSynchronize(s));
+                if (pair_hi_counted) {
+                    for (int b = 0; b < 256; ++b) {
+                        cls[2 * b + 1] = h_pair_hi[b];
+                        cls[2 * b] = h_counts[b] - h_pair_hi[b];
+                    }
+                    st.pairclass_fused = 1;
+                }
                 const uint64_t chuck1 = std::max<uint64_t>(4096, n / 256);
                 depth1.assign((size_t)sigma, Depth1Fold{});
                 for (int b = 0; b < 256; ++b) {

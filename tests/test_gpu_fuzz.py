@@ -145,6 +145,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     elif rng5.random() < 0.3: opts["vl_keys"] = 0
     if rng5.random() < 0.25: opts["group_sort"] = 0      # (the general sort for the refinement rounds; default: one pass inside the groups)
     if rng5.random() < 0.25: opts["list_rounds"] = 0     # (every round compacts from the flag array; default: later rounds from the previous list)
+    if rng5.random() < 0.25: opts["fuse_pairclass"] = 0  # (next-byte classes by their own sweep; default: counted beside the bytes)
     g = capi.GpuStringIndex()
     for k, v in opts.items():
         g.set_option(k, v)
@@ -210,6 +211,7 @@ def test_fuzz_bucket_wise_with_documents_of_real_size(seed):
     if rng.random() < 0.2: opts["initial_passes"] = int(rng.integers(2, 8))
     if rng.random() < 0.2: opts["group_sort"] = 0
     if rng.random() < 0.2: opts["list_rounds"] = 0
+    if rng.random() < 0.2: opts["fuse_pairclass"] = 0
     g = capi.GpuStringIndex()
     for k, v in opts.items():
         g.set_option(k, v)

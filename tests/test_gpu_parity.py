@@ -1674,3 +1674,29 @@ def test_later_refinement_rounds_compact_from_the_previous_list(G):
         assert g1.stat("list_rounds") == max(0, g1.stat("ext_rounds") - 1), (opts, g1.stat("list_rounds"), g1.stat("ext_rounds"), g1.stat("rounds"))
         seen += int(g1.stat("list_rounds"))
     assert seen >= 3, seen
+
+
+def test_next_byte_classes_are_counted_beside_the_bytes(G):
+    # reference order one level below the root (index.h:66-73): the split of every first-byte bucket by the class of the NEXT byte
+    # comes out of the tile byte count's sweep (sa_tile_bytecount_kernel<true>) when the first MiB of the text shows a byte >= 0x80;
+    # fuse_pairclass = 0 and texts whose high bytes start later take the separate sweep.  Ragged ends (n mod 16, n mod 8192) included.
+    for n_extra in (0, 5, 8191, 16 * 77 + 9):
+        nd = 6000
+        lens = (150 + W.random_bytes(nd, 3, 0, 200).astype(np.uint64))
+        lens[17] = (1 << 20) + n_extra                                              # 8-byte entries
+        ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        n = int(ds[-1])
+        blob = W.utf8_corpus(1, n + n // 8 + 64, seed=31 + n_extra)[0][:n].copy()
+        pats = W.sample_patterns(blob, ds, 60, 2, 9, seed=4)
+        g1, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1)
+        g0, _ = _check_parity(G, blob, ds, patterns=pats, force_big_path=1, fuse_pairclass=0)
+        assert g1.stat("pairclass_fused") == 1 and g0.stat("pairclass_fused") == 0, (n_extra, g1.stat("pairclass_fused"))
+        assert np.array_equal(g1.sa(), g0.sa()) and g1.stat("compat_rotations") == g0.stat("compat_rotations")
+    # high bytes only behind the first MiB: the sample says "none", the separate sweep runs
+    blob2 = np.concatenate([W.random_bytes(1 << 20, 5, 0x61, 0x7A), W.utf8_corpus(1, (3 << 20) + (1 << 19), seed=77)[0][: 3 << 20]])
+    assert len(blob2) == 4 << 20
+    ds2 = (np.arange(0, 4097, dtype=np.uint64) * 1024).astype(np.uint64)            # (4 MiB in 4096 documents ...
+    ds2[-1] = len(blob2)
+    ds2 = np.concatenate([ds2[:7], ds2[2000:]]).astype(np.uint64)                   # ... one of them 2 MiB long: 8-byte entries)
+    g, _ = _check_parity(G, blob2, ds2, patterns=W.sample_patterns(blob2, ds2, 40, 2, 9, seed=4), force_big_path=1)
+    assert g.stat("pairclass_fused") == 0 and g.stat("compat_rotations") > 0

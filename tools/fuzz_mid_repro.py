@@ -46,6 +46,7 @@ def corpus(seed):
     if rng.random() < 0.2: opts["initial_passes"] = int(rng.integers(2, 8))
     if rng.random() < 0.2: opts["group_sort"] = 0
     if rng.random() < 0.2: opts["list_rounds"] = 0
+    if rng.random() < 0.2: opts["fuse_pairclass"] = 0
     return kind, ids, blob, ds, opts
 
 
