@@ -1874,17 +1874,28 @@ template <typename W>
 __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __restrict__ keys, const W* __restrict__ aux, int lead, int npass,
                                                            const uint32_t* __restrict__ tile_seg, const SegInfo* __restrict__ segs,
                                                            uint32_t tiles, unsigned long long* __restrict__ hist) {
-    __shared__ uint32_t sh[8][256];
+    // (round 5) NC copies of the counters, by lane, 64 / NC banks apart: inside a bucket the high digits take few values (the symbols
+    // that can follow the bucket's symbol — 64 continuation bytes behind a UTF-8 lead byte), and 64 lanes on one copy collide on the
+    // same ADDRESS (SQ_LDS_ADDR_CONFLICT as large as the kernel's LDS issue cycles, profiles/r05e_sq_counters.txt); a copy stride of a
+    // multiple of 64 words would leave the four counters of one digit on one bank
+    constexpr int NC = 4, HC = 8 * 256 + 64 / NC;  // (8 copies: -3 % at 16 GiB, +3 % at C1 where a workgroup flushes more often)
+    __shared__ uint32_t sh4[NC * HC];
     const int tid = threadIdx.x;
+    uint32_t* const sh = sh4 + (tid & (NC - 1)) * HC;
     const uint32_t t0 = blockIdx.x * RS_MSD_HIST_TILES;
     const uint32_t t1 = t0 + RS_MSD_HIST_TILES < tiles ? t0 + RS_MSD_HIST_TILES : tiles;
     uint32_t cur = ~0u;
     auto flush = [&]() {
         __syncthreads();
         if (cur != ~0u)
-            for (int i = tid; i < npass * 256; i += 1024)
-                if ((&sh[0][0])[i]) atomicAdd(&hist[((size_t)cur * 8 + i / 256) * 256 + i % 256], (unsigned long long)(&sh[0][0])[i]);
-        for (int i = tid; i < npass * 256; i += 1024) (&sh[0][0])[i] = 0;
+            for (int i = tid; i < npass * 256; i += 1024) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) c += sh4[q * HC + i];
+                if (c) atomicAdd(&hist[((size_t)cur * 8 + i / 256) * 256 + i % 256], (unsigned long long)c);
+            }
+        __syncthreads();  // (the sums read all four copies: nobody clears a counter another thread still has to read)
+        for (int i = tid; i < NC * HC; i += 1024) sh4[i] = 0;
         __syncthreads();
     };
     for (uint32_t t = t0; t < t1; ++t) {
@@ -1903,7 +1914,7 @@ __global__ __launch_bounds__(1024) void rs_seg_hist_kernel(const uint32_t* __res
             for (int p = 0; p < 8; ++p) {
                 if (p < npass) {
                     const uint32_t dg = p < lead ? (a >> (8 * p)) & 0xFFu : (k >> (8 * (p - lead))) & 0xFFu;
-                    atomicAdd(&sh[p][dg], 1u);
+                    atomicAdd(&sh[p * 256 + dg], 1u);
                 }
             }
         };
