@@ -4,21 +4,23 @@
 
 One step = one pass of the hot path over one batch of synthetic input, per GPU:
     cdb_build_resident : suffix-array construction over the rank's corpus shard (text + document table resident in HBM)
-    cdb_query_batch_device : the whole pattern batch against that suffix array (patterns resident in HBM)
+    cdb_query_batch(_offsets)_device : the whole pattern batch against that suffix array (patterns resident in HBM)
     (N > 1) merge of the per-shard match lists into one CSR result over RCCL (cdb_shard_* of the C ABI).
-Default workload = BASELINE.json configs[1] ("c1"): 2^20 docs x 1024 B printable ASCII = 1 GiB of text
-per GPU, 100 000 patterns of length 4..16 (weak scaling: the corpus grows with N).
+Default workload = BASELINE.json configs[2] ("c2"), the largest single-GPU configuration: 2^23 docs x 1024 B over a Zipf
+alphabet of 64 symbols = 8 GiB of text per GPU (8-byte entries), 1 000 000 patterns of length 6..16 with occurrence
+offsets (weak scaling: the corpus grows with N).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline"        — the dominant kernel of the timed region, timed live with HIP events on the library's stream
-  "query_roofline"  — SURVEY §8(d): sector-granular bytes of the batched search (A_q,sector), probes/s
-  "pcie_inclusive"  — the same build / query through the host entry points (cdb_add_bulk + cdb_build, cdb_query_batch)
-  "configs"         — the other single-GPU configurations of BASELINE.json, each with its own roofline:
-                      c2 (8 GiB Zipf-64 + 1 M patterns incl. occurrence offsets), utf8_4g (north_star target: 4 GiB
-                      UTF-8, reference-compatible order), c4shard (16 GiB UTF-8 = one GPU's share of C4, 10 M patterns,
-                      $correlation ranking); at N = 4 / 8 the per-GPU shapes of C3 / C4 run on every rank instead
-  "cpu_baseline"    — the CPU restatement of the reference (oracle/, kind "port") timed on this host: C0 in full with the
-                      thread count swept, then the largest prefix of C1 that builds in bounded time (rank 0, N = 1 only).
+Rank 0 prints TWO stdout lines.  The LAST one is the contract's line and is bounded (< 6 KB, scalar values only):
+  "roofline"     — the dominant kernel of the timed region, timed live with HIP events on the library's stream
+  "cpu_baseline" — the CPU restatement of the reference (oracle/, kind "port") timed on this host on a bounded,
+                   doc-aligned slice of the SAME corpus (rank 0, N = 1 only)
+  "configs"      — a digest of the other single-GPU configurations of BASELINE.json: c1 (1 GiB ASCII, 100 k patterns; with the
+                   literal bit-exact check of the whole array against the CPU oracle: "c1_sa_bit_exact"), c0, utf8_4g
+                   (north_star target: 4 GiB UTF-8, reference-compatible order), c4shard (16 GiB UTF-8 = one GPU's share of
+                   C4, 10 M patterns, $correlation ranking); at N = 4 / 8 the per-GPU shapes of C3 / C4 run on every rank
+The line BEFORE it ({"bench_detail": ...}, also written to bench_detail.json beside this file) carries everything else:
+per-kernel times, build statistics, query rooflines, PCIe-inclusive legs, cold start, lone-keyword latency, the
+whole-corpus CPU baseline of C1.
 """
 import argparse
 import json
@@ -200,7 +202,7 @@ def query_roofline(torch, r, npat, n, width, query_s, device):
 
 
 def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None, merge_mode="counts",
-               dist=None, world=1):
+               dist=None, world=1, extras=None):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
     clamp_note = None
@@ -303,20 +305,7 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         out["query_rows_per_batch"] = int(r.nrows)
         out["query_roofline"] = query_roofline(torch, r, cfg["npat"], n, g.sa_width, min(qms[1:]) * 1e-3, device)
         if cfg.get("short"):
-            # the short-pattern tail of SURVEY §8(d)'s C2 (m from 2): keywords of 2..5 bytes match 10^4..10^8 suffixes each
-            # here; the batch is resolved in chunks of patterns under the hit budget, results stay in HBM
-            ns = cfg["short"]
-            sb_, so_, snb = W.sample_patterns_torch(text, d_ds, ns, 2, 5, seed=5, miss_byte=miss)
-            torch.cuda.synchronize()
-            sms = []
-            for i in range(2):
-                t = time.perf_counter()
-                rs, _hs = g.query_batch_offsets_device(sb_.data_ptr(), so_.data_ptr(), ns, snb)
-                sms.append((time.perf_counter() - t) * 1e3)
-            out["short_patterns"] = {"patterns": ns, "len": "2-5", "ms": [round(x, 2) for x in sms], "hits": int(rs.nhits), "rows": int(rs.nrows),
-                                     "hits_per_s": round(int(rs.nhits) / (min(sms) * 1e-3), 1),
-                                     "note": "with occurrence offsets, device-resident; chunked under query_hit_budget (2^31 hits)"}
-            del sb_, so_
+            out["short_patterns"] = short_tail(torch, W, g, text, d_ds, cfg, miss)
         if cfg.get("ranked"):
             # full $correlation ranking (interface.cpp:78-146) of the union over a keyword list: OR-merge, filter, rank
             nkw = 100_000
@@ -343,9 +332,13 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
                 out["ranked"]["global"] = {"rows": int(len(order)), "top_count": int(cat[1][keep][order[0]]) if len(order) else 0,
                                            "ms": round((time.perf_counter() - t) * 1e3, 2),
                                            "note": "per-shard top lists all-gathered and ranked (descending count, ties ascending id)"}
-        v = g.verify()
-        out["verify"] = {"invalid_entries": int(v["invalid_entries"]), "inversions": int(v["inversions"]),
-                         "tie_violations": int(v["tie_violations"]), "entry_sum_ok": bool(v["entry_sum"] == v["expected_entry_sum"])}
+        out["verify"] = verify_block(g)
+        if extras is not None:
+            try:
+                extras.before_close(g, text, ds, np.arange(ndocs, dtype=np.int64) + rank * ndocs, d_blob, d_offs, nbytes,
+                                    cfg["npat"], n, out)
+            except Exception as e:  # noqa: BLE001
+                out["c1_extras_error"] = repr(e)[:300]
     except Exception:
         if agree is not None and "merge_ms" not in out and "query_ms" not in out:
             agree(False)  # (the other ranks must not wait for this one in the merge)
@@ -355,14 +348,37 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         del text, d_blob, d_offs, d_ds, d_ids
         torch.cuda.empty_cache()
         capi.load_library().cdb_release_cached_memory()
+    if extras is not None:
+        extras.after_close(out, ndocs, cfg.get("doclen", 1024))
     return out
 
 
-def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_check=None):
-    """CPU restatement of the reference (oracle/cpu_ref.cpp, kind "port") on this host, as BASELINE.md §3 plans:
-    C0 in full with the build's thread count swept (the reference spawns hardware_concurrency() spinning workers,
-    index.cpp:225 — oversubscription is visible in the sweep), then the largest prefix of the bench corpus that
-    builds within the budget, with the query leg on that same index."""
+def short_tail(torch, W, g, text, d_ds, cfg, miss):
+    """The short-pattern tail of SURVEY §8(d)'s C2 (m from 2): keywords of 2..5 bytes match 10^4..10^8 suffixes each here; the
+    batch is resolved in chunks of patterns under the hit budget, results (rows and occurrence offsets) stay in HBM."""
+    ns = cfg["short"]
+    sb_, so_, snb = W.sample_patterns_torch(text, d_ds, ns, 2, 5, seed=5, miss_byte=miss)
+    torch.cuda.synchronize()
+    sms = []
+    for i in range(2):
+        t = time.perf_counter()
+        rs, _hs = g.query_batch_offsets_device(sb_.data_ptr(), so_.data_ptr(), ns, snb)
+        sms.append((time.perf_counter() - t) * 1e3)
+    return {"patterns": ns, "len": "2-5", "ms": [round(x, 2) for x in sms], "hits": int(rs.nhits), "rows": int(rs.nrows),
+            "hits_per_s": round(int(rs.nhits) / (min(sms) * 1e-3), 1),
+            "note": "with occurrence offsets, device-resident; chunked under query_hit_budget (2^31 hits)"}
+
+
+def verify_block(g):
+    """cdb_verify: the GPU's own adjacent-pair sweep over the whole published array (verify.hip)."""
+    v = g.verify()
+    return {"invalid_entries": int(v["invalid_entries"]), "inversions": int(v["inversions"]),
+            "tie_violations": int(v["tie_violations"]), "entry_sum_ok": bool(v["entry_sum"] == v["expected_entry_sum"])}
+
+
+def c0_sweep(W):
+    """C0 in full on the CPU port with the build's thread count swept (the reference spawns hardware_concurrency() spinning
+    workers, index.cpp:225 — oversubscription is visible in the sweep).  Returns (MiB/s by threads, best count, 1-thread q/s)."""
     from oracle import OracleIndex
     cores = os.cpu_count() or 1
     c0 = WORKLOADS["c0"]
@@ -375,11 +391,23 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
         t = time.perf_counter()
         o.build(th)
         sweep[str(th)] = round(len(blob0) / 2**20 / (time.perf_counter() - t), 3)
-    best_th = int(max(sweep, key=lambda k: sweep[k]))
     pb0, po0 = W.sample_patterns(blob0, ds0, c0["npat"], c0["mmin"], c0["mmax"], seed=99)
     t = time.perf_counter()
     o.query_batch(pb0, po0, nthreads=1, want_rows=False)
-    c0_q1 = c0["npat"] / (time.perf_counter() - t)
+    return sweep, int(max(sweep, key=lambda k: sweep[k])), c0["npat"] / (time.perf_counter() - t)
+
+
+def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_check=None, corpus="bench corpus", c0=None,
+                 mmin=4, mmax=16, whole_bytes=None):
+    """CPU restatement of the reference (oracle/cpu_ref.cpp, kind "port") on this host, as BASELINE.md §3 plans:
+    C0 in full with the thread count swept (c0_sweep), then the largest prefix of `host_text` (documents of `doclen` bytes)
+    that builds within the budget, with the query leg on that same index — and, when `full_budget_s` allows, the whole of
+    `host_text` with the literal bit-exact check against the GPU's array (`gpu_check`).  `whole_bytes`: size of the
+    configuration `host_text` is a slice of (C2: 8 GiB) — the rate is then the slice's, labelled as such."""
+    from oracle import OracleIndex
+    cores = os.cpu_count() or 1
+    sweep, best_th, c0_q1 = c0 if c0 is not None else c0_sweep(W)
+    c0 = WORKLOADS["c0"]
     # ---- prefix of the bench corpus: x4 until the next step would leave the budget
     out = {"unit": "GiB/s", "kind": "port", "c0_build_MiB_per_s_by_threads": sweep,
            "c0_query_patterns_per_s_1thread": round(c0_q1, 1)}
@@ -404,7 +432,7 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
     npat = 100_000
 
     def query_leg(o, blob, ds):
-        spb, spo = W.sample_patterns(blob, ds, npat, 4, 16, seed=99)
+        spb, spo = W.sample_patterns(blob, ds, npat, mmin, mmax, seed=99)
         t = time.perf_counter()
         o.query_batch(spb, spo, nthreads=1, want_rows=False)
         tq1 = time.perf_counter() - t
@@ -417,8 +445,10 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
         "value": round(nd * doclen / 2**30 / tb, 6),
         "cores": best_th,
         "host_threads_available": cores,
-        "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the bench corpus, SA build with {best_th} threads (the best of "
-                  f"the C0 sweep); {npat} patterns len 4-16 sampled from that prefix, queried on that same index",
+        "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the {corpus}, SA build with {best_th} threads (the best of "
+                  f"the C0 sweep); {npat} patterns len {mmin}-{mmax} sampled from that prefix, queried on that same index"
+                  + (f"; the rate of this slice stands for the {whole_bytes / 2**30:.0f} GiB corpus (linear extrapolation, SURVEY §8(d): an "
+                     f"upper bound for the CPU, whose comparison sort is n log n)" if whole_bytes else ""),
         "build_s": round(tb, 3),
         "query_patterns_per_s_1thread": round(npat / tq1, 1),
         "query_patterns_per_s_allcores": round(npat / tqa, 1),
@@ -429,7 +459,7 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
     # matches/s are measured on.  The prefix figures stay in the line as the fast fallback.
     full_docs = len(host_text) // doclen
     predicted = tb * (full_docs / nd) * 1.3
-    if full_docs > nd and predicted <= full_budget_s:
+    if full_docs > nd and full_budget_s > 0 and predicted <= full_budget_s:
         del o
         ds = W.uniform_docs(full_docs, doclen)
         o = OracleIndex()
@@ -451,27 +481,212 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
                 orp, oi, oc, ohits = o.query_batch(gpu_check["pb"], gpu_check["po"], nthreads=cores)
                 grp, gi, gc, ghits = gpu_check["rows"]
                 rows_same = bool(ohits == ghits and np.array_equal(orp, grp) and np.array_equal(oi, gi) and np.array_equal(oc, gc))
-                out["c1_sa_bit_exact"] = same
-                out["c1_rows_bit_exact"] = rows_same
-                out["c1_bit_exact_check"] = {"entries": int(len(gs)), "entry_bytes": int(gs.dtype.itemsize), "patterns": int(len(orp) - 1),
+                out["sa_bit_exact"] = same
+                out["rows_bit_exact"] = rows_same
+                out["bit_exact_check"] = {"entries": int(len(gs)), "entry_bytes": int(gs.dtype.itemsize), "patterns": int(len(orp) - 1),
                                              "rows": int(len(oi)), "hits": int(ohits), "seconds": round(time.perf_counter() - t, 2),
                                              "note": "oracle array (ties canonicalised) == cdb_sa_copy of the GPU build, element for element; "
                                                      "oracle rows == cdb_query_batch rows for the whole batch"}
             except Exception as e:  # noqa: BLE001
-                out["c1_sa_bit_exact"] = None
-                out["c1_bit_exact_check"] = {"error": repr(e)[:300]}
+                out["sa_bit_exact"] = None
+                out["bit_exact_check"] = {"error": repr(e)[:300]}
         out.update({
             "value": round(full_docs * doclen / 2**30 / tbf, 6),
-            "sample": f"the WHOLE bench corpus ({full_docs} docs, {full_docs * doclen / 2**20:.0f} MiB), SA build with {best_th} threads (the "
-                      f"best of the C0 sweep); {npat} patterns len 4-16 sampled from it, queried on that same index",
+            "sample": f"the WHOLE {corpus} ({full_docs} docs, {full_docs * doclen / 2**20:.0f} MiB), SA build with {best_th} threads (the "
+                      f"best of the C0 sweep); {npat} patterns len {mmin}-{mmax} sampled from it, queried on that same index",
             "build_s": round(tbf, 3),
             "query_patterns_per_s_1thread": round(npat / tq1, 1),
             "query_patterns_per_s_allcores": round(npat / tqa, 1),
             "prefix_sample": {k: prefix[k] for k in ("value", "sample", "build_s", "query_patterns_per_s_1thread", "query_patterns_per_s_allcores")},
         })
     else:
-        out["full_corpus_skipped"] = f"predicted {predicted:.0f} s > budget {full_budget_s:.0f} s" if full_docs > nd else "prefix is the corpus"
+        if not whole_bytes:
+            out["full_corpus_skipped"] = f"predicted {predicted:.0f} s > budget {full_budget_s:.0f} s" if full_docs > nd else "prefix is the corpus"
     return out
+
+
+CPU_SLICE_BYTES = 256 << 20   # the headline's CPU leg sees at most this much of the corpus (it stops earlier on its time budget)
+SHORT_LINE_LIMIT = 6000       # bytes; the driver keeps the last ~8 KB of stdout — the final line must fit with room to spare
+
+
+class C1Extras:
+    """What only BASELINE config 1 carries (1 GiB of text, 4-byte entries: small enough to hold on the host): the lone-keyword
+    latency of database.cpp:392's call, the PCIe-inclusive legs through the host entry points, and the literal bit-exact check
+    of the whole array against the CPU oracle.  Runs on the index of the c1 block (or on the timed one under --workload c1)."""
+
+    def __init__(self, torch, capi, W, args):
+        self.torch, self.capi, self.W, self.args = torch, capi, W, args
+        self.host_text = self.gpu_check = None
+
+    def before_close(self, g, text, doc_start, ids, d_blob, d_offs, nbytes, npat, n, out):
+        args, capi, W = self.args, self.capi, self.W
+        self.host_text = host_text = text.cpu().numpy()
+        pb = d_blob[:nbytes].cpu().numpy()
+        po = d_offs.cpu().numpy().astype(np.uint64)
+        # the call database.cpp:392 makes: ONE keyword through cdb_query (one wavefront, host-mapped result)
+        try:
+            kws = [bytes(host_text[p:p + 8]) for p in range(1000, 1000 + 97 * 64, 97)]
+            for kw in kws[:8]:
+                g.query(kw)
+            lat = []
+            for kw in kws:
+                t = time.perf_counter()
+                g.query(kw)
+                lat.append((time.perf_counter() - t) * 1e6)
+            lat.sort()
+
+            def pct(a):
+                return {"median": round(float(a[len(a) // 2]), 2), "p10": round(float(a[len(a) // 10]), 2), "p90": round(float(a[(len(a) * 9) // 10]), 2)}
+
+            sq = dict(pct(lat), keywords=len(kws), note="cdb_query through the Python ctypes binding, 8-byte keywords, one caller")
+            sq["c_caller"] = dict(pct(np.sort(g.query_latency_us(kws, reps=32))),
+                                  note="timed inside the library (cdb_debug_query_latency): what a C++ caller such as database.cpp:392 sees; "
+                                       "median over 32 calls per keyword; DEFAULT options (resident_query = 2: keywords arriving back to back "
+                                       "go to the resident workgroup after 6 calls less than 1 ms apart)")
+            for mode, key in ((1, "resident"), (0, "launched")):   # the resident workgroup forced on / off (one launch per keyword)
+                g.set_option("resident_query", mode)
+                for kw in kws[:8]:
+                    g.query(kw)
+                sq[key] = dict(pct(np.sort(g.query_latency_us(kws, reps=32))), note=f"option resident_query = {mode}, timed like c_caller")
+            g.set_option("resident_query", 2)
+            out["single_query_us"] = sq
+        except Exception as e:  # noqa: BLE001
+            out["single_query_us"] = {"error": repr(e)[:200]}
+        if not args.no_pcie:
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat)
+                # SURVEY §8(d) defines the metric INCLUDING the transfers: host column in, index built (cdb_build_view), and host
+                # patterns in, host rows out (cdb_query_batch)
+                out["sa_build_GiB_per_s_incl_h2d"] = out["pcie_inclusive"]["build_view_GiB_per_s"]
+                out["pcie_inclusive_query_patterns_per_s"] = out["pcie_inclusive"]["query_patterns_per_s"]
+            except Exception as e:  # noqa: BLE001 - reported, the block stands
+                out["pcie_inclusive"] = {"error": repr(e)[:300]}
+        if not args.no_cpu_baseline and args.cpu_full_budget > 0:
+            try:  # the array and rows of the index just built, for the literal bit-exact check in the CPU leg
+                self.gpu_check = {"sa": g.sa(), "rows": g.query_batch(pb, po), "pb": pb, "po": po}
+            except Exception as e:  # noqa: BLE001
+                out["bit_exact_check"] = {"error": "fetching the GPU array: " + repr(e)[:200]}
+
+    def after_close(self, out, ndocs, doclen):
+        if self.args.no_pcie or not isinstance(out.get("pcie_inclusive"), dict) or "error" in out["pcie_inclusive"]:
+            return
+        # what the SHIM's build() really calls (shim/index.cpp: cdb_build_views over one std::string per document,
+        # database.cpp:262-264): the C++ caller of tests/cpp at this shape, in a process of its own
+        out["pcie_inclusive"]["build_views"] = host_caller("views", ndocs, doclen, 3)
+        # ... and at the north-star size: 4 M separately allocated strings of valid UTF-8 (4 GiB), warm (repetitions 1-2)
+        out["pcie_inclusive"]["build_views_4g"] = host_caller("views", 4 << 20, 1024, 2, "utf8")
+
+    def cpu_leg(self, out, W, c0, args, doclen, top):
+        """The CPU port over the WHOLE C1 corpus (when its prefix predicts it fits the budget) + the bit-exact check."""
+        cb = cpu_baseline(W, self.host_text, doclen, full_budget_s=args.cpu_full_budget, gpu_check=self.gpu_check, c0=c0, corpus="C1 corpus")
+        for k in ("sa_bit_exact", "rows_bit_exact", "bit_exact_check"):
+            if k in cb:
+                out[("c1_" if top else "") + k] = cb.pop(k)
+        out["cpu_baseline"] = cb
+        self.host_text = self.gpu_check = None
+
+
+def _clip(x, limit):
+    x = str(x)
+    return x if len(x) <= limit else x[: limit - 3] + "..."
+
+
+def short_line(out):
+    """The FINAL stdout line: the contract's keys with scalar values only, a digest of the other configurations, and nothing
+    else — everything else lives in bench_detail.json (and in the stdout line before this one).  Bounded: the driver keeps
+    the last ~8 KB of stdout, and a line it cannot parse is an unmeasured round."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "commit", "rccl_ranks", "rows_per_rank", "sa_build_only_GiB_per_s", "sa_build_GiB_per_s_incl_h2d",
+            "query_patterns_per_s", "query_hits_per_batch", "query_rows_per_batch", "build_ms_per_step",
+            "build_algorithmic_bytes_per_suffix", "build_frac_of_hbm_peak_over_wall_time", "kernel_time_share_of_wall",
+            "peak_hbm_bytes", "c1_sa_bit_exact", "c1_rows_bit_exact")
+    s = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config") or {}
+    s["config"] = {"workload": _clip(cfg.get("workload", ""), 420), **{k: v for k, v in cfg.items() if k != "workload" and not isinstance(v, (dict, list, str))}}
+    roof = out.get("roofline")
+    if isinstance(roof, dict):
+        r = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
+                                  "algorithmic_bytes_per_launch", "share_of_kernel_time", "traffic_over_algorithmic") if k in roof}
+        src = roof.get("traffic_source")
+        if isinstance(src, dict):
+            r["traffic_source"] = _clip(f"{src.get('profile')} @ {src.get('commit')} (committed rocprofv3 PMC passes of this command; not measured in this run)", 160)
+        s["roofline"] = r
+    else:
+        s["roofline"] = None
+    qr = out.get("query_roofline")
+    if isinstance(qr, dict):
+        s["query_roofline"] = {k: qr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "patterns_per_s", "probes_per_s", "hbm_probes_per_s", "levels") if k in qr}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_threads_available", "build_s", "query_patterns_per_s_1thread",
+                                "query_patterns_per_s_allcores", "error") if k in cb}
+        if "sample" in cb:
+            c["sample"] = _clip(cb["sample"], 420)
+        s["cpu_baseline"] = c
+        qa = cb.get("query_patterns_per_s_allcores")
+        if qa and out.get("query_patterns_per_s"):
+            s["query_vs_cpu_allcores"] = round(out["query_patterns_per_s"] / qa, 1)
+    else:
+        s["cpu_baseline"] = None
+    sc = out.get("mg_selfcheck")
+    if isinstance(sc, dict):
+        s["mg_selfcheck"] = {k: (_clip(v, 200) if isinstance(v, str) else v) for k, v in sc.items()
+                             if k in ("ok", "world", "transport", "cdb_comm_world", "devices_distinct", "share_gpu", "bus_ids",
+                                      "merged_rows", "sum_of_local_rows", "error")}
+    else:
+        s["mg_selfcheck"] = None
+    if out.get("merge"):
+        s["merge"] = _clip(out["merge"], 200)
+    dig = {}
+    for name, b in (out.get("configs") or {}).items():
+        if not isinstance(b, dict):
+            continue
+        if "error" in b:
+            dig[name] = {"error": _clip(b["error"], 120)}
+            continue
+        d = {"build_ms": min(b["build_ms"]) if b.get("build_ms") else None, "sa_build_GiB_per_s": b.get("sa_build_GiB_per_s"),
+             "frac_over_wall": b.get("build_frac_of_hbm_peak_over_wall_time"),
+             "dominant_frac": (b.get("roofline") or {}).get("frac"), "query_patterns_per_s": b.get("query_patterns_per_s"),
+             "peak_hbm_bytes": b.get("peak_hbm_bytes"), "dtype": b.get("dtype")}
+        v = b.get("verify")
+        if isinstance(v, dict):
+            d["verify_ok"] = bool(v["invalid_entries"] == 0 and v["tie_violations"] == 0 and v["entry_sum_ok"])
+            d["inversions"] = v["inversions"]
+        if isinstance(b.get("cpu_baseline"), dict) and "value" in b["cpu_baseline"]:
+            d["cpu_GiB_per_s"] = b["cpu_baseline"]["value"]
+            d["cpu_query_allcores"] = b["cpu_baseline"].get("query_patterns_per_s_allcores")
+        if b.get("sa_build_GiB_per_s_incl_h2d") is not None:
+            d["incl_h2d_GiB_per_s"] = b["sa_build_GiB_per_s_incl_h2d"]
+        if isinstance(b.get("all_ranks"), dict):
+            d["aggregate_GiB_per_s"] = b["all_ranks"].get("sa_build_GiB_per_s_aggregate")
+        dig[name] = {k: v for k, v in d.items() if v is not None}
+    s["configs"] = dig
+    s["detail"] = "bench_detail.json (written beside bench.py; also the stdout line before this one)"
+    # the guard: drop the optional parts, least important first, until the line fits
+    for victim in ("build_ms_per_step", "merge", "query_roofline", "rows_per_rank", "configs"):
+        if len(json.dumps(s)) <= SHORT_LINE_LIMIT:
+            break
+        if victim == "configs":
+            s["configs"] = {k: {kk: vv for kk, vv in v.items() if kk in ("build_ms", "sa_build_GiB_per_s", "error")} for k, v in dig.items()}
+        else:
+            s.pop(victim, None)
+    return s
+
+
+def emit(out):
+    """Rank 0's output: the whole record to bench_detail.json and to an EARLIER stdout line, then the bounded final line."""
+    short = short_line(out)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+    print(json.dumps({"bench_detail": out}), flush=True)
+    line = json.dumps(short, allow_nan=False)
+    assert len(line) <= 8000, len(line)
+    print(line, flush=True)
 
 
 def host_caller(*argv, timeout=600):
@@ -555,6 +770,7 @@ def mg_selfcheck(torch, dist, capi, g, merger, rank, world, local_rank, device, 
         else:
             alld = [mine]
         devs = [int(x.item()) for x in alld]
+        out["bus_ids"] = [f"{d >> 8:02x}:{d & 255:02x}" for d in devs] if not args.share_gpu else ["shared cuda:0"] * world
         out["devices_distinct"] = len(set(devs)) == world
         out["share_gpu"] = bool(args.share_gpu)
         if not out["devices_distinct"]:
@@ -628,7 +844,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--configs", default="auto",
                     help="comma-separated extra configurations for the \"configs\" block (auto: c2,utf8_4g,c4shard at N = 1 on "
                          "the default workload, c3 at N = 4, c4 at N = 8 — the fixed 32 / 128 GiB corpora split across the ranks; none: skip)")
@@ -671,7 +887,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report the wrong GPU count")
 
     cold = None
-    if world == 1 and args.workload == "c1" and args.configs == "auto" and not args.no_cold_start:
+    if world == 1 and args.workload == "c2" and args.configs == "auto" and not args.no_cold_start:
         # server.cpp:44: the start-up build of a fresh process — measured FIRST, while this process has not touched the GPU
         # (VRAM a process released just before is scrubbed by the driver on re-allocation: the recycled case the configs
         # blocks measure)
@@ -772,6 +988,7 @@ def main():
         return tb, tq, r
 
     torch.cuda.synchronize()  # inputs complete before the library's own stream touches them
+    capi.memory_reset_peak()
     trace("inputs ready")
     selfcheck = None
     if merger is not None:
@@ -821,7 +1038,7 @@ def main():
     if rank == 0:
         gib_total = world * n * steps / 2**30
         roof = dominant(prof, builds=steps)
-        traffic = pmc_traffic()
+        traffic = pmc_traffic(args.workload)
         attach_traffic(roof, traffic if (traffic and traffic.get("suffixes") in (None, n)) else None,
                        "committed PMC profile of this same command (not measured in this run)")
         build_kernels = {k: v for k, v in prof.items() if not k.startswith("q_")}
@@ -861,6 +1078,10 @@ def main():
             "roofline": roof,
             "build_kernels_ms_per_step": round(kern_ms, 3),
             "build_algorithmic_bytes_per_suffix": round(kern_bytes / n, 1),
+            # every build kernel's algorithmic bytes over the WALL time of the builds (launch gaps and host work included)
+            "build_frac_of_hbm_peak_over_wall_time": round(kern_bytes / (build_ms * 1e-3 / steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_time_share_of_wall": round(kern_ms / (build_ms / steps), 3),
+            "peak_hbm_bytes": int(capi.memory_stats()[1] + n),
             "kernels_ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:14]},
         }
         if traffic and "kernels" in traffic and traffic.get("suffixes") in (None, n):
@@ -872,73 +1093,59 @@ def main():
     if merger is not None:
         merger.close()
 
-    # ---- everything below is outside the timed region
-    if rank == 0 and world == 1 and small:
-        # the call database.cpp:392 makes: ONE keyword through cdb_query (one wavefront, host-mapped result)
+    # ---- everything below is outside the timed region; whatever fails there is reported, the headline stands
+    c0 = None
+    cpu_slice = None
+    if rank == 0 and world == 1:
+        out["verify"] = verify_block(g)
+        if cfg.get("short"):
+            try:
+                out["short_patterns"] = short_tail(torch, W, g, text, d_doc_start, cfg, 0x7F)
+            except Exception as e:  # noqa: BLE001
+                out["short_patterns"] = {"error": repr(e)[:300]}
+        if not args.no_cpu_baseline and cfg["kind"] != "utf8":
+            # a doc-aligned slice of the headline corpus for the CPU leg at the end (documents of cfg["doclen"] bytes)
+            take = min(n, CPU_SLICE_BYTES) // cfg["doclen"] * cfg["doclen"]
+            cpu_slice = text[:take].cpu().numpy()
+    extras = None
+    if rank == 0 and world == 1 and small:   # the headline IS C1 (--workload c1): its extras run on the timed index
+        extras = C1Extras(torch, capi, W, args)
         try:
-            kws = [bytes(host_text[p:p + 8]) for p in range(1000, 1000 + 97 * 64, 97)]
-            for kw in kws[:8]:
-                g.query(kw)
-            lat = []
-            for kw in kws:
-                t = time.perf_counter()
-                g.query(kw)
-                lat.append((time.perf_counter() - t) * 1e6)
-            lat.sort()
-            out["single_query_us"] = {"median": round(lat[len(lat) // 2], 2), "p10": round(lat[len(lat) // 10], 2),
-                                      "p90": round(lat[(len(lat) * 9) // 10], 2), "keywords": len(kws),
-                                      "note": "cdb_query through the Python ctypes binding, 8-byte keywords, one caller"}
-            c_us = np.sort(g.query_latency_us(kws, reps=32))
-            out["single_query_us"]["c_caller"] = {"median": round(float(c_us[len(c_us) // 2]), 2), "p10": round(float(c_us[len(c_us) // 10]), 2),
-                                                  "p90": round(float(c_us[(len(c_us) * 9) // 10]), 2),
-                                                  "note": "the same calls timed inside the library (cdb_debug_query_latency): what a C++ caller "
-                                                          "such as database.cpp:392 sees; median over 32 calls per keyword"}
-            out["single_query_us"]["c_caller"]["note"] += ("; DEFAULT options: resident_query = 2 (automatic) hands keywords that arrive back "
-                                                           "to back to the resident workgroup after 6 calls less than 1 ms apart")
-            # the same with the resident workgroup forced on (resident_query = 1) and off (0: one launch per keyword)
-            for mode, key in ((1, "resident"), (0, "launched")):
-                g.set_option("resident_query", mode)
-                for kw in kws[:8]:
-                    g.query(kw)
-                r_us = np.sort(g.query_latency_us(kws, reps=32))
-                out["single_query_us"][key] = {"median": round(float(r_us[len(r_us) // 2]), 2), "p10": round(float(r_us[len(r_us) // 10]), 2),
-                                               "p90": round(float(r_us[(len(r_us) * 9) // 10]), 2),
-                                               "note": f"option resident_query = {mode}, timed inside the library like c_caller"}
-            g.set_option("resident_query", 2)
+            extras.before_close(g, text, doc_start, ids, d_blob, d_offs, nbytes, npat, n, out)
         except Exception as e:  # noqa: BLE001
-            out["single_query_us"] = {"error": repr(e)[:200]}
-    extra = args.configs
-    if extra == "auto":
-        extra = ("c0,c2,utf8_4g,c4shard" if world == 1 and args.workload == "c1" else
-                 "c3" if world == 4 else "c4" if world == 8 else "none")  # C3 / C4 as BASELINE.json words them
-    if rank == 0 and world == 1 and small and not args.no_pcie:
-        try:
-            out["pcie_inclusive"] = pcie_inclusive(capi, W, host_text, doc_start, ids, pb, po, n, npat)
-            # SURVEY §8(d) defines the metric INCLUDING the transfers: host column in, index built (cdb_build_view), and host
-            # patterns in, host rows out (cdb_query_batch) — `value` above is the HBM-resident rate the task contract asks for
-            out["pcie_inclusive_sa_build_GiB_per_s"] = out["pcie_inclusive"]["build_view_GiB_per_s"]
-            out["sa_build_GiB_per_s_incl_h2d"] = out["pcie_inclusive"]["build_view_GiB_per_s"]  # (beside `value`: SURVEY §8(d)'s definition)
-            out["pcie_inclusive_query_patterns_per_s"] = out["pcie_inclusive"]["query_patterns_per_s"]
-        except Exception as e:  # noqa: BLE001 - reported in the line, the headline stands
-            out["pcie_inclusive"] = {"error": repr(e)[:300]}
-    gpu_check = None
-    if rank == 0 and world == 1 and small and not args.no_cpu_baseline and args.cpu_full_budget > 0:
-        try:  # the array and rows of the index the timed region built, for the literal bit-exact check in the CPU-baseline leg
-            gpu_check = {"sa": g.sa(), "rows": g.query_batch(pb, po), "pb": pb, "po": po}
-        except Exception as e:  # noqa: BLE001
-            out["c1_bit_exact_check"] = {"error": "fetching the GPU array: " + repr(e)[:200]}
+            out["c1_extras_error"] = repr(e)[:300]
     g.close()
-    if rank == 0 and world == 1 and small and not args.no_pcie and isinstance(out.get("pcie_inclusive"), dict):
-        # what the SHIM's build() really calls (shim/index.cpp: cdb_build_views over one std::string per document,
-        # database.cpp:262-264): the C++ caller of tests/cpp at this workload's shape, in a process of its own
-        out["pcie_inclusive"]["build_views"] = host_caller("views", ndocs, cfg.get("doclen", 1024), 3)
-        # ... and at the north-star size: 4 M separately allocated strings of valid UTF-8 (4 GiB), warm (repetitions 1-2)
-        out["pcie_inclusive"]["build_views_4g"] = host_caller("views", 4 << 20, 1024, 2, "utf8")
+    if extras is not None:
+        extras.after_close(out, ndocs, cfg.get("doclen", 1024))
+    if rank == 0 and world == 1 and not small and not args.no_pcie and cfg["kind"] != "utf8":
+        # SURVEY §8(d) defines t_build INCLUDING the H2D of the text: the same corpus from host memory through
+        # cdb_build_view (the caller's buffer, chunked pinned staging inside the timed call) — beside `value`, never in it
+        try:
+            host_full = text.cpu().numpy()
+            gv = capi.GpuStringIndex(device=local_rank)
+            tv = []
+            for _ in range(2):
+                t = time.perf_counter()
+                gv.build_view(ids, host_full, doc_start)
+                tv.append(time.perf_counter() - t)
+            out["sa_build_GiB_per_s_incl_h2d"] = round(n / 2**30 / min(tv), 3)
+            out["pcie_inclusive"] = {"build_view_ms": [round(x * 1e3, 1) for x in tv], "build_device_part_ms": round(gv.stat("build_ms"), 2),
+                                     "build_upload_ms": round(gv.stat("host_upload_ms"), 2), "verify": verify_block(gv),
+                                     "note": "cdb_build_view over the whole host column (pageable numpy buffer), H2D inside the timed call"}
+            gv.close()
+            del host_full
+        except Exception as e:  # noqa: BLE001
+            out["pcie_inclusive"] = {"error": repr(e)[:300]}
     if cold is not None:
         out["cold_start"] = cold
     del text, d_blob, d_offs
     torch.cuda.empty_cache()
     capi.load_library().cdb_release_cached_memory()
+    extra = args.configs
+    if extra == "auto":
+        extra = ("c1,c0,utf8_4g,c4shard" if world == 1 and args.workload == "c2" else
+                 "c3" if world == 4 else "c4" if world == 8 else "none")  # C3 / C4 as BASELINE.json words them
+    c1x = None
     if extra != "none":
         blocks = {}
         for name in [x for x in extra.split(",") if x]:
@@ -950,8 +1157,11 @@ def main():
                     dist.all_reduce(t_, op=dist.ReduceOp.MIN)
                     return bool(t_.item())
 
+                ex = None
+                if name == "c1" and rank == 0 and world == 1:
+                    ex = c1x = C1Extras(torch, capi, W, args)
                 res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk, agree=agree if world > 1 else None,
-                                 merge_mode=args.merge, dist=dist if world > 1 else None, world=world)
+                                 merge_mode=args.merge, dist=dist if world > 1 else None, world=world, extras=ex)
             except Exception as e:  # noqa: BLE001
                 res = {"workload": name, "error": repr(e)[:300]}
             if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N
@@ -976,17 +1186,30 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(W, host_text, cfg.get("doclen", 1024), full_budget_s=args.cpu_full_budget, gpu_check=gpu_check)
-                for k in ("c1_sa_bit_exact", "c1_rows_bit_exact", "c1_bit_exact_check"):  # (top level of the line: BASELINE config 1's check)
-                    if k in out["cpu_baseline"]:
-                        out[k] = out["cpu_baseline"].pop(k)
+                c0 = c0_sweep(W)
+                # the headline's CPU leg: a bounded slice of the SAME corpus (C2: the first 256 MiB of the 8 GiB, doc-aligned)
+                if small:
+                    extras.cpu_leg(out, W, c0, args, cfg.get("doclen", 1024), top=True)
+                else:
+                    out["cpu_baseline"] = cpu_baseline(W, cpu_slice, cfg.get("doclen", 1024), full_budget_s=0, c0=c0,
+                                                       corpus=f"{args.workload} corpus", mmin=mmin, mmax=mmax,
+                                                       whole_bytes=n if cpu_slice is not None and n > len(cpu_slice) else None)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)[:300]}
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+            if c1x is not None and isinstance(out.get("configs", {}).get("c1"), dict) and "error" not in out["configs"]["c1"]:
+                # BASELINE config 1's "bit-exact SA check", literally: the oracle over the WHOLE C1 corpus against the array
+                # the GPU built in the c1 block (and the whole-corpus CPU rate)
+                try:
+                    c1x.cpu_leg(out["configs"]["c1"], W, c0, args, 1024, top=False)
+                    for k in ("sa_bit_exact", "rows_bit_exact"):
+                        if k in out["configs"]["c1"]:
+                            out["c1_" + k] = out["configs"]["c1"][k]
+                except Exception as e:  # noqa: BLE001
+                    out["configs"]["c1"]["cpu_baseline"] = {"error": repr(e)[:300]}
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
