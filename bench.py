@@ -54,6 +54,9 @@ WORKLOADS = {
     "c4shard": dict(kind="utf8", bytes=16 << 30, npat=10_000_000, mmin=4, mmax=16, ranked=True),
     # configs[3] / configs[4] as BASELINE.json words them — a FIXED corpus split across the ranks (--scaling strong):
     # 32 GiB ASCII over 4 GPUs, 128 GiB UTF-8 over 8 GPUs with 10 M patterns and $correlation ranking
+    # configs[4] in miniature (the 8-rank dress rehearsal on one GPU, tests/test_bench_launch.py): 256 MiB UTF-8 per rank,
+    # 10^6 patterns, counts merge + $correlation ranking
+    "c4mini": dict(kind="utf8", bytes=256 << 20, npat=1_000_000, mmin=4, mmax=16, ranked=True),
     "c3": dict(kind="ascii", docs=1 << 25, doclen=1024, npat=100_000, mmin=4, mmax=16, total=True),
     "c4": dict(kind="utf8", bytes=128 << 30, npat=10_000_000, mmin=4, mmax=16, ranked=True, total=True),
 }
@@ -397,7 +400,7 @@ def c0_sweep(W):
     return sweep, int(max(sweep, key=lambda k: sweep[k])), c0["npat"] / (time.perf_counter() - t)
 
 
-def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_check=None, corpus="bench corpus", c0=None,
+def cpu_baseline(W, host_text, doclen, budget_s=32.0, full_budget_s=300.0, gpu_check=None, corpus="bench corpus", c0=None,
                  mmin=4, mmax=16, whole_bytes=None):
     """CPU restatement of the reference (oracle/cpu_ref.cpp, kind "port") on this host, as BASELINE.md §3 plans:
     C0 in full with the thread count swept (c0_sweep), then the largest prefix of `host_text` (documents of `doclen` bytes)
@@ -420,12 +423,27 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
     while True:
         ds = W.uniform_docs(nd, doclen)
         blob = host_text[: nd * doclen]
-        o = OracleIndex()
-        o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
-        t = time.perf_counter()
-        o.build(best_th)
-        tb = time.perf_counter() - t
-        spent += tb
+        if nd * doclen == (32 << 20) and cores > 8:
+            # the thread count that is best on 10 k tiny documents (C0) is not the best on a real slice: sweep it once here, at
+            # 32 MiB (about 2 s per build), and keep the winner for the larger prefixes and the whole corpus
+            by_th = {}
+            for th in sorted({8, 16, 32, 64} & set(range(1, cores + 1))):
+                o = OracleIndex()
+                o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
+                t = time.perf_counter()
+                o.build(th)
+                by_th[th] = time.perf_counter() - t
+                spent += by_th[th]
+            best_th = min(by_th, key=by_th.get)
+            out["slice_32MiB_build_MiB_per_s_by_threads"] = {str(k): round(32 / v, 3) for k, v in by_th.items()}
+            tb = by_th[best_th]
+        else:
+            o = OracleIndex()
+            o.add_bulk(np.arange(nd, dtype=np.int64), blob, ds)
+            t = time.perf_counter()
+            o.build(best_th)
+            tb = time.perf_counter() - t
+            spent += tb
         if spent + 4.5 * tb > budget_s or (nd * 4) * doclen > len(host_text):
             break
         nd *= 4
@@ -446,7 +464,7 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
         "cores": best_th,
         "host_threads_available": cores,
         "sample": f"first {nd} docs ({nd * doclen / 2**20:.0f} MiB) of the {corpus}, SA build with {best_th} threads (the best of "
-                  f"the C0 sweep); {npat} patterns len {mmin}-{mmax} sampled from that prefix, queried on that same index"
+                  f"the sweeps); {npat} patterns len {mmin}-{mmax} sampled from that prefix, queried on that same index"
                   + (f"; the rate of this slice stands for the {whole_bytes / 2**30:.0f} GiB corpus (linear extrapolation, SURVEY §8(d): an "
                      f"upper bound for the CPU, whose comparison sort is n log n)" if whole_bytes else ""),
         "build_s": round(tb, 3),
@@ -493,7 +511,7 @@ def cpu_baseline(W, host_text, doclen, budget_s=25.0, full_budget_s=300.0, gpu_c
         out.update({
             "value": round(full_docs * doclen / 2**30 / tbf, 6),
             "sample": f"the WHOLE {corpus} ({full_docs} docs, {full_docs * doclen / 2**20:.0f} MiB), SA build with {best_th} threads (the "
-                      f"best of the C0 sweep); {npat} patterns len {mmin}-{mmax} sampled from it, queried on that same index",
+                      f"best of the sweeps); {npat} patterns len {mmin}-{mmax} sampled from it, queried on that same index",
             "build_s": round(tbf, 3),
             "query_patterns_per_s_1thread": round(npat / tq1, 1),
             "query_patterns_per_s_allcores": round(npat / tqa, 1),
@@ -596,7 +614,7 @@ def short_line(out):
     else — everything else lives in bench_detail.json (and in the stdout line before this one).  Bounded: the driver keeps
     the last ~8 KB of stdout, and a line it cannot parse is an unmeasured round."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "commit", "rccl_ranks", "rows_per_rank", "sa_build_only_GiB_per_s", "sa_build_GiB_per_s_incl_h2d",
+            "dtype", "data", "commit", "rccl_ranks", "rows_per_rank", "merged_rows", "sa_build_only_GiB_per_s", "sa_build_GiB_per_s_incl_h2d",
             "query_patterns_per_s", "query_hits_per_batch", "query_rows_per_batch", "build_ms_per_step",
             "build_algorithmic_bytes_per_suffix", "build_frac_of_hbm_peak_over_wall_time", "kernel_time_share_of_wall",
             "peak_hbm_bytes", "c1_sa_bit_exact", "c1_rows_bit_exact")
@@ -970,6 +988,8 @@ def main():
     g.set_option("profile", 1)
     merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device, mode=args.merge) if (world > 1 or args.force_merge) else None
 
+    merged_rows = [None]   # row_ptr[-1] of the last step's merged CSR (N > 1)
+
     def step():
         # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
         trace("build")
@@ -983,7 +1003,11 @@ def main():
         tq = g.stat("query_ms")
         if merger is not None:
             trace("merge")
-            merger.merge(r, npat)
+            m = merger.merge(r, npat)
+            if merger.comm is not None:
+                merged_rows[0] = int(m.nrows_total) if merger.mode == "counts" else int(m.nrows)
+            else:
+                merged_rows[0] = int(m[0][-1].item())
         trace("step done")
         return tb, tq, r
 
@@ -1068,6 +1092,7 @@ def main():
             "merge": merger.note if merger is not None else None,
             "rccl_ranks": int(merger.comm.world) if (merger is not None and merger.comm is not None) else None,
             "rows_per_rank": rows_per_rank,
+            "merged_rows": merged_rows[0],
             "mg_selfcheck": selfcheck,
             "sa_build_only_GiB_per_s": round(world * n * steps / 2**30 / (build_ms * 1e-3), 4),
             "query_patterns_per_s": round(world * npat * steps / (query_ms * 1e-3), 1),

@@ -22,7 +22,7 @@ EXPORTS = [
     "cdb_query", "cdb_query_or", "cdb_query_ranked", "cdb_query_and", "cdb_query_spans", "cdb_spans_free", "cdb_free", "cdb_query_batch", "cdb_query_batch_offsets", "cdb_hits_free", "cdb_result_free", "cdb_query_batch_device", "cdb_query_batch_offsets_device", "cdb_size", "cdb_bits",
     "cdb_mask", "cdb_sa_width", "cdb_sa_copy", "cdb_set_option", "cdb_get_stat", "cdb_profile_get",
     "cdb_profile_dump", "cdb_profile_reset", "cdb_release_cached_memory", "cdb_cached_memory_bytes", "cdb_set_cache_limit", "cdb_memory_stats", "cdb_memory_reset_peak",
-    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_debug_self_check", "cdb_layout_rule", "cdb_debug_query_latency",
+    "cdb_debug_radix_sort", "cdb_debug_verify", "cdb_debug_verify_reference", "cdb_debug_self_check", "cdb_proof_wait", "cdb_layout_rule", "cdb_debug_query_latency",
     "cdb_shards_create", "cdb_shards_destroy", "cdb_shards_last_error", "cdb_shards_add", "cdb_shards_add_bulk", "cdb_shards_set_option",
     "cdb_shards_build", "cdb_shards_query", "cdb_shards_query_batch", "cdb_shards_query_or", "cdb_shards_query_ranked", "cdb_shards_query_spans", "cdb_shards_count", "cdb_shards_get", "cdb_shards_first_doc",
     "cdb_shards_transport", "cdb_shards_build_views", "cdb_shards_query_batch_offsets", "cdb_shards_query_and", "cdb_shards_add_raw_dir", "cdb_shards_save", "cdb_shards_load",
@@ -148,6 +148,8 @@ def load_library():
     lib.cdb_debug_verify.argtypes = [vp, C.POINTER(u64)]
     lib.cdb_debug_verify_reference.argtypes = [vp, C.POINTER(u64)]
     lib.cdb_debug_self_check.argtypes = [vp, C.c_int, C.POINTER(u64)]
+    lib.cdb_proof_wait.argtypes = [vp, C.c_double]
+    lib.cdb_proof_wait.restype = C.c_int
     lib.cdb_debug_radix_sort.argtypes = [C.c_int, vp, vp, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_int)]
     lib.cdb_shards_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
@@ -439,6 +441,10 @@ class GpuStringIndex:
         out = (C.c_uint64 * 4)()
         self._check(self._lib.cdb_debug_verify_reference(self._h, out))
         return {"violations": out[0], "mixed_pairs": out[1], "radix_node_pairs": out[2], "tie_violations": out[3]}
+
+    def proof_wait(self, timeout_ms=-1.0):
+        """State of the order proof behind the last build / load (cdb_proof_wait): 2 proved, 3 damage found and repaired, ..."""
+        return int(self._lib.cdb_proof_wait(self._h, float(timeout_ms)))
 
     def self_check(self, full=False):
         """(pairs out of order, invalid entries) among 2^15 random adjacent pairs, or among all of them (cdb_debug_self_check)."""

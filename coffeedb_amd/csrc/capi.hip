@@ -242,6 +242,8 @@ void upload_views(void* dst, const char* const* ptrs, const uint64_t* doc_start,
 
 // back to "never built" (queries answer {}): a failed build or load must not leave new parameters over an old array
 void reset_unbuilt(Index& ix) {
+    proof_stop(ix);           // (the order proof reads the arrays released below)
+    ix.proof.state.store(0);
     query_resident_stop(ix);  // (the resident query workgroup reads the arrays released below)
     (void)hipStreamSynchronize(ix.stream);
     ix.release_sa();
@@ -340,6 +342,10 @@ struct ReserveJob {
     }
 };
 ReserveJob& reserve_job() {
+    // (the pools exist BEFORE the job, so they are destroyed AFTER it: a reservation still building at process exit is joined
+    //  while the block caches it allocates from are alive)
+    (void)DevPool::get();
+    (void)HostPool::get();
     static ReserveJob j;
     return j;
 }
@@ -396,6 +402,9 @@ void cdb_destroy(cdb_index* h) {
     if (!h) return;
     (void)hipSetDevice(h->ix.device);
     hipStream_t s = h->ix.stream;
+    proof_stop(h->ix);
+    if (h->ix.proof.stream) (void)hipStreamDestroy(h->ix.proof.stream);
+    if (h->ix.proof.d_out) (void)hipFree(h->ix.proof.d_out);
     query_resident_stop(h->ix);
     if (s) (void)hipStreamSynchronize(s);
     if (h->ix.res_stream) (void)hipStreamDestroy(h->ix.res_stream);
@@ -736,6 +745,12 @@ int cdb_load(cdb_index* h, const char* path) {
         }
         ix.d_doc_start = std::move(d_start);
         ix.d_ids = std::move(d_ids);
+        // a file's entries were checked one by one (each names a real suffix), their ORDER was not: the proof behind a build runs
+        // behind a load as well (damage -> the array is rebuilt from the loaded text)
+        if (ix.self_check >= 3) {
+            ix.proof.of_loaded_file = true;
+            proof_start(ix);
+        }
     });
 }
 
@@ -775,9 +790,11 @@ int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sam
         }
         for (; at < 4096; ++at) table[at] = at ? table[at - 1] : (uint8_t)0x20;
     }
-    reserve_join();
+    // device < 0 = the CALLER's current device (the helper thread's own current device is always 0)
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return CDB_E_DEVICE;
     ReserveJob& j = reserve_job();
-    std::lock_guard<std::mutex> g(j.mu);
+    std::lock_guard<std::mutex> g(j.mu);  // join and assignment under ONE lock: two concurrent calls cannot assign to a joinable thread
+    if (j.th.joinable()) j.th.join();
     try {
         j.th = std::thread([device, text_bytes, ndocs, table] {
             t_in_reserve = true;
@@ -786,6 +803,7 @@ int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sam
             try {
                 if (cdb_create(&h, device) != CDB_OK) return;
                 Index& ix = h->ix;
+                ix.self_check = 1;  // (a throw-away array: no order proof behind it)
                 CDB_HIP(hipSetDevice(ix.device));
                 DevBuf text, d_table, d_start, d_ids;
                 text.alloc(text_bytes + TEXT_PAD);
@@ -1649,7 +1667,8 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "debug_fail_build")) ix.debug_fail_build = value != 0;
     else if (!std::strcmp(name, "debug_no_segcap")) ix.debug_no_segcap = value != 0;  // test hook: "a bucket does not fit the record memory"
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = (int)value;  // 1 = reported after the sorts, 2 = error flag up before the initial sort
-    else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 2 ? 2 : (int)value;  // 0 off, 1 sample, 2 every pair
+    else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 3 ? 3 : (int)value;  // 0 off, 1 sample, 2 every pair inline, 3 sample + proof after publish
+    else if (!std::strcmp(name, "debug_damage_after_build")) ix.debug_damage_after_build = value < 0 ? 0 : (uint64_t)value;
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
     else if (!std::strcmp(name, "key_coding")) ix.key_coding = (int)value;
@@ -1684,7 +1703,11 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"build_ms", b.build_ms}, {"alloc_ms", b.alloc_ms}, {"free_ms", b.free_ms}, {"rounds", (double)b.rounds}, {"ext_rounds", (double)b.ext_rounds},
         {"dbl_rounds", (double)b.dbl_rounds}, {"unresolved_after_initial", (double)b.unresolved_initial},
         {"unresolved_max", (double)b.unresolved_max}, {"sort_passes", (double)b.sort_passes},
-        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"sweep_records", (double)b.sweep_records}, {"vl_key_bits", (double)b.vl_key_bits}, {"partial_levels", (double)b.partial_levels}, {"list_rounds", (double)b.list_rounds}, {"pairclass_fused", (double)b.pairclass_fused}, {"group_sorts", (double)b.group_sorts}, {"group_sort_fallbacks", (double)b.group_sort_fallbacks}, {"vl_avg_len", b.vl_avg_len}, {"vl_rate", b.vl_rate}, {"vl_est_unresolved", b.vl_est_unresolved}, {"fixed_est_unresolved", b.fixed_est_unresolved}, {"gen_prebased", (double)b.gen_prebased}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
+        {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"sweep_records", (double)b.sweep_records}, {"vl_key_bits", (double)b.vl_key_bits}, {"partial_levels", (double)b.partial_levels}, {"list_rounds", (double)b.list_rounds}, {"pairclass_fused", (double)b.pairclass_fused}, {"group_sorts", (double)b.group_sorts}, {"group_sort_fallbacks", (double)b.group_sort_fallbacks}, {"vl_avg_len", b.vl_avg_len}, {"vl_rate", b.vl_rate}, {"vl_est_unresolved", b.vl_est_unresolved}, {"fixed_est_unresolved", b.fixed_est_unresolved}, {"gen_prebased", (double)b.gen_prebased}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"dense_key_retries", (double)h->ix.dense_key_retries}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
+        {"order_proved", (h->ix.proof.state.load() == 2 || h->ix.proof.state.load() == 3 || (h->ix.self_check == 2 && h->ix.width != 0)) ? 1.0 : 0.0},
+        {"proof_state", (double)h->ix.proof.state.load()}, {"proof_ms", h->ix.proof.ms}, {"proof_repair_ms", h->ix.proof.repair_ms},
+        {"proof_pairs", (double)h->ix.proof.pairs}, {"proof_bad_pairs", (double)h->ix.proof.found[0]}, {"proof_invalid_entries", (double)h->ix.proof.found[1]},
+        {"proof_runs", (double)h->ix.proof.runs},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
@@ -1746,6 +1769,18 @@ int cdb_debug_self_check(cdb_index* h, int full, uint64_t out[2]) {
         if (ix.width == 0) throw Error("index has not been built");
         spot_check_suffix_array(ix, full ? 0u : (uint32_t)std::min<uint64_t>(1u << 15, ix.size > 1 ? ix.size - 1 : 1), out);
     });
+}
+
+int cdb_proof_wait(cdb_index* h, double timeout_ms) {
+    if (!h) return CDB_E_INVALID;
+    // (no lock: the state is atomic, and a repair in progress holds ix.mu itself)
+    const double t0 = wall_ms();
+    for (;;) {
+        const int st = h->ix.proof.state.load();
+        if (st != 1) return st;
+        if (timeout_ms >= 0 && wall_ms() - t0 >= timeout_ms) return 1;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]) {

@@ -18,6 +18,11 @@ namespace cdb {
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+// the bucket-wise build chose a key form that exists in the sweep kernels only (variable-length keys, partial symbol) and then had
+// to take another records form: build_suffix_array redoes the build with plain dense keys (counted: stat "dense_key_retries")
+struct RetryWithDenseKeys : Error {
+    using Error::Error;
+};
 
 #define CDB_HIP(expr)                                                                            \
     do {                                                                                         \

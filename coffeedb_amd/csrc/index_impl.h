@@ -1,7 +1,9 @@
 // index_impl.h — state of one GPU string index (the object behind the opaque cdb_index handle).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -243,14 +245,38 @@ struct Index {
                               // (u32, u32) records (radix_sort_msd); 0 = LSD split sort with the low digit as a travelling byte
     bool msd_pair = true;     // ... 6-symbol keys: top digit from the first two symbols (pair count of the text, 32-bit part arithmetic)
     bool keyhist3 = true;     // 24-bit part arithmetic in the key-histogram sweep when the key has 3 P symbols (0 = rolling 64-bit keys)
+    int dense_key_retries = 0;  // builds redone with dense keys after the sweep-only key form did not apply (sa_build.hip: RetryWithDenseKeys)
     int group_fallbacks = 0;  // builds redone in plain ticket order after a starved XCD-ordered pass (sa_build.hip)
     uint64_t bucket_group_limit = 0;  // test hook: cap on suffixes per bucket group (0 = what memory allows)
     uint64_t self_check_pairs = 0;    // adjacent pairs the last build's check compared (size - 1 with self_check = 2)
     double self_check_ms = 0;
-    int self_check = 1;           // spot check of random adjacent pairs after every build (verify.hip); a failure makes
-                                      // the build fall back to the ballot ranking once, then fail
+    // 0 off; 1 a sample of random adjacent pairs behind every build (verify.hip): a failure makes the build fall back to the ballot
+    // ranking once, then fail; 2 EVERY adjacent pair before the build returns (a proof, 1.2-1.5 x the build); 3 (default) the sample
+    // before the build returns + the proof AFTER it, off the caller's path (verify.hip: proof_start)
+    int self_check = 3;
     int self_check_fallbacks = 0;
     bool debug_fail_self_check = false;  // test hook: the first spot check of a build reports a failure
+    // ---- proof after publish (self_check = 3).  The reference's array is sorted by construction (std::sort leaves, index.cpp:86-95);
+    // here the order rests on an observed LDS lane order (radix_sort.h:12-15) and a sample proves nothing about one stray pair.  So
+    // the build publishes as before and a helper thread then compares EVERY adjacent pair against the text on a low-priority stream
+    // of its own, slice by slice, beside the queries (it reads arrays that nothing changes until proof_stop).  Damage found: the
+    // thread takes ix.mu (queries wait: a wrong array is not served while it is being replaced), switches the device to the ballot
+    // ranking, rebuilds with the full check inline and counts self_check_fallbacks.  Every path that replaces or frees the arrays
+    // (reset_unbuilt, build_suffix_array, cdb_destroy) calls proof_stop first; it may be called with ix.mu held.
+    struct Proof {
+        std::thread th;
+        std::atomic<int> state{0};       // 0 none, 1 running, 2 proved, 3 damage found and repaired, 4 repair failed, 5 cancelled, 6 could not run
+        std::atomic<bool> cancel{false};
+        hipStream_t stream = nullptr;    // lowest priority
+        void* d_out = nullptr;           // 2 x u64 on the device
+        double ms = 0, repair_ms = 0;    // wall time of the sweep / of the repair
+        uint64_t pairs = 0;              // adjacent pairs compared
+        uint64_t found[2] = {0, 0};      // pairs out of order, invalid entries
+        uint64_t runs = 0;
+        bool of_loaded_file = false;     // the array came from cdb_load: damage says nothing about this device's ranking
+    } proof;
+    bool proof_in_repair = false;        // (build_suffix_array called BY the proof thread: no stop / start of itself)
+    uint64_t debug_damage_after_build = 0;  // test hook: swap entries k, k + 1 behind the build's own check (once)
     bool debug_no_segcap = false;   // test hook: the bucket-wise build takes its per-bucket fallback ("a bucket does not fit the record memory")
     int debug_starve_group = 0;     // test hook: a build in XCD-aware tile order reports a look-back timeout once
     bool debug_fail_build = false;  // test hook: the build throws after its sorts (exercises the failure paths)
@@ -287,6 +313,9 @@ void sa_pack_inplace(Index& ix);                                           // ve
 void sa_pack_chunk(hipStream_t s, const uint64_t* d_in, uint64_t cnt, uint32_t* lo, uint8_t* hi, uint64_t first);  // verify.hip
 inline bool sa_packable(const Index& ix) { return ix.pack_sa && ix.width == 8 && (int)ix.bits + ix.off_bits <= 40; }
 void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // verify.hip: the check behind every build
+void proof_start(Index& ix);   // verify.hip: the full check behind a published build, on its own thread and stream (ix.mu held)
+void proof_stop(Index& ix);    // ... cancelled and joined (before the arrays change; callable with ix.mu held)
+void debug_swap_entries(Index& ix, uint64_t k);  // verify.hip (test hook): entries k and k + 1 of the finished array swapped
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
 // out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,
 // equal suffixes not ascending by document}

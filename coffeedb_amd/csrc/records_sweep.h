@@ -29,6 +29,17 @@ namespace cdb {
 #ifndef RS_SWEEP_UNALIGNED
 #define RS_SWEEP_UNALIGNED 0   // (measured: unaligned 8-byte LDS reads of the code windows, see rs_sweep_msd_kernel)
 #endif
+// A wave-uniform switch, pinned to an SGPR AT THE POINT OF USE.  Round 5 met a wrong-code shape of hipcc (ROCm 7.2): booleans
+// derived from wave-uniform kernel arguments (2 q < nsym - 1, part_m > 1, ...) were carried across basic blocks as LANE MASKS,
+// re-materialised inside a divergent loop under the loop's current exec and tested again BEHIND the loop by lanes that had left it
+// earlier — which read zeros (see the note in rs_sweep_records_kernel).  The volatile asm makes every call a fresh scalar value
+// the optimiser can neither hoist nor merge with another copy of the same body, so the compares derived from it are computed
+// (s_cmp, from the SGPR) inside the copy that uses them, under an exec that covers all of its lanes.  No instruction is emitted.
+__device__ __forceinline__ int rs_uniform(int x) {
+    int y = __builtin_amdgcn_readfirstlane(x);
+    asm volatile("" : "+s"(y));
+    return y;
+}
 // inclusive prefix sum over the 64 lanes of a wavefront by DPP adds (row shifts inside 16 lanes, then the row totals broadcast to
 // the rows behind them): seven vector instructions, no LDS — __shfl_up costs a ds_bpermute and three vector instructions per step
 __device__ __forceinline__ uint32_t rs_wave_incl_scan(uint32_t x) {
@@ -239,10 +250,12 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
     const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_text);
     const uint32_t B = gen.base, B2 = B * B;
     const uint32_t wlo = B | (1u << 8), whi = (B << 16) | (1u << 24);  // dot4 weights: bytes 0,1 / bytes 2,3
-    const int ns1 = gen.nsym - 1;
-    const int nsx = ns1 + (gen.part_m > 1 ? 1 : 0);  // symbols the key looks at (incl. the quantised one in its leftover bits)
+    const int ns1_arg = gen.nsym - 1, part_arg = gen.part_m > 1 ? 1 : 0;
     const uint64_t lmask = (1ull << gen.rec_low_bits) - 1ull;
     auto emit = [&](uint32_t p, uint32_t li, uint64_t e64, uint32_t rem1) {  // rem1: key symbols left in the document
+        // (the body's wave-uniform switches, scalar and private to THIS inlined copy of it: rs_uniform above)
+        const int ns1 = rs_uniform(ns1_arg), part_on = rs_uniform(part_arg);
+        const int nsx = ns1 + part_on;  // symbols the key looks at (incl. the quantised one in its leftover bits)
         const uint32_t sl = s_slotc[s_text[li]];
         const uint32_t l1 = li + 1u, wi = l1 >> 2, sel = l1 & 3u;
         const uint32_t w0 = s_words[wi], w1 = s_words[wi + 1], w2 = s_words[wi + 2];
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(512, 8) void rs_sweep_records_kernel(TextGen gen, c
                 else acc = acc * (uint64_t)mult + pv;
             }
         }
-        if (gen.part_m > 1) {  // (uniform) the leftover key bits: the next symbol, quantised (TextGen::part_m)
+        if (part_on) {  // (uniform) the leftover key bits: the next symbol, quantised (TextGen::part_m)
             const uint32_t xq = ns1 < 4 ? x0 : (ns1 < 8 ? x1 : x2);
             const uint32_t cq = (xq >> (8 * (ns1 & 3))) & 0xFFu;
             acc = acc * (uint64_t)gen.part_m + (uint64_t)((cq * gen.part_r) >> gen.part_s);

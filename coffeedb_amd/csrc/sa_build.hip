@@ -2697,7 +2697,7 @@ void build_typed(Index& ix, bool big) {
         const bool sweep_fused = fuse_rec && tile_bytes && ix.sweep_records && (vl_bits || rs_sweep_records_ok(bbase, nsym));
         // (variable-length keys exist in the sweep kernels only: build_suffix_array redoes the build with dense keys)
         const char* vl_retry = "variable-length keys: the sweep form does not apply (retry with dense keys)";
-        if ((vl_bits || part_m > 1) && !sweep_rec && !sweep_fused) throw Error(vl_retry);
+        if ((vl_bits || part_m > 1) && !sweep_rec && !sweep_fused) throw RetryWithDenseKeys(vl_retry);
         // partition + gather with packed output: the partitioned entries ARE stored packed from the start (E = low words,
         // sa_hi_buf = bits 32..39): the gather reads them through Sa40, the last pass of every group writes the finished
         // entries back in that form — 16 GiB of text: 80 instead of 128 GiB of suffix array, during the build and after it
@@ -2866,7 +2866,7 @@ void build_typed(Index& ix, bool big) {
             }
             if (!fuse_rec && ix.debug_no_segcap) seg_cap = 0;  // (test hook: "a bucket does not fit the record memory")
             if (fuse_rec && !seg_cap) throw Error("bucket-wise build: fused records without the segmented sort (internal)");
-            if ((vl_bits || part_m > 1) && !seg_cap) throw Error(vl_retry);
+            if ((vl_bits || part_m > 1) && !seg_cap) throw RetryWithDenseKeys(vl_retry);
             if (sweep_rec && !seg_cap) {  // (a bucket larger than the record memory: partition + gather, bucket by bucket)
                 sweep_rec = false;
                 sweep_doc.release();
@@ -3594,6 +3594,8 @@ void build_typed(Index& ix, bool big) {
 
 void build_suffix_array(Index& ix) {
     const double t0 = now_ms();
+    proof_stop(ix);           // (the order proof of the previous array reads what this build replaces)
+    if (!ix.proof_in_repair) ix.proof.state.store(0);  // (whatever was proved, it was the previous array)
     query_resident_stop(ix);  // (a resident query workgroup reads the arrays this build replaces)
     struct GroupScope {  // the build's sorts may use the XCD-aware tile order: a starved pass is redone below
         RadixWorkspace& ws;
@@ -3616,8 +3618,8 @@ void build_suffix_array(Index& ix) {
     auto run_dense_after_vl = [&]() {
         try {
             run();
-        } catch (const Error& e) {
-            if (std::strstr(e.what(), "variable-length keys: the sweep form does not apply") == nullptr) throw;
+        } catch (const RetryWithDenseKeys&) {
+            ix.dense_key_retries += 1;  // (visible: a column that pays two build prologues on every build is a regression)
             (void)hipStreamSynchronize(ix.stream);
             ix.prof.resolve();
             ix.release_sa();
@@ -3673,14 +3675,16 @@ void build_suffix_array(Index& ix) {
     if (ix.self_check && ix.size >= 2) {
         uint64_t sc[2] = {0, 0};
         auto check = [&]() {
-            // self_check = 1: n / 4096 random adjacent pairs, at least 2^15 and at most 2^21 (a sample: notices a ranking that went
-            // wrong, which scatters inversions over the whole array, and local damage down to a few thousand bad pairs per 2^32
-            // entries; proves nothing about one stray pair — round 5's wrong sweep records, 1 295 inversions among 8.6 x 10^9
-            // pairs, passed the 2^15 pairs of earlier rounds).  self_check = 2: EVERY adjacent pair — a proof of the order at
-            // the cost of one sweep over the array with a random text access per entry (DESIGN §4.4 has the times).
+            // The sample: n / 4096 random adjacent pairs, at least 2^15 and at most 2^21.  It notices a ranking that went wrong —
+            // that scatters inversions over the whole array — and nothing smaller: with b bad pairs among n the 2^21 samples miss
+            // them all with probability exp(-2^21 b / n) (round 5's wrong sweep records, 1 295 inversions among 8.6 x 10^9 pairs:
+            // 73 % missed; 95 % detection needs ~12 000 bad pairs at that size).  It is a smoke alarm, not a proof.
+            // self_check = 2: EVERY adjacent pair before the build returns (1.2-1.5 x the build).  self_check = 3 (default): the
+            // sample here and every pair AFTER the build has returned, on a helper thread (verify.hip: proof_start).
             const double tc = now_ms();
             const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(1u << 15, ix.size >> 12), 1u << 21);
-            const uint32_t samples = ix.self_check >= 2 ? 0u : (uint32_t)std::min<uint64_t>(want, ix.size - 1);
+            // self_check = 3 (default): the sample here, the proof behind the publish (below)
+            const uint32_t samples = ix.self_check == 2 ? 0u : (uint32_t)std::min<uint64_t>(want, ix.size - 1);
             spot_check_suffix_array(ix, samples, sc);
             ix.self_check_pairs = samples ? samples : ix.size - 1;
             ix.self_check_ms = now_ms() - tc;
@@ -3718,6 +3722,13 @@ void build_suffix_array(Index& ix) {
         }
     }
     ix.bstats.build_ms = now_ms() - t0;
+    if (ix.self_check >= 3 && !ix.proof_in_repair) {
+        // every adjacent pair against the text, AFTER the caller has its index: a helper thread on a low-priority stream
+        // (verify.hip: proof_start); cdb_get_stat("order_proved") goes 0 -> 1, damage is repaired under ix.mu
+        if (ix.debug_damage_after_build) debug_swap_entries(ix, ix.debug_damage_after_build);
+        ix.proof.of_loaded_file = false;
+        proof_start(ix);
+    }
     if (getenv("CDB_BUILD_TRACE"))
         std::fprintf(stderr, "[build] n=%llu: %.1f ms (allocation %.1f ms, release %.1f ms, self check %.2f ms), host upload before it %.1f ms\n",
                      (unsigned long long)ix.size, ix.bstats.build_ms, ix.bstats.alloc_ms, ix.bstats.free_ms, ix.self_check_ms, ix.host_upload_ms);

@@ -6,10 +6,14 @@
 //   * permutation        : every entry is a valid (doc, off) and the wrapped sum of all entries equals
 //                          the closed-form sum over all (doc, off) pairs — with strict tie order this
 //                          rules out duplicates and omissions.
+#include <chrono>
+#include <thread>
+
 #include "index_impl.h"
 
 namespace cdb {
 namespace {
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename V>
 __global__ __launch_bounds__(256) void sa_verify_kernel(typename SaOf<V>::ptr sa, uint64_t n,
@@ -170,13 +174,15 @@ __device__ __forceinline__ SfxHead sfx_head(typename SaOf<V>::ptr sa, uint64_t i
 template <typename V>
 __global__ __launch_bounds__(256) void sa_full_check_kernel(typename SaOf<V>::ptr sa, uint64_t n, const uint8_t* __restrict__ text,
                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
-                                                            uint64_t mask, bool plain, unsigned long long* __restrict__ out) {
+                                                            uint64_t mask, bool plain, unsigned long long* __restrict__ out,
+                                                            uint64_t first, uint64_t end) {
+    // entries [first, end) with the pair (first - 1, first) included: slices of one sweep add up to every adjacent pair
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     unsigned long long nbad = 0, ninvalid = 0;
-    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < n; base += stride) {  // (uniform trip count: the shuffles need every lane)
+    for (uint64_t base = first + (uint64_t)blockIdx.x * 256; base < end; base += stride) {  // (uniform trip count: the shuffles need every lane)
         const uint64_t i = base + threadIdx.x;
-        const bool valid = i < n;
+        const bool valid = i < end;
         SfxHead b = valid ? sfx_head<V>(sa, i, n, text, doc_start, ndocs, bits, mask) : SfxHead{0, 0, 0, 0, 0, 0u};
         if (valid && !b.ok) ninvalid += 1;
         SfxHead a;
@@ -383,7 +389,7 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
             const unsigned g2 = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16);
             hipLaunchKernelGGL((sa_full_check_kernel<T>), dim3(g2), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
                                (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, ix.sa_sorted,
-                               d_out.as<unsigned long long>());
+                               d_out.as<unsigned long long>(), (uint64_t)0, ix.size);
         });
     } else
     sa_dispatch(ix, [&](auto tag) {
@@ -393,6 +399,165 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
                            ix.size * 0x9E3779B97F4A7C15ull + ix.ndocs, ix.sa_sorted, d_out.as<unsigned long long>());
     });
     CDB_HIP(hipMemcpyAsync(out, d_out.p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    CDB_HIP(hipStreamSynchronize(s));
+}
+
+// ---- proof after publish (index_impl.h: Index::Proof; option self_check = 3) ---------------------------------------------
+namespace {
+template <typename W>
+__global__ void sa_debug_swap_kernel(W* a, uint64_t k) {
+    const W t = a[k];
+    a[k] = a[k + 1];
+    a[k + 1] = t;
+}
+constexpr uint64_t PROOF_SLICE = 1ull << 25;  // entries per launch: ~1 ms — what a build that wants the arrays waits for at most
+
+// the sweep itself: false = cancelled.  Reads the arrays as they were when the thread started (nothing changes them before
+// proof_stop); its launches and the 16-byte result copies are the only work on proof.stream.
+bool proof_sweep(Index& ix, uint64_t found[2]) {
+    Index::Proof& pf = ix.proof;
+    found[0] = found[1] = 0;
+    CDB_HIP(hipMemsetAsync(pf.d_out, 0, 2 * sizeof(uint64_t), pf.stream));
+    for (uint64_t first = 0; first < ix.size; first += PROOF_SLICE) {
+        if (pf.cancel.load(std::memory_order_acquire)) return false;
+        const uint64_t end = std::min<uint64_t>(ix.size, first + PROOF_SLICE);
+        sa_dispatch(ix, [&](auto tag) {
+            using T = decltype(tag);
+            const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(end - first, 256), 1u << 14);
+            hipLaunchKernelGGL((sa_full_check_kernel<T>), dim3(grid), dim3(256), 0, pf.stream, ix.sa_view<T>(), ix.size, ix.d_text,
+                               (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, ix.sa_sorted,
+                               static_cast<unsigned long long*>(pf.d_out), first, end);
+        });
+        CDB_HIP(hipStreamSynchronize(pf.stream));
+    }
+    CDB_HIP(hipMemcpyAsync(found, pf.d_out, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, pf.stream));
+    CDB_HIP(hipStreamSynchronize(pf.stream));
+    return true;
+}
+
+void proof_thread(Index* pix) {
+    Index& ix = *pix;
+    Index::Proof& pf = ix.proof;
+    try {
+        CDB_HIP(hipSetDevice(ix.device));
+        const double t0 = now_ms();
+        uint64_t found[2] = {0, 0};
+        if (!proof_sweep(ix, found)) {
+            pf.state.store(5);
+            return;
+        }
+        pf.ms = now_ms() - t0;
+        pf.pairs = ix.size - 1;
+        pf.found[0] = found[0];
+        pf.found[1] = found[1];
+        if (found[0] == 0 && found[1] == 0) {
+            pf.state.store(2);
+            return;
+        }
+        // ---- damage: replace the array.  ix.mu keeps the queries out meanwhile; a caller that holds it and waits for this thread
+        // (proof_stop from a build that replaces the arrays anyway) is seen through the cancel flag
+        std::unique_lock<std::mutex> lk(ix.mu, std::defer_lock);
+        while (!lk.try_lock()) {
+            if (pf.cancel.load(std::memory_order_acquire)) {
+                pf.state.store(5);
+                return;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        if (pf.cancel.load(std::memory_order_acquire)) {
+            pf.state.store(5);
+            return;
+        }
+        const double t1 = now_ms();
+        if (getenv("CDB_BUILD_TRACE"))
+            std::fprintf(stderr, "[proof] n=%llu: %llu pairs out of order, %llu invalid entries -> rebuilding with the ballot ranking\n",
+                         (unsigned long long)ix.size, (unsigned long long)found[0], (unsigned long long)found[1]);
+        StreamScope ss(ix.stream);
+        const bool hooked = ix.debug_damage_after_build != 0;
+        ix.debug_damage_after_build = 0;
+        // (the test hook leaves the device alone; so does a damaged FILE — its array was not sorted here)
+        if (!hooked && !pf.of_loaded_file && rs_atomic_rank_ok(ix.stream)) rs_atomic_rank_disable(ix.device);
+        pf.of_loaded_file = false;
+        ix.self_check_fallbacks += 1;
+        const int level = ix.self_check;
+        ix.self_check = 2;  // the replacement proves itself before it is served
+        ix.proof_in_repair = true;
+        struct Restore {
+            Index& ix;
+            int level;
+            ~Restore() {
+                ix.self_check = level;
+                ix.proof_in_repair = false;
+            }
+        } restore{ix, level};
+        query_resident_stop(ix);
+        (void)hipStreamSynchronize(ix.stream);
+        ix.release_sa();
+        ix.drop_keys();
+        ix.d_pivots.release();
+        ix.pivot_levels = 0;
+        ix.q_spec_cap = 0;
+        try {
+            build_suffix_array(ix);
+            pf.repair_ms = now_ms() - t1;
+            pf.state.store(3);
+        } catch (const std::exception& e) {
+            // (build_suffix_array left the handle "never built": queries answer {} instead of reading a wrong array)
+            std::lock_guard<std::mutex> g(ix.err_mu);
+            ix.err = std::string("order proof failed and the rebuild did not succeed: ") + e.what();
+            pf.state.store(4);
+        }
+    } catch (...) {
+        (void)hipGetLastError();
+        pf.state.store(6);
+    }
+}
+}  // namespace
+
+void proof_stop(Index& ix) {
+    Index::Proof& pf = ix.proof;
+    if (!pf.th.joinable() || pf.th.get_id() == std::this_thread::get_id()) return;
+    pf.cancel.store(true, std::memory_order_release);
+    pf.th.join();
+    pf.cancel.store(false, std::memory_order_release);
+}
+
+void proof_start(Index& ix) {
+    Index::Proof& pf = ix.proof;
+    if (ix.proof_in_repair) return;
+    proof_stop(ix);
+    pf.state.store(0);
+    if (ix.size < 2 || ix.width == 0) {
+        pf.state.store(2);  // (nothing to compare)
+        return;
+    }
+    try {
+        if (!pf.stream) {
+            int lo = 0, hi = 0;
+            CDB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (lo = the numerically largest = least urgent)
+            CDB_HIP(hipStreamCreateWithPriority(&pf.stream, hipStreamNonBlocking, lo));
+        }
+        if (!pf.d_out) CDB_HIP(hipMalloc(&pf.d_out, 2 * sizeof(uint64_t)));
+        pf.runs += 1;
+        pf.state.store(1);
+        pf.th = std::thread(proof_thread, &ix);
+    } catch (...) {
+        (void)hipGetLastError();
+        pf.state.store(6);
+    }
+}
+
+void debug_swap_entries(Index& ix, uint64_t k) {
+    if (k + 1 >= ix.size) return;
+    hipStream_t s = ix.stream;
+    if (ix.sa_packed) {
+        hipLaunchKernelGGL((sa_debug_swap_kernel<uint32_t>), dim3(1), dim3(1), 0, s, ix.d_sa.as<uint32_t>(), k);
+        hipLaunchKernelGGL((sa_debug_swap_kernel<uint8_t>), dim3(1), dim3(1), 0, s, ix.d_sa_hi.as<uint8_t>(), k);
+    } else if (ix.width == 8) {
+        hipLaunchKernelGGL((sa_debug_swap_kernel<uint64_t>), dim3(1), dim3(1), 0, s, ix.d_sa.as<uint64_t>(), k);
+    } else {
+        hipLaunchKernelGGL((sa_debug_swap_kernel<uint32_t>), dim3(1), dim3(1), 0, s, ix.d_sa.as<uint32_t>(), k);
+    }
     CDB_HIP(hipStreamSynchronize(s));
 }
 

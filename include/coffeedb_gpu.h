@@ -389,6 +389,17 @@ int cdb_debug_verify_reference(cdb_index* h, uint64_t out[4]);
  * pairs, or (full != 0) on every adjacent pair.  out[0] = pairs out of order, out[1] = entries that are no valid (doc, off). */
 int cdb_debug_self_check(cdb_index* h, int full, uint64_t out[2]);
 
+/* The order proof behind a published build (option self_check = 3, the default).  The reference's array is sorted by
+ * construction (std::sort leaves, index.cpp:86-95); this library's passes rest on an observed LDS lane order, so after
+ * cdb_build* / cdb_load return (with a sample of adjacent pairs checked) a helper thread compares EVERY adjacent pair of the
+ * published array against the text on a low-priority stream of its own, beside the queries.  cdb_get_stat "order_proved" goes
+ * 0 -> 1 when it is through; damage makes the handle rebuild itself with the ballot ranking under its lock (queries wait; stat
+ * "self_check_fallbacks" counts it).  cdb_proof_wait blocks until the proof of the CURRENT array has ended, at most timeout_ms
+ * (< 0: no limit), and returns its state: 0 no proof was started (self_check < 3, or not built), 1 still running, 2 proved,
+ * 3 damage found and repaired (the replacement was checked pair by pair before it was served), 4 damage found and the rebuild
+ * failed (the handle is unbuilt), 5 cancelled by a build that replaced the array, 6 the proof could not run; < 0: an error. */
+int cdb_proof_wait(cdb_index* h, double timeout_ms);
+
 /* Test hook for the radix-sort primitive (tests/test_gpu_sort.py, tools/sort_bench.py): stable sort of
  * n 64-bit keys (+ optional 4- or 8-byte values, val_bytes = 0/4/8) held in DEVICE memory by key bits
  * [0, key_bits), in place.  variant = kernel configuration (0 = default).  Reports the summed HIP-event

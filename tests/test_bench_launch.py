@@ -118,3 +118,29 @@ def test_emit_prints_the_short_line_last(tmp_path, monkeypatch, capsys):
     assert len(lines) == 2 and lines[0].startswith('{"bench_detail"') and len(lines[1]) < 8192
     assert json.loads(lines[1])["metric"] == "sa_build_GiB_per_s"
     assert json.load(open(tmp_path / "bench_detail.json"))["cold_start"]
+
+
+@pytest.mark.gpu
+def test_gpus_8_dress_rehearsal_on_one_gpu():
+    """The first 8-GPU run of bench.py is the driver's.  Here the same command runs 8 ranks that share
+    cuda:0 (gloo rendezvous) on BASELINE config 4 in miniature — 8 x 256 MiB of valid UTF-8, 10^6 patterns, the counts merge and
+    the $correlation ranking over the shards: rank arithmetic, row bases, the self check before the timed region, the per-config
+    block and the bounded final line are the ones the driver's `--gpus 8` run will execute."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu",
+                        "--workload", "c4mini", "--steps", "2", "--warmup", "1", "--configs", "c4mini", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines[-1]) < 8192
+    line = json.loads(lines[-1])
+    detail = json.loads(lines[-2])["bench_detail"]
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["value"] > 0 and line["cpu_baseline"] is None
+    sc = line["mg_selfcheck"]
+    assert sc["ok"] and sc["world"] == 8 and len(sc["bus_ids"]) == 8 and sc["merged_rows"] == sc["sum_of_local_rows"]
+    assert len(line["rows_per_rank"]) == 8 and sum(line["rows_per_rank"]) == line["merged_rows"] > 0
+    blk = detail["configs"]["c4mini"]
+    assert "error" not in blk, blk
+    assert len(blk["rows_per_rank"]) == 8 and sum(blk["rows_per_rank"]) == blk["merged_rows"] > 0
+    assert blk["ranked"]["rows"] == 1000 and blk["ranked"]["global"]["rows"] == 1000
+    assert blk["all_ranks"]["n_gpus"] == 8 and line["configs"]["c4mini"]["aggregate_GiB_per_s"] > 0

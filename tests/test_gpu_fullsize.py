@@ -753,3 +753,93 @@ def test_rebuild_16gib_utf8_shard_beside_the_serving_index_and_with_8gb_held():
     old.close()
     capi.load_library().cdb_release_cached_memory()
     assert outcome == "built", outcome
+
+
+def test_c4_shape_eight_ranks_on_one_gpu_ten_million_patterns():
+    """Dress rehearsal of BASELINE.json configs[4]'s 8-rank code path on ONE device: the first 8-GPU run is the
+    driver's, so everything but the xGMI hop runs here.  8 GiB of printable ASCII = 8 doc-aligned shards of 1 GiB (index.h:61-65:
+    suffixes never cross documents), one suffix array per shard, eight ranks of cdb_comm_create_group on device 0 (one host thread
+    each), 10^7 patterns answered by every shard, the counts-only merge (8 x 10^7 u32 row counts all-gathered, 64-bit row bases) —
+    and the merged rows compared, ROW FOR ROW, with ONE index over the whole 8 GiB (index.cpp:317-321: rows ascend by document, so
+    the single index's rows of a pattern are the shards' rows in shard order)."""
+    import threading
+    import torch
+    from coffeedb_amd import capi, workloads as W
+    free, _total = torch.cuda.mem_get_info()
+    if free < (250 << 30):
+        pytest.skip("needs a whole 288 GB MI355X")
+    G, nd, dl, npat = 8, 1 << 20, 1024, 10_000_000
+    n = nd * dl
+    text = W.random_bytes_torch(G * n, 4321, 0x20, 0x7E, device="cuda")
+    ds_all = W.uniform_docs(G * nd, dl)
+    d_ds_all = torch.from_numpy(ds_all.astype(np.int64)).cuda()
+    d_blob, d_offs, nb = W.sample_patterns_torch(text, d_ds_all, npat, 4, 16, seed=17, miss_byte=0x7F)
+    torch.cuda.synchronize()
+
+    def dev(ptr, cnt):
+        if cnt == 0:
+            return torch.zeros(0, dtype=torch.int64, device="cuda")
+        return torch.as_tensor(_Dev(ptr, cnt), device="cuda")
+
+    # ---- the referee: one index over the whole corpus (8-byte entries), its rows copied out, then released
+    d_ids_all = torch.arange(G * nd, dtype=torch.int64, device="cuda")
+    one = capi.GpuStringIndex()
+    one.build_resident(text.data_ptr(), d_ds_all.data_ptr(), d_ids_all.data_ptr(), G * nd)
+    assert (one.size, one.sa_width) == (G * n, 8)
+    r1 = one.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nb)
+    total_rows = int(r1.nrows)
+    want_rp = dev(r1.d_row_ptr, npat + 1).clone()
+    want_ids = dev(r1.d_ids, total_rows).clone()
+    want_cnt = dev(r1.d_counts, total_rows).clone()
+    assert total_rows > npat and int(want_cnt.sum()) == int(r1.nhits)
+    assert one.proof_wait(120_000) == 2                              # (the order proof behind the build: every pair)
+    one.close()
+    del d_ids_all
+    torch.cuda.empty_cache()
+    capi.load_library().cdb_release_cached_memory()
+    # ---- eight shards of the same text, global object ids
+    d_ds = torch.from_numpy(W.uniform_docs(nd, dl).astype(np.int64)).cuda()
+    shards, keep = [], []
+    for r in range(G):
+        d_ids = torch.arange(nd, dtype=torch.int64, device="cuda") + r * nd
+        g = capi.GpuStringIndex()
+        g.build_resident(text[r * n:].data_ptr(), d_ds.data_ptr(), d_ids.data_ptr(), nd)
+        assert (g.size, g.sa_width) == (n, 4) and g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0
+        shards.append(g)
+        keep.append(d_ids)
+    local = [g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nb) for g in shards]
+    comms = capi.ShardComm.group([0] * G)
+    assert all(c.world == G for c in comms)
+    out, err = [None] * G, []
+
+    def run(r):
+        try:
+            out[r] = comms[r].merge_counts(local[r])
+        except Exception as e:  # noqa: BLE001
+            err.append(repr(e))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err[:2]
+    assert sum(int(r.nrows) for r in local) == total_rows
+    pat_of = None
+    for r in range(G):
+        sl, lr = out[r], local[r]
+        assert int(sl.nrows_total) == total_rows and int(sl.nrows_local) == int(lr.nrows)
+        assert torch.equal(dev(sl.d_row_ptr, npat + 1), want_rp)     # merged row_ptr == the single index's
+        k = int(lr.nrows)
+        lrp = dev(lr.d_row_ptr, npat + 1)
+        base = dev(sl.d_row_base, npat)
+        cnt = lrp[1:] - lrp[:-1]
+        pat_of = torch.repeat_interleave(torch.arange(npat, device="cuda"), cnt)           # pattern of every local row
+        dest = base[pat_of] + (torch.arange(k, device="cuda") - lrp[:-1][pat_of])          # its slot in the merged CSR
+        assert torch.equal(want_ids[dest], dev(lr.d_ids, k)) and torch.equal(want_cnt[dest], dev(lr.d_counts, k)), r
+        assert int(dev(lr.d_ids, k).min()) >= r * nd and int(dev(lr.d_ids, k).max()) < (r + 1) * nd
+        del lrp, base, cnt, dest
+    for g in shards:
+        assert g.proof_wait(60_000) == 2
+    for c in comms:
+        c.close()
+    for g in shards:
+        g.close()
+    capi.load_library().cdb_release_cached_memory()

@@ -813,6 +813,7 @@ def test_full_self_check_finds_what_a_sample_can_miss(G, tmp_path):
             open(bad_path, "wb").write(bytes(raw))
             put(k, saved[0]); put(k + 1, saved[1])
             h = G()
+            h.set_option("self_check", 1)                        # (no order proof behind the load: it would repair what this test looks for)
             for kk, v in opts.items():
                 h.set_option(kk, v)
             try:

@@ -1,0 +1,171 @@
+"""Verify after publish (option self_check = 3, the default): the order proof behind every build.
+
+The reference's suffix array is sorted by construction (std::sort leaves, index.cpp:86-95).  This library's radix passes rest on
+an observed LDS lane order (radix_sort.h:12-15), and the sample behind a build proves nothing about one stray pair — so after
+cdb_build* / cdb_load return, a helper thread compares EVERY adjacent pair of the published array against the text, beside the
+queries; damage makes the handle rebuild itself under its lock.  Checked here with the oracle as the referee."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from coffeedb_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(nd=60000, wide=False, seed=3):
+    lens = W.random_bytes(nd, seed, 1, 200).astype(np.uint64)
+    if wide:
+        lens[nd // 2] = 150_000          # one long document: 8-byte entries (stored packed)
+    ds = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob = W.random_bytes(int(ds[-1]), seed + 1, 0x61, 0x6A)
+    return blob, ds
+
+
+def _oracle(blob, ds, ids):
+    from oracle import OracleIndex
+    o = OracleIndex()
+    o.add_bulk(ids, blob, ds)
+    o.build(4)
+    o.canonicalize(4)
+    return o
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_default_build_is_proved_after_it_returns(wide):
+    from coffeedb_amd import capi
+    blob, ds = _corpus(wide=wide)
+    ids = np.arange(len(ds) - 1, dtype=np.int64)
+    g = capi.GpuStringIndex()
+    g.add_bulk(ids, blob, ds)
+    g.build()
+    assert g.proof_wait(20_000) == 2                       # proved
+    assert g.stat("order_proved") == 1 and g.stat("proof_pairs") == g.size - 1
+    assert g.stat("proof_bad_pairs") == 0 and g.stat("proof_invalid_entries") == 0 and g.stat("self_check_fallbacks") == 0
+    assert g.stat("self_check_coverage") < 1               # (the build itself only sampled)
+    # the other levels: 1 = sample only (nothing is proved), 2 = every pair before the build returns
+    g.set_option("self_check", 1)
+    g.build()
+    assert g.proof_wait(0) == 0 and g.stat("order_proved") == 0
+    g.set_option("self_check", 2)
+    g.build()
+    assert g.proof_wait(0) == 0 and g.stat("order_proved") == 1 and g.stat("self_check_coverage") == 1
+    g.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_one_damaged_pair_is_found_and_repaired_while_four_threads_query(wide):
+    """ONE swapped adjacent pair behind the build's own check (test hook debug_damage_after_build): the sample cannot see it (it ran
+    before), the proof must; the handle rebuilds itself and serves the right array afterwards.  Four threads send lone keywords
+    the whole time: none of their calls may fail, and every answer from the moment the proof reports "repaired" is the oracle's."""
+    from coffeedb_amd import capi
+    blob, ds = _corpus(wide=wide, seed=11)
+    nd = len(ds) - 1
+    ids = np.arange(nd, dtype=np.int64) * 2 + 1
+    o = _oracle(blob, ds, ids)
+    pb, po = W.sample_patterns(blob, ds, 64, 3, 7, seed=5)
+    kws = [bytes(pb[int(po[j]):int(po[j + 1])]) for j in range(64)]
+    want = {kw: o.query(kw) for kw in kws}
+    g = capi.GpuStringIndex()
+    g.add_bulk(ids, blob, ds)
+    g.set_option("debug_damage_after_build", int(ds[-1]) // 2)
+    stop = threading.Event()
+    repaired_at = [None]
+    errors, served, late_wrong = [], [0, 0, 0, 0], []
+
+    def client(t):
+        j = t
+        while not stop.is_set():
+            kw = kws[j % len(kws)]
+            try:
+                asked = time.monotonic()
+                got = g.query(kw)
+            except Exception as e:  # noqa: BLE001 - the assertion below reports it
+                errors.append(repr(e))
+                return
+            if repaired_at[0] is not None and asked > repaired_at[0] and got != want[kw]:
+                late_wrong.append((kw, got, want[kw]))
+            served[t] += 1
+            j += 4
+
+    g.build()
+    threads = [threading.Thread(target=client, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    state = g.proof_wait(60_000)
+    repaired_at[0] = time.monotonic()
+    time.sleep(0.3)                                        # (the clients keep asking the repaired index for a while)
+    stop.set()
+    for th in threads:
+        th.join()
+    assert state == 3, state                               # damage found and repaired
+    assert not errors, errors[:3]
+    assert not late_wrong, late_wrong[:3]
+    assert min(served) > 0
+    assert g.stat("proof_bad_pairs") >= 1 and g.stat("self_check_fallbacks") == 1 and g.stat("order_proved") == 1
+    assert g.stat("proof_repair_ms") > 0
+    assert np.array_equal(g.sa(), o.sa())                  # the replacement is the oracle's array
+    for kw in kws:
+        assert g.query(kw) == want[kw]
+    # the next build of the same handle is undamaged (the hook fires once) and is proved like any other
+    g.build()
+    assert g.proof_wait(20_000) == 2 and g.stat("self_check_fallbacks") == 1
+    g.close()
+
+
+def test_a_loaded_file_with_entries_out_of_order_is_repaired(tmp_path):
+    """cdb_load checks every entry (it names a real suffix) but not the ORDER of the entries: the proof runs behind a load too."""
+    import struct
+    from coffeedb_amd import capi
+    blob, ds = _corpus(seed=21)
+    ids = np.arange(len(ds) - 1, dtype=np.int64)
+    o = _oracle(blob, ds, ids)
+    g = capi.GpuStringIndex()
+    g.add_bulk(ids, blob, ds)
+    g.build()
+    assert g.proof_wait(20_000) == 2
+    path = str(tmp_path / "ix.cdb")
+    g.save(path)
+    raw = bytearray(open(path, "rb").read())
+    w = g.sa_width
+    sa_off = len(raw) - g.size * w
+    k = g.size // 3
+    a = bytes(raw[sa_off + k * w: sa_off + (k + 1) * w])
+    raw[sa_off + k * w: sa_off + (k + 1) * w] = raw[sa_off + (k + 1) * w: sa_off + (k + 2) * w]
+    raw[sa_off + (k + 1) * w: sa_off + (k + 2) * w] = a
+    open(path, "wb").write(bytes(raw))
+    g2 = capi.GpuStringIndex()
+    g2.load(path)
+    assert g2.proof_wait(60_000) == 3 and g2.stat("self_check_fallbacks") == 1
+    assert np.array_equal(g2.sa(), o.sa())
+    g.close()
+    g2.close()
+
+
+def test_a_build_cancels_the_proof_of_the_array_it_replaces():
+    """database.cpp:276-280 builds again whenever it is told to: a build must not wait for a proof of the array it is about to
+    replace (it waits for at most one slice of the sweep), and the last array is the one that ends up proved."""
+    import torch
+    from coffeedb_amd import capi
+    nd, dl = 1 << 18, 1024
+    text = W.random_bytes_torch(nd * dl, 99, device="cuda")
+    dsz = W.uniform_docs(nd, dl)
+    ids = np.arange(nd, dtype=np.int64)
+    torch.cuda.synchronize()
+    g = capi.GpuStringIndex()
+    times = []
+    for _ in range(4):
+        t = time.perf_counter()
+        g.build_device(text.data_ptr(), dsz, ids)
+        times.append(time.perf_counter() - t)
+    assert g.stat("proof_runs") == 4
+    assert g.proof_wait(30_000) == 2 and g.stat("order_proved") == 1
+    v = g.verify()
+    assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0
+    g.close()                                               # (destroying a handle joins its proof)
+    g = capi.GpuStringIndex()
+    g.build_device(text.data_ptr(), dsz, ids)
+    g.close()                                               # ... also one that is still running
+    del text
