@@ -184,24 +184,43 @@ def build_stats(g):
     return out
 
 
-def query_roofline(torch, r, npat, n, width, query_s, device):
-    """A_q,sector = 2 ceil(log2 n) x 128 B of probes + the hit range at 64-byte sectors + 16 B per row,
-    summed over the batch with the hit counts the query really found."""
+def query_traffic():
+    """Committed counters of the query kernels and the measured random-sector ceiling (profiles/query_traffic_latest.json, written
+    by tools/query_pmc.sh: memory-side read requests of the L2 per batch from rocprofv3 PMC passes of this same command, and
+    tools/experiments/gather_ceiling.hip).  Like roofline.traffic: tagged with its profile, NOT measured in this run."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "query_traffic_latest.json")))
+    except (OSError, ValueError):
+        return None
+
+
+def query_roofline(torch, r, npat, n, width, query_s, device, prof=None, workload=None, stored_entry_bytes=None):
+    """The batched search (index.cpp:260-287) against the roofline that bounds it: the RANDOM-SECTOR rate of the memory system, not
+    its streaming bandwidth.  peak = the best rate tools/experiments/gather_ceiling.hip reaches on a working set of this size
+    (dependent or independent random 64-byte-sector reads, 1-32 waves per CU); achieved = memory-side read requests of q_search per
+    batch (committed PMC profile of this workload: TCC_EA0_RDREQ, one per random sector read — calibrated on the same program) ÷ the
+    kernel's duration by HIP events in THIS run.  The probes that never leave the LDS pivot table or the L2 are not in it."""
     levels = max(1, math.ceil(math.log2(max(n, 2))))
-    nrows = int(r.nrows)
-    hit_bytes = 0
-    if nrows:
-        rp = torch.as_tensor(_DevArr(r.d_row_ptr, npat + 1, "<i8"), device=device)
-        cnt = torch.as_tensor(_DevArr(r.d_counts, nrows, "<i8"), device=device)
-        cs = torch.zeros(nrows + 1, dtype=torch.int64, device=device)
-        torch.cumsum(cnt, 0, out=cs[1:])
-        hits = cs[rp[1:]] - cs[rp[:-1]]
-        hit_bytes = int((((hits * width + 63) // 64) * 64).sum().item())
-    a_q = npat * 2 * levels * 128 + hit_bytes + 16 * nrows
-    return {"patterns_per_s": round(npat / query_s, 1), "probes_per_s": round(npat * 2 * levels / query_s, 1),
-            "sector_bytes_per_batch": a_q, "achieved": round(a_q / query_s / 1e9, 2), "unit": "GB/s",
-            "levels": levels, "note": "A_q,sector of SURVEY §8(d) with measured hit and row counts; the search itself is "
-                                       "latency-bound (dependent probes), so this is reported, not priced against HBM peak"}
+    out = {"bound": "hbm-random-sector", "patterns_per_s": round(npat / query_s, 1), "probes_per_s": round(npat * 2 * levels / query_s, 1),
+           "levels": levels, "hits": int(r.nhits), "rows": int(r.nrows), "achieved": None, "peak": None, "unit": "G sectors/s", "frac": None}
+    qt = query_traffic()
+    ent = ((qt or {}).get("batches", {}).get(workload) or {})
+    k = (ent.get("kernels") or {}).get("q_search_fast_kernel")
+    ps = (prof or {}).get("q_search")
+    if k and ps and ps["launches"] and ent.get("patterns") == npat:
+        ms = ps["ms"] / ps["launches"]
+        ws_gb = n * (1 + (stored_entry_bytes or width)) / 1e9
+        tab = {float(g_): v for g_, v in qt["ceiling"]["G_sectors_per_s_by_working_set_GB"].items()}
+        near = min(tab, key=lambda g_: abs(math.log(max(g_, 1e-3) / max(ws_gb, 1e-3))))
+        req = k["TCC_EA0_RDREQ_sum"]
+        out.update({"kernel": "q_search", "achieved": round(req / (ms * 1e-3) / 1e9, 2), "peak": tab[near], "frac": round(req / (ms * 1e-3) / 1e9 / tab[near], 4),
+                    "kernel_ms": round(ms, 4), "memory_requests_per_batch": req, "memory_requests_per_pattern": round(req / npat, 1),
+                    "l2_hit_share_of_l1_misses": round(1 - req / max(k.get("TCP_TCC_READ_REQ_sum", req), 1), 3),
+                    "working_set_GB": round(ws_gb, 1), "peak_measured_at_working_set_GB": near,
+                    "traffic_source": f"{qt.get('profile')} (committed rocprofv3 PMC pass of this workload + gather_ceiling.hip; not measured in this run)"})
+    else:
+        out["note"] = "no committed counters for this workload / batch size: rates only"
+    return out
 
 
 def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None, merge_mode="counts",
@@ -306,7 +325,8 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         out["query_patterns_per_s"] = round(cfg["npat"] / (min(qms[1:]) * 1e-3), 1)
         out["query_hits_per_batch"] = int(r.nhits)
         out["query_rows_per_batch"] = int(r.nrows)
-        out["query_roofline"] = query_roofline(torch, r, cfg["npat"], n, g.sa_width, min(qms[1:]) * 1e-3, device)
+        out["query_roofline"] = query_roofline(torch, r, cfg["npat"], n, g.sa_width, min(qms[1:]) * 1e-3, device, prof=g.profile(), workload=name,
+                                               stored_entry_bytes=g.stat("sa_bytes_per_entry"))
         if cfg.get("short"):
             out["short_patterns"] = short_tail(torch, W, g, text, d_ds, cfg, miss)
         if cfg.get("ranked"):
@@ -335,6 +355,7 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
                 out["ranked"]["global"] = {"rows": int(len(order)), "top_count": int(cat[1][keep][order[0]]) if len(order) else 0,
                                            "ms": round((time.perf_counter() - t) * 1e3, 2),
                                            "note": "per-shard top lists all-gathered and ranked (descending count, ties ascending id)"}
+        out["order_proof"] = proof_block(g)   # (of the last build; it ran beside the queries above)
         out["verify"] = verify_block(g)
         if extras is not None:
             try:
@@ -370,6 +391,16 @@ def short_tail(torch, W, g, text, d_ds, cfg, miss):
     return {"patterns": ns, "len": "2-5", "ms": [round(x, 2) for x in sms], "hits": int(rs.nhits), "rows": int(rs.nrows),
             "hits_per_s": round(int(rs.nhits) / (min(sms) * 1e-3), 1),
             "note": "with occurrence offsets, device-resident; chunked under query_hit_budget (2^31 hits)"}
+
+
+def proof_block(g, timeout_ms=180_000):
+    """The order proof behind the last build (option self_check = 3, default: every adjacent pair against the text on a helper
+    thread, AFTER the build returned — verify.hip: proof_start): waits for it and reports what it found."""
+    st = g.proof_wait(timeout_ms)
+    return {"state": {0: "not started", 1: "still running", 2: "proved", 3: "damage found and repaired", 4: "repair failed",
+                      5: "cancelled", 6: "could not run"}.get(st, str(st)),
+            "order_proved": bool(g.stat("order_proved")), "proof_ms": round(g.stat("proof_ms"), 2), "pairs": int(g.stat("proof_pairs")),
+            "bad_pairs": int(g.stat("proof_bad_pairs")), "self_check_fallbacks": int(g.stat("self_check_fallbacks"))}
 
 
 def verify_block(g):
@@ -617,7 +648,7 @@ def short_line(out):
             "dtype", "data", "commit", "rccl_ranks", "rows_per_rank", "merged_rows", "sa_build_only_GiB_per_s", "sa_build_GiB_per_s_incl_h2d",
             "query_patterns_per_s", "query_hits_per_batch", "query_rows_per_batch", "build_ms_per_step",
             "build_algorithmic_bytes_per_suffix", "build_frac_of_hbm_peak_over_wall_time", "kernel_time_share_of_wall",
-            "peak_hbm_bytes", "c1_sa_bit_exact", "c1_rows_bit_exact")
+            "peak_hbm_bytes", "order_proved", "proof_ms", "c1_sa_bit_exact", "c1_rows_bit_exact")
     s = {k: out[k] for k in keep if k in out}
     cfg = out.get("config") or {}
     s["config"] = {"workload": _clip(cfg.get("workload", ""), 420), **{k: v for k, v in cfg.items() if k != "workload" and not isinstance(v, (dict, list, str))}}
@@ -633,7 +664,8 @@ def short_line(out):
         s["roofline"] = None
     qr = out.get("query_roofline")
     if isinstance(qr, dict):
-        s["query_roofline"] = {k: qr[k] for k in ("bound", "achieved", "peak", "unit", "frac", "patterns_per_s", "probes_per_s", "hbm_probes_per_s", "levels") if k in qr}
+        s["query_roofline"] = {k: qr[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "patterns_per_s", "probes_per_s", "levels",
+                                                  "memory_requests_per_pattern", "kernel_ms") if k in qr}
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         c = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_threads_available", "build_s", "query_patterns_per_s_1thread",
@@ -665,7 +697,10 @@ def short_line(out):
         d = {"build_ms": min(b["build_ms"]) if b.get("build_ms") else None, "sa_build_GiB_per_s": b.get("sa_build_GiB_per_s"),
              "frac_over_wall": b.get("build_frac_of_hbm_peak_over_wall_time"),
              "dominant_frac": (b.get("roofline") or {}).get("frac"), "query_patterns_per_s": b.get("query_patterns_per_s"),
+             "query_frac": (b.get("query_roofline") or {}).get("frac"),
              "peak_hbm_bytes": b.get("peak_hbm_bytes"), "dtype": b.get("dtype")}
+        if isinstance(b.get("order_proof"), dict) and "order_proved" in b["order_proof"]:
+            d["order_proved"] = b["order_proof"]["order_proved"]
         v = b.get("verify")
         if isinstance(v, dict):
             d["verify_ok"] = bool(v["invalid_entries"] == 0 and v["tie_violations"] == 0 and v["entry_sum_ok"])
@@ -1114,7 +1149,8 @@ def main():
                       if not str(k.get("phase", "")).startswith("q"))
             out["build_hbm_traffic_per_suffix_profiled"] = {"bytes": round(tot / traffic.get("suffixes", n), 1),
                                                             "profile": traffic.get("profile"), "commit": traffic.get("commit")}
-        out["query_roofline"] = query_roofline(torch, r, npat, n, g.sa_width, query_ms * 1e-3 / steps, device)
+        out["query_roofline"] = query_roofline(torch, r, npat, n, g.sa_width, query_ms * 1e-3 / steps, device, prof=prof, workload=args.workload,
+                                               stored_entry_bytes=g.stat("sa_bytes_per_entry"))
     if merger is not None:
         merger.close()
 
@@ -1122,6 +1158,27 @@ def main():
     c0 = None
     cpu_slice = None
     if rank == 0 and world == 1:
+        try:
+            # the order proof and what it costs the queries it runs beside: a fresh build, the batch at once (the proof of that build
+            # is sweeping the array meanwhile), the proof awaited, the batch again
+            def one_batch():
+                t = time.perf_counter()
+                if cfg.get("offsets"):
+                    g.query_batch_offsets_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+                else:
+                    g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
+                return (time.perf_counter() - t) * 1e3
+            g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), ndocs)
+            q_during = one_batch()
+            state_then = g.proof_wait(0)
+            out["order_proof"] = proof_block(g)
+            q_after = min(one_batch(), one_batch())
+            out["order_proof"].update({"query_ms_while_proving": round(q_during, 3), "query_ms_after": round(q_after, 3),
+                                       "proof_was_running_during_that_query": state_then == 1})
+            out["order_proved"] = out["order_proof"]["order_proved"]
+            out["proof_ms"] = out["order_proof"]["proof_ms"]
+        except Exception as e:  # noqa: BLE001
+            out["order_proof"] = {"error": repr(e)[:300]}
         out["verify"] = verify_block(g)
         if cfg.get("short"):
             try:

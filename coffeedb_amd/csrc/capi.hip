@@ -30,6 +30,7 @@ void set_error(Index& ix, const char* msg) {
 
 template <typename F>
 int guarded(cdb_index* h, F&& f) {
+    ForegroundCall fg;  // (the order proof of any handle yields to calls in flight: common.h)
     try {
         f();
         return CDB_OK;
@@ -747,7 +748,7 @@ int cdb_load(cdb_index* h, const char* path) {
         ix.d_ids = std::move(d_ids);
         // a file's entries were checked one by one (each names a real suffix), their ORDER was not: the proof behind a build runs
         // behind a load as well (damage -> the array is rebuilt from the loaded text)
-        if (ix.self_check >= 3) {
+        if (ix.self_check >= 3 || ix.premap_generation) {
             ix.proof.of_loaded_file = true;
             proof_start(ix);
         }
@@ -800,10 +801,14 @@ int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sam
             t_in_reserve = true;
             const double t_start = wall_ms();
             cdb_index* h = nullptr;
+            std::vector<size_t> twin_sizes;
+            int twin_dev = 0;
             try {
                 if (cdb_create(&h, device) != CDB_OK) return;
                 Index& ix = h->ix;
-                ix.self_check = 1;  // (a throw-away array: no order proof behind it)
+                twin_dev = ix.device;
+                ix.self_check = 1;  // (a throw-away array: no order proof behind it, no second generation)
+                ix.premap_generation = false;
                 CDB_HIP(hipSetDevice(ix.device));
                 DevBuf text, d_table, d_start, d_ids;
                 text.alloc(text_bytes + TEXT_PAD);
@@ -822,12 +827,27 @@ int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sam
                     for (void* q : pins) (void)HostPool::get().release(q);
                 }
                 const int rc = cdb_build_resident(h, text.p, d_start.as<uint64_t>(), d_ids.as<int64_t>(), ndocs);
+                // ... and the SECOND generation: the first `build` operation after start-up constructs a new index while this one
+                // serves (database.cpp:276-280) and asks for the arrays an index keeps once more — twins of those blocks are mapped
+                // now, while nothing is being served (marked spare: the first build does not take them; DevPool::premap)
+                if (rc == CDB_OK) {
+                    for (const DevBuf* b : {&ix.d_sa, &ix.d_sa_hi, &ix.d_keys, &ix.d_keys32, &ix.d_keylow, &ix.d_doc_start, &ix.d_ids})
+                        if (b->p && b->bytes >= (16u << 20)) twin_sizes.push_back(b->bytes);
+                    twin_sizes.push_back(text.bytes);  // (the real index owns its text: cdb_build / cdb_build_view(s))
+                }
                 if (getenv("CDB_BUILD_TRACE"))
                     std::fprintf(stderr, "[reserve] %llu bytes, %llu documents: throw-away build rc %d, %.1f ms in all\n", (unsigned long long)text_bytes,
                                  (unsigned long long)ndocs, rc, wall_ms() - t_start);
             } catch (...) {
             }
             if (h) cdb_destroy(h);  // (its arrays and the build's scratch go back to the block cache: that is the reservation)
+            try {
+                const double t2 = wall_ms();
+                const size_t got = twin_sizes.empty() ? 0 : DevPool::get().premap(twin_sizes, twin_dev, true);
+                if (getenv("CDB_BUILD_TRACE"))
+                    std::fprintf(stderr, "[reserve] second generation: %.1f GB mapped in %.1f ms\n", (double)got / 1e9, wall_ms() - t2);
+            } catch (...) {
+            }
         });
     } catch (...) {
         return CDB_E_DEVICE;
@@ -1668,6 +1688,7 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "debug_no_segcap")) ix.debug_no_segcap = value != 0;  // test hook: "a bucket does not fit the record memory"
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = (int)value;  // 1 = reported after the sorts, 2 = error flag up before the initial sort
     else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 3 ? 3 : (int)value;  // 0 off, 1 sample, 2 every pair inline, 3 sample + proof after publish
+    else if (!std::strcmp(name, "premap_generation")) ix.premap_generation = value != 0;
     else if (!std::strcmp(name, "debug_damage_after_build")) ix.debug_damage_after_build = value < 0 ? 0 : (uint64_t)value;
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;
@@ -1707,7 +1728,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"order_proved", (h->ix.proof.state.load() == 2 || h->ix.proof.state.load() == 3 || (h->ix.self_check == 2 && h->ix.width != 0)) ? 1.0 : 0.0},
         {"proof_state", (double)h->ix.proof.state.load()}, {"proof_ms", h->ix.proof.ms}, {"proof_repair_ms", h->ix.proof.repair_ms},
         {"proof_pairs", (double)h->ix.proof.pairs}, {"proof_bad_pairs", (double)h->ix.proof.found[0]}, {"proof_invalid_entries", (double)h->ix.proof.found[1]},
-        {"proof_runs", (double)h->ix.proof.runs},
+        {"proof_runs", (double)h->ix.proof.runs}, {"premap_ms", h->ix.proof.premap_ms}, {"premap_bytes", (double)h->ix.proof.premap_bytes},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},
@@ -1777,8 +1798,8 @@ int cdb_proof_wait(cdb_index* h, double timeout_ms) {
     const double t0 = wall_ms();
     for (;;) {
         const int st = h->ix.proof.state.load();
-        if (st != 1) return st;
-        if (timeout_ms >= 0 && wall_ms() - t0 >= timeout_ms) return 1;
+        if (st != 1 && !h->ix.proof.busy.load(std::memory_order_acquire)) return st;
+        if (timeout_ms >= 0 && wall_ms() - t0 >= timeout_ms) return st;
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
 }

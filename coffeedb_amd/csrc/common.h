@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,21 @@ inline int bit_width64(uint64_t x) { return x == 0 ? 0 : 64 - __builtin_clzll(x)
 // may still touch it is tagged (stream, event) and handed to ANOTHER stream only once the event has completed;
 // the same stream may take it back at once (stream order).
 inline thread_local hipStream_t tls_stream = nullptr;
+// Library calls in flight (every C-ABI entry that does device work counts itself in: capi.hip guarded(), shards.hip guarded_on()).
+// The order proof behind a build (verify.hip) launches its slices in the gaps: a batched search is bound by the memory system's
+// random-sector rate, and a sweep that reads a random text sector per suffix beside it cost the query 5 x its time (8 GiB Zipf:
+// 18 -> 100 ms per million patterns).
+inline std::atomic<int>& foreground_calls() {
+    static std::atomic<int> c{0};
+    return c;
+}
+struct ForegroundCall {
+    ForegroundCall() { foreground_calls().fetch_add(1, std::memory_order_acq_rel); }
+    ~ForegroundCall() { foreground_calls().fetch_sub(1, std::memory_order_acq_rel); }
+    ForegroundCall(const ForegroundCall&) = delete;
+    ForegroundCall& operator=(const ForegroundCall&) = delete;
+};
+
 struct StreamScope {
     hipStream_t prev;
     explicit StreamScope(hipStream_t s) : prev(tls_stream) { tls_stream = s; }
@@ -84,7 +100,8 @@ public:
                     (void)hipGetLastError();  // hipErrorNotReady is not an error
                 }
                 if (ready) {
-                    if (best < 0 || b.bytes < free_[best].bytes) best = i;
+                    // (blocks premap() put aside for the next generation go last: a rebuild of the SAME handle never needs them)
+                    if (best < 0 || (b.spare != free_[best].spare ? !b.spare : b.bytes < free_[best].bytes)) best = i;
                 } else if (best_busy < 0 || b.bytes < free_[best_busy].bytes) {
                     best_busy = i;
                 }
@@ -93,6 +110,7 @@ public:
                 Block b = free_[best];
                 free_.erase(free_.begin() + best);
                 cached_ -= b.bytes;
+                if (b.spare) spare_ -= std::min(spare_, b.bytes);
                 if (b.ev) put_event(b.device, b.ev);
                 actual = b.bytes;
                 account(actual);
@@ -159,6 +177,52 @@ public:
         }
         return (double)fre >= (double)need * 1.05 + (double)(256u << 20);
     }
+    // Maps what the NEXT generation will miss.  `sizes` = the blocks a published index keeps; a rebuild beside it (database.cpp:
+    // 276-280: the new index is built while the old one serves) asks for them again while they are held, so the cache — which
+    // holds the build's scratch — comes up short by that much, and a fresh hipMalloc of tens of GB costs more than the build
+    // (0.6-1 s for 30 GB on a fresh box).  Twins of those blocks are allocated HERE, off the caller's path, and go straight into
+    // the cache marked `spare` (no accounting: nothing is handed out; alloc() takes spare blocks last).  Only when this index is
+    // the one generation alive (in steady state the old generation's blocks return to the cache and ARE the spare generation),
+    // only while no earlier spare set is still unused, and never at the price of the device's last free memory.
+    // Returns the bytes newly mapped.
+    size_t premap(std::vector<size_t> sizes, int device, bool unconditional = false) {
+        size_t total = 0;
+        for (size_t& b : sizes) {
+            const size_t gran = b >= (8u << 20) ? (2u << 20) : 256;
+            b = (b + gran - 1) / gran * gran;
+            total += b;
+        }
+        if (!unconditional) {
+            std::lock_guard<std::mutex> g(mu_);
+            if (in_use_ > total + total / 4) return 0;     // another generation (or other columns' indexes) is alive
+            if (spare_ * 10 >= total * 9) return 0;        // the last spare set has not been used
+        }
+        std::sort(sizes.begin(), sizes.end(), [](size_t a, size_t b) { return a > b; });
+        size_t mapped = 0;
+        for (size_t need : sizes) {
+            size_t fre = 0, tot = 0;
+            if (hipMemGetInfo(&fre, &tot) != hipSuccess || (double)fre < (double)need * 1.1 + (double)(2ull << 30)) {
+                (void)hipGetLastError();
+                break;
+            }
+            void* p = nullptr;
+            if (hipMalloc(&p, need) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            std::lock_guard<std::mutex> g(mu_);
+            if (cached_ + need <= limit_) {
+                free_.push_back(Block{p, need, device, nullptr, nullptr, true});
+                cached_ += need;
+                spare_ += need;
+                mapped += need;
+            } else {
+                (void)hipFree(p);
+                break;
+            }
+        }
+        return mapped;
+    }
     // bytes handed out right now / the most ever handed out since reset_peak() (what an index and its build really hold
     // in HBM: cdb_memory_stats; cached blocks are not counted, the caller's own buffers — a resident text — neither)
     void stats(size_t& in_use, size_t& peak, size_t& cached) {
@@ -196,7 +260,7 @@ public:
         {
             std::lock_guard<std::mutex> g(mu_);
             if (cached_ + bytes <= limit_) {
-                free_.push_back(Block{p, bytes, device, st, ev});
+                free_.push_back(Block{p, bytes, device, st, ev, false});
                 cached_ += bytes;
                 return;
             }
@@ -241,6 +305,7 @@ public:
             std::lock_guard<std::mutex> g(mu_);
             blocks.swap(free_);
             cached_ = 0;
+            spare_ = 0;
         }
         int cur = 0;
         (void)hipGetDevice(&cur);
@@ -260,7 +325,7 @@ public:
     }
 
 private:
-    struct Block { void* p; size_t bytes; int device; hipStream_t stream; hipEvent_t ev; };
+    struct Block { void* p; size_t bytes; int device; hipStream_t stream; hipEvent_t ev; bool spare; };
     // (both called with mu_ held.  Events are not recycled: one that was recorded on a stream which has been destroyed
     //  since still points at it)
     hipEvent_t get_event(int) {
@@ -280,6 +345,7 @@ private:
     std::vector<Block> free_;
     size_t cached_ = 0;
     size_t in_use_ = 0, peak_ = 0;
+    size_t spare_ = 0;  // bytes of cached blocks premap() put aside and nobody has taken yet
     size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
                                  // the working set of a multi-GiB build costs more than the build itself
 };

@@ -274,7 +274,17 @@ struct Index {
         uint64_t found[2] = {0, 0};      // pairs out of order, invalid entries
         uint64_t runs = 0;
         bool of_loaded_file = false;     // the array came from cdb_load: damage says nothing about this device's ranking
+        std::atomic<bool> busy{false};   // the helper thread is at work (pre-mapping and / or proof)
+        bool want_proof = false;         // (this run of the thread: self_check >= 3)
+        double premap_ms = 0;
+        uint64_t premap_bytes = 0;       // device memory the helper mapped for the next generation (DevPool::premap)
     } proof;
+    // option (default off): behind every build the helper thread maps, into the block cache, the blocks a REBUILD beside this index
+    // will ask for and not find (the arrays this index keeps) — database.cpp:276-280 builds the next generation while this one
+    // serves.  Off by default: hipMalloc of tens of GB holds a driver lock that kernel launches wait for — the lone keywords of the
+    // first half second after a 4 GiB build took 496 instead of 21 ms.  cdb_reserve maps the second generation BEFORE the process
+    // serves anything (start-up: server.cpp:43-44), which is where that time belongs.
+    bool premap_generation = false;
     bool proof_in_repair = false;        // (build_suffix_array called BY the proof thread: no stop / start of itself)
     uint64_t debug_damage_after_build = 0;  // test hook: swap entries k, k + 1 behind the build's own check (once)
     bool debug_no_segcap = false;   // test hook: the bucket-wise build takes its per-bucket fallback ("a bucket does not fit the record memory")

@@ -3722,7 +3722,7 @@ void build_suffix_array(Index& ix) {
         }
     }
     ix.bstats.build_ms = now_ms() - t0;
-    if (ix.self_check >= 3 && !ix.proof_in_repair) {
+    if ((ix.self_check >= 3 || ix.premap_generation) && !ix.proof_in_repair) {
         // every adjacent pair against the text, AFTER the caller has its index: a helper thread on a low-priority stream
         // (verify.hip: proof_start); cdb_get_stat("order_proved") goes 0 -> 1, damage is repaired under ix.mu
         if (ix.debug_damage_after_build) debug_swap_entries(ix, ix.debug_damage_after_build);

@@ -371,6 +371,7 @@ void merge_counts_core(MergeRank& mr, const cdb_device_result& local, cdb_shard_
 
 template <typename T, typename F>
 int guarded_on(T* obj, F&& f) {
+    ForegroundCall fg;  // (order proofs yield to calls in flight: common.h)
     try {
         f();
         return CDB_OK;

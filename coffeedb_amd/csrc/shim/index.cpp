@@ -110,13 +110,19 @@ string_index::string_index() {
     }
     if (cdb_create(&handle, -1) != CDB_OK || !handle)
         throw std::runtime_error("GPU index: no usable MI355X (gfx950) device");
-    // COFFEEDB_RESIDENT_QUERY=1: lone query() calls (database.cpp:392) are answered by a workgroup that stays on the GPU
-    // (7.6-8.2 us instead of 12 us per call; INTEGRATION.md says what it costs)
+    // The resident workgroup that answers lone query() calls (database.cpp:392) in ~6.7 us instead of ~12 us per call switches
+    // itself on for keywords arriving back to back (library default resident_query = 2); COFFEEDB_RESIDENT_QUERY=1 pins it on
+    // from the first keyword (INTEGRATION.md says what it costs)
     if (const char* r = std::getenv("COFFEEDB_RESIDENT_QUERY"); r && *r == '1') (void)cdb_set_option(handle, "resident_query", 1);
 }
 void string_index::reserve(uint64_t bytes, std::string_view sample) {
     if (!shard_devices().empty()) return;  // (several GPUs: every shard maps its own share when it builds)
     (void)cdb_reserve(-1, bytes, 0, sample.data(), sample.size());
+}
+bool string_index::settle() const {
+    if (!handle) return true;  // (several GPUs: every shard settles behind its own build)
+    const int st = cdb_proof_wait(handle, -1.0);
+    return st == 2 || st == 3 || st == 0;
 }
 string_index::~string_index() {
     cdb_destroy(handle);

@@ -99,6 +99,10 @@ public:
     // directory (and any document as a sample of the alphabet) it lets the GPU map the first build's working set on a helper
     // thread while init() reads the files.  Returns at once; build() waits for it.  Purely an optimisation (cdb_reserve).
     static void reserve(uint64_t bytes, std::string_view sample = {});
+    // NEW: waits for what the library does BEHIND build() on a helper thread — the order proof of the published array (every
+    // adjacent pair against the text) and the mapping of the device memory a rebuild beside this index will ask for — and says
+    // whether the order is proved.  Nothing needs to call it: queries are answered meanwhile, a later build() joins it (cdb_proof_wait).
+    bool settle() const;
 
 private:
     std::vector<int64_t> ids;        // index.h:58-59: ids and (non-owning) views of the documents, in add() order

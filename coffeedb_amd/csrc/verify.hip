@@ -410,7 +410,9 @@ __global__ void sa_debug_swap_kernel(W* a, uint64_t k) {
     a[k] = a[k + 1];
     a[k + 1] = t;
 }
-constexpr uint64_t PROOF_SLICE = 1ull << 25;  // entries per launch: ~1 ms — what a build that wants the arrays waits for at most
+constexpr uint64_t PROOF_SLICE = 1ull << 24;  // entries per launch: ~0.5 ms — what a build that wants the arrays waits for at most,
+                                              // and the longest a library call that arrives mid-slice shares the memory system with it
+constexpr double PROOF_MAX_WAIT_MS = 25.0;    // under sustained load one slice runs at least this often (a duty cycle of ~2 %)
 
 // the sweep itself: false = cancelled.  Reads the arrays as they were when the thread started (nothing changes them before
 // proof_stop); its launches and the 16-byte result copies are the only work on proof.stream.
@@ -420,6 +422,12 @@ bool proof_sweep(Index& ix, uint64_t found[2]) {
     CDB_HIP(hipMemsetAsync(pf.d_out, 0, 2 * sizeof(uint64_t), pf.stream));
     for (uint64_t first = 0; first < ix.size; first += PROOF_SLICE) {
         if (pf.cancel.load(std::memory_order_acquire)) return false;
+        // slices run in the gaps between library calls (common.h: foreground_calls): beside a batched search the sweep costs the
+        // search several times its own duration
+        for (const double tw = now_ms(); foreground_calls().load(std::memory_order_acquire) > 0 && now_ms() - tw < PROOF_MAX_WAIT_MS;) {
+            if (pf.cancel.load(std::memory_order_acquire)) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         const uint64_t end = std::min<uint64_t>(ix.size, first + PROOF_SLICE);
         sa_dispatch(ix, [&](auto tag) {
             using T = decltype(tag);
@@ -435,11 +443,30 @@ bool proof_sweep(Index& ix, uint64_t found[2]) {
     return true;
 }
 
+// the blocks a rebuild beside this index will miss in the cache: mapped now, on this thread (DevPool::premap)
+void premap_next_generation(Index& ix) {
+    Index::Proof& pf = ix.proof;
+    const double t0 = now_ms();
+    std::vector<size_t> sizes;
+    for (const DevBuf* b : {&ix.d_text_owned, &ix.d_sa, &ix.d_sa_hi, &ix.d_keys, &ix.d_keys32, &ix.d_keylow, &ix.d_doc_start, &ix.d_ids})
+        if (b->p && b->bytes >= (16u << 20)) sizes.push_back(b->bytes);
+    pf.premap_bytes = sizes.empty() ? 0 : DevPool::get().premap(sizes, ix.device);
+    pf.premap_ms = now_ms() - t0;
+    if (getenv("CDB_BUILD_TRACE") && pf.premap_bytes)
+        std::fprintf(stderr, "[premap] %.1f GB mapped for the next generation in %.1f ms\n", (double)pf.premap_bytes / 1e9, pf.premap_ms);
+}
+
 void proof_thread(Index* pix) {
     Index& ix = *pix;
     Index::Proof& pf = ix.proof;
+    struct Idle {
+        Index::Proof& pf;
+        ~Idle() { pf.busy.store(false, std::memory_order_release); }
+    } idle{pf};
     try {
         CDB_HIP(hipSetDevice(ix.device));
+        if (ix.premap_generation && !pf.cancel.load(std::memory_order_acquire)) premap_next_generation(ix);
+        if (!pf.want_proof) return;
         const double t0 = now_ms();
         uint64_t found[2] = {0, 0};
         if (!proof_sweep(ix, found)) {
@@ -509,7 +536,7 @@ void proof_thread(Index* pix) {
         }
     } catch (...) {
         (void)hipGetLastError();
-        pf.state.store(6);
+        if (pf.want_proof) pf.state.store(6);
     }
 }
 }  // namespace
@@ -527,10 +554,13 @@ void proof_start(Index& ix) {
     if (ix.proof_in_repair) return;
     proof_stop(ix);
     pf.state.store(0);
-    if (ix.size < 2 || ix.width == 0) {
-        pf.state.store(2);  // (nothing to compare)
+    pf.want_proof = ix.self_check >= 3;
+    if (ix.width == 0) return;
+    if (ix.size < 2) {
+        if (pf.want_proof) pf.state.store(2);  // (nothing to compare)
         return;
     }
+    if (!pf.want_proof && !ix.premap_generation) return;
     try {
         if (!pf.stream) {
             int lo = 0, hi = 0;
@@ -538,12 +568,16 @@ void proof_start(Index& ix) {
             CDB_HIP(hipStreamCreateWithPriority(&pf.stream, hipStreamNonBlocking, lo));
         }
         if (!pf.d_out) CDB_HIP(hipMalloc(&pf.d_out, 2 * sizeof(uint64_t)));
-        pf.runs += 1;
-        pf.state.store(1);
+        if (pf.want_proof) {
+            pf.runs += 1;
+            pf.state.store(1);
+        }
+        pf.busy.store(true, std::memory_order_release);
         pf.th = std::thread(proof_thread, &ix);
     } catch (...) {
         (void)hipGetLastError();
-        pf.state.store(6);
+        pf.busy.store(false, std::memory_order_release);
+        if (pf.want_proof) pf.state.store(6);
     }
 }
 

@@ -24,34 +24,59 @@ for W in $WORKLOADS; do
   timeout 900 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $O/$W -o p -- \
     python bench.py --workload $W --configs none --no-cpu-baseline --no-pcie --steps 1 --warmup 0 > $O/$W.bench.out 2> $O/$W.err
 done
-python3 - $O "$WORKLOADS" > gpurun_out/qpmc_$TAG.txt <<'PY'
+python3 - $O "$WORKLOADS" $TAG > gpurun_out/qpmc_$TAG.txt <<'PY'
 import csv, glob, collections, json, re, sys
-O, wl = sys.argv[1], sys.argv[2].split()
+O, wl, tag = sys.argv[1], sys.argv[2].split(), sys.argv[3]
 def fam(n):
-    m = re.match(r'(?:void )?(?:cdb::)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+)', n.split('(')[0].split('<')[0].strip())
+    n = n.replace('(anonymous namespace)::', '')
+    m = re.match(r'(?:void )?(?:cdb::)?([A-Za-z0-9_]+)', n.strip())
     return m.group(1) if m else n[:40]
-def table(d):
-    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+def launches(d):
+    """{family: [ {counter: value} per dispatch, in dispatch order ]}"""
+    per = collections.defaultdict(dict)
     for f in glob.glob(f'{d}/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            a = acc[fam(r['Kernel_Name'])][r['Counter_Name']]
-            a[0] += float(r['Counter_Value']); a[1] += 1
-    return acc
+            per[(int(r['Dispatch_Id']), fam(r['Kernel_Name']))][r['Counter_Name']] = float(r['Counter_Value'])
+    out = collections.defaultdict(list)
+    for (did, k), cs in sorted(per.items()):
+        out[k].append(cs)
+    return out
+summary = {"profile": f"qpmc_{tag}", "source": "tools/query_pmc.sh: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum over "
+           "bench.py --workload W --steps 1 --warmup 0; gather_ceiling.hip by HIP events", "ceiling": {}, "calibration": {}, "batches": {}}
+best = collections.defaultdict(float)
+for l in open(f'{O}/gather_ceiling.jsonl'):
+    if l.startswith('{'):
+        r = json.loads(l)
+        if 'G_sectors_per_s' in r:
+            best[str(r['working_set_GB'])] = max(best[str(r['working_set_GB'])], r['G_sectors_per_s'])
+summary["ceiling"] = {"G_sectors_per_s_by_working_set_GB": dict(best),
+                      "note": "best of dependent / independent random 64-byte-sector reads over 1-32 waves per CU (saturates at 4 waves per CU)"}
+print('== gather_ceiling: best G sectors/s by working set (GB):', dict(best))
 print('== gather_ceiling at 40 GB under the counters (per launch, 16 waves per CU: 256 x 16 x 64 lanes x 512 loads = 134 217 728 sector reads per launch)')
-for k, cs in sorted(table(f'{O}/gather_pmc').items()):
+for k, ls in sorted(launches(f'{O}/gather_pmc').items()):
     if k.startswith('gather'):
-        print(k, {c: round(v[0] / v[1]) for c, v in sorted(cs.items())}, 'launches', max(v[1] for v in cs.values()))
+        avg = {c: round(sum(x.get(c, 0) for x in ls) / len(ls)) for c in ls[0]}
+        print(k, avg, 'launches', len(ls))
+        summary["calibration"][k] = dict(avg, sector_reads_per_launch=134217728)
 for W in wl:
-    print(f'== {W}: query kernels, totals over the run (one step: one batch)')
-    for k, cs in sorted(table(f'{O}/{W}').items()):
-        if k.startswith('q_') or 'query' in k:
-            print(W, k, {c: round(v[0]) for c, v in sorted(cs.items())}, 'launches', max(v[1] for v in cs.values()))
+    print(f'== {W}: query kernels, per launch')
     try:
         line = [l for l in open(f'{O}/{W}.bench.out').read().splitlines() if l.startswith('{')][-1]
-        j = json.loads(line)
-        print(W, 'bench (under the profiler):', {k: j.get(k) for k in ('query_patterns_per_s', 'query_hits_per_batch', 'query_rows_per_batch')})
+        npat = json.loads(line)["config"]["patterns"]
     except Exception as e:
-        print(W, 'bench line unreadable', e)
+        npat = None
+    fams = {}
+    for k, ls in sorted(launches(f'{O}/{W}').items()):
+        if not k.startswith('q_'):
+            continue
+        # the batch launches of the timed step are the LARGEST ones of a family (the lone-keyword probes and the short tail are small)
+        top = max(x.get('TCP_TCC_READ_REQ_sum', 0) for x in ls)
+        big = [x for x in ls if x.get('TCP_TCC_READ_REQ_sum', 0) >= 0.5 * top]
+        avg = {c: round(sum(x.get(c, 0) for x in big) / len(big)) for c in big[0]}
+        print(W, k, avg, 'launches', len(ls), 'of which batch-sized', len(big))
+        fams[k] = dict(avg, launches_averaged=len(big))
+    summary["batches"][W] = {"patterns": npat, "kernels": fams}
+json.dump(summary, open(f'{O}/query_counters.json', 'w'), indent=1)
 PY
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*counter_collection.csv" -size +16M -delete
