@@ -648,7 +648,8 @@ def short_line(out):
             "dtype", "data", "commit", "rccl_ranks", "rows_per_rank", "merged_rows", "sa_build_only_GiB_per_s", "sa_build_GiB_per_s_incl_h2d",
             "query_patterns_per_s", "query_hits_per_batch", "query_rows_per_batch", "build_ms_per_step",
             "build_algorithmic_bytes_per_suffix", "build_frac_of_hbm_peak_over_wall_time", "kernel_time_share_of_wall",
-            "peak_hbm_bytes", "order_proved", "proof_ms", "c1_sa_bit_exact", "c1_rows_bit_exact")
+            "peak_hbm_bytes", "order_proved", "proof_ms", "c1_sa_bit_exact", "c1_rows_bit_exact", "utf8_256m_sa_bit_exact", "utf8_256m_rows_bit_exact",
+            "zipf_256m_sa_bit_exact", "zipf_256m_rows_bit_exact")
     s = {k: out[k] for k in keep if k in out}
     cfg = out.get("config") or {}
     s["config"] = {"workload": _clip(cfg.get("workload", ""), 420), **{k: v for k, v in cfg.items() if k != "workload" and not isinstance(v, (dict, list, str))}}
@@ -740,6 +741,61 @@ def emit(out):
     line = json.dumps(short, allow_nan=False)
     assert len(line) <= 8000, len(line)
     print(line, flush=True)
+
+
+def midsize_bit_exact(torch, capi, W, nbytes=256 << 20):
+    """Literal oracle parity on the bucket-wise (>= 2^32-style) build path at a size with real tiles — the siblings of
+    `c1_sa_bit_exact` (the same check runs as tests/test_gpu_midsize_oracle.py with more option sets): 256 MiB of
+    valid UTF-8 and 256 MiB of Zipf-64 text in documents of ~1 KiB + one long one (8-byte entries), force_big_path, two uneven
+    bucket groups, reference_compat = 1 (index.h:66-73, index.cpp:86-126); cdb_sa_copy == oracle array (ties canonicalised),
+    element for element, and the rows of 10 000 patterns.  The oracle is the checker, outside every timed region."""
+    from oracle import OracleIndex
+    out = {}
+    threads = min(32, os.cpu_count() or 1)
+    for kind in ("utf8", "zipf"):
+        key = f"{kind}_{nbytes >> 20}m"
+        t0 = time.perf_counter()
+        try:
+            if kind == "utf8":
+                text, ds = W.utf8_bytes_torch(nbytes, seed=41, device="cuda")
+                blob = text.cpu().numpy()
+                del text
+            else:
+                blob = W.zipf_bytes_torch(nbytes, seed=43, device="cuda").cpu().numpy()
+                ds = W.uniform_docs(nbytes // 1024, 1024)
+            torch.cuda.empty_cache()
+            mid = len(ds) // 3   # one long document (64 merged: ~64 KiB), so that the entries need more than 32 bits
+            ds = np.concatenate([ds[:mid + 1], ds[mid + 64:]]).astype(np.uint64)
+            nd, n = len(ds) - 1, int(ds[-1])
+            ids = (np.arange(nd, dtype=np.int64) * 5 + 3)[::-1].copy()
+            g = capi.GpuStringIndex()
+            for k, v in {"force_big_path": 1, "bucket_group_limit": int(n * 0.62), **({"vl_keys": 40} if kind == "zipf" else {})}.items():
+                g.set_option(k, v)
+            g.add_bulk(ids, blob, ds)
+            g.build()
+            gsa = g.sa()
+            pb, po = W.sample_patterns(blob, ds, 10_000, 2, 14, seed=7, miss_frac=0.1, miss_byte=0xFF if kind == "utf8" else 0x7F)
+            grows = g.query_batch(pb, po)
+            info = {k: g.stat(k) for k in ("bucketed", "bucket_groups", "sweep_records", "vl_key_bits", "partial_levels", "self_check_fallbacks")}
+            proved = g.proof_wait(60_000)
+            g.close()
+            o = OracleIndex()
+            o.add_bulk(ids, blob, ds)
+            o.build(threads)
+            o.canonicalize(threads)
+            osa = o.sa_view()
+            same = bool(osa.dtype == gsa.dtype and osa.shape == gsa.shape and np.array_equal(osa, gsa))
+            orows = o.query_batch(pb, po, nthreads=threads)
+            rows_same = bool(orows[3] == grows[3] and all(np.array_equal(a, b) for a, b in zip(orows[:3], grows[:3])))
+            out[key + "_sa_bit_exact"] = same
+            out[key + "_rows_bit_exact"] = rows_same
+            out[key] = dict(info, entries=int(len(gsa)), entry_bytes=int(gsa.dtype.itemsize), order_proof_state=proved,
+                            seconds=round(time.perf_counter() - t0, 1))
+            del o, osa, gsa
+        except Exception as e:  # noqa: BLE001
+            out[key + "_sa_bit_exact"] = None
+            out[key] = {"error": repr(e)[:300]}
+    return out
 
 
 def host_caller(*argv, timeout=600):
@@ -906,6 +962,8 @@ def main():
                     help="seconds the CPU baseline may spend on the WHOLE bench corpus (0: prefix only); it runs when the "
                          "128 MiB prefix predicts it fits")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-midsize-check", action="store_true",
+                    help="skip the 256 MiB UTF-8 / Zipf oracle-parity check of the bucket-wise path (about a minute of CPU oracle)")
     ap.add_argument("--no-cold-start", action="store_true",
                     help="skip the cold-start leg (a fresh C++ process builds a 4 GiB UTF-8 column from host memory once, before "
                          "this process touches the GPU; N = 1, default workload only)")
@@ -1269,6 +1327,14 @@ def main():
         dist.barrier()
     if rank == 0:
         out["cpu_baseline"] = None
+        if world == 1 and not args.no_cpu_baseline and not args.no_midsize_check and args.configs == "auto":
+            try:
+                out["midsize_bit_exact"] = midsize_bit_exact(torch, capi, W)
+                for k, v in out["midsize_bit_exact"].items():
+                    if k.endswith("_bit_exact"):
+                        out[k] = v
+            except Exception as e:  # noqa: BLE001
+                out["midsize_bit_exact"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 c0 = c0_sweep(W)

@@ -403,7 +403,7 @@ void cdb_destroy(cdb_index* h) {
     if (!h) return;
     (void)hipSetDevice(h->ix.device);
     hipStream_t s = h->ix.stream;
-    proof_stop(h->ix);
+    proof_forget(h->ix);
     if (h->ix.proof.stream) (void)hipStreamDestroy(h->ix.proof.stream);
     if (h->ix.proof.d_out) (void)hipFree(h->ix.proof.d_out);
     query_resident_stop(h->ix);

@@ -325,6 +325,7 @@ inline bool sa_packable(const Index& ix) { return ix.pack_sa && ix.width == 8 &&
 void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // verify.hip: the check behind every build
 void proof_start(Index& ix);   // verify.hip: the full check behind a published build, on its own thread and stream (ix.mu held)
 void proof_stop(Index& ix);    // ... cancelled and joined (before the arrays change; callable with ix.mu held)
+void proof_forget(Index& ix);  // ... and the handle forgotten (cdb_destroy)
 void debug_swap_entries(Index& ix, uint64_t k);  // verify.hip (test hook): entries k and k + 1 of the finished array swapped
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
 // out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,

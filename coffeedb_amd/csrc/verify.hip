@@ -541,6 +541,38 @@ void proof_thread(Index* pix) {
 }
 }  // namespace
 
+// Helper threads still at work when the process ends (a handle nobody destroyed: an interpreter shutting down) are cancelled and
+// joined BEFORE the block caches and the HIP runtime go away: the registry is constructed after the pools, so it is destroyed first.
+namespace {
+struct ProofRegistry {
+    std::mutex mu;
+    std::vector<Index*> live;
+    ~ProofRegistry() {
+        std::vector<Index*> v;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            v.swap(live);
+        }
+        for (Index* ix : v) {
+            ix->proof.cancel.store(true, std::memory_order_release);
+            if (ix->proof.th.joinable() && ix->proof.th.get_id() != std::this_thread::get_id()) ix->proof.th.join();
+        }
+    }
+};
+ProofRegistry& proof_registry() {
+    (void)DevPool::get();
+    (void)HostPool::get();
+    static ProofRegistry r;
+    return r;
+}
+}  // namespace
+void proof_forget(Index& ix) {  // (cdb_destroy: the handle goes away)
+    proof_stop(ix);
+    ProofRegistry& r = proof_registry();
+    std::lock_guard<std::mutex> g(r.mu);
+    r.live.erase(std::remove(r.live.begin(), r.live.end(), &ix), r.live.end());
+}
+
 void proof_stop(Index& ix) {
     Index::Proof& pf = ix.proof;
     if (!pf.th.joinable() || pf.th.get_id() == std::this_thread::get_id()) return;
@@ -571,6 +603,11 @@ void proof_start(Index& ix) {
         if (pf.want_proof) {
             pf.runs += 1;
             pf.state.store(1);
+        }
+        {
+            ProofRegistry& r = proof_registry();
+            std::lock_guard<std::mutex> g(r.mu);
+            if (std::find(r.live.begin(), r.live.end(), &ix) == r.live.end()) r.live.push_back(&ix);
         }
         pf.busy.store(true, std::memory_order_release);
         pf.th = std::thread(proof_thread, &ix);

@@ -169,3 +169,24 @@ def test_a_build_cancels_the_proof_of_the_array_it_replaces():
     g.build_device(text.data_ptr(), dsz, ids)
     g.close()                                               # ... also one that is still running
     del text
+
+
+def test_a_process_may_end_while_a_proof_is_still_running():
+    """A handle nobody destroyed (an interpreter shutting down): the helper thread is cancelled and joined at process exit, before
+    the block caches and the HIP runtime go away — the process ends with exit code 0, not with a crash in a static destructor."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from coffeedb_amd import capi, workloads as W\n"
+            "nd, dl = 1 << 19, 1024\n"
+            "text = W.random_bytes_torch(nd * dl, 5, device='cuda'); torch.cuda.synchronize()\n"
+            "g = capi.GpuStringIndex()\n"
+            "g.build_device(text.data_ptr(), W.uniform_docs(nd, dl), np.arange(nd, dtype=np.int64))\n"
+            "assert g.proof_wait(0) in (1, 2)\n"
+            "capi.GpuStringIndex.__del__ = lambda self: None   # (nobody closes the handle)\n"
+            "print('LEAVING', flush=True)\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "LEAVING" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
