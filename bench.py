@@ -224,7 +224,7 @@ def query_roofline(torch, r, npat, n, width, query_s, device, prof=None, workloa
 
 
 def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merger=None, agree=None, merge_mode="counts",
-               dist=None, world=1, extras=None):
+               dist=None, world=1, extras=None, in_turn=None):
     """One of the non-default configurations: build (1 warm-up + reps) and query (1 warm-up + reps), HBM-resident."""
     cfg = WORKLOADS[name]
     clamp_note = None
@@ -236,13 +236,13 @@ def run_config(torch, capi, W, name, rank, device, local_rank, reps=2, make_merg
         # be ~10^9 rows per rank — the batch is cut to 10^6 patterns (the counts-only merge runs the whole batch)
         cfg = dict(cfg, npat=1_000_000)
     t_gen = time.perf_counter()
-    text, ds, n = make_corpus(torch, W, cfg, rank, device)
+    text, ds, n = (in_turn or (lambda f: f()))(lambda: make_corpus(torch, W, cfg, rank, device))
     ndocs = len(ds) - 1
     d_ds = torch.from_numpy(ds.astype(np.int64)).to(device)
     d_ids = torch.arange(ndocs, dtype=torch.int64, device=device) + rank * ndocs
     miss = 0xFF if cfg["kind"] == "utf8" else 0x7F
-    d_blob, d_offs, nbytes = W.sample_patterns_torch(text, d_ds, cfg["npat"], cfg["mmin"], cfg["mmax"], seed=99,
-                                                     miss_byte=miss, utf8=cfg["kind"] == "utf8")
+    d_blob, d_offs, nbytes = (in_turn or (lambda f: f()))(lambda: W.sample_patterns_torch(
+        text, d_ds, cfg["npat"], cfg["mmin"], cfg["mmax"], seed=99, miss_byte=miss, utf8=cfg["kind"] == "utf8"))
     torch.cuda.synchronize()
     # (by now this process has released VRAM — the main run's tensors and block cache — so the first build of a configuration
     #  is served recycled pages, which the driver scrubs when they are allocated again: 53 ms per GiB against 7.5 ms per GiB for
@@ -962,6 +962,9 @@ def main():
                     help="seconds the CPU baseline may spend on the WHOLE bench corpus (0: prefix only); it runs when the "
                          "128 MiB prefix predicts it fits")
     ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-proof-leg", action="store_true",
+                    help="skip the order-proof leg behind the timed region (one more build + three batches; the rocprofv3 passes of "
+                         "tools/profile_round.sh use it so that a profiled run holds exactly --steps builds)")
     ap.add_argument("--no-midsize-check", action="store_true",
                     help="skip the 256 MiB UTF-8 / Zipf oracle-parity check of the bucket-wise path (about a minute of CPU oracle)")
     ap.add_argument("--no-cold-start", action="store_true",
@@ -1026,10 +1029,29 @@ def main():
             dist.init_process_group("gloo")
 
     trace = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("CDB_BENCH_TRACE") else (lambda m: None)
+    if os.environ.get("CDB_BENCH_TRACE"):   # (where every thread of a rank that got stuck is: after 45 s, then every 45 s)
+        import faulthandler
+        faulthandler.dump_traceback_later(45, repeat=True, file=sys.stderr)
     cfg, clamp_note = per_rank_cfg(WORKLOADS[args.workload], world, args.scaling)
     if cfg.get("total") and args.scaling != "strong":
         raise SystemExit(f"--workload {args.workload} is a fixed-size corpus: run it with --scaling strong")
-    text, doc_start, n = make_corpus(torch, W, cfg, rank, device)
+    trace("process group up")
+
+    def in_turn(fn):
+        """--share-gpu (several ranks on ONE device, testing only): torch's generation kernels of four or more processes at once
+        on one GPU never finish (every rank stuck in its first .item(); two processes are fine) — the ranks take turns."""
+        if not (args.share_gpu and world > 1):
+            return fn()
+        res = None
+        for r_ in range(world):
+            if r_ == rank:
+                res = fn()
+                torch.cuda.synchronize()
+            dist.barrier()
+        return res
+
+    text, doc_start, n = in_turn(lambda: make_corpus(torch, W, cfg, rank, device))
+    trace("corpus generated")
     ndocs = len(doc_start) - 1
     npat, mmin, mmax = cfg["npat"], cfg["mmin"], cfg["mmax"]
     ids = np.arange(ndocs, dtype=np.int64) + rank * ndocs
@@ -1062,6 +1084,7 @@ def main():
             dist.broadcast(c, 0)
             t.copy_(c)
 
+    trace("patterns sampled")
     bcast(meta)
     nbytes = int(meta.item())
     d_blob = torch.zeros(nbytes + 16, dtype=torch.uint8, device=device)
@@ -1076,6 +1099,7 @@ def main():
             del b_, o_
     bcast(d_blob)
     bcast(d_offs)
+    trace("patterns broadcast")
 
     g = capi.GpuStringIndex(device=local_rank)
     g.set_option("profile", 1)
@@ -1217,6 +1241,8 @@ def main():
     cpu_slice = None
     if rank == 0 and world == 1:
         try:
+            if args.no_proof_leg:
+                raise RuntimeError("skipped (--no-proof-leg)")
             # the order proof and what it costs the queries it runs beside: a fresh build, the batch at once (the proof of that build
             # is sweeping the array meanwhile), the proof awaited, the batch again
             def one_batch():
@@ -1301,7 +1327,7 @@ def main():
                 if name == "c1" and rank == 0 and world == 1:
                     ex = c1x = C1Extras(torch, capi, W, args)
                 res = run_config(torch, capi, W, name, rank, device, local_rank, make_merger=mk, agree=agree if world > 1 else None,
-                                 merge_mode=args.merge, dist=dist if world > 1 else None, world=world, extras=ex)
+                                 merge_mode=args.merge, dist=dist if world > 1 else None, world=world, extras=ex, in_turn=in_turn)
             except Exception as e:  # noqa: BLE001
                 res = {"workload": name, "error": repr(e)[:300]}
             if world > 1:  # per-GPU shapes of C3 / C4 on every rank: report the slowest rank's rate x N

@@ -49,7 +49,7 @@ def test_gpus_2_self_launches_two_ranks_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
                         "--workload", "mid", "--steps", "2", "--warmup", "1", "--configs", "none", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=env, timeout=900)
+                       capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and len(line["rows_per_rank"]) == 2 and line["value"] > 0
@@ -129,7 +129,7 @@ def test_gpus_8_dress_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu",
                         "--workload", "c4mini", "--steps", "2", "--warmup", "1", "--configs", "c4mini", "--no-cpu-baseline"],
-                       capture_output=True, text=True, env=env, timeout=1500)
+                       capture_output=True, text=True, env=env, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines[-1]) < 8192

@@ -4,7 +4,9 @@
 set -u
 TAG=${1:-r03}
 SRC=gpurun_out/prof_$TAG
-[ -f $SRC/bench.json ] && cp $SRC/bench.json profiles/${TAG}_bench.json
+[ -f $SRC/bench_stdout.txt ] && cp $SRC/bench_stdout.txt profiles/${TAG}_bench_stdout.txt
+[ -f $SRC/bench_stdout.txt ] && tail -n 1 $SRC/bench_stdout.txt > profiles/${TAG}_bench_line.json
+[ -f $SRC/bench_detail.json ] && cp $SRC/bench_detail.json profiles/${TAG}_bench_detail.json
 for D in $SRC/*/; do
   W=$(basename $D)
   [ -f $D/summary.txt ] && cp $D/summary.txt profiles/${TAG}_${W}_summary.txt

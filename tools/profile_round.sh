@@ -15,13 +15,16 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
-  python bench.py > $OUT/bench.json 2> $OUT/bench.err
-  tail -c 400 $OUT/bench.json
+  ( time python bench.py ) > $OUT/bench_stdout.txt 2> $OUT/bench.err   # two lines: {"bench_detail": ...}, then the bounded contract line
+  cp bench_detail.json $OUT/bench_detail.json 2>/dev/null
+  tail -n 1 $OUT/bench_stdout.txt | wc -c
+  tail -n 1 $OUT/bench_stdout.txt | cut -c1-600
+  tail -n 4 $OUT/bench.err
 fi
 for W in $WORKLOADS; do
   D=$OUT/$W
   mkdir -p $D
-  CMD="python bench.py --workload $W --configs none --no-cpu-baseline --no-pcie"
+  CMD="python bench.py --workload $W --configs none --no-cpu-baseline --no-pcie --no-proof-leg"
   case $W in
     c1) N=1073741824;; utf8_4g) N=4294967296;; c2|c3shard) N=8589934592;; c4shard) N=17179869184;; *) N=0;;
   esac
