@@ -60,7 +60,7 @@ def family(name):
 stats = find("trace", "*kernel_stats.csv")
 if stats:
     print("== rocprofv3 --kernel-trace --stats ==")
-    for r in list(csv.DictReader(open(stats)))[:12]:
+    for r in list(csv.DictReader(open(stats)))[:30]:
         print(f"{family(r['Name']):34s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={r['Percentage']}")
 
