@@ -460,15 +460,26 @@ __global__ __launch_bounds__(256) void q_expand_kernel(typename SaOf<V>::ptr sa,
                                                        int obits, const int64_t* __restrict__ left,
                                                        const uint64_t* __restrict__ hoff, uint64_t j0, uint64_t j1,
                                                        uint64_t H, uint64_t* __restrict__ keys) {
+    // (round 6: the workgroup's first and last slot are located in the whole chunk — ~20 dependent loads each —, every other thread
+    //  only between those two patterns: a handful of patterns for 256 consecutive slots)
+    __shared__ uint64_t s_rng[2];
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= H) return;
-    const uint64_t slot = hoff[j0] + t;
-    uint64_t lo = j0, hi = j1 - 1;  // largest j with hoff[j] <= slot
-    while (lo < hi) {
-        const uint64_t mid = lo + (hi - lo + 1) / 2;
-        if (hoff[mid] <= slot) lo = mid; else hi = mid - 1;
+    const uint64_t h0 = hoff[j0];
+    auto owner = [&](uint64_t slot, uint64_t lo, uint64_t hi) {  // largest j in [lo, hi] with hoff[j] <= slot
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo + 1) / 2;
+            if (hoff[mid] <= slot) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    if (threadIdx.x == 0 || threadIdx.x == 255) {
+        const uint64_t tb = (uint64_t)blockIdx.x * 256 + (threadIdx.x ? 255u : 0u);
+        s_rng[threadIdx.x ? 1 : 0] = owner(h0 + (tb < H ? tb : H - 1), j0, j1 - 1);
     }
-    const uint64_t j = lo;
+    __syncthreads();
+    if (t >= H) return;
+    const uint64_t slot = h0 + t;
+    const uint64_t j = owner(slot, s_rng[0], s_rng[1]);
     const uint64_t i = (uint64_t)left[j] + (slot - hoff[j]);
     // obits > 0: the occurrence offset rides along as the least significant field (offset emission)
     const auto e = sa[i];
@@ -476,30 +487,71 @@ __global__ __launch_bounds__(256) void q_expand_kernel(typename SaOf<V>::ptr sa,
     keys[t] = obits ? (pd << obits) | ((uint64_t)e >> bits) : pd;
 }
 
-struct RunIn {  // 1 at the first hit of every (pattern, doc) run
-    const uint64_t* keys;
-    int obits;
-    __device__ __forceinline__ uint64_t operator()(uint64_t t) const {
-        return (t == 0 || (keys[t] >> obits) != (keys[t - 1] >> obits)) ? 1ull : 0ull;
+// Rows of a sorted hit list: a row = a run of hits with one (pattern, doc), index.cpp:316-322.  Round 6: two kernels of their own
+// instead of the generic scan with functors.  The generic scan gives every thread 16 CONSECUTIVE items, so one load instruction of a
+// wave touched 64 different 128-byte lines and the occurrence offsets went out as 64 partial lines per store instruction: 1.55 +
+// 6.75 ms for the 1.05 x 10^8 hits of BASELINE config 2's batch (0.25 TB/s) — a third of the whole query.  Here a wave's lanes
+// take consecutive hits (16 rows of 256 per tile of SC_TILE), heads are ranked by wave ballots, and all traffic is coalesced.
+__global__ __launch_bounds__(256) void q_run_count_kernel(const uint64_t* __restrict__ keys, uint64_t H, int obits,
+                                                          uint64_t* __restrict__ partials) {
+    static_assert(SC_TILE == 4096, "run kernels assume 4096-hit tiles (16 rows of 256)");
+    __shared__ uint32_t s_w[4];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * SC_TILE;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t i = tile0 + (uint64_t)j * 256 + threadIdx.x;
+        if (i < H) cnt += (i == 0 || (keys[i] >> obits) != (keys[i - 1] >> obits)) ? 1u : 0u;
     }
-};
-struct RunOut {  // row r starts at hit slot t: remember t, decode the doc
-    const uint64_t* keys;
-    uint64_t* row_first;  // [nrows + 1] first hit slot of each row
-    uint64_t* row_key;
-    uint64_t H;
-    int obits;
-    uint64_t* hit_off;  // optional: occurrence offset of every hit slot, in sorted order
-    __device__ __forceinline__ void operator()(uint64_t t, uint64_t ex, uint64_t in) const {
-        const uint64_t k = keys[t];
-        if (in != ex) {
-            row_first[ex] = t;
-            row_key[ex] = k >> obits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (uint64_t)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// partials: exclusive scan of the tile counts.  row r starts at hit slot row_first[r] (row_first[nrows] = H), row_key[r] =
+// (pattern ∘ doc) of the row; hit_off (optional): occurrence offset of every hit slot, in sorted order
+__global__ __launch_bounds__(256) void q_run_apply_kernel(const uint64_t* __restrict__ keys, uint64_t H, int obits,
+                                                          const uint64_t* __restrict__ partials, uint64_t* __restrict__ row_first,
+                                                          uint64_t* __restrict__ row_key, uint64_t* __restrict__ hit_off) {
+    __shared__ uint32_t s_cnt[16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * SC_TILE;
+    const uint64_t omask = (1ull << obits) - 1ull;
+    uint64_t k[16];
+    uint32_t below[16], heads = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t i = tile0 + (uint64_t)j * 256 + threadIdx.x;
+        const bool valid = i < H;
+        k[j] = valid ? keys[i] : 0ull;
+        const bool head = valid && (i == 0 || (k[j] >> obits) != (keys[i - 1] >> obits));
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(head);
+        below[j] = (uint32_t)__popcll(bal & lt_mask);
+        heads |= (head ? 1u : 0u) << j;
+        if (lane == 0) s_cnt[j][wave] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    uint64_t run = partials[blockIdx.x];  // rows in front of this tile
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t c0 = s_cnt[j][0], c1 = s_cnt[j][1], c2 = s_cnt[j][2], c3 = s_cnt[j][3];
+        const uint32_t pre = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+        const uint64_t i = tile0 + (uint64_t)j * 256 + threadIdx.x;
+        if (i < H) {
+            const uint32_t head = (heads >> j) & 1u;
+            const uint64_t ex = run + pre + below[j];
+            if (head) {
+                row_first[ex] = i;
+                row_key[ex] = k[j] >> obits;
+            }
+            if (hit_off) hit_off[i] = k[j] & omask;
+            if (i + 1 == H) row_first[ex + head] = H;
         }
-        if (hit_off) hit_off[t] = k & ((1ull << obits) - 1ull);
-        if (t + 1 == H) row_first[in] = H;
+        run += (uint64_t)c0 + c1 + c2 + c3;
     }
-};
+}
 
 __global__ __launch_bounds__(256) void q_rows_kernel(const uint64_t* __restrict__ row_first,
                                                      const uint64_t* __restrict__ row_key, uint64_t nrows, int dbits,
@@ -936,13 +988,17 @@ DeviceCsr query_typed(Index& ix, const uint8_t* d_blob, const uint64_t* d_offs, 
         const uint64_t* keys = sel == 0 ? ix.q_keys0.as<uint64_t>() : ix.q_keys1.as<uint64_t>();
         uint64_t* spare = sel == 0 ? ix.q_keys1.as<uint64_t>() : ix.q_keys0.as<uint64_t>();
 
-        RunIn rin{keys, obits};
-        const uint64_t nrows = scan_totals<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0);
+        const uint64_t nbr = ceil_div(Hc, (uint64_t)SC_TILE);
+        ix.scan_partials.ensure(scan_partials_slots(nbr) * sizeof(uint64_t));
+        t = ix.prof.begin(s);
+        hipLaunchKernelGGL(q_run_count_kernel, dim3((unsigned)nbr), dim3(256), 0, s, keys, Hc, obits, ix.scan_partials.as<uint64_t>());
+        const uint64_t nrows = scan_totals_from_partials<uint64_t>(s, ix.scan_partials, Hc, OpAdd{}, (uint64_t)0);
         ix.q_flags.ensure((nrows + 1) * 8);  // row_first
         // row keys go to the spare key buffer (nrows <= Hc)
-        scan_apply<uint64_t>(s, ix.scan_partials, rin, Hc, OpAdd{}, (uint64_t)0,
-                             RunOut{keys, ix.q_flags.as<uint64_t>(), spare, Hc, obits,
-                                    with_offsets ? ix.q_hitoff.as<uint64_t>() + hits_done : (uint64_t*)nullptr});
+        hipLaunchKernelGGL(q_run_apply_kernel, dim3((unsigned)nbr), dim3(256), 0, s, keys, Hc, obits,
+                           (const uint64_t*)ix.scan_partials.as<uint64_t>(), ix.q_flags.as<uint64_t>(), spare,
+                           with_offsets ? ix.q_hitoff.as<uint64_t>() + hits_done : (uint64_t*)nullptr);
+        ix.prof.end(t, "q_runs", Hc * (16 + (with_offsets ? 8 : 0)) + nrows * 16, s);
         grow_keep(ix.q_ids, (rows_total + nrows) * 8, rows_total * 8, s);
         grow_keep(ix.q_counts, (rows_total + nrows) * 8, rows_total * 8, s);
         if (with_offsets) grow_keep(ix.q_hitptr, (rows_total + nrows + 1) * 8, rows_total * 8, s);

@@ -69,7 +69,16 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys
             if (p < npass) {
                 uint32_t d = (uint32_t)(k >> (begin_bit + dbits * p)) & ((1u << dbits) - 1u);
                 if (p == npass - 1) d &= last_mask;
-                atomicAdd(&sh[p * 256 + d], 1u);
+                // (keys that arrive nearly sorted — the hit keys of a query batch come in pattern order — agree on their high
+                //  digits: 64 same-address atomics serialise, one add of the lane count does not.  8 GiB Zipf batch: 0.92 -> ms below)
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const uint64_t same = __builtin_amdgcn_ballot_w64(d == d0);
+                const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                if (same == act) {
+                    if ((uint32_t)__builtin_ffsll((long long)act) - 1u == (threadIdx.x & 63u)) atomicAdd(&sh[p * 256 + d0], (uint32_t)__popcll(act));
+                } else {
+                    atomicAdd(&sh[p * 256 + d], 1u);
+                }
             }
         }
     }
