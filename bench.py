@@ -1106,11 +1106,14 @@ def main():
     merger = shard.ShardMerger(capi, g, dist, rank, world, coll_device, device, mode=args.merge) if (world > 1 or args.force_merge) else None
 
     merged_rows = [None]   # row_ptr[-1] of the last step's merged CSR (N > 1)
+    call_wall = []         # (build call, query call) wall ms per step, as the caller sees them
 
     def step():
         # the document table is resident like the text (cdb_build_resident): nothing but scalars crosses PCIe in a step
         trace("build")
+        tw0 = time.perf_counter()
         g.build_resident(text.data_ptr(), d_doc_start.data_ptr(), d_ids.data_ptr(), ndocs)
+        tw1 = time.perf_counter()
         trace(f"query (build {g.stat('build_ms'):.1f} ms, group_fallbacks {g.stat('group_fallbacks'):.0f})")
         tb = g.stat("build_ms")
         if cfg.get("offsets"):
@@ -1118,6 +1121,7 @@ def main():
         else:
             r = g.query_batch_device(d_blob.data_ptr(), d_offs.data_ptr(), npat, nbytes)
         tq = g.stat("query_ms")
+        call_wall.append((round((tw1 - tw0) * 1e3, 3), round((time.perf_counter() - tw1) * 1e3, 3)))
         if merger is not None:
             trace("merge")
             m = merger.merge(r, npat)
@@ -1151,12 +1155,15 @@ def main():
     build_ms = query_ms = 0.0
     step_build_ms = []
     r = None
+    del call_wall[:]
     for _ in range(args.steps):
         tb, tq, r = step()
         build_ms += tb
         query_ms += tq
         step_build_ms.append(round(tb, 3))
+    t_sync = time.perf_counter()
     torch.cuda.synchronize()
+    t_sync = (time.perf_counter() - t_sync) * 1e3
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -1216,6 +1223,8 @@ def main():
             "query_hits_per_batch": hits,
             "query_rows_per_batch": rows,
             "build_ms_per_step": step_build_ms,
+            "call_wall_ms_per_step": list(call_wall),       # (build call, query call) as the caller's clock sees them
+            "closing_synchronize_ms": round(t_sync, 3),     # torch.cuda.synchronize() behind the last step (waits for every stream)
             "build_stats": build_stats(g),
             "roofline": roof,
             "build_kernels_ms_per_step": round(kern_ms, 3),

@@ -71,6 +71,7 @@ def test_c1_full_size_properties():
         a, b = int(rp[j]), int(rp[j + 1])
         got = {(int(i) - 7) // 3: int(c) for i, c in zip(ri[a:b], rc[a:b])}
         assert got == want, (j, bytes(kw))
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
 
 
@@ -114,6 +115,7 @@ def test_beyond_4gib_on_one_gpu():
                 per_doc[a] = per_doc.get(a, 0) + b
         a, b = int(rp[j]), int(rp[j + 1])
         assert {int(i) - 1_000_000: int(c) for i, c in zip(ri[a:b], rc[a:b])} == per_doc
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
     capi.load_library().cdb_release_cached_memory()
 
@@ -226,6 +228,7 @@ def test_c2_full_size_zipf_one_million_patterns_with_offsets():
         assert bool(((ri_d[a:b] - 1) // 2 == want_docs).all()) and bool((rc_d[a:b] == want_cnt).all()), (j, bytes(kw))
         assert bool((off_d[int(hp_d[a]):int(hp_d[b])] == pos % dl).all()), (j, bytes(kw))
         del pos, want_docs, want_cnt
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
     capi.load_library().cdb_release_cached_memory()
 
@@ -263,6 +266,7 @@ def test_utf8_4gib_reference_order_and_true_order():
     for j in range(0, 2000, 97):
         a, b = int(rp[j]), int(rp[j + 1])
         assert g.query(bytes(pb[int(po[j]):int(po[j + 1])])) == list(zip(ri[a:b].tolist(), rc[a:b].tolist())), j
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
 
     g = capi.GpuStringIndex()
@@ -283,6 +287,7 @@ def test_utf8_4gib_reference_order_and_true_order():
         wd, wc = torch.unique(doc, return_counts=True)
         a, b = int(rp[j]), int(rp[j + 1])
         assert np.array_equal(ri[a:b], wd.cpu().numpy()) and np.array_equal(rc[a:b], wc.cpu().numpy()), (j, bytes(kw))
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
     capi.load_library().cdb_release_cached_memory()
 
@@ -332,6 +337,7 @@ def test_c4_shard_16gib_utf8_ten_million_patterns():
     union = dict(g.query_or(kws))
     assert len(ranked) == min(50, len(union)) and all(union[i] == c for i, c in ranked)
     assert [c for _, c in ranked] == sorted(union.values(), reverse=True)[: len(ranked)]
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
     capi.load_library().cdb_release_cached_memory()
 
@@ -397,6 +403,7 @@ def test_reference_test_highlight_sequential_replace():
             out.append(text[last:])
             assert b"".join(out) == want, i
     assert set(spans) == changed and len(changed) > 200
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
 
 
@@ -435,6 +442,7 @@ def test_c3_shard_8gib_ascii():
         wd, wc = torch.unique(pos // dl, return_counts=True)
         a, b = int(rp[j]), int(rp[j + 1])
         assert np.array_equal(ri[a:b], wd.cpu().numpy()) and np.array_equal(rc[a:b], wc.cpu().numpy()), (j, bytes(kw))
+    assert g.proof_wait(300_000) == 2 and g.stat("self_check_fallbacks") == 0   # order proof behind the build: every adjacent pair
     g.close()
 
 

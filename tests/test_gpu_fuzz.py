@@ -1,5 +1,6 @@
 """Seeded fuzz parity: random corpus shapes x build options against the CPU oracle (suffix array
-bit-exact after tie canonicalisation, batched query rows, OR-merge and highlight spans)."""
+bit-exact after tie canonicalisation, batched query rows, OR-merge and highlight spans); every build is also awaited through
+its order proof (self_check = 3: every adjacent pair against the text, verify.hip)."""
 import numpy as np
 import pytest
 
@@ -91,6 +92,7 @@ def test_fuzz_parity(seed):
     assert g.query_spans(kws) == o.highlight_spans(kws, ids), (seed, opts)
     for kw in kws[:6]:   # a lone keyword takes the one-wavefront kernel (<= 4096 hits) or hands over to the batch path
         assert g.query(kw) == o.query(kw), (seed, opts, kw)
+    assert g.proof_wait(60_000) == 2 and g.stat("self_check_fallbacks") == 0   # the order proof behind the build: every adjacent pair
     g.close()
 
 
@@ -162,6 +164,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     else:              # plain unsigned order: a sorted permutation (the oracle restates the reference's order)
         v = g.verify()
         assert v["inversions"] == v["tie_violations"] == v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"], (seed, kind, opts)
+    assert g.proof_wait(60_000) == 2 and g.stat("self_check_fallbacks") == 0   # the order proof behind the build: every adjacent pair
     g.close()
 
 
@@ -225,4 +228,5 @@ def test_fuzz_bucket_wise_with_documents_of_real_size(seed):
     pb, po = W.sample_patterns(blob, ds, 100, 1, 9, seed=seed, miss_frac=0.1, miss_byte=int(blob[0]) ^ 0x55)
     got, want = g.query_batch(pb, po), o.query_batch(pb, po)
     assert got[3] == want[3] and all(np.array_equal(a, b) for a, b in zip(got[:3], want[:3])), info
+    assert g.proof_wait(60_000) == 2 and g.stat("self_check_fallbacks") == 0   # the order proof behind the build: every adjacent pair
     g.close()
