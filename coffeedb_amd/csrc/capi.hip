@@ -831,8 +831,7 @@ int cdb_reserve(int device, uint64_t text_bytes, uint64_t ndocs, const char* sam
                 // serves (database.cpp:276-280) and asks for the arrays an index keeps once more — twins of those blocks are mapped
                 // now, while nothing is being served (marked spare: the first build does not take them; DevPool::premap)
                 if (rc == CDB_OK) {
-                    for (const DevBuf* b : {&ix.d_sa, &ix.d_sa_hi, &ix.d_keys, &ix.d_keys32, &ix.d_keylow, &ix.d_doc_start, &ix.d_ids})
-                        if (b->p && b->bytes >= (16u << 20)) twin_sizes.push_back(b->bytes);
+                    twin_sizes = retained_block_sizes(ix);
                     twin_sizes.push_back(text.bytes);  // (the real index owns its text: cdb_build / cdb_build_view(s))
                 }
                 if (getenv("CDB_BUILD_TRACE"))
@@ -1728,7 +1727,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"order_proved", (h->ix.proof.state.load() == 2 || h->ix.proof.state.load() == 3 || (h->ix.self_check == 2 && h->ix.width != 0)) ? 1.0 : 0.0},
         {"proof_state", (double)h->ix.proof.state.load()}, {"proof_ms", h->ix.proof.ms}, {"proof_repair_ms", h->ix.proof.repair_ms},
         {"proof_pairs", (double)h->ix.proof.pairs}, {"proof_bad_pairs", (double)h->ix.proof.found[0]}, {"proof_invalid_entries", (double)h->ix.proof.found[1]},
-        {"proof_runs", (double)h->ix.proof.runs}, {"premap_ms", h->ix.proof.premap_ms}, {"premap_bytes", (double)h->ix.proof.premap_bytes},
+        {"proof_runs", (double)h->ix.proof.runs}, {"pool_big_mallocs", (double)DevPool::get().big_mallocs()}, {"premap_ms", h->ix.proof.premap_ms}, {"premap_bytes", (double)h->ix.proof.premap_bytes},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},
         {"compat_depth", (double)b.compat_depth},

@@ -139,6 +139,7 @@ public:
             return busy.p;
         }
         void* p = nullptr;
+        if (need >= (16u << 20)) big_mallocs_.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipMalloc(&p, need);
         if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
             (void)hipGetLastError();
@@ -323,6 +324,9 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         return cached_;
     }
+    // requests of 16 MiB and more that the cache could not serve and went to hipMalloc (what cdb_reserve's spare generation and
+    // premap() exist to avoid on a caller's path; stat "pool_big_mallocs")
+    uint64_t big_mallocs() const { return big_mallocs_.load(std::memory_order_relaxed); }
 
 private:
     struct Block { void* p; size_t bytes; int device; hipStream_t stream; hipEvent_t ev; bool spare; };
@@ -346,6 +350,7 @@ private:
     size_t cached_ = 0;
     size_t in_use_ = 0, peak_ = 0;
     size_t spare_ = 0;  // bytes of cached blocks premap() put aside and nobody has taken yet
+    std::atomic<uint64_t> big_mallocs_{0};
     size_t limit_ = ~(size_t)0;  // bytes kept for reuse (cdb_set_cache_limit); unlimited by default: re-allocating
                                  // the working set of a multi-GiB build costs more than the build itself
 };

@@ -326,6 +326,16 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]);  // 
 void proof_start(Index& ix);   // verify.hip: the full check behind a published build, on its own thread and stream (ix.mu held)
 void proof_stop(Index& ix);    // ... cancelled and joined (before the arrays change; callable with ix.mu held)
 void proof_forget(Index& ix);  // ... and the handle forgotten (cdb_destroy)
+// sizes (>= 16 MiB) of the device blocks a published index holds on to: its arrays and the work spaces a handle keeps across calls —
+// what a second generation built beside it will ask the block cache for once more (cdb_reserve, DevPool::premap)
+inline std::vector<size_t> retained_block_sizes(const Index& ix) {
+    std::vector<size_t> out;
+    for (const DevBuf* b : {&ix.d_text_owned, &ix.d_sa, &ix.d_sa_hi, &ix.d_keys, &ix.d_keys32, &ix.d_keylow, &ix.d_doc_start, &ix.d_ids,
+                            &ix.rws.status, &ix.rws.tile_doc, &ix.msd_ws.segs, &ix.msd_ws.tile_seg, &ix.msd_ws.hist, &ix.msd_ws.starts,
+                            &ix.scan_partials, &ix.tbw.partial, &ix.tbw.blockbase, &ix.tbw.totals, &ix.tbw.base})
+        if (b->p && b->bytes >= (16u << 20)) out.push_back(b->bytes);
+    return out;
+}
 void debug_swap_entries(Index& ix, uint64_t k);  // verify.hip (test hook): entries k and k + 1 of the finished array swapped
 // the REFERENCE's order (signed child order inside radix nodes, unsigned below), checked pair by pair:
 // out = {pairs out of reference order, pairs whose next bytes differ in sign class, of those inside radix nodes,

@@ -447,9 +447,7 @@ bool proof_sweep(Index& ix, uint64_t found[2]) {
 void premap_next_generation(Index& ix) {
     Index::Proof& pf = ix.proof;
     const double t0 = now_ms();
-    std::vector<size_t> sizes;
-    for (const DevBuf* b : {&ix.d_text_owned, &ix.d_sa, &ix.d_sa_hi, &ix.d_keys, &ix.d_keys32, &ix.d_keylow, &ix.d_doc_start, &ix.d_ids})
-        if (b->p && b->bytes >= (16u << 20)) sizes.push_back(b->bytes);
+    const std::vector<size_t> sizes = retained_block_sizes(ix);
     pf.premap_bytes = sizes.empty() ? 0 : DevPool::get().premap(sizes, ix.device);
     pf.premap_ms = now_ms() - t0;
     if (getenv("CDB_BUILD_TRACE") && pf.premap_bytes)

@@ -190,3 +190,46 @@ def test_a_process_may_end_while_a_proof_is_still_running():
             "print('LEAVING', flush=True)\n" % root)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "LEAVING" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_reserve_maps_a_spare_generation_for_the_rebuild_beside_a_serving_index():
+    """database.cpp:276-280 builds the next generation while the old one serves: the second build asks for the arrays an index keeps
+    once more while they are held.  cdb_reserve therefore maps twins of those blocks as SPARE blocks of the cache (round 6).  Not a
+    timing test: the pool counts the requests of 16 MiB and more that had to go to hipMalloc (stat pool_big_mallocs) — after a
+    reservation neither the first build nor the second one beside it may cause any; without the reservation both do."""
+    import torch
+    from coffeedb_amd import capi
+    lib = capi.load_library()
+    nd, dl = 3 << 18, 1024                                    # 768 MiB: the reservation's 4 % + 64 MiB of head room stay inside the
+    blob = W.random_bytes_torch(nd * dl, 31, device="cuda").cpu().numpy()   # cache's 25 % slack for a fitting block
+    torch.cuda.empty_cache()
+    ds = W.uniform_docs(nd, dl)
+    ids = np.arange(nd, dtype=np.int64)
+
+    def two_generations(**opts):
+        g1 = capi.GpuStringIndex()
+        for k, v in opts.items():
+            g1.set_option(k, v)
+        m0 = g1.stat("pool_big_mallocs"); g1.build_view(ids, blob, ds); m1 = g1.stat("pool_big_mallocs")
+        assert g1.proof_wait(60_000) == 2
+        spare = g1.stat("premap_bytes")
+        m1b = g1.stat("pool_big_mallocs")                      # (premap_generation maps on the helper thread: not the caller's path)
+        g2 = capi.GpuStringIndex(); g2.build_view(ids, blob, ds); m2 = g2.stat("pool_big_mallocs")
+        v = g2.verify()
+        assert v["inversions"] == 0 and v["tie_violations"] == 0 and v["invalid_entries"] == 0 and v["entry_sum"] == v["expected_entry_sum"]
+        g1.close(); g2.close()
+        return m1 - m0, m2 - m1b, spare
+
+    lib.cdb_release_cached_memory()
+    first, second, _ = two_generations()
+    assert first > 0 and second > 0                            # cold cache: the first build maps its working set, the second its arrays
+    lib.cdb_release_cached_memory()
+    assert lib.cdb_reserve(0, len(blob), nd, bytes(blob[:4096]), 4096) == 0
+    lib.cdb_reserve_wait()
+    first, second, _ = two_generations()
+    assert first == 0 and second == 0, (first, second)        # both generations come out of the reservation
+    lib.cdb_release_cached_memory()
+    # the same BEHIND a build instead of before it (option premap_generation, off by default: hipMalloc of tens of GB holds up launches)
+    first, second, spare = two_generations(premap_generation=1)
+    assert first > 0 and second == 0 and spare > 4 * len(blob), (first, second, spare)
+    lib.cdb_release_cached_memory()
