@@ -36,7 +36,7 @@ def _corpus(rng):
     return blob, ds
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_N", "24"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_N", "40"))))
 def test_fuzz_parity(seed):
     from coffeedb_amd import capi
     from oracle import OracleIndex
@@ -96,7 +96,7 @@ def test_fuzz_parity(seed):
     g.close()
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_SEG_N", "16"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_SEG_N", "28"))))
 def test_fuzz_segmented_bucket_wise_parity(seed):
     """The >= 2^32 code path with 8-byte entries (packed records, segmented passes, entries + flags from the last pass,
     reference order folded into the sort) on seeded corpora small enough for the oracle: tens of thousands of tiny
@@ -168,7 +168,7 @@ def test_fuzz_segmented_bucket_wise_parity(seed):
     g.close()
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_MID_N", "20"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CDB_FUZZ_MID_N", "32"))))
 def test_fuzz_bucket_wise_with_documents_of_real_size(seed):
     """The >= 2^32 code path on corpora whose documents are hundreds of bytes long — what the full-size configurations look like
     and what the tiny-document fuzz above never reaches: tiles whose document table fits the LDS take the FAST phase B of the
