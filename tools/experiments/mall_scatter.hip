@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void read16_rounds(const uint4* __restrict__ a
 
 // tile t (16 Ki elements, two u32 streams) -> D runs; run d of tile t lands at seg_base + d * (seg_len / D) + (t % tiles_per_seg) * RUN
 // seg_len = elements per "bucket" (the in-bucket passes scatter inside a bucket); seg_len = n: whole-array scatter
-template <int D, bool GROUPED>
+// SHIFT (round 6, VERDICT r5 item 4 i): every run starts at a pseudo-random offset of 0..15 elements from its 64-byte-aligned place
+// — what the runs of a real pass look like (their starts are prefix sums of digit counts) — so a wave's 256-byte store covers
+// five partial lines instead of four whole ones.  The difference to SHIFT = false is what a destination-aligned write-out
+// could buy at most.
+template <int D, bool GROUPED, bool SHIFT = false>
 __global__ __launch_bounds__(1024) void scatter_runs(const uint32_t* __restrict__ k, const uint32_t* __restrict__ v,
                                                      uint32_t* __restrict__ ko, uint32_t* __restrict__ vo, size_t seg_len) {
     constexpr int RUN = 16384 / D;
@@ -51,23 +55,81 @@ __global__ __launch_bounds__(1024) void scatter_runs(const uint32_t* __restrict_
     for (int j = 0; j < 16; ++j) {
         const uint32_t i = j * 1024 + threadIdx.x;
         const uint32_t d = i / RUN, r = i % RUN;
-        const size_t dst = seg * seg_len + (size_t)d * (seg_len / D) + tin * RUN + r;
+        const uint32_t sh = SHIFT ? (uint32_t)((tile * 2654435761ull + d * 40503u) >> 7) & 15u : 0u;
+        const size_t dst = seg * seg_len + (size_t)d * (seg_len / D) + tin * RUN + r + sh;
         ko[dst] = kk[j];
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t i = j * 1024 + threadIdx.x;
         const uint32_t d = i / RUN, r = i % RUN;
-        const size_t dst = seg * seg_len + (size_t)d * (seg_len / D) + tin * RUN + r;
+        const uint32_t sh = SHIFT ? (uint32_t)((tile * 2654435761ull + d * 40503u) >> 7) & 15u : 0u;
+        const size_t dst = seg * seg_len + (size_t)d * (seg_len / D) + tin * RUN + r + sh;
         vo[dst] = vv[j];
     }
 }
 
-template <int D, bool GROUPED = true>
-float time_scatter(uint32_t* a, uint32_t* c, uint32_t* b, uint32_t* d, size_t n, size_t seg_len, hipEvent_t e0, hipEvent_t e1) {
-    scatter_runs<D, GROUPED><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, seg_len);
+// ---- round 6: the FAITHFUL form of the alignment question.  Runs of a real pass ABUT: run (tile t, digit d) starts where run
+// (t - 1, d) ended, so every line is eventually written in full (by two tiles at a run boundary) — the shifted form above leaves
+// gaps and overlaps instead, which no pass produces.  Here run (t, d) has 49..64 elements (64 - hash & 15), its start is the
+// prefix sum over the earlier tiles (table `starts`, [tiles + 1][256]), a wave writes one run per trip (lanes behind the run's end
+// idle).  ALIGNED: the same runs, the same number of elements, but every run starts on its own 64-byte boundary (64 t) — what a
+// destination-aligned write-out would produce if it cost nothing.
+__global__ void ragged_lens_kernel(uint32_t* __restrict__ starts, uint32_t tiles) {   // one thread per digit: prefix over the tiles
+    const uint32_t d = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t <= tiles; ++t) {
+        starts[(size_t)t * 256 + d] = run;
+        run += 64u - ((uint32_t)(((uint64_t)t * 2654435761ull + d * 40503u) >> 7) & 15u);
+    }
+}
+template <bool ALIGNED>
+__global__ __launch_bounds__(1024) void scatter_ragged(const uint32_t* __restrict__ k, const uint32_t* __restrict__ v,
+                                                       uint32_t* __restrict__ ko, uint32_t* __restrict__ vo,
+                                                       const uint32_t* __restrict__ starts, size_t seg_len) {
+    const size_t slot = blockIdx.x / 8, x = blockIdx.x % 8;
+    const size_t tile = ((slot / 8) * 8 + x) * 8 + slot % 8;
+    const size_t base = tile * 16384;
+    const size_t tiles_per_seg = seg_len / 16384;
+    const size_t seg = tile / tiles_per_seg, tin = tile % tiles_per_seg;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t kk[16], vv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kk[j] = k[base + j * 1024 + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vv[j] = v[base + j * 1024 + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t d = j * 16 + wave;
+        const uint32_t s0 = starts[tin * 256 + d], len = starts[(tin + 1) * 256 + d] - s0;
+        const size_t dst = seg * seg_len + (size_t)d * (seg_len / 256) + (ALIGNED ? tin * 64 : (size_t)s0) + lane;
+        if (lane < len) ko[dst] = kk[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t d = j * 16 + wave;
+        const uint32_t s0 = starts[tin * 256 + d], len = starts[(tin + 1) * 256 + d] - s0;
+        const size_t dst = seg * seg_len + (size_t)d * (seg_len / 256) + (ALIGNED ? tin * 64 : (size_t)s0) + lane;
+        if (lane < len) vo[dst] = vv[j];
+    }
+}
+template <bool ALIGNED>
+float time_ragged(uint32_t* a, uint32_t* c, uint32_t* b, uint32_t* d, const uint32_t* starts, size_t n, size_t seg_len, hipEvent_t e0, hipEvent_t e1) {
+    scatter_ragged<ALIGNED><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, starts, seg_len);
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 5; ++r) scatter_runs<D, GROUPED><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, seg_len);
+    for (int r = 0; r < 5; ++r) scatter_ragged<ALIGNED><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, starts, seg_len);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / 5;
+}
+
+template <int D, bool GROUPED = true, bool SHIFT = false>
+float time_scatter(uint32_t* a, uint32_t* c, uint32_t* b, uint32_t* d, size_t n, size_t seg_len, hipEvent_t e0, hipEvent_t e1) {
+    scatter_runs<D, GROUPED, SHIFT><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, seg_len);
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) scatter_runs<D, GROUPED, SHIFT><<<(unsigned)(n / 16384), 1024>>>(a, c, b, d, seg_len);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -78,7 +140,7 @@ float time_scatter(uint32_t* a, uint32_t* c, uint32_t* b, uint32_t* d, size_t n,
 int main() {
     const size_t n = 1ull << 30;
     void *a, *b, *c, *d;
-    CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4)); CK(hipMalloc(&c, n * 4)); CK(hipMalloc(&d, n * 4));
+    CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4 + 256)); CK(hipMalloc(&c, n * 4)); CK(hipMalloc(&d, n * 4 + 256));
     CK(hipMemset(a, 1, n * 4)); CK(hipMemset(b, 2, n * 4)); CK(hipMemset(c, 3, n * 4)); CK(hipMemset(d, 4, n * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -109,6 +171,23 @@ int main() {
         const float t256p = time_scatter<256, false>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, n, seg_len, e0, e1);
         const float t2kp = time_scatter<2048, false>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, n, seg_len, e0, e1);
         printf("  (tiles in blockIdx order instead of the XCD-aware order: D = 256 %.3f ms, D = 2048 %.3f ms)\n", t256p, t2kp);
+        const float t256s = time_scatter<256, true, true>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, n, seg_len, e0, e1);
+        const float t256a = time_scatter<256>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, n, seg_len, e0, e1);
+        printf("  D = 256, run starts 64-byte aligned %.3f ms / shifted by 0..15 elements (as in a real pass) %.3f ms: alignment is worth %.1f %%\n",
+               t256a, t256s, 100.0 * (t256s - t256a) / t256s);
+        {
+            const uint32_t tps = (uint32_t)(seg_len / 16384);
+            uint32_t* starts;
+            CK(hipMalloc(&starts, ((size_t)tps + 1) * 256 * 4));
+            ragged_lens_kernel<<<1, 256>>>(starts, tps);
+            CK(hipDeviceSynchronize());
+            const float ta = time_ragged<true>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, starts, n, seg_len, e0, e1);
+            const float tu = time_ragged<false>((uint32_t*)a, (uint32_t*)c, (uint32_t*)b, (uint32_t*)d, starts, n, seg_len, e0, e1);
+            printf("  D = 256, ABUTTING runs of 49..64 elements (88 %% of the elements written): starts as the prefix sums give them %.3f ms / "
+                   "each run on its own 64-byte boundary %.3f ms: a destination-aligned write-out is worth at most %.1f %%\n",
+                   tu, ta, 100.0 * (tu - ta) / tu);
+            CK(hipFree(starts));
+        }
         printf("  D =   16 (4 KiB runs): %.3f ms  %.2f TB/s\n", t16, 16.0 * n / t16 / 1e9);
         printf("  D =  256 (256 B runs): %.3f ms  %.2f TB/s\n", t256, 16.0 * n / t256 / 1e9);
         printf("  D =  512 (128 B runs): %.3f ms  %.2f TB/s\n", t512, 16.0 * n / t512 / 1e9);
