@@ -400,7 +400,10 @@ def proof_block(g, timeout_ms=180_000):
     return {"state": {0: "not started", 1: "still running", 2: "proved", 3: "damage found and repaired", 4: "repair failed",
                       5: "cancelled", 6: "could not run"}.get(st, str(st)),
             "order_proved": bool(g.stat("order_proved")), "proof_ms": round(g.stat("proof_ms"), 2), "pairs": int(g.stat("proof_pairs")),
-            "bad_pairs": int(g.stat("proof_bad_pairs")), "self_check_fallbacks": int(g.stat("self_check_fallbacks"))}
+            "bad_pairs": int(g.stat("proof_bad_pairs")), "self_check_fallbacks": int(g.stat("self_check_fallbacks")),
+            # pairs whose first differing bytes lie on both sides of 0x80 (reference-compat order: judged by the size of their bucket,
+            # the proof's second stage) / pairs left unjudged
+            "mixed_pairs": int(g.stat("proof_mixed_pairs")), "skipped_pairs": int(g.stat("proof_skipped_pairs"))}
 
 
 def verify_block(g):

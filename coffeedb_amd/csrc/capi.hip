@@ -1726,7 +1726,7 @@ int cdb_get_stat(const cdb_index* h, const char* name, double* value) {
         {"sort_passes_skipped", (double)b.sort_passes_skipped}, {"isa_built", (double)b.isa_built}, {"fused_keygen", (double)b.fused_keygen}, {"dense_keys", (double)b.dense_keys}, {"key_layout", (double)b.key_layout}, {"bucketed", (double)b.bucketed}, {"bucket_groups", (double)b.bucket_groups}, {"segmented", (double)b.segmented}, {"fused_records", (double)b.fused_records}, {"sweep_records", (double)b.sweep_records}, {"vl_key_bits", (double)b.vl_key_bits}, {"partial_levels", (double)b.partial_levels}, {"list_rounds", (double)b.list_rounds}, {"pairclass_fused", (double)b.pairclass_fused}, {"group_sorts", (double)b.group_sorts}, {"group_sort_fallbacks", (double)b.group_sort_fallbacks}, {"vl_avg_len", b.vl_avg_len}, {"vl_rate", b.vl_rate}, {"vl_est_unresolved", b.vl_est_unresolved}, {"fixed_est_unresolved", b.fixed_est_unresolved}, {"gen_prebased", (double)b.gen_prebased}, {"root_folded", (double)b.root_folded}, {"flags_in_last_pass", (double)b.flags_in_last_pass}, {"msd_first", (double)b.msd_first}, {"bucket_low_digits", (double)b.bucket_low_digits}, {"key_directory_cells", h->ix.h_keydir.empty() ? 0.0 : (double)(h->ix.h_keydir.size() - 1)}, {"group_fallbacks", (double)h->ix.group_fallbacks}, {"dense_key_retries", (double)h->ix.dense_key_retries}, {"self_check_fallbacks", (double)h->ix.self_check_fallbacks}, {"sa_packed", h->ix.sa_packed ? 1.0 : 0.0}, {"sa_bytes_per_entry", h->ix.sa_packed ? 5.0 : (double)h->ix.width}, {"self_check_pairs", (double)h->ix.self_check_pairs}, {"self_check_ms", h->ix.self_check_ms}, {"self_check_coverage", h->ix.size > 1 ? (double)h->ix.self_check_pairs / (double)(h->ix.size - 1) : 0.0},
         {"order_proved", (h->ix.proof.state.load() == 2 || h->ix.proof.state.load() == 3 || (h->ix.self_check == 2 && h->ix.width != 0)) ? 1.0 : 0.0},
         {"proof_state", (double)h->ix.proof.state.load()}, {"proof_ms", h->ix.proof.ms}, {"proof_repair_ms", h->ix.proof.repair_ms},
-        {"proof_pairs", (double)h->ix.proof.pairs}, {"proof_bad_pairs", (double)h->ix.proof.found[0]}, {"proof_invalid_entries", (double)h->ix.proof.found[1]},
+        {"proof_pairs", (double)h->ix.proof.pairs}, {"proof_bad_pairs", (double)h->ix.proof.found[0]}, {"proof_invalid_entries", (double)h->ix.proof.found[1]}, {"proof_skipped_pairs", (double)h->ix.proof.skipped}, {"proof_mixed_pairs", (double)h->ix.proof.mixed},
         {"proof_runs", (double)h->ix.proof.runs}, {"pool_big_mallocs", (double)DevPool::get().big_mallocs()}, {"premap_ms", h->ix.proof.premap_ms}, {"premap_bytes", (double)h->ix.proof.premap_bytes},
         {"key_symbols", (double)b.key_symbols}, {"symbol_bits", (double)b.symbol_bits},
         {"alphabet", (double)b.alphabet}, {"digit_bits", (double)b.digit_bits}, {"final_depth", (double)b.final_depth}, {"compat_rotations", (double)b.compat_rotations},

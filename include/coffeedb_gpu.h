@@ -395,7 +395,8 @@ int cdb_debug_self_check(cdb_index* h, int full, uint64_t out[2]);
 /* The order proof behind a published build (option self_check = 3, the default).  The reference's array is sorted by
  * construction (std::sort leaves, index.cpp:86-95); this library's passes rest on an observed LDS lane order, so after
  * cdb_build* / cdb_load return (with a sample of adjacent pairs checked) a helper thread compares EVERY adjacent pair of the
- * published array against the text on a low-priority stream of its own, beside the queries.  cdb_get_stat "order_proved" goes
+ * published array against the text on a low-priority stream of its own, beside the queries (text with bytes >= 0x80 in the
+ * reference's order: also the pairs whose order depends on the size of the reference's radix buckets, index.h:66-73).  cdb_get_stat "order_proved" goes
  * 0 -> 1 when it is through; damage makes the handle rebuild itself with the ballot ranking under its lock (queries wait; stat
  * "self_check_fallbacks" counts it).  cdb_proof_wait blocks until the proof of the CURRENT array has ended, at most timeout_ms
  * (< 0: no limit), and returns its state: 0 no proof was started (self_check < 3, or not built), 1 still running, 2 proved,
