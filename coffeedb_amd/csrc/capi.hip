@@ -1688,6 +1688,9 @@ int cdb_set_option(cdb_index* h, const char* name, int64_t value) {
     else if (!std::strcmp(name, "debug_starve_group")) ix.debug_starve_group = (int)value;  // 1 = reported after the sorts, 2 = error flag up before the initial sort
     else if (!std::strcmp(name, "self_check")) ix.self_check = value < 0 ? 0 : value > 3 ? 3 : (int)value;  // 0 off, 1 sample, 2 every pair inline, 3 sample + proof after publish
     else if (!std::strcmp(name, "premap_generation")) ix.premap_generation = value != 0;
+    else if (!std::strcmp(name, "proof_cancel")) {  // stops the order proof in flight (state 5); the next build / load starts a new one
+        if (value) proof_stop(ix);
+    }
     else if (!std::strcmp(name, "debug_damage_after_build")) ix.debug_damage_after_build = value < 0 ? 0 : (uint64_t)value;
     else if (!std::strcmp(name, "debug_fail_self_check")) ix.debug_fail_self_check = value != 0;
     else if (!std::strcmp(name, "plain_tile_order")) ix.rws.plain_order = value != 0;

@@ -272,8 +272,8 @@ struct Index {
         double ms = 0, repair_ms = 0;    // wall time of the sweep / of the repair
         uint64_t pairs = 0;              // adjacent pairs compared
         uint64_t found[2] = {0, 0};      // pairs out of order, invalid entries
-        uint64_t skipped = 0;            // pairs left unjudged (0 since the second stage exists: kept as a stat)
-        uint64_t mixed = 0;              // pairs whose first differing bytes lie on both sides of 0x80, judged by bucket size (stage 2)
+        uint64_t skipped = 0;            // pairs left unjudged (0: mixed pairs are judged in place; kept as a stat)
+        uint64_t mixed = 0;              // pairs whose first differing bytes lie on both sides of 0x80, judged by the size of their bucket
         uint64_t runs = 0;
         bool of_loaded_file = false;     // the array came from cdb_load: damage says nothing about this device's ranking
         std::atomic<bool> busy{false};   // the helper thread is at work (pre-mapping and / or proof)

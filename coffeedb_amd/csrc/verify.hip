@@ -126,6 +126,93 @@ __global__ __launch_bounds__(256) void sa_spot_check_kernel(typename SaOf<V>::pt
     if (ninvalid) atomicAdd(&out[1], ninvalid);
 }
 
+// ---- the REFERENCE's order (SURVEY.md Q2) --------------------------------------------------------------
+// For text with bytes >= 0x80 the reference's array is not globally sorted: a radix node (bucket of more than
+// chuck_size = max(4096, n / 256) suffixes, index.cpp:96-126,218) lays its children out by
+// `(int)char - CHAR_MIN + 1` of a SIGNED char (index.h:66-73): [end of document][0x80..0xFF][0x00..0x7F]; buckets of
+// at most chuck_size suffixes are std::sort-ed by unsigned string_view order (index.cpp:86-95).  Checked here pair
+// by pair, by code that shares nothing with apply_reference_order: for adjacent entries with common prefix length l,
+//   * both end at l                      -> equal suffixes: ascending document (canonical tie order);
+//   * exactly one ends at l              -> it comes first (either order);
+//   * next bytes of the same sign class  -> ascending (signed and unsigned order agree);
+//   * one byte >= 0x80, the other < 0x80 -> the bucket of their common l-prefix decides: more than chuck_size
+//     suffixes share that prefix <=> it was a radix node <=> the byte >= 0x80 comes first; otherwise the byte < 0x80.
+// Buckets are contiguous in the reference's order (its permutation only moves whole child ranges), so the size
+// of the l-prefix bucket is found by galloping outwards from the pair until the prefix no longer matches.
+template <typename V>
+struct RefOrderCtx {
+    typename SaOf<V>::ptr sa;
+    uint64_t n;
+    const uint8_t* text;
+    const uint64_t* doc_start;
+    int bits;
+    uint64_t mask;
+    uint64_t ndocs = ~0ull;  // (set by callers that may meet entries naming no document: such an entry is an empty suffix here)
+    __device__ __forceinline__ void suffix(uint64_t i, const uint8_t*& p, uint64_t& len) const {
+        const auto e = sa[i];
+        const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
+        if (d >= ndocs) {
+            p = text;
+            len = 0;
+            return;
+        }
+        const uint64_t ds = doc_start[d], dl = doc_start[d + 1] - ds;
+        p = text + ds + (o < dl ? o : dl);
+        len = o < dl ? dl - o : 0;
+    }
+    // does entry i share the first l bytes of q (a suffix known to have >= l bytes)?
+    __device__ __forceinline__ bool shares(uint64_t i, const uint8_t* q, uint64_t l) const {
+        const uint8_t* p;
+        uint64_t len;
+        suffix(i, p, len);
+        if (len < l) return false;
+        for (uint64_t k = 0; k < l; ++k)
+            if (p[k] != q[k]) return false;
+        return true;
+    }
+};
+
+// is the bucket of the l-prefix that entries i - 1 and i share a radix node of the reference (more than `chuck` suffixes)?  pa =
+// suffix of entry i - 1 (>= l bytes).  Counted outwards from the pair, capped at chuck + 1.
+template <typename V>
+__device__ __forceinline__ bool ref_bucket_is_node(const RefOrderCtx<V>& c, uint64_t i, const uint8_t* pa, uint64_t l, uint64_t chuck) {
+    uint64_t cnt = 2;
+    {   // backwards from i - 1
+        uint64_t good = 0, step = 1, lim_b = i - 1;  // entries i-1-good .. i-1 share the prefix
+        uint64_t badp = lim_b + 1;                   // first distance known not to share (or beyond the array)
+        while (good + step <= lim_b && good + step <= chuck) {
+            if (c.shares(i - 1 - (good + step), pa, l)) { good += step; step <<= 1; }
+            else { badp = good + step; break; }
+        }
+        if (badp > good + step && good + step > lim_b) badp = lim_b + 1;
+        if (good < chuck) {
+            uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;  // answer in [good, hi)
+            while (good + 1 < hi) {
+                const uint64_t mid = good + (hi - good) / 2;
+                if (mid <= lim_b && c.shares(i - 1 - mid, pa, l)) good = mid; else hi = mid;
+            }
+        }
+        cnt += good;
+    }
+    if (cnt <= chuck) {  // forwards from i
+        uint64_t good = 0, step = 1, lim_f = c.n - 1 - i;
+        uint64_t badp = lim_f + 1;
+        while (good + step <= lim_f && good + step <= chuck) {
+            if (c.shares(i + good + step, pa, l)) { good += step; step <<= 1; }
+            else { badp = good + step; break; }
+        }
+        if (good < chuck) {
+            uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;
+            while (good + 1 < hi) {
+                const uint64_t mid = good + (hi - good) / 2;
+                if (mid <= lim_f && c.shares(i + mid, pa, l)) good = mid; else hi = mid;
+            }
+        }
+        cnt += good;
+    }
+    return cnt > chuck;
+}
+
 // The FULL sweep (self_check = 2) by the same rules, laid out for throughput: every lane fetches ONE suffix — its entry, the
 // document bounds and the first 16 bytes as two big-endian words — and gets its left neighbour's through a lane shuffle, so a
 // pair costs one random 64-byte sector instead of two and is decided by two 64-bit compares; only pairs that agree on
@@ -176,9 +263,11 @@ __global__ __launch_bounds__(256) void sa_full_check_kernel(typename SaOf<V>::pt
                                                             const uint64_t* __restrict__ doc_start, uint64_t ndocs, int bits,
                                                             uint64_t mask, bool plain, unsigned long long* __restrict__ out,
                                                             uint64_t first, uint64_t end,
-                                                            unsigned long long* __restrict__ out_skip = nullptr) {
-    // out_skip (optional): pairs NOT judged — reference-compat order of text with bytes >= 0x80, first differing bytes on different
-    // sides of 0x80: which comes first depends on the size of the bucket they share (cdb_debug_verify_reference walks those)
+                                                            unsigned long long* __restrict__ out_mixed = nullptr, uint64_t chuck = 0) {
+    // Reference-compat order of text with bytes >= 0x80 (plain = false): a pair whose first differing bytes lie on different sides of
+    // 0x80 ("mixed") is right in EITHER order, depending on the size of the bucket the two suffixes share (rules above RefOrderCtx).
+    // chuck = 0: such pairs pass (the sample behind a build); chuck = the reference's chuck_size: the lane that meets one finds the
+    // bucket size by galloping over the array and judges it (the order proof).  out_mixed (optional) counts them.
     // entries [first, end) with the pair (first - 1, first) included: slices of one sweep add up to every adjacent pair
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -209,7 +298,13 @@ __global__ __launch_bounds__(256) void sa_full_check_kernel(typename SaOf<V>::pt
             } else {
                 const uint32_t ca = (uint32_t)(x >> (56 - 8 * byte)) & 0xFFu, cb = (uint32_t)(y >> (56 - 8 * byte)) & 0xFFu;
                 bad = ca > cb && (plain || ((ca ^ cb) & 0x80u) == 0);
-                if (!plain && ((ca ^ cb) & 0x80u)) nskip += 1;
+                if (!plain && ((ca ^ cb) & 0x80u)) {
+                    nskip += 1;
+                    if (chuck) {
+                        const RefOrderCtx<V> c{sa, n, text, doc_start, bits, mask, ndocs};
+                        bad = (ca >= 0x80u) != ref_bucket_is_node(c, i, text + a.pos, l, chuck);
+                    }
+                }
             }
         } else if (len <= 16) {  // equal through the end of the shorter one
             bad = a.len > b.len || (a.len == b.len && a.doc >= b.doc);
@@ -222,54 +317,21 @@ __global__ __launch_bounds__(256) void sa_full_check_kernel(typename SaOf<V>::pt
             if (l == len) bad = a.len > b.len || (a.len == b.len && a.doc >= b.doc);
             else if (l < cap) {
                 bad = pa[l] > pb[l] && (plain || ((pa[l] ^ pb[l]) & 0x80u) == 0);
-                if (!plain && ((pa[l] ^ pb[l]) & 0x80u)) nskip += 1;
+                if (!plain && ((pa[l] ^ pb[l]) & 0x80u)) {
+                    nskip += 1;
+                    if (chuck) {
+                        const RefOrderCtx<V> c{sa, n, text, doc_start, bits, mask, ndocs};
+                        bad = (pa[l] >= 0x80u) != ref_bucket_is_node(c, i, pa, l, chuck);
+                    }
+                }
             }
         }
         if (bad) nbad += 1;
     }
     if (nbad) atomicAdd(&out[0], nbad);
     if (ninvalid) atomicAdd(&out[1], ninvalid);
-    if (nskip && out_skip) atomicAdd(out_skip, nskip);
+    if (nskip && out_mixed) atomicAdd(out_mixed, nskip);
 }
-
-// ---- the REFERENCE's order (SURVEY.md Q2) --------------------------------------------------------------
-// For text with bytes >= 0x80 the reference's array is not globally sorted: a radix node (bucket of more than
-// chuck_size = max(4096, n / 256) suffixes, index.cpp:96-126,218) lays its children out by
-// `(int)char - CHAR_MIN + 1` of a SIGNED char (index.h:66-73): [end of document][0x80..0xFF][0x00..0x7F]; buckets of
-// at most chuck_size suffixes are std::sort-ed by unsigned string_view order (index.cpp:86-95).  Checked here pair
-// by pair, by code that shares nothing with apply_reference_order: for adjacent entries with common prefix length l,
-//   * both end at l                      -> equal suffixes: ascending document (canonical tie order);
-//   * exactly one ends at l              -> it comes first (either order);
-//   * next bytes of the same sign class  -> ascending (signed and unsigned order agree);
-//   * one byte >= 0x80, the other < 0x80 -> the bucket of their common l-prefix decides: more than chuck_size
-//     suffixes share that prefix <=> it was a radix node <=> the byte >= 0x80 comes first; otherwise the byte < 0x80.
-// Buckets are contiguous in the reference's order (its permutation only moves whole child ranges), so the size
-// of the l-prefix bucket is found by galloping outwards from the pair until the prefix no longer matches.
-template <typename V>
-struct RefOrderCtx {
-    typename SaOf<V>::ptr sa;
-    uint64_t n;
-    const uint8_t* text;
-    const uint64_t* doc_start;
-    int bits;
-    uint64_t mask;
-    __device__ __forceinline__ void suffix(uint64_t i, const uint8_t*& p, uint64_t& len) const {
-        const auto e = sa[i];
-        const uint64_t d = (uint64_t)e & mask, o = (uint64_t)e >> bits;
-        p = text + doc_start[d] + o;
-        len = doc_start[d + 1] - doc_start[d] - o;
-    }
-    // does entry i share the first l bytes of q (a suffix known to have >= l bytes)?
-    __device__ __forceinline__ bool shares(uint64_t i, const uint8_t* q, uint64_t l) const {
-        const uint8_t* p;
-        uint64_t len;
-        suffix(i, p, len);
-        if (len < l) return false;
-        for (uint64_t k = 0; k < l; ++k)
-            if (p[k] != q[k]) return false;
-        return true;
-    }
-};
 
 template <typename V>
 __global__ __launch_bounds__(256) void sa_verify_reference_kernel(RefOrderCtx<V> c, uint64_t chuck, unsigned long long* __restrict__ out,
@@ -299,42 +361,7 @@ __global__ __launch_bounds__(256) void sa_verify_reference_kernel(RefOrderCtx<V>
             continue;
         }
         mixed += 1;
-        // size of the bucket of the common l-prefix, counted outwards from the pair and capped at chuck + 1
-        uint64_t cnt = 2;
-        {   // backwards from i - 1
-            uint64_t good = 0, step = 1, lim_b = i - 1;  // entries i-1-good .. i-1 share the prefix
-            uint64_t badp = lim_b + 1;                   // first distance known not to share (or beyond the array)
-            while (good + step <= lim_b && good + step <= chuck) {
-                if (c.shares(i - 1 - (good + step), pa, l)) { good += step; step <<= 1; }
-                else { badp = good + step; break; }
-            }
-            if (badp > good + step && good + step > lim_b) badp = lim_b + 1;
-            if (good < chuck) {
-                uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;  // answer in [good, hi)
-                while (good + 1 < hi) {
-                    const uint64_t mid = good + (hi - good) / 2;
-                    if (mid <= lim_b && c.shares(i - 1 - mid, pa, l)) good = mid; else hi = mid;
-                }
-            }
-            cnt += good;
-        }
-        if (cnt <= chuck) {  // forwards from i
-            uint64_t good = 0, step = 1, lim_f = c.n - 1 - i;
-            uint64_t badp = lim_f + 1;
-            while (good + step <= lim_f && good + step <= chuck) {
-                if (c.shares(i + good + step, pa, l)) { good += step; step <<= 1; }
-                else { badp = good + step; break; }
-            }
-            if (good < chuck) {
-                uint64_t hi = badp < chuck + 1 ? badp : chuck + 1;
-                while (good + 1 < hi) {
-                    const uint64_t mid = good + (hi - good) / 2;
-                    if (mid <= lim_f && c.shares(i + mid, pa, l)) good = mid; else hi = mid;
-                }
-            }
-            cnt += good;
-        }
-        const bool node = cnt > chuck;  // a radix node of the reference: signed child order
+        const bool node = ref_bucket_is_node(c, i, pa, l, chuck);  // a radix node of the reference: signed child order
         if (node) big += 1;
         const bool high_first = x >= 0x80;
         if (high_first != node) bad += 1;
@@ -446,43 +473,17 @@ bool proof_sweep(Index& ix, uint64_t found[3]) {
             const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(end - first, 256), 1u << 14);
             hipLaunchKernelGGL((sa_full_check_kernel<T>), dim3(grid), dim3(256), 0, pf.stream, ix.sa_view<T>(), ix.size, ix.d_text,
                                (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, ix.sa_sorted,
-                               static_cast<unsigned long long*>(pf.d_out), first, end, static_cast<unsigned long long*>(pf.d_out) + 2);
+                               static_cast<unsigned long long*>(pf.d_out), first, end, static_cast<unsigned long long*>(pf.d_out) + 2,
+                               ix.sa_sorted ? (uint64_t)0 : std::max<uint64_t>(4096, ix.size / 256) /* index.cpp:218 */);
         });
         CDB_HIP(hipStreamSynchronize(pf.stream));
     }
     CDB_HIP(hipMemcpyAsync(found, pf.d_out, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, pf.stream));
     CDB_HIP(hipStreamSynchronize(pf.stream));
-    pf.mixed = 0;
-    if (ix.sa_sorted || found[0] || found[1] || found[2] == 0) return true;
-    // ---- stage 2, reference-compat order of text with bytes >= 0x80 only: the pairs stage 1 could not judge (first differing bytes
-    // on different sides of 0x80: 8 % of the pairs of synthetic UTF-8).  Inside a radix node of the reference (a bucket of more
-    // than chuck_size suffixes, index.cpp:96-126,218) the byte >= 0x80 comes first (signed child order, index.h:66-73), below
-    // that the byte < 0x80 (std::sort leaves, index.cpp:86-95): sa_verify_reference_kernel finds the size of the bucket the two
-    // suffixes share by galloping outwards over the array.  Entries are known to be valid (stage 1 found none that is not).
-    unsigned long long* d4 = static_cast<unsigned long long*>(pf.d_out) + 4;
-    CDB_HIP(hipMemsetAsync(d4, 0, 4 * sizeof(uint64_t), pf.stream));
-    const uint64_t chuck = std::max<uint64_t>(4096, ix.size / 256);
-    for (uint64_t first = 0; first < ix.size; first += PROOF_SLICE) {
-        if (pf.cancel.load(std::memory_order_acquire)) return false;
-        for (const double tw = now_ms(); foreground_calls().load(std::memory_order_acquire) > 0 && now_ms() - tw < PROOF_MAX_WAIT_MS;) {
-            if (pf.cancel.load(std::memory_order_acquire)) return false;
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
-        }
-        const uint64_t end = std::min<uint64_t>(ix.size, first + PROOF_SLICE);
-        sa_dispatch(ix, [&](auto tag) {
-            using T = decltype(tag);
-            RefOrderCtx<T> c{ix.sa_view<T>(), ix.size, ix.d_text, ix.d_doc_start.as<uint64_t>(), (int)ix.bits, ix.mask};
-            const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(end - first, 256), 1u << 14);
-            hipLaunchKernelGGL((sa_verify_reference_kernel<T>), dim3(grid), dim3(256), 0, pf.stream, c, chuck, d4, first, end);
-        });
-        CDB_HIP(hipStreamSynchronize(pf.stream));
-    }
-    uint64_t r4[4] = {0, 0, 0, 0};
-    CDB_HIP(hipMemcpyAsync(r4, d4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, pf.stream));
-    CDB_HIP(hipStreamSynchronize(pf.stream));
-    found[0] += r4[0] + r4[3];  // pairs out of the reference's order + equal suffixes not ascending by document
-    pf.mixed = r4[1];
-    found[2] = 0;               // every pair has been judged now
+    // (reference-compat order of text with bytes >= 0x80: the pairs whose order depends on the size of the reference's radix buckets
+    //  — 8 % of the pairs of synthetic UTF-8 — were judged in place, sa_full_check_kernel with chuck > 0; none is left out)
+    pf.mixed = found[2];
+    found[2] = 0;
     return true;
 }
 

@@ -120,9 +120,9 @@ def test_the_proof_also_judges_the_pairs_whose_order_depends_on_bucket_sizes():
     """Under reference_compat (default) text with bytes >= 0x80 is laid out in the reference's signed child order inside radix nodes
     (index.h:66-73, buckets of more than chuck_size suffixes) and in unsigned order below them (index.cpp:86-95): for a pair whose
     first differing bytes lie on different sides of 0x80 the right order depends on the size of the bucket the two suffixes share.
-    The proof's first stage cannot judge those (8 % of the pairs of synthetic UTF-8); its second stage finds the bucket size by
-    galloping over the array (the kernel of cdb_debug_verify_reference, in slices on the proof's stream).  Nothing is left unjudged,
-    and damage among exactly those pairs is found and repaired."""
+    A local comparison cannot judge those (8 % of the pairs of synthetic UTF-8); the lane that meets one finds the bucket size by
+    galloping over the array (ref_bucket_is_node, the code of cdb_debug_verify_reference).  Nothing is left unjudged, and damage
+    among exactly those pairs is found and repaired."""
     from coffeedb_amd import capi
     blob, ds = W.utf8_corpus(4000, 300, seed=17)
     ids = np.arange(len(ds) - 1, dtype=np.int64)
