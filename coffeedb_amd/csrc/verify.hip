@@ -428,7 +428,9 @@ void spot_check_suffix_array(Index& ix, uint32_t samples, uint64_t out[2]) {
             const unsigned g2 = (unsigned)std::min<uint64_t>(ceil_div(ix.size, 256), 1u << 16);
             hipLaunchKernelGGL((sa_full_check_kernel<T>), dim3(g2), dim3(256), 0, s, ix.sa_view<T>(), ix.size, ix.d_text,
                                (const uint64_t*)ix.d_doc_start.as<uint64_t>(), ix.ndocs, (int)ix.bits, ix.mask, ix.sa_sorted,
-                               d_out.as<unsigned long long>(), (uint64_t)0, ix.size);
+                               d_out.as<unsigned long long>(), (uint64_t)0, ix.size, (unsigned long long*)nullptr,
+                               // (every pair means every pair: the bucket-size-dependent ones of a reference-compat order too)
+                               ix.sa_sorted ? (uint64_t)0 : std::max<uint64_t>(4096, ix.size / 256));
         });
     } else
     sa_dispatch(ix, [&](auto tag) {
