@@ -718,6 +718,10 @@ def short_line(out):
             d["aggregate_GiB_per_s"] = b["all_ranks"].get("sa_build_GiB_per_s_aggregate")
         dig[name] = {k: v for k, v in d.items() if v is not None}
     s["configs"] = dig
+    c1 = dig.get("c1") or {}
+    if c1.get("cpu_query_allcores") and c1.get("query_patterns_per_s"):
+        # north_star: ">= 10 x the CPU reference's matches/sec on 100k batched patterns" = BASELINE config 1, CPU port on all host threads
+        s["c1_query_vs_cpu_allcores"] = round(c1["query_patterns_per_s"] / c1["cpu_query_allcores"], 1)
     s["detail"] = "bench_detail.json (written beside bench.py; also the stdout line before this one)"
     # the guard: drop the optional parts, least important first, until the line fits
     for victim in ("build_ms_per_step", "merge", "query_roofline", "rows_per_rank", "configs"):
