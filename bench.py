@@ -173,7 +173,7 @@ def attach_traffic(roof, tr, note):
 
 def build_stats(g):
     keys = ("rounds", "ext_rounds", "dbl_rounds", "unresolved_after_initial", "sort_passes", "sort_passes_skipped",
-            "key_symbols", "symbol_bits", "alphabet", "isa_built", "bucketed", "bucket_groups", "segmented", "key_layout", "root_folded", "compat_rotations", "group_fallbacks", "self_check_fallbacks", "bucket_low_digits",
+            "key_symbols", "symbol_bits", "alphabet", "isa_built", "bucketed", "bucket_groups", "segmented", "key_layout", "root_folded", "compat_rotations", "group_fallbacks", "self_check_fallbacks", "dense_key_retries", "bucket_low_digits",
             "fused_records", "sweep_records", "gen_prebased", "vl_key_bits", "partial_levels", "list_rounds", "pairclass_fused", "group_sorts", "group_sort_fallbacks", "vl_avg_len", "vl_rate", "vl_est_unresolved")
     out = {}
     for k in keys:

@@ -89,6 +89,7 @@ def test_bucket_wise_build_equals_the_oracle_at_256_mib(corpus, share, min_group
         assert g.stat("bucketed") == 1 and g.sa_width == 8, info
         assert g.stat("bucket_groups") >= min_groups or g.stat("sweep_records") == 0, info
         assert g.stat("self_check_fallbacks") == 0 and g.stat("group_fallbacks") == 0, info    # (a fallback would mask a wrong array)
+        assert g.stat("dense_key_retries") == 0, info           # (the key form chosen must be one the records path can take: no second prologue)
         if kind == "zipf":
             assert g.stat("vl_key_bits") == (0 if other_keys else 40), info
             assert other_keys or g.stat("sweep_records") == 1, info
